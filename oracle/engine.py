@@ -1,0 +1,412 @@
+"""Generation loops of the hot path, restated in numpy (oracle; test infrastructure).
+
+Reference functions followed (paths relative to the reference checkout):
+    stochopy/optimize/_common.py:109-120   lhs
+    stochopy/optimize/_common.py:123-160   selection_sync
+    stochopy/optimize/de/_de.py:176-301    de loop, :314-351 de_sync
+    stochopy/optimize/de/_strategy.py:1-38 rand1bin/rand2bin/best1bin/best2bin
+    stochopy/optimize/de/_constraints.py:13-28  Random
+    stochopy/optimize/cpso/_cpso.py:182-321 cpso loop, :324-329 mutation,
+                                     :332-361 pso_sync, :405-426 restart
+    stochopy/optimize/cpso/_constraints.py:4-10, 44-53  NoConstraint / Shrink (sync form)
+    stochopy/optimize/cmaes/_cmaes.py:143-357 cmaes loop, :360-434 converge
+Only synchronous ("deferred") updating is restated: it is what every parallel
+backend of the reference runs (de/_de.py:142-145, cpso/_cpso.py:147-150).
+
+The loops take the random draws from a stream object (oracle/streams.py) so the
+same arithmetic serves the numpy-legacy stream (reference parity) and the
+Philox layout (CPU<->GPU parity at sizes the reference cannot run).
+"""
+import numpy as np
+
+from .objectives import OBJECTIVES
+from .streams import LegacyStream, PhiloxStream
+
+MESSAGES = {
+    -8: "TolX",
+    -7: "TolFun",
+    -6: "TolXUp",
+    -5: "EqualFunValues",
+    -4: "ConditionCov",
+    -3: "NoEffectCoord",
+    -2: "NoEffectAxis",
+    -1: "maximum number of iterations is reached",
+    0: "best solution changes less than xtol",
+    1: "best solution value is lower than ftol",
+}
+
+DONORS = {"rand1bin": 3, "rand2bin": 5, "best1bin": 2, "best2bin": 4}
+
+
+class Result(dict):
+    __getattr__ = dict.__getitem__
+
+
+def make_stream(rng, seed):
+    if rng in (None, "numpy-legacy"):
+        return LegacyStream(seed)
+    if rng == "philox":
+        return PhiloxStream(seed)
+    raise ValueError(rng)
+
+
+def latin_hypercube(stream, P, n, lower, upper):
+    """_common.py:109-120 (jitter is 1/P wide inside strata 2/P wide -- reproduced as is)."""
+    u, perms = stream.lhs_draws(P, n)
+    x = u / P
+    x += np.linspace(-1.0, 1.0, P, endpoint=False)[:, None]
+    pop = np.empty((P, n))
+    for j in range(n):
+        pop[:, j] = x[perms[j], j]
+    pop *= 0.5 * (upper - lower)
+    pop += 0.5 * (upper + lower)
+    return pop
+
+
+def termination(it, maxiter, dx, fbest, xtol, ftol):
+    """Status ladder of _common.py:134-158: 0, then 1, then -1, else None."""
+    if dx <= xtol and fbest <= ftol:
+        return 0
+    if fbest <= ftol:
+        return 1
+    if it >= maxiter:
+        return -1
+    return None
+
+
+def greedy_select(it, cand, candfun, xbest, x, xfun, maxiter, xtol, ftol):
+    """_common.py:127-158 after the evaluation: strict <, in-place, first argmin."""
+    better = candfun < xfun
+    xfun[better] = candfun[better]
+    x[better] = cand[better]
+    k = int(np.argmin(xfun))
+    dx = np.linalg.norm(xbest - x[k])
+    status = termination(it, maxiter, dx, xfun[k], xtol, ftol)
+    return x[k].copy(), xfun[k], status
+
+
+class History:
+    """return_all bookkeeping of de/_de.py:221-234, 270-278 (same for cpso)."""
+
+    def __init__(self, enabled, maxiter, P, n, verbosity):
+        self.enabled = enabled
+        if enabled:
+            self.nout = int(np.ceil(verbosity * P))
+            rows = max(self.nout, 1)
+            self.xall = np.empty((maxiter, rows, n))
+            self.funall = np.empty((maxiter, rows))
+
+    def put(self, slot, X, f, gbest=None, gfit=None):
+        if not self.enabled:
+            return
+        if self.nout > 0:
+            self.xall[slot] = X[: self.nout]
+            self.funall[slot] = f[: self.nout]
+        elif gbest is not None:
+            self.xall[slot] = gbest
+            self.funall[slot] = gfit
+        else:
+            k = int(np.argmin(f))
+            self.xall[slot] = X[k]
+            self.funall[slot] = f[k]
+
+    def fill(self, res, it):
+        if self.enabled:
+            res["xall"] = self.xall[:it]
+            res["funall"] = self.funall[:it]
+
+
+def _final(x, fun, status, nfev, nit, hist):
+    res = Result(x=x, success=status >= 0, status=status, message=MESSAGES[status], fun=fun, nfev=nfev, nit=nit)
+    hist.fill(res, nit)
+    return res
+
+
+# --------------------------------------------------------------------------- #
+# DE  (de/_de.py:176-301, 314-351)
+# --------------------------------------------------------------------------- #
+def de_mutants(strategy, d, F, X, gbest):
+    """de/_strategy.py:1-38, same association order."""
+    if strategy == "rand1bin":
+        return X[d[0]] + F * (X[d[1]] - X[d[2]])
+    if strategy == "rand2bin":
+        return X[d[0]] + F * (X[d[1]] + X[d[2]] - X[d[3]] - X[d[4]])
+    if strategy == "best1bin":
+        return gbest + F * (X[d[0]] - X[d[1]])
+    if strategy == "best2bin":
+        return gbest + F * (X[d[0]] + X[d[1]] - X[d[2]] - X[d[3]])
+    raise KeyError(strategy)
+
+
+def de_candidates(X, gbest, draws, F, CR, strategy, lower, upper, constraints):
+    """de/_de.py:333-344: mutation, binomial crossover (r1 <= CR, forced index), bound repair."""
+    P = X.shape[0]
+    V = de_mutants(strategy, draws["donors"], F, X, gbest)
+    take = draws["r1"] <= CR
+    take[np.arange(P), draws["irand"]] = True
+    U = np.where(take, V, X)
+    if constraints == "Random":
+        U = np.where((U < lower) | (U > upper), draws["resample"], U)  # de/_constraints.py:21-26
+    return U
+
+
+def run_de(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, mutation=0.5,
+           recombination=0.9, strategy="best1bin", xtol=1e-8, ftol=1e-8, constraints=None,
+           return_all=False, verbosity=1.0, **_ignored):
+    n = len(lower)
+    P = popsize
+    k = DONORS[strategy]
+    X = np.array(x0, dtype=np.float64) if x0 is not None else latin_hypercube(stream, P, n, lower, upper)
+    pfit = fobj(X)
+    fit = pfit.copy()
+    g = int(np.argmin(fit))
+    gfit = fit[g]
+    gbest = X[g].copy()
+    hist = History(return_all, maxiter, P, n, verbosity)
+    hist.put(0, X, pfit, gbest, gfit)
+    if callback is not None:
+        callback(X, Result(x=gbest, fun=gfit, nfev=P, nit=1))
+    it = 1
+    while True:
+        it += 1
+        draws = stream.de_generation(it, P, n, k, (lower, upper) if constraints == "Random" else None)
+        U = de_candidates(X, gbest, draws, mutation, recombination, strategy, lower, upper, constraints)
+        pfit = fobj(U)  # NB de/_de.py:270-273: funall pairs post-selection X with CANDIDATE fitness
+        gbest, gfit, status = greedy_select(it, U, pfit, gbest, X, fit, maxiter, xtol, ftol)
+        hist.put(it - 1, X, pfit)
+        if callback is not None:
+            callback(X, Result(x=gbest, fun=gfit, nfev=it * P, nit=it))
+        if status is not None:
+            break
+    return _final(gbest, gfit, status, it * P, it, hist)
+
+
+# --------------------------------------------------------------------------- #
+# PSO / CPSO  (cpso/_cpso.py:182-321, 324-361, 405-426)
+# --------------------------------------------------------------------------- #
+def shrink_factor(X, V, lower, upper):
+    """cpso/_constraints.py:22-53 (sync form): per-row min over violated dims, else 1."""
+    Xc = X + V
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bl = np.where(Xc < lower, (lower - X) / V, np.inf)
+        bu = np.where(Xc > upper, (upper - X) / V, np.inf)
+    beta = np.minimum(bl.min(axis=1), bu.min(axis=1))
+    return np.where(np.isinf(beta), 1.0, beta)
+
+
+def pso_move(X, V, pbest, gbest, w, c1, c2, r1, r2, lower, upper, constraints):
+    """cpso/_cpso.py:324-329, left-to-right association; then the constraint."""
+    V = w * V + c1 * r1 * (pbest - X) + c2 * r2 * (gbest - X)
+    if constraints == "Shrink":
+        V = V * shrink_factor(X, V, lower, upper)[:, None]
+    return X + V, V
+
+
+def swarm_radius(X, gbest, n):
+    """cpso/_cpso.py:410-411."""
+    d = X - gbest
+    return np.sqrt((d * d).sum(axis=1)).max() / np.sqrt(4.0 * n)
+
+
+def restart_count(it, maxiter, P, gamma):
+    """cpso/_cpso.py:415-416."""
+    inorm = it / maxiter
+    return int((P - 1.0) / (1.0 + np.exp(1.0 / 0.09 * (inorm - gamma + 0.5))))
+
+
+def run_pso(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, inertia=0.7298,
+            cognitivity=1.49618, sociability=1.49618, competitivity=None, xtol=1e-8, ftol=1e-8,
+            constraints=None, return_all=False, verbosity=1.0, **_ignored):
+    n = len(lower)
+    P = popsize
+    gamma = competitivity
+    if gamma:
+        delta = np.log(1.0 + 0.003 * P) / np.max((0.2, np.log(0.01 * maxiter)))
+    X = np.array(x0, dtype=np.float64) if x0 is not None else latin_hypercube(stream, P, n, lower, upper)
+    V = np.zeros((P, n))
+    pbest = X.copy()
+    pfit = fobj(X)
+    pbestfit = pfit.copy()
+    g = int(np.argmin(pbestfit))
+    gfit = pbestfit[g]
+    gbest = X[g].copy()
+    hist = History(return_all, maxiter, P, n, verbosity)
+    hist.put(0, X, pfit, gbest, gfit)
+    if callback is not None:
+        callback(X, Result(x=gbest, fun=gfit, nfev=P, nit=1))
+    it = 1
+    restarts = []
+    while True:
+        it += 1
+        r1, r2 = stream.pso_generation(it, P, n)
+        X, V = pso_move(X, V, pbest, gbest, inertia, cognitivity, sociability, r1, r2, lower, upper, constraints)
+        pfit = fobj(X)
+        gbest, gfit, status = greedy_select(it, X, pfit, gbest, pbest, pbestfit, maxiter, xtol, ftol)
+        hist.put(it - 1, X, pfit)
+        if callback is not None:
+            callback(X, Result(x=gbest, fun=gfit, nfev=it * P, nit=it))
+        if status is not None:
+            break
+        if gamma:
+            # d = X - gbest; per-row sqrt(dot) exactly as np.linalg.norm does for 1-D input
+            rad = (max(np.linalg.norm(X[i] - gbest) for i in range(P)) / np.sqrt(4.0 * n)) if P <= 32768 else swarm_radius(X, gbest, n)
+            if rad < delta:
+                nw = restart_count(it, maxiter, P, gamma)
+                if nw > 0:
+                    rows = pbestfit.argsort()[: -nw - 1 : -1]
+                    V[rows] = 0.0
+                    X[rows] = stream.restart_rows(it, lower, upper, rows, n)
+                    pbest[rows] = X[rows]
+                    pbestfit[rows] = 1.0e30
+                    restarts.append((it, nw))
+    res = _final(gbest, gfit, status, it * P, it, hist)
+    res["_restarts"] = restarts
+    return res
+
+
+# --------------------------------------------------------------------------- #
+# CMA-ES  (cmaes/_cmaes.py:143-357, 360-434)
+# --------------------------------------------------------------------------- #
+def cma_constants(n, P, muperc):
+    """cmaes/_cmaes.py:184-205."""
+    mu = int(muperc * P)
+    w = np.log(mu + 0.5) - np.log(np.arange(1, mu + 1))
+    w /= w.sum()
+    mueff = w.sum() ** 2 / np.square(w).sum()
+    cc = (4.0 + mueff / n) / (n + 4.0 + 2.0 * mueff / n)
+    cs = (mueff + 2.0) / (n + mueff + 5.0)
+    c1 = 2.0 / ((n + 1.3) ** 2 + mueff)
+    cmu = min(1.0 - c1, 2.0 * (mueff - 2.0 + 1.0 / mueff) / ((n + 2.0) ** 2 + mueff))
+    damps = 1.0 + 2.0 * max(0.0, np.sqrt((mueff - 1.0) / (n + 1.0)) - 1.0) + cs
+    chind = np.sqrt(n) * (1.0 - 1.0 / (4.0 * n) + 1.0 / (21.0 * n**2))
+    return dict(mu=mu, w=w, mueff=mueff, cc=cc, cs=cs, c1=c1, cmu=cmu, damps=damps, chind=chind)
+
+
+def cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, insigma, ilim, pc, xtol, ftol, diagC, B, D):
+    """cmaes/_cmaes.py:360-434, the ten ordered rules (incl. the zero-padding artefacts)."""
+    i = int(np.floor(np.mod(it, n)))
+    sq = np.sqrt(diagC)
+    fb = arfit[order[0]]
+    if it >= maxiter:
+        return -1
+    if np.linalg.norm(xold - xmean) <= xtol and fb < ftol:
+        return 0
+    if fb <= ftol:
+        return 1
+    if (np.abs(0.1 * sigma * B[:, i] * D[i]) < 1.0e-10).all():
+        return -2
+    if (0.2 * sigma * sq < 1.0e-10).any():
+        return -3
+    if D.max() > 1.0e7 * D.min():
+        return -4
+    if it >= ilim:
+        win = bestfit_hist[it - ilim : it + 1]
+        if win.max() - win.min() < 1.0e-10:
+            return -5
+    if (sigma * sq > 1.0e3 * insigma).any():
+        return -6
+    if it > 2:
+        both = np.append(arfit, bestfit_hist)
+        if both.max() - both.min() < 1.0e-12:
+            return -7
+    if (sigma * np.append(np.abs(pc), sq.max()) < 1.0e-11 * insigma).all():
+        return -8
+    return None
+
+
+def cma_sample(xmean, sigma, B, D, Z):
+    """cmaes/_cmaes.py:232-237, row by row as the reference does (matvec per individual)."""
+    return np.array([xmean + sigma * np.dot(B, D * z) for z in Z])
+
+
+def cma_covariance(C, arx_sel, xold, sigma, w, pc, cond, c1, cmu, cc):
+    """cmaes/_cmaes.py:290-295 (tmp uses the PRE-update C)."""
+    mu = arx_sel.shape[0]
+    artmp = (arx_sel - np.tile(xold, (mu, 1))) / sigma
+    tmp = 0.0 if cond else c1 * cc * (2.0 - cc) * C
+    C = C * (1.0 - c1 - cmu)
+    C += cmu * np.dot(np.dot(artmp.T, np.diag(w)), artmp)
+    C += c1 * np.outer(pc, pc)
+    C += tmp
+    return C
+
+
+def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, sigma=0.1, muperc=0.5,
+              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, **_ignored):
+    if constraints is not None:
+        raise NotImplementedError("Penalize is outside the hot-path scope (SURVEY.md section 2 row 10)")
+    n = len(lower)
+    P = popsize
+    xm = 0.5 * (upper + lower)
+    xstd = 0.5 * (upper - lower)
+    unstd = lambda x: x * xstd + xm  # noqa: E731  cmaes/_cmaes.py:167-173
+    xmean = stream.cma_initial_mean(n) if x0 is None else (np.asarray(x0, dtype=np.float64) - xm) / xstd
+    xold = np.empty(n)
+    k = cma_constants(n, P, muperc)
+    mu, w, mueff, cc, cs, c1, cmu, damps, chind = (k[s] for s in ("mu", "w", "mueff", "cc", "cs", "c1", "cmu", "damps", "chind"))
+    pc = np.zeros(n)
+    ps = np.zeros(n)
+    B = np.eye(n)
+    D = np.ones(n)
+    C = np.eye(n)
+    invsqrtC = np.eye(n)
+    hist = History(return_all, maxiter, P, n, verbosity)
+    nfev = 0
+    eigeneval = 0
+    bestfit_hist = np.zeros(maxiter)
+    ilim = int(10.0 + 30.0 * n / P)
+    insigma = sigma
+    it = 0
+    while True:
+        it += 1
+        Z = stream.cma_normals(it, P, n)
+        arx = cma_sample(xmean, sigma, B, D, Z)
+        arfit = fobj(unstd(arx))
+        nfev += P
+        hist.put(it - 1, unstd(arx), arfit)
+        order = np.argsort(arfit)
+        xold = xmean.copy()
+        xmean = np.dot(w, arx[order[:mu], :])
+        bestfit_hist[it - 1] = arfit[order[0]]
+        ps = (1.0 - cs) * ps + np.sqrt(cs * (2.0 - cs) * mueff) * np.dot(invsqrtC, xmean - xold) / sigma
+        cond = np.linalg.norm(ps) / np.sqrt(1.0 - (1.0 - cs) ** (2.0 * nfev / P)) / chind < 1.4 + 2.0 / (n + 1.0)
+        pc *= 1.0 - cc
+        pc += np.sqrt(cc * (2.0 - cc) * mueff) * (xmean - xold) / sigma if cond else 0.0
+        C = cma_covariance(C, arx[order[:mu], :], xold, sigma, w, pc, cond, c1, cmu, cc)
+        sigma *= np.exp((cs / damps) * (np.linalg.norm(ps) / chind - 1.0))
+        if nfev - eigeneval > P / (c1 + cmu) / n / 10.0:
+            eigeneval = nfev
+            C = np.triu(C) + np.triu(C, 1).T
+            D, B = np.linalg.eigh(C)
+            o = np.argsort(D)
+            D = D[o]
+            B = B[:, o]
+            D = np.sqrt(D)
+            invsqrtC = np.dot(np.dot(B, np.diag(1.0 / D)), B.T)
+        status = cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, insigma, ilim, pc,
+                          xtol, ftol, np.diag(C), B, D)
+        if callback is not None:
+            callback(unstd(arx), Result(x=unstd(arx[order[0]]), fun=arfit[order[0]], nfev=nfev, nit=it))
+        if status is not None:
+            break
+    return _final(unstd(arx[order[0]]), arfit[order[0]], status, nfev, it, hist)
+
+
+RUNNERS = {"de": run_de, "pso": run_pso, "cpso": run_pso, "cmaes": run_cmaes}
+
+
+def minimize(objective, bounds, x0=None, method="de", options=None, callback=None, rng="numpy-legacy"):
+    """Oracle counterpart of stochopy.optimize.minimize (_helpers.py:44-94) for named objectives."""
+    opts = dict(options or {})
+    opts.pop("updating", None)
+    opts.pop("workers", None)
+    opts.pop("backend", None)
+    seed = opts.pop("seed", None)
+    fobj = OBJECTIVES[objective] if isinstance(objective, str) else objective
+    lower, upper = np.transpose(np.asarray(bounds, dtype=np.float64))
+    stream = rng if hasattr(rng, "lhs_draws") else make_stream(rng, seed)
+    if method == "pso":
+        opts["competitivity"] = None
+    elif method == "cpso":
+        opts.setdefault("competitivity", 1.0)
+    return RUNNERS[method](fobj, lower, upper, x0, stream, callback=callback, **opts)

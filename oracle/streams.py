@@ -1,0 +1,195 @@
+"""Random draws of the hot path, in the order the reference consumes them (oracle).
+
+Two providers with one interface:
+
+* ``LegacyStream`` -- numpy's legacy global MT19937 stream, i.e. exactly what the
+  reference draws after ``np.random.seed(seed)`` (de/_de.py:148-149,
+  cpso/_cpso.py:153-154, cmaes/_cmaes.py:116-117).  It calls
+  ``numpy.random.RandomState`` (the reference's own third-party dependency), in
+  the reference's call order:
+    LHS      _common.py:111-113   uniform(size=(P,n)) then n x permutation(P)
+    DE       de/_de.py:250, 304-311, 340, de/_constraints.py:24
+    PSO      cpso/_cpso.py:262-263, 422
+    CMA-ES   cmaes/_cmaes.py:180, 234
+* ``PhiloxStream`` -- the counter-based Philox4x32-10 layout the HIP kernels use in
+  throughput mode (``rng="philox"``; DESIGN.md section "Philox layout").  Not a
+  reference algorithm: it exists so CPU<->GPU parity can be checked at sizes the
+  reference's O(P^2) donor permutations cannot reach.
+"""
+import numpy as np
+
+# purposes (counter word 3)
+PURPOSE_DE_CROSS = 0
+PURPOSE_DE_DONOR = 1
+PURPOSE_DE_RESAMPLE = 2
+PURPOSE_PSO_R1 = 3
+PURPOSE_PSO_R2 = 4
+PURPOSE_PSO_RESTART = 5
+PURPOSE_CMA_NORMAL = 6
+
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = 0x9E3779B9
+_W1 = 0xBB67AE85
+_MASK = np.uint64(0xFFFFFFFF)
+_S32 = np.uint64(32)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) on broadcastable uint32 counter arrays."""
+    c0, c1, c2, c3 = np.broadcast_arrays(*[np.asarray(c, dtype=np.uint64) & _MASK for c in (c0, c1, c2, c3)])
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        n0 = (p1 >> _S32) ^ c1 ^ np.uint64(k0)
+        n1 = p1 & _MASK
+        n2 = (p0 >> _S32) ^ c3 ^ np.uint64(k1)
+        n3 = p0 & _MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def u53(a, b):
+    """numpy legacy double from two 32-bit words: ((a>>5)*2^26 + (b>>6)) / 2^53."""
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    return ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
+
+
+def _mulhi(w, m):
+    return ((np.asarray(w, dtype=np.uint64) * np.uint64(m)) >> _S32).astype(np.int64)
+
+
+class LegacyStream:
+    """The reference's np.random.* stream (numpy legacy MT19937)."""
+
+    kind = "numpy-legacy"
+
+    def __init__(self, seed=None):
+        self.rs = np.random.RandomState(seed) if seed is not None else np.random.RandomState()
+
+    # -- initial population: _common.py:109-120 -------------------------------
+    def lhs_draws(self, P, n):
+        u = self.rs.uniform(size=(P, n))
+        perms = [self.rs.permutation(P) for _ in range(n)]
+        return u, perms
+
+    # -- DE generation: de/_de.py:250 then :304-311 then :340 then constraints --
+    def de_generation(self, gen, P, n, k, resample_bounds=None, row0=0):
+        rs = self.rs
+        r1 = rs.rand(P, n)
+        donors = np.empty((k, P), dtype=np.int64)
+        for i in range(P):
+            # permutation(delete(arange(P), i)) == delete(...)[permutation(P-1)]: same draws
+            p = rs.permutation(P - 1)[:k]
+            donors[:, i] = p + (p >= i)
+        irand = rs.randint(n, size=P)
+        resample = None
+        if resample_bounds is not None:
+            lo, hi = resample_bounds
+            resample = rs.uniform(lo, hi, (P, n))
+        return {"r1": r1, "donors": donors, "irand": irand, "resample": resample}
+
+    # -- PSO generation: cpso/_cpso.py:262-263 ---------------------------------
+    def pso_generation(self, gen, P, n, row0=0):
+        r1 = self.rs.rand(P, n)
+        r2 = self.rs.rand(P, n)
+        return r1, r2
+
+    # -- CPSO restart: cpso/_cpso.py:422, rows in descending-fitness order -----
+    def restart_rows(self, gen, lower, upper, rows, n, row0=0):
+        return self.rs.uniform(lower, upper, (len(rows), n))
+
+    # -- CMA-ES: cmaes/_cmaes.py:180 and :232-237 ------------------------------
+    def cma_initial_mean(self, n):
+        return self.rs.uniform(-1.0, 1.0, n)
+
+    def cma_normals(self, gen, P, n, row0=0):
+        return np.array([self.rs.randn(n) for _ in range(P)])
+
+
+class PhiloxStream:
+    """Counter-based draws, identical to the HIP kernels' device generator.
+
+    key = (seed & 0xffffffff, seed >> 32); counter = (slot, row, gen, purpose).
+    One call yields two doubles d0 = u53(w0, w1), d1 = u53(w2, w3).
+    Element e of a row uses slot = ((e >> 4) << 3) | (e & 7) and half = (e >> 3) & 1,
+    i.e. lane j = e & 7 of the row's 8-lane group gets both doubles of its call for
+    the blocks q = e >> 3 even / odd.
+    Initial population / initial mean: the legacy stream (host-side init step).
+    """
+
+    kind = "philox"
+
+    def __init__(self, seed):
+        if seed is None:
+            raise ValueError("philox draws need an explicit seed")
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.k0 = self.seed & 0xFFFFFFFF
+        self.k1 = self.seed >> 32
+        self.init = LegacyStream(int(seed) & 0xFFFFFFFF)
+
+    def lhs_draws(self, P, n):
+        return self.init.lhs_draws(P, n)
+
+    def cma_initial_mean(self, n):
+        return self.init.cma_initial_mean(n)
+
+    def _uniform_block(self, rows, n, gen, purpose):
+        rows = np.asarray(rows, dtype=np.uint64)[:, None]
+        e = np.arange(n, dtype=np.uint64)[None, :]
+        slot = ((e >> np.uint64(4)) << np.uint64(3)) | (e & np.uint64(7))
+        half = ((e >> np.uint64(3)) & np.uint64(1)).astype(bool)
+        w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, purpose, self.k0, self.k1)
+        return np.where(half, u53(w2, w3), u53(w0, w1))
+
+    def de_generation(self, gen, P, n, k, resample_bounds=None, row0=0):
+        rows = np.arange(P, dtype=np.uint64) + np.uint64(row0)
+        r1 = self._uniform_block(rows, n, gen, PURPOSE_DE_CROSS)
+        a = philox4x32_10(0, rows, gen, PURPOSE_DE_DONOR, self.k0, self.k1)
+        b = philox4x32_10(1, rows, gen, PURPOSE_DE_DONOR, self.k0, self.k1)
+        words = list(a) + list(b)
+        donors = np.empty((k, P), dtype=np.int64)
+        local = np.arange(P, dtype=np.int64)
+        excl = local[None, :].copy()  # sorted exclusion list per row, grows by one per donor
+        for t in range(k):
+            v = _mulhi(words[t], P - 1 - t)
+            for s in range(excl.shape[0]):
+                v = v + (v >= excl[s])
+            donors[t] = v
+            excl = np.sort(np.vstack([excl, v[None, :]]), axis=0)
+        irand = _mulhi(words[5], n)
+        resample = None
+        if resample_bounds is not None:
+            lo, hi = resample_bounds
+            d = self._uniform_block(rows, n, gen, PURPOSE_DE_RESAMPLE)
+            resample = lo + (hi - lo) * d
+        return {"r1": r1, "donors": donors, "irand": irand, "resample": resample}
+
+    def pso_generation(self, gen, P, n, row0=0):
+        rows = np.arange(P, dtype=np.uint64) + np.uint64(row0)
+        return (
+            self._uniform_block(rows, n, gen, PURPOSE_PSO_R1),
+            self._uniform_block(rows, n, gen, PURPOSE_PSO_R2),
+        )
+
+    def restart_rows(self, gen, lower, upper, rows, n, row0=0):
+        d = self._uniform_block(np.asarray(rows, dtype=np.uint64) + np.uint64(row0), n, gen, PURPOSE_PSO_RESTART)
+        return lower + (upper - lower) * d
+
+    def cma_normals(self, gen, P, n, row0=0):
+        """Box-Muller on the two doubles of a call: half 0 -> cos branch, half 1 -> sin branch."""
+        rows = (np.arange(P, dtype=np.uint64) + np.uint64(row0))[:, None]
+        e = np.arange(n, dtype=np.uint64)[None, :]
+        slot = ((e >> np.uint64(4)) << np.uint64(3)) | (e & np.uint64(7))
+        half = ((e >> np.uint64(3)) & np.uint64(1)).astype(bool)
+        w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, PURPOSE_CMA_NORMAL, self.k0, self.k1)
+        d0 = u53(w0, w1)
+        d1 = u53(w2, w3)
+        rad = np.sqrt(-2.0 * np.log(1.0 - d0))
+        ang = 6.283185307179586 * d1
+        return np.where(half, rad * np.sin(ang), rad * np.cos(ang))
