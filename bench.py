@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-generation hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
+A "step" is one DE generation (donor gather, mutation, crossover, objective,
+selection, best/termination) over the whole resident population.
+
+Workload at N=1 (BASELINE.json metric): DE best1bin, Rosenbrock, dim=128,
+popsize=4096, F=0.5, CR=0.9, bounds +-5.12, in-kernel Philox draws, ftol=-1 /
+xtol=0 so every step does the full work.  N>1: the same shard per GPU (weak
+scaling), one process per GPU, global best exchanged every generation.
+
+`value` = objective evaluations per second = N * popsize * K / t(K steps),
+population resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (objective, n, P, strategy)
+    "de_rosenbrock_n128_p4096": ("rosenbrock", 128, 4096, "best1bin"),
+    "de_rastrigin_n128_p4096": ("rastrigin", 128, 4096, "best1bin"),
+    "de_rosenbrock_n1024_p16384": ("rosenbrock", 1024, 16384, "best1bin"),
+    "de_rosenbrock_n1024_p131072": ("rosenbrock", 1024, 131072, "best1bin"),
+}
+
+
+def algorithmic_bytes_per_eval(n, k):
+    """read X_i + k donor rows, write the candidate row, r/w fitness."""
+    return 8 * n * (k + 2) + 16
+
+
+def cpu_baseline(objective, n, P, strategy, budget_s=12.0):
+    """The oracle (numpy port of the reference loop, numpy-legacy stream) on ONE host core."""
+    import oracle
+
+    gens = []
+
+    def cb(X, r):
+        gens.append(time.perf_counter())
+        if len(gens) >= 3 and gens[-1] - gens[0] > budget_s:
+            raise StopIteration
+
+    t0 = time.perf_counter()
+    try:
+        oracle.minimize(objective, [[-5.12, 5.12]] * n, method="de", callback=cb,
+                        options={"maxiter": 10**6, "popsize": P, "seed": 0, "strategy": strategy, "ftol": -1.0,
+                                 "xtol": 0.0})
+    except StopIteration:
+        pass
+    done = len(gens) - 1  # generations after the initial evaluation
+    dt = gens[-1] - gens[0]
+    return {
+        "value": P * done / dt,
+        "unit": "evals/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle DE {strategy} {objective} n={n} P={P}, {done} generations in {dt:.1f}s, serial numpy "
+                  f"(numpy-legacy stream incl. the reference's O(P^2) donor permutations), "
+                  f"host cpu_count={os.cpu_count()}",
+        "t_first_eval_s": gens[0] - t0,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="de_rosenbrock_n128_p4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-timing-launches", type=int, default=400)
+    args = ap.parse_args()
+
+    import torch
+
+    import stochopy_amd as sa
+    from stochopy_amd import _lib
+    from stochopy_amd.optimize import _de
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    objective, n, P, strategy = WORKLOADS[args.workload]
+    k = _lib.DE_DONORS[strategy]
+    K, W = args.steps, args.warmup
+    lower = np.full(n, -5.12)
+    upper = np.full(n, 5.12)
+    run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, P, 0.5, 0.9, strategy, None, 0.0, -1.0,
+                     False, 1.0, None, "philox", 1234 + rank, 1, autorun=False)
+    if world > 1:
+        from stochopy_amd import parallel
+
+        run.attach_world(parallel.World(dist, row0=rank * P))
+    ctx = run.ctx
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(ctx.stream):
+        run._setup()
+        run.enqueue(W)
+        ctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        run.enqueue(K)
+        ctx.sync()
+        barrier()
+        t1 = time.perf_counter()
+        st = ctx.read_state(run.state)
+        assert st.it == 1 + W + K, (st.it, W, K)
+
+        # dominant kernel: HIP events on the engine stream around back-to-back launches of the
+        # fused generation kernel alone (finalize=0), average per launch
+        nl = args.kernel_timing_launches
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        for _ in range(20):
+            _lib.check(ctx.L.sx_de_generation(run.args, 0, ctx.stream_ptr), "sx_de_generation")
+        ev0.record(ctx.stream)
+        for _ in range(nl):
+            _lib.check(ctx.L.sx_de_generation(run.args, 0, ctx.stream_ptr), "sx_de_generation")
+        ev1.record(ctx.stream)
+        ctx.sync()
+        kern_ms = ev0.elapsed_time(ev1) / nl
+    run.close()
+
+    dt = t1 - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    value = world * P * K / dt
+
+    if rank == 0:
+        bytes_per_launch = algorithmic_bytes_per_eval(n, k) * P
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "objective-fn evals/sec",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload,
+                "method": "de", "strategy": strategy, "objective": objective, "dim": n,
+                "popsize_per_gpu": P, "popsize_total": world * P, "rng": "philox", "F": 0.5, "CR": 0.9,
+                "exchange": "none" if world == 1 else "global best per generation (RCCL all_gather)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "de_generation_kernel<%s,philox>" % objective,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "kernel_us": kern_ms * 1e3,
+                "timing": "HIP events on the engine stream around %d back-to-back launches" % nl,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(objective, n, min(P, 4096), strategy)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

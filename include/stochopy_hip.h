@@ -1,0 +1,201 @@
+/*
+ * stochopy_hip.h -- C ABI of the MI355X (gfx950) population-evaluation engine.
+ *
+ * Drop-in boundary for the per-generation hot path of keurfonluu/stochopy v2.3.0
+ * (a pure-Python/numpy package: there is no FFI in the reference; these are the
+ * entry points a `backend="hip"` branch of its backend hook would bind through
+ * ctypes -- see INTEGRATION.md).  Each entry point cites the reference code it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy types.
+ *   - every `double*` / `int*` marked DEVICE points into HBM owned by the caller;
+ *     the library never allocates or frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *     All kernels are asynchronous on that stream.
+ *   - return value: 0 = ok, negative = error (text via sx_last_error()).
+ *   - float64 throughout, as in the reference; compiled
+ *     with -ffp-contract=off so a*b+c rounds twice like numpy does.
+ *   - populations are row-major (P, ld) with ld >= n (row stride in doubles).
+ */
+#ifndef STOCHOPY_HIP_H
+#define STOCHOPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_ABI_VERSION 1
+
+/* objective ids: stochopy/factory/benchmark.py:14-156 */
+enum {
+    SX_FUN_ACKLEY = 0,          /* benchmark.py:14-34   */
+    SX_FUN_GRIEWANK = 1,        /* benchmark.py:37-56   */
+    SX_FUN_QUARTIC = 2,         /* benchmark.py:59-76   */
+    SX_FUN_RASTRIGIN = 3,       /* benchmark.py:79-97   */
+    SX_FUN_ROSENBROCK = 4,      /* benchmark.py:100-118 */
+    SX_FUN_SPHERE = 5,          /* benchmark.py:121-136 */
+    SX_FUN_STYBLINSKI_TANG = 6, /* benchmark.py:139-156 */
+    SX_FUN_COUNT = 7
+};
+
+/* DE strategies: stochopy/optimize/de/_strategy.py:1-46 */
+enum { SX_DE_RAND1BIN = 0, SX_DE_RAND2BIN = 1, SX_DE_BEST1BIN = 2, SX_DE_BEST2BIN = 3 };
+
+/* random-draw source for the generation kernels */
+enum {
+    SX_RNG_HOST = 0,   /* draws uploaded by the host (numpy-legacy MT19937 stream, parity mode) */
+    SX_RNG_PHILOX = 1  /* Philox4x32-10 generated in-kernel, counter = (slot,row,gen,purpose)    */
+};
+
+/* termination status, stochopy/optimize/_common.py:13-24 */
+#define SX_STATUS_NONE 100
+
+int sx_abi_version(void);
+const char *sx_last_error(void);
+/* number of visible HIP devices (<0 on error); used by the loader to fail loudly */
+int sx_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * Summation plan: numpy's pairwise add.reduce order for a length-m vector
+ * (numpy/_core/src/umath/loops_utils.h.src, blocksize 128).
+ * The objective kernels follow it so fitness values are bit-identical to the
+ * reference's `.sum()` for +,-,* objectives.  Host function, exported so tests can
+ * pin the order; the kernels receive the plan in their arguments (scalar loads),
+ * built by the library from (fun_id, n).
+ *   out[0]=nleaf out[1]=tail out[2]=full 8-blocks out[3]=stack depth
+ *   out[4+2t]=end block of leaf t, out[5+2t]=merges after leaf t
+ * Returns the number of int32 written (<= cap), or <0 if cap is too small.
+ * ------------------------------------------------------------------------- */
+int sx_sum_plan(int64_t m, int32_t *out, int cap);
+/* number of terms the objective sums for an n-vector (n or n-1) */
+int64_t sx_fun_terms(int fun_id, int n);
+
+/* ------------------------------------------------------------------------- *
+ * Batched objective evaluation  f[i] = fun(X[i,:])
+ * replaces: the population wrapper stochopy/optimize/_common.py:34-90
+ *           (serial :79-80, joblib :39-43, MPI :58-72) applied to the
+ *           benchmark objectives, and cmaes/_cmaes.py:167-173 when xm/xstd are
+ *           given (x -> x*xstd + xm before the objective).
+ * X DEVICE (P,ldx); f DEVICE (P); xm/xstd DEVICE (n) or NULL.
+ * part_f/part_i DEVICE (sx_num_partials(P,n)) or NULL: per-workgroup (min f, first row)
+ * records for sx_select_finalize.  One wavefront evaluates one individual; n <= 6144.
+ * ------------------------------------------------------------------------- */
+int64_t sx_num_partials(int64_t P, int n);
+int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd,
+            double *f, double *part_f, int64_t *part_i, void *stream);
+
+/* argmin with numpy's first-minimum tie rule (np.argmin, _common.py:132, de/_de.py:216)
+ * f DEVICE (P); ws_f/ws_i DEVICE scratch of ws_len >= 1 entries; out_idx/out_val DEVICE (1). */
+int sx_argmin(const double *f, int64_t P, double *ws_f, int64_t *ws_i, int64_t ws_len, int64_t *out_idx,
+              double *out_val, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Generation state shared by DE and PSO (64 bytes, DEVICE; host reads it back)
+ * ------------------------------------------------------------------------- */
+typedef struct sx_state {
+    int64_t it;      /* generations completed (the reference's `it`; initial evaluation = 1) */
+    int64_t gbidx;   /* row of the current best                                             */
+    double gfit;     /* best fitness                                                         */
+    double dx;       /* ||xbest_prev - xbest|| of the last selection (_common.py:135)        */
+    int32_t status;  /* SX_STATUS_NONE while running, else -1 / 0 / 1 (_common.py:134-158)   */
+    int32_t done;    /* 1 once status is set: later generation launches are no-ops           */
+    int64_t reserved[3];
+} sx_state;
+
+/* ------------------------------------------------------------------------- *
+ * Differential Evolution, synchronous generation
+ * replaces: de/_de.py:314-351 de_sync (mutation via _strategy.py, binomial
+ *           crossover `r1 <= CR` + forced index, de/_constraints.py:13-28 Random)
+ *           + _common.py:123-160 selection_sync + the objective calls, fused.
+ * Population storage: two row buffers buf0/buf1 (P,ld); generation g (= state->it)
+ * lives in buf[g & 1].  A generation reads X_i and its k donor rows from the
+ * current buffer and writes row i of the other one (the trial vector if it wins
+ * with strict <, else the unchanged row), so donor reads never race with
+ * selection writes and a generation moves (k+2) rows per individual
+ * (SURVEY.md section 8d).
+ * ------------------------------------------------------------------------- */
+typedef struct sx_de_args {
+    double *buf0, *buf1;    /* DEVICE (P,ld) each                                     */
+    double *fit;            /* DEVICE (P) personal-best fitness (pbestfit)            */
+    double *candfit;        /* DEVICE (P) candidate fitness `pfit` or NULL            */
+    double *gbest;          /* DEVICE (n) copy of the best row (maintained by sx_select_finalize);
+                               NULL = read row state->gbidx of the current buffer       */
+    const double *lower;    /* DEVICE (n)                                             */
+    const double *upper;    /* DEVICE (n)                                             */
+    sx_state *state;        /* DEVICE                                                 */
+    double *part_f;         /* DEVICE (sx_num_partials(P))                            */
+    int64_t *part_i;        /* DEVICE (sx_num_partials(P))                            */
+    /* SX_RNG_HOST inputs for ONE generation (the numpy-legacy stream, App. B):      */
+    const double *r1;       /* DEVICE (P,n) rand(P,n), de/_de.py:250                  */
+    const int32_t *donors;  /* DEVICE (k,P) first k rows of delete_shuffle_sync, :304 */
+    const int32_t *irand;   /* DEVICE (P) randint(n,size=P), :340                     */
+    const double *resample; /* DEVICE (P,n) uniform(lo,hi,(P,n)) or NULL, _constraints.py:24 */
+    int64_t P;
+    int64_t ld;
+    int64_t row0;           /* global index of local row 0 (Philox counters; multi-GPU shards) */
+    int32_t n;
+    int32_t fun_id;
+    int32_t strategy;
+    int32_t constraints;    /* 0 none, 1 Random                                       */
+    int32_t rng;            /* SX_RNG_HOST / SX_RNG_PHILOX                            */
+    int32_t maxiter;
+    double F, CR, xtol, ftol;
+    uint32_t key0, key1;    /* Philox key = seed                                      */
+} sx_de_args;
+
+/* one generation: propose+evaluate+select kernel, then (if finalize) the
+ * best/termination kernel.  finalize=0 is for multi-GPU, where the caller
+ * exchanges the shard bests first and then calls sx_select_finalize itself. */
+int sx_de_generation(const sx_de_args *a, int finalize, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Best-of-generation + termination: _common.py:131-158 (argmin, xtol/ftol/maxiter ladder)
+ * Reduces the per-workgroup partials, computes dx against `gbest`, sets status,
+ * copies the new best row into `gbest`, increments state->it.
+ * The best row is read from rows[(state->it+1) & 1] (the generation being
+ * finalised; pass rows0 == rows1 for state that is updated in place, e.g. PSO pbest).
+ * ------------------------------------------------------------------------- */
+int sx_select_finalize(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                       const double *rows1, int64_t ld, int n, double *gbest, sx_state *state, int maxiter,
+                       double xtol, double ftol, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * hipGraph of `ngen` identical generations (all per-generation state lives in
+ * `state` on the device, so one instantiated graph is replayed).
+ * Only valid for SX_RNG_PHILOX (host draws change every generation).
+ * ------------------------------------------------------------------------- */
+typedef struct sx_graph sx_graph;
+int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out);
+int sx_graph_launch(sx_graph *g, void *stream);
+int sx_graph_destroy(sx_graph *g);
+
+/* ------------------------------------------------------------------------- *
+ * numpy-legacy random stream (host): bit-exact MT19937 replica of what the
+ * reference draws through np.random.* after np.random.seed(seed)
+ * (de/_de.py:148-149, cpso/_cpso.py:153-154, cmaes/_cmaes.py:116-117;
+ * algorithms: SURVEY.md Appendix A).  Host memory only.
+ * ------------------------------------------------------------------------- */
+typedef struct sx_mt sx_mt;
+sx_mt *sx_mt_create(uint32_t seed);                       /* np.random.seed(seed)                 */
+void sx_mt_destroy(sx_mt *g);
+void sx_mt_seed(sx_mt *g, uint32_t seed);
+void sx_mt_random(sx_mt *g, double *out, int64_t count);  /* rand / uniform(size=)               */
+void sx_mt_uniform(sx_mt *g, double lo, double hi, double *out, int64_t count); /* uniform(lo,hi,size) */
+void sx_mt_uniform_rows(sx_mt *g, const double *lo, const double *hi, int n, int64_t rows,
+                        double *out);                     /* uniform(lo[n],hi[n],(rows,n))       */
+void sx_mt_randn(sx_mt *g, double *out, int64_t count);   /* randn / normal(0,1) (polar, cached) */
+void sx_mt_randint(sx_mt *g, int64_t high, int64_t *out, int64_t count); /* randint(high,size=)  */
+void sx_mt_permutation(sx_mt *g, int64_t n, int64_t *out); /* permutation(n)                     */
+/* de/_de.py:304-311 delete_shuffle_sync: P permutations of P-1, first k rows kept: donors[k][P] */
+void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors);
+/* interchange with np.random.get_state()/set_state(): key[624], pos, has_gauss, cached_gaussian */
+void sx_mt_get_state(sx_mt *g, uint32_t *key, int *pos, int *has_gauss, double *gauss);
+void sx_mt_set_state(sx_mt *g, const uint32_t *key, int pos, int has_gauss, double gauss);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STOCHOPY_HIP_H */

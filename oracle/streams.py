@@ -116,10 +116,11 @@ class PhiloxStream:
     """Counter-based draws, identical to the HIP kernels' device generator.
 
     key = (seed & 0xffffffff, seed >> 32); counter = (slot, row, gen, purpose).
-    One call yields two doubles d0 = u53(w0, w1), d1 = u53(w2, w3).
-    Element e of a row uses slot = ((e >> 4) << 3) | (e & 7) and half = (e >> 3) & 1,
-    i.e. lane j = e & 7 of the row's 8-lane group gets both doubles of its call for
-    the blocks q = e >> 3 even / odd.
+    Element e of a row belongs to lane l = e & 63 of the row's wavefront at step q = e >> 6.
+    53-bit uniforms: one call yields d0 = u53(w0, w1), d1 = u53(w2, w3);
+    slot = (q >> 1) * 64 + l, half = q & 1.
+    32-bit uniforms (DE crossover decisions): word * 2^-32 with
+    slot = (q >> 2) * 64 + l, word = q & 3.
     Initial population / initial mean: the legacy stream (host-side init step).
     """
 
@@ -139,20 +140,37 @@ class PhiloxStream:
     def cma_initial_mean(self, n):
         return self.init.cma_initial_mean(n)
 
-    def _uniform_block(self, rows, n, gen, purpose):
-        rows = np.asarray(rows, dtype=np.uint64)[:, None]
+    @staticmethod
+    def _lanes(n):
+        """Element e sits in lane l = e & 63 of its row's wavefront at step q = e >> 6."""
         e = np.arange(n, dtype=np.uint64)[None, :]
-        slot = ((e >> np.uint64(4)) << np.uint64(3)) | (e & np.uint64(7))
-        half = ((e >> np.uint64(3)) & np.uint64(1)).astype(bool)
+        return e >> np.uint64(6), e & np.uint64(63)
+
+    def _uniform_block(self, rows, n, gen, purpose):
+        """53-bit uniforms: slot = (q >> 1) * 64 + l, half = q & 1."""
+        rows = np.asarray(rows, dtype=np.uint64)[:, None]
+        q, l = self._lanes(n)
+        slot = (q >> np.uint64(1)) * np.uint64(64) + l
+        half = (q & np.uint64(1)).astype(bool)
         w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, purpose, self.k0, self.k1)
         return np.where(half, u53(w2, w3), u53(w0, w1))
 
+    def _uniform32_block(self, rows, n, gen, purpose):
+        """32-bit uniforms word * 2^-32: slot = (q >> 2) * 64 + l, word = q & 3."""
+        rows = np.asarray(rows, dtype=np.uint64)[:, None]
+        q, l = self._lanes(n)
+        slot = (q >> np.uint64(2)) * np.uint64(64) + l
+        wi = (q & np.uint64(3)).astype(np.int64)
+        w = philox4x32_10(slot, rows, gen, purpose, self.k0, self.k1)
+        pick = np.choose(np.broadcast_to(wi, w[0].shape), w)
+        return pick.astype(np.float64) / 4294967296.0
+
     def de_generation(self, gen, P, n, k, resample_bounds=None, row0=0):
         rows = np.arange(P, dtype=np.uint64) + np.uint64(row0)
-        r1 = self._uniform_block(rows, n, gen, PURPOSE_DE_CROSS)
+        r1 = self._uniform32_block(rows, n, gen, PURPOSE_DE_CROSS)  # Bernoulli(CR) decisions: 32 bits suffice
         a = philox4x32_10(0, rows, gen, PURPOSE_DE_DONOR, self.k0, self.k1)
         b = philox4x32_10(1, rows, gen, PURPOSE_DE_DONOR, self.k0, self.k1)
-        words = list(a) + list(b)
+        words = list(a[1:]) + list(b)  # word 0 -> irand, word 1+t -> donor t
         donors = np.empty((k, P), dtype=np.int64)
         local = np.arange(P, dtype=np.int64)
         excl = local[None, :].copy()  # sorted exclusion list per row, grows by one per donor
@@ -162,7 +180,7 @@ class PhiloxStream:
                 v = v + (v >= excl[s])
             donors[t] = v
             excl = np.sort(np.vstack([excl, v[None, :]]), axis=0)
-        irand = _mulhi(words[5], n)
+        irand = _mulhi(a[0], n)
         resample = None
         if resample_bounds is not None:
             lo, hi = resample_bounds
@@ -184,9 +202,9 @@ class PhiloxStream:
     def cma_normals(self, gen, P, n, row0=0):
         """Box-Muller on the two doubles of a call: half 0 -> cos branch, half 1 -> sin branch."""
         rows = (np.arange(P, dtype=np.uint64) + np.uint64(row0))[:, None]
-        e = np.arange(n, dtype=np.uint64)[None, :]
-        slot = ((e >> np.uint64(4)) << np.uint64(3)) | (e & np.uint64(7))
-        half = ((e >> np.uint64(3)) & np.uint64(1)).astype(bool)
+        q, l = self._lanes(n)
+        slot = (q >> np.uint64(1)) * np.uint64(64) + l
+        half = (q & np.uint64(1)).astype(bool)
         w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, PURPOSE_CMA_NORMAL, self.k0, self.k1)
         d0 = u53(w0, w1)
         d1 = u53(w2, w3)

@@ -1,0 +1,92 @@
+"""Device plumbing (PyTorch-ROCm): HBM buffers, the engine stream, plan upload.
+
+PyTorch is used for memory, streams and torch.distributed only; all compute is
+in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_torch = None
+
+
+def torch():
+    global _torch
+    if _torch is None:
+        import torch as _t
+
+        _torch = _t
+    return _torch
+
+
+class NoDeviceError(RuntimeError):
+    pass
+
+
+def require_device(index=None):
+    """Fail loudly when no MI355X is visible -- there is no CPU path."""
+    t = torch()
+    if not t.cuda.is_available():
+        raise NoDeviceError("stochopy_amd: no ROCm device visible (torch.cuda.is_available() is False); "
+                            "backend='hip' has no CPU fallback")
+    _lib.lib()
+    dev = t.device("cuda", t.cuda.current_device() if index is None else index)
+    return dev
+
+
+def ptr(tensor):
+    return C.c_void_p(tensor.data_ptr()) if tensor is not None else C.c_void_p(None)
+
+
+class Context:
+    """One device + one non-default stream the engine launches on."""
+
+    def __init__(self, device=None):
+        t = torch()
+        self.device = require_device(device)
+        self.L = _lib.lib()
+        with t.cuda.device(self.device):
+            self.stream = t.cuda.Stream(device=self.device)
+
+    @property
+    def stream_ptr(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def empty(self, shape, dtype=None):
+        t = torch()
+        return t.empty(shape, dtype=dtype or t.float64, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        t = torch()
+        return t.zeros(shape, dtype=dtype or t.float64, device=self.device)
+
+    def upload(self, array, dtype=None):
+        t = torch()
+        a = np.ascontiguousarray(array)
+        x = t.from_numpy(a).to(self.device, non_blocking=False)
+        return x if dtype is None else x.to(dtype)
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def read_state(self, state_tensor):
+        """D2H of the 64-byte sx_state."""
+        t = torch()
+        with t.cuda.stream(self.stream):
+            host = state_tensor.cpu()
+        raw = host.numpy().tobytes()
+        return _lib.SxState.from_buffer_copy(raw)
+
+
+def evaluate(ctx, fun_id, X, n, f=None, xm=None, xstd=None, part=None):
+    """f[i] = objective(X[i]) on the device (sx_eval)."""
+    P = X.shape[0]
+    if f is None:
+        f = ctx.empty((P,))
+    pf, pi = (part if part is not None else (None, None))
+    ldx = X.stride(0) if P > 1 else max(X.stride(0), n)  # a length-1 axis may carry any stride
+    _lib.check(ctx.L.sx_eval(fun_id, ptr(X), P, n, ldx, ptr(xm), ptr(xstd), ptr(f), ptr(pf),
+                             ptr(pi), ctx.stream_ptr), "sx_eval")
+    return f

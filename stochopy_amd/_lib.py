@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI declared in include/stochopy_hip.h.
+
+The product path has NO CPU fallback: if the shared library was not built, or
+it cannot be loaded, importing a device op raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstochopy_hip.so")
+
+SX_STATUS_NONE = 100
+SX_RNG_HOST, SX_RNG_PHILOX = 0, 1
+
+FUN_IDS = {
+    "ackley": 0,
+    "griewank": 1,
+    "quartic": 2,
+    "rastrigin": 3,
+    "rosenbrock": 4,
+    "sphere": 5,
+    "styblinski_tang": 6,
+}
+DE_STRATEGIES = {"rand1bin": 0, "rand2bin": 1, "best1bin": 2, "best2bin": 3}
+DE_DONORS = {"rand1bin": 3, "rand2bin": 5, "best1bin": 2, "best2bin": 4}
+
+vp = C.c_void_p
+i64 = C.c_int64
+i32 = C.c_int32
+f64 = C.c_double
+
+
+class SxState(C.Structure):
+    _fields_ = [("it", i64), ("gbidx", i64), ("gfit", f64), ("dx", f64), ("status", i32), ("done", i32),
+                ("reserved", i64 * 3)]
+
+
+class SxDeArgs(C.Structure):
+    _fields_ = [
+        ("buf0", vp), ("buf1", vp), ("fit", vp), ("candfit", vp), ("gbest", vp), ("lower", vp),
+        ("upper", vp), ("state", vp), ("part_f", vp), ("part_i", vp), ("r1", vp), ("donors", vp),
+        ("irand", vp), ("resample", vp),
+        ("P", i64), ("ld", i64), ("row0", i64),
+        ("n", i32), ("fun_id", i32), ("strategy", i32), ("constraints", i32), ("rng", i32), ("maxiter", i32),
+        ("F", f64), ("CR", f64), ("xtol", f64), ("ftol", f64),
+        ("key0", C.c_uint32), ("key1", C.c_uint32),
+    ]
+
+
+class SxPsoArgs(C.Structure):
+    _fields_ = [
+        ("X", vp), ("V", vp), ("pbest", vp), ("pbestfit", vp), ("candfit", vp), ("gbest", vp), ("lower", vp),
+        ("upper", vp), ("state", vp), ("part_f", vp), ("part_i", vp), ("plan", vp), ("r1", vp), ("r2", vp),
+        ("P", i64), ("ld", i64), ("row0", i64),
+        ("n", i32), ("fun_id", i32), ("constraints", i32), ("rng", i32), ("maxiter", i32), ("pad", i32),
+        ("w", f64), ("c1", f64), ("c2", f64), ("xtol", f64), ("ftol", f64),
+        ("key0", C.c_uint32), ("key1", C.c_uint32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/stochopy_hip.h declares
+PROTOTYPES = {
+    "sx_abi_version": (C.c_int, []),
+    "sx_last_error": (C.c_char_p, []),
+    "sx_device_count": (C.c_int, []),
+    "sx_sum_plan": (C.c_int, [i64, vp, C.c_int]),
+    "sx_fun_terms": (i64, [C.c_int, C.c_int]),
+    "sx_num_partials": (i64, [i64, C.c_int]),
+    "sx_eval": (C.c_int, [C.c_int, vp, i64, C.c_int, i64, vp, vp, vp, vp, vp, vp]),
+    "sx_argmin": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp]),
+    "sx_de_generation": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, vp]),
+    "sx_select_finalize": (C.c_int, [vp, vp, i64, vp, vp, i64, C.c_int, vp, vp, C.c_int, f64, f64, vp]),
+    "sx_de_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.POINTER(vp)]),
+    "sx_graph_launch": (C.c_int, [vp, vp]),
+    "sx_graph_destroy": (C.c_int, [vp]),
+    "sx_mt_create": (vp, [C.c_uint32]),
+    "sx_mt_destroy": (None, [vp]),
+    "sx_mt_seed": (None, [vp, C.c_uint32]),
+    "sx_mt_random": (None, [vp, vp, i64]),
+    "sx_mt_uniform": (None, [vp, f64, f64, vp, i64]),
+    "sx_mt_uniform_rows": (None, [vp, vp, vp, C.c_int, i64, vp]),
+    "sx_mt_randn": (None, [vp, vp, i64]),
+    "sx_mt_randint": (None, [vp, i64, vp, i64]),
+    "sx_mt_permutation": (None, [vp, i64, vp]),
+    "sx_mt_de_donors": (None, [vp, i64, C.c_int, vp]),
+    "sx_mt_get_state": (None, [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64)]),
+    "sx_mt_set_state": (None, [vp, vp, C.c_int, C.c_int, f64]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Raises HipLibraryError if it is missing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C stochopy_amd/csrc`.  stochopy_amd has no CPU fallback.")
+    try:
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.sx_abi_version() != 1:
+        raise HipLibraryError("ABI version mismatch; rebuild the library")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed (rc={rc}): {lib().sx_last_error().decode()}")

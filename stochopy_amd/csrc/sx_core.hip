@@ -1,0 +1,326 @@
+// Core of the C ABI: error channel, summation plans, batched objective
+// evaluation, argmin and the best-of-generation / termination kernel.
+//
+// Reference code replaced (paths relative to the reference checkout):
+//   stochopy/factory/benchmark.py:14-156              the seven objectives
+//   stochopy/optimize/_common.py:34-90                population wrapper fun(X) -> f
+//   stochopy/optimize/_common.py:131-158              argmin + termination ladder
+#include <string>
+#include <vector>
+
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+#include "sx_rowops.hpp"
+
+namespace sx {
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" int sx_abi_version(void) { return SX_ABI_VERSION; }
+extern "C" const char *sx_last_error(void) { return g_error.c_str(); }
+extern "C" int sx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return -1;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// numpy pairwise-sum plan (host)
+// ---------------------------------------------------------------------------
+namespace {
+struct PlanBuilder {
+    std::vector<int> end_block, merges;
+    int blocks = 0;
+    int depth = 0, max_depth = 0;
+    void rec(int64_t m) {
+        if (m <= 128) {
+            blocks += (int)(m / 8);
+            end_block.push_back(blocks);
+            merges.push_back(0);
+            ++depth;
+            if (depth > max_depth) max_depth = depth;
+            return;
+        }
+        int64_t h = m / 2;
+        h -= h % 8;
+        rec(h);
+        rec(m - h);
+        merges.back() += 1;
+        --depth;
+    }
+};
+}  // namespace
+
+extern "C" int sx_sum_plan(int64_t m, int32_t *out, int cap) {
+    if (m < 0 || cap < 4) return -1;
+    if (m < 8) {
+        out[0] = 0;
+        out[1] = (int32_t)m;
+        out[2] = 0;
+        out[3] = 1;
+        return 4;
+    }
+    PlanBuilder b;
+    b.rec(m);
+    const int nleaf = (int)b.end_block.size();
+    const int need = 4 + 2 * nleaf;
+    if (cap < need) return -need;
+    out[0] = nleaf;
+    out[1] = (int32_t)(m % 8);
+    out[2] = (int32_t)(m / 8);
+    out[3] = b.max_depth;
+    for (int t = 0; t < nleaf; ++t) {
+        out[4 + 2 * t] = b.end_block[t];
+        out[5 + 2 * t] = b.merges[t];
+    }
+    return need;
+}
+
+extern "C" int64_t sx_fun_terms(int fun_id, int n) {
+    if (fun_id == SX_FUN_ROSENBROCK) return n > 0 ? n - 1 : 0;
+    return n;
+}
+
+extern "C" int64_t sx_num_partials(int64_t P, int n) {
+    const int rpb = rows_per_block(n);
+    return (P + rpb - 1) / rpb;
+}
+
+namespace sx {
+int make_plan_arg(int fun_id, int n, PlanArg *out) {
+    if (n > kMaxDim) {
+        set_error("dimension above the LDS staging limit (n <= 6144)");
+        return -1;
+    }
+    const int64_t m = sx_fun_terms(fun_id, n);
+    std::vector<int32_t> buf(4 + 2 * (size_t)(m / 64 + 2));
+    const int got = sx_sum_plan(m, buf.data(), (int)buf.size());
+    if (got < 0 || buf[0] > kMaxLeaf || buf[3] > 12) {
+        set_error("dimension too large for the kernel-argument summation plan");
+        return -1;
+    }
+    out->nleaf = buf[0];
+    out->tail = buf[1];
+    out->mb = buf[2];
+    out->depth = buf[3];
+    for (int t = 0; t < buf[0]; ++t) {
+        out->end[t] = (uint16_t)buf[4 + 2 * t];
+        out->merges[t] = (uint8_t)buf[5 + 2 * t];
+    }
+    return 0;
+}
+}  // namespace sx
+
+// ---------------------------------------------------------------------------
+// Batched evaluation kernel: one wavefront per individual.
+// ---------------------------------------------------------------------------
+template <int FUN>
+__global__ __launch_bounds__(kMaxRowsPerBlock *kWave) void eval_kernel(
+    const double *__restrict__ X, int64_t P, int n, int64_t ldx, const double *__restrict__ xm,
+    const double *__restrict__ xstd, double *__restrict__ f, const PlanArg plan, double *__restrict__ part_f,
+    int64_t *__restrict__ part_i) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sf[kMaxRowsPerBlock];
+    __shared__ int64_t si[kMaxRowsPerBlock];
+    const RowIds id(P);
+    double *U = lds + id.wave * lds_row_stride(n);
+    const double *xr = X + id.rowc * ldx;
+    const bool affine = xm != nullptr;
+    for (int e = id.lane; e < n; e += kWave) {
+        double v = xr[e];
+        if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
+        U[e] = v;
+    }
+    const double val = row_objective<FUN>(U, n, plan, id.lane);
+    if (id.active && id.lane == 0) f[id.row] = val;
+    if (part_f != nullptr) block_partial(val, id, sf, si, part_f, part_i);
+}
+
+template <int FUN>
+static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
+                       const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s) {
+    const int rpb = rows_per_block(n);
+    const int64_t nblk = (P + rpb - 1) / rpb;
+    const size_t lds = (size_t)rpb * lds_row_stride(n) * sizeof(double);
+    hipLaunchKernelGGL(eval_kernel<FUN>, dim3((unsigned)nblk), dim3(rpb * kWave), lds, s, X, P, n, ldx, xm, xstd, f,
+                       plan, part_f, part_i);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm,
+                       const double *xstd, double *f, double *part_f, int64_t *part_i, void *stream) {
+    SX_REQUIRE(X && f, "sx_eval: null pointer");
+    SX_REQUIRE(P >= 1 && n >= 1 && ldx >= n, "sx_eval: bad shape");
+    SX_REQUIRE(fun_id >= 0 && fun_id < SX_FUN_COUNT, "sx_eval: unknown fun_id");
+    SX_REQUIRE((xm == nullptr) == (xstd == nullptr), "sx_eval: xm and xstd must be given together");
+    SX_REQUIRE((part_f == nullptr) == (part_i == nullptr), "sx_eval: part_f and part_i must be given together");
+    hipStream_t s = (hipStream_t)stream;
+    PlanArg plan;
+    if (make_plan_arg(fun_id, n, &plan)) return -1;
+    switch (fun_id) {
+#define SX_CASE(ID) \
+    case ID:        \
+        return launch_eval<ID>(X, P, n, ldx, xm, xstd, f, plan, part_f, part_i, s);
+        SX_CASE(SX_FUN_ACKLEY)
+        SX_CASE(SX_FUN_GRIEWANK)
+        SX_CASE(SX_FUN_QUARTIC)
+        SX_CASE(SX_FUN_RASTRIGIN)
+        SX_CASE(SX_FUN_ROSENBROCK)
+        SX_CASE(SX_FUN_SPHERE)
+        SX_CASE(SX_FUN_STYBLINSKI_TANG)
+#undef SX_CASE
+    }
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// argmin: stage 1 (grid) -> partials, stage 2 (one workgroup) -> result
+// ---------------------------------------------------------------------------
+constexpr int kFinalThreads = 256;
+
+__device__ __forceinline__ void block_argmin(double &bf, int64_t &bi, double *sf, int64_t *si) {
+    wave_argmin_all(bf, bi);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sf[w] = bf;
+        si[w] = bi;
+    }
+    __syncthreads();
+    bf = sf[0];
+    bi = si[0];
+    for (int k = 1; k < kFinalThreads / kWave; ++k) argmin_combine(bf, bi, sf[k], si[k]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFinalThreads) void argmin_stage1(const double *__restrict__ f, int64_t P,
+                                                               double *__restrict__ part_f,
+                                                               int64_t *__restrict__ part_i) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int64_t k = (int64_t)blockIdx.x * kFinalThreads + threadIdx.x; k < P; k += (int64_t)gridDim.x * kFinalThreads)
+        argmin_combine(bf, bi, f[k], k);
+    block_argmin(bf, bi, sf, si);
+    if (threadIdx.x == 0) {
+        part_f[blockIdx.x] = bf;
+        part_i[blockIdx.x] = bi;
+    }
+}
+
+__global__ __launch_bounds__(kFinalThreads) void argmin_stage2(const double *__restrict__ part_f,
+                                                               const int64_t *__restrict__ part_i, int64_t npart,
+                                                               int64_t *__restrict__ out_idx,
+                                                               double *__restrict__ out_val) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int64_t k = threadIdx.x; k < npart; k += kFinalThreads) argmin_combine(bf, bi, part_f[k], part_i[k]);
+    block_argmin(bf, bi, sf, si);
+    if (threadIdx.x == 0) {
+        *out_idx = bi;
+        *out_val = bf;
+    }
+}
+
+extern "C" int sx_argmin(const double *f, int64_t P, double *ws_f, int64_t *ws_i, int64_t ws_len, int64_t *out_idx,
+                         double *out_val, void *stream) {
+    SX_REQUIRE(f && ws_f && ws_i && out_idx && out_val && P >= 1 && ws_len >= 1, "sx_argmin: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nblk = (P + kFinalThreads - 1) / kFinalThreads;
+    if (nblk > ws_len) nblk = ws_len;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(argmin_stage1, dim3((unsigned)nblk), dim3(kFinalThreads), 0, s, f, P, ws_f, ws_i);
+    SX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(kFinalThreads), 0, s, ws_f, ws_i, nblk, out_idx, out_val);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Best-of-generation + termination (stochopy/optimize/_common.py:131-158)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
+    const double *__restrict__ part_f, const int64_t *__restrict__ part_i, int64_t npart,
+    const double *__restrict__ rows0, const double *__restrict__ rows1, int64_t ld, int n,
+    double *__restrict__ gbest, sx_state *__restrict__ state, int maxiter, double xtol, double ftol) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    if (state->done) return;
+    const int64_t it = state->it + 1;  // the generation being finalised
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int64_t k = threadIdx.x; k < npart; k += kFinalThreads) argmin_combine(bf, bi, part_f[k], part_i[k]);
+    block_argmin(bf, bi, sf, si);
+
+    // generation g lives in rows[g & 1] (double-buffered populations); rows0 == rows1 for in-place state
+    const double *src = ((it & 1) ? rows1 : rows0) + bi * ld;
+    // dx = ||xbest_prev - x[k]||_2 (np.linalg.norm, _common.py:135)
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) {
+        const double d = gbest[e] - src[e];
+        acc += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double ss = 0.0;
+    for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
+    const double dx = sqrt(ss);
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) gbest[e] = src[e];
+    if (threadIdx.x == 0) {
+        int status = SX_STATUS_NONE;
+        if (dx <= xtol && bf <= ftol)
+            status = 0;
+        else if (bf <= ftol)
+            status = 1;
+        else if (it >= maxiter)
+            status = -1;
+        state->it = it;
+        state->gbidx = bi;
+        state->gfit = bf;
+        state->dx = dx;
+        state->status = status;
+        state->done = status != SX_STATUS_NONE;
+    }
+}
+
+extern "C" int sx_select_finalize(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                                  const double *rows1, int64_t ld, int n, double *gbest, sx_state *state, int maxiter,
+                                  double xtol, double ftol, void *stream) {
+    SX_REQUIRE(part_f && part_i && rows0 && rows1 && gbest && state && npart >= 1 && n >= 1,
+               "sx_select_finalize: bad arguments");
+    hipLaunchKernelGGL(select_finalize_kernel, dim3(1), dim3(kFinalThreads), 0, (hipStream_t)stream, part_f, part_i,
+                       npart, rows0, rows1, ld, n, gbest, state, maxiter, xtol, ftol);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace sx {
+int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
+                      int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,
+                      sx_state *state, int maxiter, double xtol, double ftol) {
+    void *kargs[] = {&part_f, &part_i, &npart, &rows0, &rows1, &ld, &n, &gbest, &state, &maxiter, &xtol, &ftol};
+    hipKernelNodeParams kp = {};
+    kp.func = (void *)select_finalize_kernel;
+    kp.gridDim = dim3(1);
+    kp.blockDim = dim3(kFinalThreads);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = kargs;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    SX_HIP(hipGraphAddKernelNode(&node, graph, *prev ? prev : nullptr, *prev ? 1 : 0, &kp));
+    *prev = node;
+    return 0;
+}
+}  // namespace sx

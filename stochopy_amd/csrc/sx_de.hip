@@ -1,0 +1,312 @@
+// Differential Evolution: one fused kernel per generation
+// (donor gather -> mutation -> binomial crossover -> bound repair -> objective
+//  -> greedy selection -> per-workgroup best), plus the hipGraph of generations.
+//
+// Reference code replaced (paths relative to the reference checkout):
+//   stochopy/optimize/de/_de.py:304-311   delete_shuffle_sync (donor indices)
+//   stochopy/optimize/de/_de.py:314-351   de_sync
+//   stochopy/optimize/de/_strategy.py:1-38  rand1bin / rand2bin / best1bin / best2bin
+//   stochopy/optimize/de/_constraints.py:13-28  Random
+//   stochopy/optimize/_common.py:123-130  selection (strict <, in place)
+//   stochopy/factory/benchmark.py         objective, fused
+//
+// One wavefront per individual; the population is double-buffered: generation g
+// lives in buf[g & 1], its successor is written to the other buffer (winner or
+// unchanged row), so donor reads never race with selection writes.
+#include <vector>
+
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+#include "sx_rowops.hpp"
+
+namespace sx {
+int make_plan_arg(int fun_id, int n, PlanArg *out);
+int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
+                      int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,
+                      sx_state *state, int maxiter, double xtol, double ftol);
+}
+using namespace sx;
+
+#ifdef SX_TRACE
+// debug build only: per-workgroup checkpoints (s_memrealtime, 100 MHz) of the generation kernel
+__device__ unsigned long long sx_trace_buf[1024 * 8];
+#define SX_TP(k)                                                                              \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) sx_trace_buf[blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+extern "C" int sx_trace_read(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sx_trace_buf), sizeof(unsigned long long) * 1024 * 8);
+}
+#else
+#define SX_TP(k) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int kMaxDonors = 5;
+
+__host__ __device__ inline int donors_of(int strategy) {
+    return strategy == SX_DE_RAND1BIN ? 3 : strategy == SX_DE_RAND2BIN ? 5 : strategy == SX_DE_BEST1BIN ? 2 : 4;
+}
+
+// Philox donors: k distinct rows != i, uniform without replacement.  Word 1+t of the
+// donor calls gives r_t = mulhi(w, P-1-t); r_t is then shifted past the
+// sorted exclusion list {i, d_0..d_{t-1}} (oracle/streams.py PhiloxStream.de_generation).
+__device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint32_t grow, uint32_t gen, uint32_t k0,
+                                              uint32_t k1, int n, int64_t (&d)[kMaxDonors], int &irand) {
+    // word 0 -> forced crossover index, word 1+t -> donor t; the second call only for 4- and 5-donor strategies
+    const U4 a = philox4x32_10(0u, grow, gen, kPurposeDeDonor, k0, k1);
+    U4 b = {0u, 0u, 0u, 0u};
+    if (k > 3) b = philox4x32_10(1u, grow, gen, kPurposeDeDonor, k0, k1);
+    const uint32_t w[5] = {a.y, a.z, a.w, b.x, b.y};
+    uint32_t excl[kMaxDonors + 1];  // P < 2^31 (checked on the host): 32-bit index arithmetic
+    excl[0] = (uint32_t)i;
+    const uint32_t Pm1 = (uint32_t)(P - 1);
+#pragma unroll
+    for (int t = 0; t < kMaxDonors; ++t) {
+        if (t < k) {
+            uint32_t v = __umulhi(w[t], Pm1 - (uint32_t)t);
+#pragma unroll
+            for (int s = 0; s <= t; ++s) v += (v >= excl[s]) ? 1u : 0u;
+            d[t] = (int64_t)v;
+            uint32_t carry = v;  // insert v into the sorted list excl[0..t]
+#pragma unroll
+            for (int s = 0; s <= t; ++s) {
+                if (carry < excl[s]) {
+                    const uint32_t tmp = excl[s];
+                    excl[s] = carry;
+                    carry = tmp;
+                }
+            }
+            excl[t + 1] = carry;
+        } else {
+            d[t] = 0;
+        }
+    }
+    irand = (int)__umulhi(a.x, (uint32_t)n);
+}
+
+template <int FUN, int RNG>
+__global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void de_generation_kernel(const sx_de_args a,
+                                                                                 const PlanArg plan) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sf[kMaxRowsPerBlock];
+    __shared__ int64_t si[kMaxRowsPerBlock];
+    SX_TP(0);
+    const sx_state *st = a.state;
+    if (st->done) return;
+    const int64_t it = st->it;  // generations completed; this launch produces it+1
+    const int64_t gbidx = st->gbidx;
+    SX_TP(6);
+    const uint32_t gen = (uint32_t)(it + 1);
+    const double *__restrict__ cur = (it & 1) ? a.buf1 : a.buf0;
+    double *__restrict__ nxt = (it & 1) ? a.buf0 : a.buf1;
+    const int n = a.n;
+    const int64_t P = a.P, ld = a.ld;
+    const RowIds id(P);
+    const int lane = id.lane;
+    const int64_t rowc = id.rowc;
+    double *U = lds + id.wave * lds_row_stride(n);
+
+    const double fold = a.fit[rowc];
+    const double *__restrict__ xi = cur + rowc * ld;
+    const uint32_t grow = (uint32_t)(a.row0 + rowc);
+    const int strategy = a.strategy;
+    const int k = donors_of(strategy);
+    const bool repair = a.constraints != 0;
+
+    int64_t d[kMaxDonors];
+    int irand;
+    if (RNG == SX_RNG_PHILOX) {
+        philox_donors(P, k, rowc, grow, gen, a.key0, a.key1, n, d, irand);
+    } else {
+#pragma unroll
+        for (int t = 0; t < kMaxDonors; ++t) d[t] = t < k ? (int64_t)a.donors[(int64_t)t * P + rowc] : 0;
+        irand = a.irand[rowc];
+    }
+    SX_TP(1);
+    const double *__restrict__ p0 = cur + d[0] * ld;
+    const double *__restrict__ p1 = cur + d[1] * ld;
+    const double *__restrict__ p2 = cur + d[2] * ld;
+    const double *__restrict__ p3 = cur + d[3] * ld;
+    const double *__restrict__ p4 = cur + d[4] * ld;
+    // best row: the caller's copy (multi-GPU: it may come from another shard) or row gbidx of this generation
+    const double *__restrict__ gb = a.gbest != nullptr ? a.gbest : cur + gbidx * ld;
+    const double F = a.F, CR = a.CR;
+    const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
+    const double *rsrow = (RNG == SX_RNG_HOST && repair) ? a.resample + rowc * (int64_t)n : nullptr;
+
+    // ---- trial vector: mutation (de/_strategy.py, same association), crossover
+    //      (de/_de.py:344 forced index OR r <= CR), Random repair (de/_constraints.py:21-26) -> LDS
+    U4 w = {0u, 0u, 0u, 0u};
+    int q = 0;
+    for (int e = lane; e < n; e += kWave, ++q) {
+        const double x = xi[e];
+        double v;
+        if (strategy == SX_DE_BEST1BIN)
+            v = gb[e] + F * (p0[e] - p1[e]);
+        else if (strategy == SX_DE_RAND1BIN)
+            v = p0[e] + F * (p1[e] - p2[e]);
+        else if (strategy == SX_DE_BEST2BIN)
+            v = gb[e] + F * (((p0[e] + p1[e]) - p2[e]) - p3[e]);
+        else
+            v = p0[e] + F * (((p1[e] + p2[e]) - p3[e]) - p4[e]);
+        double r, rs = 0.0;
+        if (RNG == SX_RNG_PHILOX) {
+            // 32-bit crossover uniforms: one call per 4 steps (slot = (q>>2)*64 + lane, word = q&3)
+            if ((q & 3) == 0)
+                w = philox4x32_10((uint32_t)(q >> 2) * 64u + (uint32_t)lane, grow, gen, kPurposeDeCross, a.key0,
+                                  a.key1);
+            const int wi = q & 3;
+            r = u32(wi == 0 ? w.x : wi == 1 ? w.y : wi == 2 ? w.z : w.w);
+            if (repair)  // np.random.uniform(lo, hi): lo + (hi-lo)*double
+                rs = a.lower[e] + (a.upper[e] - a.lower[e]) *
+                                      philox_u53(e, grow, gen, kPurposeDeResample, a.key0, a.key1);
+        } else {
+            r = r1row[e];
+            if (repair) rs = rsrow[e];
+        }
+        double cand = (e == irand || r <= CR) ? v : x;
+        if (repair && (cand < a.lower[e] || cand > a.upper[e])) cand = rs;
+        U[e] = cand;
+    }
+
+    SX_TP(2);
+    const double fc = row_objective<FUN>(U, n, plan, lane);
+    SX_TP(3);
+    const bool better = fc < fold;  // _common.py:127 strict <
+    if (id.active) {
+        double *__restrict__ xo = nxt + id.row * ld;
+        if (better) {
+            for (int e = lane; e < n; e += kWave) xo[e] = U[e];
+        } else {
+            for (int e = lane; e < n; e += kWave) xo[e] = xi[e];
+        }
+        if (lane == 0) {
+            if (better) a.fit[id.row] = fc;
+            if (a.candfit != nullptr) a.candfit[id.row] = fc;
+        }
+    }
+    SX_TP(4);
+    block_partial(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+    SX_TP(5);
+}
+
+typedef void (*de_kernel_t)(const sx_de_args, const PlanArg);
+
+template <int RNG>
+de_kernel_t pick_kernel(int fun_id) {
+    switch (fun_id) {
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG>;
+    }
+    return nullptr;
+}
+
+int check_args(const sx_de_args *a) {
+    SX_REQUIRE(a != nullptr, "sx_de: null args");
+    SX_REQUIRE(a->buf0 && a->buf1 && a->fit && a->state && a->part_f && a->part_i, "sx_de: null device pointer");
+    SX_REQUIRE(a->P >= 2 && a->P < (int64_t)1 << 31 && a->n >= 1 && a->ld >= a->n, "sx_de: bad shape");
+    SX_REQUIRE(a->fun_id >= 0 && a->fun_id < SX_FUN_COUNT, "sx_de: unknown objective");
+    SX_REQUIRE(a->strategy >= 0 && a->strategy <= 3, "sx_de: unknown strategy");
+    SX_REQUIRE(a->P - 1 >= donors_of(a->strategy), "sx_de: popsize too small for the strategy");
+    SX_REQUIRE(a->rng == SX_RNG_HOST || a->rng == SX_RNG_PHILOX, "sx_de: unknown rng mode");
+    if (a->rng == SX_RNG_HOST) {
+        SX_REQUIRE(a->r1 && a->donors && a->irand, "sx_de: host draws missing");
+        SX_REQUIRE(a->constraints == 0 || a->resample, "sx_de: resample block missing");
+    }
+    SX_REQUIRE(a->constraints == 0 || (a->lower && a->upper), "sx_de: bounds missing");
+    return 0;
+}
+
+de_kernel_t kernel_for(const sx_de_args *a) {
+    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id) : pick_kernel<SX_RNG_HOST>(a->fun_id);
+}
+
+struct Geometry {
+    unsigned blocks, threads;
+    size_t lds;
+};
+Geometry geometry(const sx_de_args *a) {
+    const int rpb = rows_per_block(a->n);
+    return Geometry{(unsigned)((a->P + rpb - 1) / rpb), (unsigned)(rpb * kWave),
+                    (size_t)rpb * lds_row_stride(a->n) * sizeof(double)};
+}
+
+}  // namespace
+
+extern "C" int sx_de_generation(const sx_de_args *a, int finalize, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a);
+    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan);
+    SX_LAUNCH_CHECK();
+    if (finalize) {
+        SX_REQUIRE(a->gbest != nullptr, "sx_de_generation: the separate finalize kernel needs the gbest buffer");
+        return sx_select_finalize(a->part_f, a->part_i, g.blocks, a->buf0, a->buf1, a->ld, a->n, a->gbest, a->state,
+                                  a->maxiter, a->xtol, a->ftol, stream);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// hipGraph of ngen generations: 2*ngen kernel nodes in a chain, every node
+// identical (per-generation state is read from a.state on the device).
+// ---------------------------------------------------------------------------
+struct sx_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(out != nullptr && ngen >= 1 && a->gbest != nullptr, "sx_de_graph_create: bad arguments");
+    SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_de_graph_create: graphs need in-kernel (Philox) draws");
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a);
+    sx_graph *gr = new sx_graph();
+    SX_HIP(hipGraphCreate(&gr->graph, 0));
+    sx_de_args args = *a;
+    void *kargs[] = {&args, &plan};
+    hipGraphNode_t prev = nullptr;
+    for (int i = 0; i < ngen; ++i) {
+        hipKernelNodeParams kp = {};
+        kp.func = (void *)kernel_for(a);
+        kp.gridDim = dim3(g.blocks);
+        kp.blockDim = dim3(g.threads);
+        kp.sharedMemBytes = (unsigned)g.lds;
+        kp.kernelParams = kargs;
+        kp.extra = nullptr;
+        hipGraphNode_t node;
+        SX_HIP(hipGraphAddKernelNode(&node, gr->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+        prev = node;
+        if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->buf0, a->buf1, a->ld, a->n,
+                                       a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
+            return rc;
+    }
+    SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
+    *out = gr;
+    return 0;
+}
+
+extern "C" int sx_graph_launch(sx_graph *g, void *stream) {
+    SX_REQUIRE(g && g->exec, "sx_graph_launch: null graph");
+    SX_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int sx_graph_destroy(sx_graph *g) {
+    if (!g) return 0;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return 0;
+}

@@ -1,0 +1,332 @@
+// Device-side building blocks shared by the generation kernels (gfx950, wave64).
+//
+// Thread layout: ONE WAVEFRONT PER INDIVIDUAL.  Lane l holds elements e = 64*q + l of
+// the row, so every vector load/store of a row is one fully coalesced 512-byte
+// access.  The trial vector U and the per-element objective terms are staged in
+// LDS; the row sum is then taken from LDS in numpy's pairwise add.reduce order
+// (8 running accumulators over blocks of 8, combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), recursion above 128 terms; SURVEY.md
+// App. C): lane j&7 walks chain j, the 8-lane tree is three DPP steps.  Fitness
+// values therefore reproduce the reference's `.sum()` bit for bit for +,-,*
+// objectives.  The leaf table of the recursion travels in the kernel arguments
+// (scalar loads, uniform control flow).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stochopy_hip.h"
+
+namespace sx {
+
+constexpr int kGroup = 8;     // numpy's 8 running accumulators
+constexpr int kWave = 64;     // gfx950 wavefront = one individual
+constexpr int kMaxRowsPerBlock = 4;
+constexpr int kMaxLeaf = 96;  // leaves carried in kernel arguments (n up to ~6k..12k)
+constexpr int kMaxDim = 6144; // LDS staging: 3 arrays of n doubles per wave (< 160 KiB)
+
+// rows (= waves) per workgroup: 4 while the LDS staging of a workgroup stays <= 32 KiB
+__host__ __device__ inline int rows_per_block(int n) { return n <= 256 ? 4 : (n <= 640 ? 2 : 1); }
+// doubles of LDS per wave: U[n+8] | A[n] | B[n] | stack[24]
+__host__ __device__ inline int lds_row_stride(int n) { return 3 * n + 8 + 24; }
+
+// numpy pairwise-summation plan for an m-term row sum, passed BY VALUE as a kernel argument
+struct PlanArg {
+    int32_t nleaf;  // 0 when m < 8 (plain left-to-right sum)
+    int32_t tail;   // m % 8: terms added one by one after the last leaf's tree
+    int32_t mb;     // m / 8
+    int32_t depth;  // stack depth of the recursion
+    uint16_t end[kMaxLeaf];    // end block (exclusive) of leaf t
+    uint8_t merges[kMaxLeaf];  // stack merges after leaf t
+};
+
+// ---------------------------------------------------------------------------
+// cross-lane moves inside the 8-lane group (DPP: VALU, no LDS round trip)
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // row_half_mirror: lane i <-> 7-i inside each 8 lanes
+
+template <bool MUL>
+__device__ __forceinline__ double combine(double a, double b) {
+    return MUL ? a * b : a + b;
+}
+
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); + and * commute exactly, so every lane ends with the same bits
+template <bool MUL>
+__device__ __forceinline__ double group_tree(double r) {
+    r = combine<MUL>(r, dpp_f64<kDppXor1>(r));
+    r = combine<MUL>(r, dpp_f64<kDppXor2>(r));
+    r = combine<MUL>(r, dpp_f64<kDppHalfMirror>(r));  // quads are uniform by now: mirror == xor 4
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011); counter = (slot,row,gen,purpose), key = seed
+// ---------------------------------------------------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// numpy legacy double from two words: ((a>>5)*2^26 + (b>>6)) / 2^53
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+// 32-bit uniform in [0,1): word * 2^-32 (exact)
+__device__ __forceinline__ double u32(uint32_t a) { return (double)a * (1.0 / 4294967296.0); }
+
+enum : uint32_t {
+    kPurposeDeCross = 0,
+    kPurposeDeDonor = 1,
+    kPurposeDeResample = 2,
+    kPurposePsoR1 = 3,
+    kPurposePsoR2 = 4,
+    kPurposePsoRestart = 5,
+    kPurposeCmaNormal = 6,
+};
+
+// Element e of a row sits in lane l = e & 63 at step q = e >> 6.
+// 53-bit uniform: slot = (q >> 1) * 64 + l, half = q & 1   (two per call)
+__device__ __forceinline__ double philox_u53(int e, uint32_t row, uint32_t gen, uint32_t purpose, uint32_t k0,
+                                             uint32_t k1) {
+    const uint32_t q = (uint32_t)e >> 6, l = (uint32_t)e & 63u;
+    const U4 w = philox4x32_10((q >> 1) * 64u + l, row, gen, purpose, k0, k1);
+    return (q & 1u) ? u53(w.z, w.w) : u53(w.x, w.y);
+}
+// 32-bit uniform: slot = (q >> 2) * 64 + l, word = q & 3   (four per call)
+__device__ __forceinline__ double philox_u32(int e, uint32_t row, uint32_t gen, uint32_t purpose, uint32_t k0,
+                                             uint32_t k1) {
+    const uint32_t q = (uint32_t)e >> 6, l = (uint32_t)e & 63u;
+    const U4 w = philox4x32_10((q >> 2) * 64u + l, row, gen, purpose, k0, k1);
+    const uint32_t wi = q & 3u;
+    return u32(wi == 0 ? w.x : wi == 1 ? w.y : wi == 2 ? w.z : w.w);
+}
+
+// ---------------------------------------------------------------------------
+// Objectives: stochopy/factory/benchmark.py:14-156.  term() gives this lane's
+// contribution(s) for element e (x = value, xn = value of element e+1).
+// ---------------------------------------------------------------------------
+constexpr double kTwoPi = 6.283185307179586;  // 2.0 * np.pi
+
+template <int FUN>
+struct Obj;
+
+template <>
+struct Obj<SX_FUN_ACKLEY> {  // benchmark.py:14-34
+    static constexpr bool NEXT = false, BMUL = false, TWO = true;
+    static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
+        a = x * x;
+        b = cos(kTwoPi * x);
+    }
+    static __device__ __forceinline__ double finish(double sa, double sb, int n) {
+        const double e = 2.7182818284590451;
+        const double inv = 1.0 / (double)n;
+        const double s1 = sqrt(inv * sa);
+        const double s2 = inv * sb;
+        return ((20.0 + e) - 20.0 * exp(-0.2 * s1)) - exp(s2);
+    }
+};
+
+template <>
+struct Obj<SX_FUN_GRIEWANK> {  // benchmark.py:37-56
+    static constexpr bool NEXT = false, BMUL = true, TWO = true;
+    static __device__ __forceinline__ void term(double x, double, int e, double &a, double &b) {
+        a = x * x;
+        b = cos(x / sqrt((double)(e + 1)));
+    }
+    static __device__ __forceinline__ double finish(double sa, double pb, int) {
+        return (1.0 + sa / 4000.0) - pb;
+    }
+};
+
+template <>
+struct Obj<SX_FUN_QUARTIC> {  // benchmark.py:59-76
+    static constexpr bool NEXT = false, BMUL = false, TWO = false;
+    static __device__ __forceinline__ void term(double x, double, int e, double &a, double &b) {
+        const double x2 = x * x;
+        a = (double)(e + 1) * (x2 * x2);
+        b = 0.0;
+    }
+    static __device__ __forceinline__ double finish(double sa, double, int) { return sa; }
+};
+
+template <>
+struct Obj<SX_FUN_RASTRIGIN> {  // benchmark.py:79-97
+    static constexpr bool NEXT = false, BMUL = false, TWO = false;
+    static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
+        a = x * x - 10.0 * cos(kTwoPi * x);
+        b = 0.0;
+    }
+    static __device__ __forceinline__ double finish(double sa, double, int n) { return 10.0 * (double)n + sa; }
+};
+
+template <>
+struct Obj<SX_FUN_ROSENBROCK> {  // benchmark.py:100-118
+    static constexpr bool NEXT = true, BMUL = false, TWO = true;
+    static __device__ __forceinline__ void term(double x, double xn, int, double &a, double &b) {
+        const double t = xn - x * x;
+        a = t * t;
+        const double u = 1.0 - x;
+        b = u * u;
+    }
+    static __device__ __forceinline__ double finish(double sa, double sb, int) { return 100.0 * sa + sb; }
+};
+
+template <>
+struct Obj<SX_FUN_SPHERE> {  // benchmark.py:121-136
+    static constexpr bool NEXT = false, BMUL = false, TWO = false;
+    static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
+        a = x * x;
+        b = 0.0;
+    }
+    static __device__ __forceinline__ double finish(double sa, double, int) { return sa; }
+};
+
+template <>
+struct Obj<SX_FUN_STYBLINSKI_TANG> {  // benchmark.py:139-156
+    static constexpr bool NEXT = false, BMUL = false, TWO = false;
+    static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
+        const double x2 = x * x;
+        a = (x2 * x2 - 16.0 * x2) + 5.0 * x;
+        b = 0.0;
+    }
+    static __device__ __forceinline__ double finish(double sa, double, int n) {
+        return 0.5 * sa + 39.16599 * (double)n;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Row sum in numpy order from LDS-staged terms.  Executed by all 64 lanes: the 8
+// lane groups compute the same sum redundantly (LDS broadcasts), so every lane
+// ends with identical bits and no cross-lane broadcast is needed.
+// ---------------------------------------------------------------------------
+constexpr int kLeafBlocks = 16;  // a leaf of numpy's recursion has at most 128 terms
+constexpr int kStack = 12;       // leaf sums awaiting their sibling; depth <= log2(m/64)+1
+
+// Two value streams at once (A: sum, B: sum or product) so their dependent chains
+// interleave; LDS reads are issued 8 blocks ahead of the adds.  S: 2*kStack doubles of
+// LDS scratch per wave for the stack of leaf sums (only touched when the row has > 1 leaf).
+template <bool TWO, bool BMUL>
+__device__ __forceinline__ void row_reduce2(const double *A, const double *B, double *S, const PlanArg &p, int lane,
+                                            double &sa, double &sb) {
+    const int j = lane & (kGroup - 1);
+    const double identB = BMUL ? 1.0 : 0.0;
+    // tail terms (after the last leaf's tree; the whole row when m < 8), fetched up front
+    double ta[kGroup - 1], tb[kGroup - 1];
+    const int t0 = p.mb * kGroup;
+#pragma unroll
+    for (int k = 0; k < kGroup - 1; ++k) {
+        ta[k] = (k < p.tail) ? A[t0 + k] : 0.0;
+        tb[k] = (TWO && k < p.tail) ? B[t0 + k] : identB;
+    }
+    int sp = 0;
+    double curA = 0.0, curB = identB;
+    int b0 = 0;
+    for (int leaf = 0; leaf < p.nleaf; ++leaf) {
+        const int b1 = (int)p.end[leaf];
+        const int cnt = b1 - b0;
+        double chA = 0.0, chB = identB;
+#pragma unroll
+        for (int h = 0; h < kLeafBlocks; h += 8) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool in = h + t < cnt;
+                va[t] = in ? A[(b0 + h + t) * kGroup + j] : 0.0;
+                vb[t] = (TWO && in) ? B[(b0 + h + t) * kGroup + j] : identB;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (h + t == 0) {
+                    chA = va[0];
+                    chB = vb[0];
+                } else if (h + t < cnt) {  // uniform
+                    chA = chA + va[t];
+                    if (TWO) chB = combine<BMUL>(chB, vb[t]);
+                }
+            }
+        }
+        curA = group_tree<false>(chA);
+        if (TWO) curB = group_tree<BMUL>(chB);
+        if (leaf == p.nleaf - 1) {
+#pragma unroll
+            for (int k = 0; k < kGroup - 1; ++k) {
+                if (k < p.tail) {
+                    curA = curA + ta[k];
+                    if (TWO) curB = combine<BMUL>(curB, tb[k]);
+                }
+            }
+        }
+        if (p.nleaf > 1) {  // push, then merge with finished siblings; every lane stores the same bits
+            S[sp] = curA;
+            if (TWO) S[kStack + sp] = curB;
+            ++sp;
+            for (int merges = (int)p.merges[leaf]; merges > 0; --merges) {
+                S[sp - 2] = S[sp - 2] + S[sp - 1];
+                if (TWO) S[kStack + sp - 2] = combine<BMUL>(S[kStack + sp - 2], S[kStack + sp - 1]);
+                --sp;
+            }
+        }
+        b0 = b1;
+    }
+    if (p.nleaf == 0) {  // m < 8: plain left-to-right
+#pragma unroll
+        for (int k = 0; k < kGroup - 1; ++k) {
+            if (k < p.tail) {
+                curA = curA + ta[k];
+                if (TWO) curB = combine<BMUL>(curB, tb[k]);
+            }
+        }
+    }
+    if (p.nleaf > 1) {
+        curA = S[0];
+        if (TWO) curB = S[kStack];
+    }
+    sa = 0.0 + curA;  // add.reduce starts from the identity
+    sb = (TWO && !BMUL) ? 0.0 + curB : curB;
+}
+
+// lexicographic (value, index) minimum = np.argmin's first-minimum rule
+__device__ __forceinline__ void argmin_combine(double &f, int64_t &i, double f2, int64_t i2) {
+    if (f2 < f || (f2 == f && i2 < i)) {
+        f = f2;
+        i = i2;
+    }
+}
+
+__device__ __forceinline__ void wave_argmin_all(double &f, int64_t &i) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double f2 = __shfl_xor(f, off, kWave);
+        const int64_t i2 = __shfl_xor((long long)i, off, kWave);
+        argmin_combine(f, i, f2, i2);
+    }
+}
+
+}  // namespace sx

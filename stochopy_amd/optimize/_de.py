@@ -1,0 +1,296 @@
+"""Differential Evolution front end + generation loop for ``backend="hip"``.
+
+Reference: stochopy/optimize/de/_de.py:13-173 (``minimize``: signature, defaults,
+validation, sync rule, seeding) and :176-301 (``de`` loop: initial population,
+per-generation draw order, return_all bookkeeping, callback, result).  The
+per-generation work -- de_sync (:314-351), the strategies (de/_strategy.py),
+``Random`` (de/_constraints.py), selection_sync (_common.py:123-160) and the
+objective -- is ONE fused HIP kernel (csrc/sx_de.hip) plus a one-workgroup
+best/termination kernel.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _device, _lib, _rng
+from . import _common
+from ._helpers import OptimizeResult, register
+
+__all__ = ["minimize"]
+
+
+def minimize(
+    fun,
+    bounds,
+    x0=None,
+    args=(),
+    maxiter=100,
+    popsize=10,
+    mutation=0.5,
+    recombination=0.9,
+    strategy="best1bin",
+    seed=None,
+    xtol=1.0e-8,
+    ftol=1.0e-8,
+    constraints=None,
+    updating="immediate",
+    workers=1,
+    backend=None,
+    return_all=False,
+    verbosity=1.0,
+    callback=None,
+    rng=None,
+):
+    """Minimize an objective function using Differential Evolution on MI355X.
+
+    Parameters are those of the reference (de/_de.py:13-33); ``backend`` must be
+    ``"hip"`` (default), ``workers`` is the number of GPUs, and ``rng`` selects the
+    random-draw source: ``"numpy-legacy"`` (default; the reference's stream, so the
+    same seed gives the reference's result) or ``"philox"`` (in-kernel counter-based
+    draws, the throughput mode).  As in the reference, choosing a parallel backend
+    forces ``updating="deferred"`` (de/_de.py:142-145).
+    """
+    fun_id = _common.resolve_objective(fun, args)
+    lower, upper = _common.as_bounds(bounds)
+    if x0 is not None:
+        if np.ndim(x0) != 2 or np.shape(x0)[1] != len(bounds):
+            raise ValueError()
+    if popsize < 2:
+        raise ValueError()
+    if x0 is not None and len(x0) != popsize:
+        raise ValueError()
+    if not 0.0 <= mutation <= 2.0:
+        raise ValueError()
+    if not 0.0 <= recombination <= 1.0:
+        raise ValueError()
+    if updating not in {"immediate", "deferred"}:
+        raise ValueError()
+    if strategy not in _lib.DE_STRATEGIES:
+        raise KeyError(strategy)
+    if constraints not in (None, "Random"):
+        raise KeyError(constraints)
+    if callback is not None and not hasattr(callback, "__call__"):
+        raise ValueError()
+    _common.resolve_backend(backend)
+    rng = _common.resolve_rng(rng)
+    workers = _common.resolve_workers(workers)
+    if popsize - 1 < _lib.DE_DONORS[strategy]:
+        raise ValueError()
+
+    run = _DeRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(mutation), float(recombination),
+                 strategy, constraints, float(xtol), float(ftol), bool(return_all), float(verbosity), callback, rng,
+                 seed, workers)
+    return run.result()
+
+
+class _DeRun:
+    GRAPH_CHUNK = 50
+
+    def __init__(self, fun_id, lower, upper, x0, maxiter, P, F, CR, strategy, constraints, xtol, ftol, return_all,
+                 verbosity, callback, rng, seed, workers, autorun=True):
+        self.fun_id, self.lower, self.upper = fun_id, lower, upper
+        self.maxiter, self.P, self.n = maxiter, P, len(lower)
+        self.F, self.CR, self.strategy, self.constraints = F, CR, strategy, constraints
+        self.xtol, self.ftol = xtol, ftol
+        self.return_all, self.verbosity, self.callback = return_all, verbosity, callback
+        self.rng, self.seed = rng, seed
+        self.k = _lib.DE_DONORS[strategy]
+        if workers != 1:
+            from ..parallel import require_world
+
+            require_world(workers)
+        self.x0 = x0
+        self.ctx = _device.Context()
+        self._graph = None
+        if autorun:
+            t = _device.torch()
+            with t.cuda.stream(self.ctx.stream):
+                try:
+                    self._run()
+                finally:
+                    self.close()
+
+    def close(self):
+        if self._graph is not None:
+            self.ctx.L.sx_graph_destroy(self._graph)
+            self._graph = None
+
+    def enqueue(self, ngen):
+        """Enqueue `ngen` generations on the engine stream without any host synchronisation.
+
+        Philox mode only.  Full chunks replay one instantiated hipGraph (two kernel nodes per
+        generation); the remainder is launched eagerly.  Generations after convergence are no-ops.
+        """
+        ctx = self.ctx
+        while ngen >= self.GRAPH_CHUNK:
+            if self._graph is None:
+                g = C.c_void_p()
+                _lib.check(ctx.L.sx_de_graph_create(C.byref(self.args), self.GRAPH_CHUNK, C.byref(g)),
+                           "sx_de_graph_create")
+                self._graph = g
+            _lib.check(ctx.L.sx_graph_launch(self._graph, ctx.stream_ptr), "sx_graph_launch")
+            ngen -= self.GRAPH_CHUNK
+        for _ in range(ngen):
+            _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")
+
+    # ------------------------------------------------------------------ setup
+    def _setup(self):
+        ctx, P, n = self.ctx, self.P, self.n
+        t = _device.torch()
+        self.stream = _rng.make_init_stream(self.rng, self.seed)
+        if self.x0 is not None:
+            X0 = np.array(self.x0, dtype=np.float64)
+        else:
+            X0 = self.stream.latin_hypercube(P, n, self.lower, self.upper)
+        # generation g lives in bufs[g & 1]; the initial population is generation 1
+        self.bufs = [ctx.empty((P, n)), ctx.upload(X0)]
+        self.fit = ctx.empty((P,))
+        self.candfit = ctx.empty((P,))
+        self.d_lower = ctx.upload(self.lower)
+        self.d_upper = ctx.upload(self.upper)
+        npart = int(ctx.L.sx_num_partials(P, n))
+        self.part_f = ctx.empty((npart,))
+        self.part_i = ctx.empty((npart,), dtype=t.int64)
+        # initial evaluation and best (de/_de.py:212-218)
+        _device.evaluate(ctx, self.fun_id, self.bufs[1], n, f=self.fit)
+        self.candfit.copy_(self.fit)
+        out_i = ctx.empty((1,), dtype=t.int64)
+        out_f = ctx.empty((1,))
+        _lib.check(ctx.L.sx_argmin(_device.ptr(self.fit), P, _device.ptr(self.part_f), _device.ptr(self.part_i),
+                                   npart, _device.ptr(out_i), _device.ptr(out_f), ctx.stream_ptr), "sx_argmin")
+        g = int(out_i.cpu()[0])
+        st = _lib.SxState(it=1, gbidx=g, gfit=float(out_f.cpu()[0]), dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
+        self.state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
+        self.gbest = self.bufs[1][g].clone()
+        key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
+        a = _lib.SxDeArgs()
+        a.buf0, a.buf1 = self.bufs[0].data_ptr(), self.bufs[1].data_ptr()
+        a.fit, a.candfit = self.fit.data_ptr(), self.candfit.data_ptr()
+        a.lower, a.upper, a.state = self.d_lower.data_ptr(), self.d_upper.data_ptr(), self.state.data_ptr()
+        a.part_f, a.part_i = self.part_f.data_ptr(), self.part_i.data_ptr()
+        a.gbest = self.gbest.data_ptr()
+        a.P, a.ld, a.row0, a.n = P, n, 0, n
+        a.fun_id, a.strategy = self.fun_id, _lib.DE_STRATEGIES[self.strategy]
+        a.constraints = 1 if self.constraints == "Random" else 0
+        a.rng = _lib.SX_RNG_PHILOX if self.rng == "philox" else _lib.SX_RNG_HOST
+        a.maxiter = self.maxiter
+        a.F, a.CR, a.xtol, a.ftol = self.F, self.CR, self.xtol, self.ftol
+        a.key0, a.key1 = key0, key1
+        self.args = a
+        if self.rng == "numpy-legacy":
+            # pinned staging + device buffers for one generation of host draws
+            self.h_r1 = t.empty((P, n), dtype=t.float64).pin_memory()
+            self.h_don = t.empty((self.k, P), dtype=t.int32).pin_memory()
+            self.h_irand = t.empty((P,), dtype=t.int32).pin_memory()
+            self.d_r1 = ctx.empty((P, n))
+            self.d_don = ctx.empty((self.k, P), dtype=t.int32)
+            self.d_irand = ctx.empty((P,), dtype=t.int32)
+            a.r1, a.donors, a.irand = self.d_r1.data_ptr(), self.d_don.data_ptr(), self.d_irand.data_ptr()
+            if a.constraints:
+                self.h_rs = t.empty((P, n), dtype=t.float64).pin_memory()
+                self.d_rs = ctx.empty((P, n))
+                a.resample = self.d_rs.data_ptr()
+        # return_all history (de/_de.py:221-234) kept in HBM, copied out once at the end
+        if self.return_all:
+            self.nout = int(np.ceil(self.verbosity * P))
+            rows = max(self.nout, 1)
+            self.xall = ctx.empty((self.maxiter, rows, n))
+            self.funall = ctx.empty((self.maxiter, rows))
+            if self.nout > 0:
+                self.xall[0].copy_(self.bufs[1][: self.nout])
+                self.funall[0].copy_(self.fit[: self.nout])
+            else:
+                self.xall[0, 0].copy_(self.bufs[1][g])
+                self.funall[0, 0] = st.gfit
+        self.st = st
+
+    # --------------------------------------------------------------- helpers
+    def _population(self, it):
+        """Device view of generation `it`'s population (P, n)."""
+        return self.bufs[it & 1]
+
+    def _record(self, it):
+        """return_all bookkeeping for generation `it` (de/_de.py:270-278)."""
+        if not self.return_all:
+            return
+        X = self._population(it)
+        if self.nout > 0:
+            self.xall[it - 1].copy_(X[: self.nout])
+            self.funall[it - 1].copy_(self.candfit[: self.nout])  # candidate fitness, de/_de.py:270-273
+        else:
+            k = int(self.candfit.argmin())
+            self.xall[it - 1, 0].copy_(X[k])
+            self.funall[it - 1, 0] = self.candfit[k]
+
+    def _best_row(self, st):
+        """The best individual of generation st.it (host copy)."""
+        return self.gbest.cpu().numpy()
+
+    def _partial_result(self, st):
+        res = OptimizeResult(x=self._best_row(st), fun=st.gfit, nfev=st.it * self.P, nit=st.it)
+        if self.return_all:
+            res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
+        return res
+
+    def _host_draws(self):
+        """One generation of the numpy-legacy stream, in the reference's order."""
+        s = self.stream
+        s.random(None, out=self.h_r1.numpy())                      # de/_de.py:250
+        s.de_donors(self.P, self.k, out=self.h_don.numpy())        # :304-311
+        self.h_irand.numpy()[:] = s.randint(self.n, self.P)        # :340
+        self.d_r1.copy_(self.h_r1, non_blocking=True)
+        self.d_don.copy_(self.h_don, non_blocking=True)
+        self.d_irand.copy_(self.h_irand, non_blocking=True)
+        if self.args.constraints:
+            s.uniform_rows(self.lower, self.upper, self.P, out=self.h_rs.numpy())  # de/_constraints.py:24
+            self.d_rs.copy_(self.h_rs, non_blocking=True)
+
+    # ------------------------------------------------------------------ loop
+    def _run(self):
+        ctx = self.ctx
+        self._setup()
+        st = self.st
+        if self.callback is not None:
+            self.callback(self._population(1).cpu().numpy(), self._partial_result(st))
+        stepwise = self.rng == "numpy-legacy" or self.callback is not None or self.return_all
+        while not st.done:
+            # maxiter <= 1: the reference still runs one generation before it tests `it >= maxiter`
+            remaining = max(self.maxiter - st.it, 1)
+            if stepwise:
+                if self.rng == "numpy-legacy":
+                    self._host_draws()
+                _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")
+                self._record(st.it + 1)
+                st = ctx.read_state(self.state)
+                if self.callback is not None:
+                    self.callback(self._population(st.it).cpu().numpy(), self._partial_result(st))
+            else:
+                # termination is tested on the device every generation; the host looks every <=4 chunks
+                self.enqueue(min(remaining, 4 * self.GRAPH_CHUNK))
+                st = ctx.read_state(self.state)
+        self.st = st
+        status = int(st.status)
+        res = OptimizeResult(
+            x=self._best_row(st),
+            success=status >= 0,
+            status=status,
+            message=_common.messages[status],
+            fun=float(st.gfit),
+            nfev=int(st.it) * self.P,
+            nit=int(st.it),
+        )
+        if self.return_all:
+            res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
+        # the reference works in place on x0 (de/_de.py:208 + _common.py:128-129): mirror that
+        if isinstance(self.x0, np.ndarray) and self.x0.dtype == np.float64:
+            self.x0[...] = self._population(st.it).cpu().numpy()
+        if self.rng == "numpy-legacy":
+            self.stream.sync_back()
+        ctx.sync()
+        self._res = res
+
+    def result(self):
+        return self._res
+
+
+register("de", minimize)

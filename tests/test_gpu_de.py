@@ -1,0 +1,123 @@
+"""GPU parity: objectives and DE generations through the C ABI vs the oracle / golden vectors."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle.objectives import OBJECTIVES
+from conftest import case_bounds, load_golden, unhex
+
+pytestmark = pytest.mark.gpu
+
+# objectives made only of + - * reproduce numpy bit for bit; the others contain cos/exp/sqrt/pow
+EXACT = {"rosenbrock", "sphere"}
+RTOL_TRANSCENDENTAL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import stochopy_amd
+
+    return stochopy_amd
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 13, 16, 17, 64, 127, 128, 129, 130, 255, 256, 257, 1000, 1023, 1024, 1025, 2049])
+@pytest.mark.parametrize("name", sorted(OBJECTIVES))
+def test_objectives_vs_oracle(sa, name, n):
+    rs = np.random.RandomState(n * 7 + 1)
+    X = rs.uniform(-5.12, 5.12, (37, n))
+    got = getattr(sa.factory, name)(X)
+    ref = OBJECTIVES[name](X)
+    if name in EXACT:
+        assert np.array_equal(got, ref)
+    else:
+        assert np.allclose(got, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
+
+
+def test_objective_known_answers(sa):
+    """reference tests/test_factory.py:7-23"""
+    refs = load_golden("factory_kat.json")["test_factory_refs"]
+    for name, ref in refs.items():
+        assert np.allclose(ref, getattr(sa.factory, name)(np.ones(10)))
+
+
+def _run_hip(sa, case, rng="numpy-legacy", **extra):
+    trace = []
+    opts = dict(case["options"])
+    opts.update({"backend": "hip", "rng": rng})
+    opts.update(extra)
+    fun = getattr(sa.factory, case["objective"])
+    res = sa.optimize.minimize(fun, case_bounds(case), x0=case["x0"], method=case["method"], options=opts,
+                               callback=lambda X, r: trace.append((float(r.fun), X.copy())))
+    return res, trace
+
+
+DE_CASES = [c for c in load_golden("configs.json")["cases"] if c["method"] == "de"]
+
+
+@pytest.mark.parametrize("case", DE_CASES, ids=lambda c: c["tag"])
+def test_de_matches_reference_golden(sa, case):
+    """numpy-legacy stream: same seed => the reference's per-generation best-f, x, nit, status."""
+    res, trace = _run_hip(sa, case)
+    ref = case["result"]
+    got = np.array([t[0] for t in trace])
+    want = unhex(case["fun_trace"])
+    if case["objective"] in EXACT:
+        assert np.array_equal(got, want)
+        assert float(res.fun).hex() == ref["fun"]
+        for g, rows in case["pop_rows"].items():
+            for r, row in enumerate(rows):
+                assert np.array_equal(unhex(row), trace[int(g)][1][r, : len(row)])
+    else:
+        assert np.allclose(got, want, rtol=1e-6, atol=0)  # north-star tolerance: best-f within 1e-6 rel
+    assert (res.nit, res.nfev, res.status, res.success, res.message) == (
+        ref["nit"], ref["nfev"], ref["status"], ref["success"], ref["message"])
+
+
+@pytest.mark.parametrize("tag", ["de_rand1bin", "de_rand2bin", "de_best1bin", "de_best2bin", "de_rand1bin_random"])
+def test_de_reference_suite_xrefs(sa, tag):
+    """The reference's own xrefs (tests/test_optimize.py:51-86, deferred rows) incl. return_all."""
+    import os
+    from conftest import GOLDEN
+
+    case = {c["tag"]: c for c in load_golden("suite_rosen2d.json")["cases"]}[tag]
+    res, _ = _run_hip(sa, case)
+    assert np.allclose(case["xref_from_reference_tests"], res.x)
+    arrays = np.load(os.path.join(GOLDEN, "suite_rosen2d_xall.npz"))
+    assert np.array_equal(arrays[tag + "__xall"], res.xall)
+    assert np.array_equal(arrays[tag + "__funall"], res.funall)
+
+
+@pytest.mark.parametrize("strategy", ["rand1bin", "rand2bin", "best1bin", "best2bin"])
+@pytest.mark.parametrize("constraints", [None, "Random"])
+@pytest.mark.parametrize("shape", [(5, 12), (37, 100), (128, 256), (300, 64)])
+def test_de_philox_matches_oracle(sa, strategy, constraints, shape):
+    """Philox mode: device draws == oracle/streams.py PhiloxStream, so traces are bit-identical."""
+    n, P = shape
+    opts = {"maxiter": 8, "popsize": P, "seed": 1234567 + n, "strategy": strategy, "constraints": constraints,
+            "mutation": 0.7, "recombination": 0.6, "updating": "deferred"}
+    bounds = [[-2.0, 2.0]] * n
+    t_ref, t_got = [], []
+    r_ref = oracle.minimize("rosenbrock", bounds, method="de", options=dict(opts), rng="philox",
+                            callback=lambda X, r: t_ref.append((r.fun, X.copy())))
+    o = dict(opts, backend="hip", rng="philox")
+    r_got = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=o,
+                                 callback=lambda X, r: t_got.append((r.fun, X.copy())))
+    assert len(t_ref) == len(t_got)
+    for (fa, Xa), (fb, Xb) in zip(t_ref, t_got):
+        assert fa == fb
+        assert np.array_equal(Xa, Xb)
+    assert np.array_equal(r_ref.x, r_got.x) and r_ref.nit == r_got.nit and r_ref.status == r_got.status
+
+
+def test_de_graph_equals_stepwise(sa):
+    """hipGraph replay (no callback) must give the same result as per-generation launches."""
+    n, P = 128, 4096
+    bounds = [[-5.12, 5.12]] * n
+    o = {"maxiter": 130, "popsize": P, "seed": 5, "updating": "deferred", "backend": "hip", "rng": "philox",
+         "ftol": -1.0, "xtol": 0.0}
+    a = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o))
+    b = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o), callback=lambda X, r: None)
+    assert a.nit == b.nit == 130 and a.fun == b.fun and np.array_equal(a.x, b.x)
+    ref = oracle.minimize("rosenbrock", bounds, method="de", options={k: v for k, v in o.items() if k not in ("backend", "rng")} | {"maxiter": 12}, rng="philox")
+    c = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o, maxiter=12))
+    assert ref.fun == c.fun and np.array_equal(ref.x, c.x)
