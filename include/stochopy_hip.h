@@ -173,6 +173,57 @@ int sx_graph_launch(sx_graph *g, void *stream);
 int sx_graph_destroy(sx_graph *g);
 
 /* ------------------------------------------------------------------------- *
+ * PSO / CPSO, synchronous generation
+ * replaces: cpso/_cpso.py:324-329 mutation (V = w*V + c1*r1*(pbest-X) + c2*r2*(gbest-X),
+ *           left-to-right), cpso/_constraints.py:4-10 / 44-53 (X+V, or Shrink: per-row
+ *           beta = min over violated dims of (bound-x)/v), cpso/_cpso.py:332-361 pso_sync
+ *           + _common.py:123-160 selection_sync (cand = X, x = pbest) + the objective.
+ * X, V, pbest, pbestfit are updated in place (row-local state).
+ * ------------------------------------------------------------------------- */
+typedef struct sx_pso_args {
+    double *X, *V, *pbest;  /* DEVICE (P,ld) each                                     */
+    double *pbestfit;       /* DEVICE (P)                                             */
+    double *candfit;        /* DEVICE (P) fitness of the new positions `pfit`, or NULL */
+    double *gbest;          /* DEVICE (n) copy of the best row (sx_select_finalize)   */
+    const double *lower;    /* DEVICE (n)                                             */
+    const double *upper;    /* DEVICE (n)                                             */
+    sx_state *state;        /* DEVICE                                                 */
+    double *part_f;         /* DEVICE (sx_num_partials(P,n))                          */
+    int64_t *part_i;        /* DEVICE (sx_num_partials(P,n))                          */
+    const double *r1;       /* DEVICE (P,n) rand(P,n), cpso/_cpso.py:262  (SX_RNG_HOST) */
+    const double *r2;       /* DEVICE (P,n) rand(P,n), cpso/_cpso.py:263  (SX_RNG_HOST) */
+    int64_t P;
+    int64_t ld;
+    int64_t row0;           /* global index of local row 0 (Philox counters; shards)  */
+    int32_t n;
+    int32_t fun_id;
+    int32_t constraints;    /* 0 none, 1 Shrink                                       */
+    int32_t rng;
+    int32_t maxiter;
+    int32_t pad_;
+    double w, c1, c2, xtol, ftol;
+    uint32_t key0, key1;
+} sx_pso_args;
+
+int sx_pso_generation(const sx_pso_args *a, int finalize, void *stream);
+
+/* Competitive restart, cpso/_cpso.py:405-426.
+ * sx_pso_radius: part_r[b] = max over the rows of workgroup b of ||X_i - gbest||_2 (:410)
+ *   part_r DEVICE (sx_num_partials(P,n)).
+ * sx_pso_restart_select (one workgroup, P <= 32768): radius = max(part_r)/sqrt(4n); if
+ *   radius < delta: nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09))) and the nw-th largest
+ *   pbestfit (radix descent).  out3 DEVICE uint64[3] = {nw, threshold key, radius bits}.
+ * sx_pso_restart_apply: rows with pbestfit among the nw worst get V=0, X=uniform(lower,upper),
+ *   pbest=X, pbestfit=1e30 (:420-424).  Either sel3 (device selection, Philox positions keyed
+ *   by row) or host_rows/host_x (DEVICE copies of the reference-ordered row ids and their
+ *   numpy-legacy positions, host_count rows). */
+int sx_pso_radius(const sx_pso_args *a, double *part_r, void *stream);
+int sx_pso_restart_select(const sx_pso_args *a, const double *part_r, double delta, double gamma, uint64_t *out3,
+                          void *stream);
+int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, const int64_t *host_rows, const double *host_x,
+                         int64_t host_count, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * numpy-legacy random stream (host): bit-exact MT19937 replica of what the
  * reference draws through np.random.* after np.random.seed(seed)
  * (de/_de.py:148-149, cpso/_cpso.py:153-154, cmaes/_cmaes.py:116-117;

@@ -189,11 +189,16 @@ class PhiloxStream:
         return {"r1": r1, "donors": donors, "irand": irand, "resample": resample}
 
     def pso_generation(self, gen, P, n, row0=0):
-        rows = np.arange(P, dtype=np.uint64) + np.uint64(row0)
-        return (
-            self._uniform_block(rows, n, gen, PURPOSE_PSO_R1),
-            self._uniform_block(rows, n, gen, PURPOSE_PSO_R2),
-        )
+        """32-bit uniforms, one call per two steps: slot = (q >> 1) * 64 + l;
+        words (0, 1) -> (r1, r2) for even q, words (2, 3) for odd q."""
+        rows = (np.arange(P, dtype=np.uint64) + np.uint64(row0))[:, None]
+        q, l = self._lanes(n)
+        slot = (q >> np.uint64(1)) * np.uint64(64) + l
+        odd = np.broadcast_to((q & np.uint64(1)).astype(bool), (P, n))
+        w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, PURPOSE_PSO_R1, self.k0, self.k1)
+        r1 = np.where(odd, w2, w0).astype(np.float64) / 4294967296.0
+        r2 = np.where(odd, w3, w1).astype(np.float64) / 4294967296.0
+        return r1, r2
 
     def restart_rows(self, gen, lower, upper, rows, n, row0=0):
         d = self._uniform_block(np.asarray(rows, dtype=np.uint64) + np.uint64(row0), n, gen, PURPOSE_PSO_RESTART)

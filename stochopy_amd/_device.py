@@ -64,7 +64,7 @@ class Context:
 
     def upload(self, array, dtype=None):
         t = torch()
-        a = np.ascontiguousarray(array)
+        a = np.array(array, order="C", copy=True)  # also normalises negative / zero strides
         x = t.from_numpy(a).to(self.device, non_blocking=False)
         return x if dtype is None else x.to(dtype)
 

@@ -50,7 +50,7 @@ class SxDeArgs(C.Structure):
 class SxPsoArgs(C.Structure):
     _fields_ = [
         ("X", vp), ("V", vp), ("pbest", vp), ("pbestfit", vp), ("candfit", vp), ("gbest", vp), ("lower", vp),
-        ("upper", vp), ("state", vp), ("part_f", vp), ("part_i", vp), ("plan", vp), ("r1", vp), ("r2", vp),
+        ("upper", vp), ("state", vp), ("part_f", vp), ("part_i", vp), ("r1", vp), ("r2", vp),
         ("P", i64), ("ld", i64), ("row0", i64),
         ("n", i32), ("fun_id", i32), ("constraints", i32), ("rng", i32), ("maxiter", i32), ("pad", i32),
         ("w", f64), ("c1", f64), ("c2", f64), ("xtol", f64), ("ftol", f64),
@@ -73,6 +73,10 @@ PROTOTYPES = {
     "sx_de_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.POINTER(vp)]),
     "sx_graph_launch": (C.c_int, [vp, vp]),
     "sx_graph_destroy": (C.c_int, [vp]),
+    "sx_pso_generation": (C.c_int, [C.POINTER(SxPsoArgs), C.c_int, vp]),
+    "sx_pso_radius": (C.c_int, [C.POINTER(SxPsoArgs), vp, vp]),
+    "sx_pso_restart_select": (C.c_int, [C.POINTER(SxPsoArgs), vp, f64, f64, vp, vp]),
+    "sx_pso_restart_apply": (C.c_int, [C.POINTER(SxPsoArgs), vp, vp, vp, i64, vp]),
     "sx_mt_create": (vp, [C.c_uint32]),
     "sx_mt_destroy": (None, [vp]),
     "sx_mt_seed": (None, [vp, C.c_uint32]),

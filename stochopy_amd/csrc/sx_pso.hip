@@ -1,0 +1,339 @@
+// PSO / CPSO: one fused kernel per generation (velocity + position update, Shrink
+// clamp, objective, personal-best selection, per-workgroup best) and the
+// competitive-restart kernels (swarm radius, worst-nw selection, re-seeding).
+//
+// Reference code replaced (paths relative to the reference checkout):
+//   stochopy/optimize/cpso/_cpso.py:324-329   mutation (left-to-right association)
+//   stochopy/optimize/cpso/_cpso.py:332-361   pso_sync
+//   stochopy/optimize/cpso/_constraints.py:4-10, 44-53  NoConstraint / Shrink (sync form)
+//   stochopy/optimize/cpso/_cpso.py:405-426   restart (radius, nw, worst-nw reset)
+//   stochopy/optimize/_common.py:123-130      selection (strict <, in place)
+//   stochopy/factory/benchmark.py             objective, fused
+//
+// One wavefront per particle; X, V, pbest, pbestfit are row-local and updated in place.
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+#include "sx_rowops.hpp"
+
+namespace sx {
+int make_plan_arg(int fun_id, int n, PlanArg *out);
+}
+using namespace sx;
+
+namespace {
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+template <int FUN, int RNG>
+__global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void pso_generation_kernel(const sx_pso_args a,
+                                                                                  const PlanArg plan) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sf[kMaxRowsPerBlock];
+    __shared__ int64_t si[kMaxRowsPerBlock];
+    const sx_state *st = a.state;
+    if (st->done) return;
+    const uint32_t gen = (uint32_t)(st->it + 1);
+    const int n = a.n;
+    const int64_t P = a.P, ld = a.ld;
+    const RowIds id(P);
+    const int lane = id.lane;
+    const int64_t rowc = id.rowc;
+    double *U = lds + id.wave * lds_row_stride(n);
+    double *Vn = U + n + 8;  // staging for the new velocity (the objective's A region, free until then)
+
+    const double fold = a.pbestfit[rowc];
+    double *__restrict__ xr = a.X + rowc * ld;
+    double *__restrict__ vr = a.V + rowc * ld;
+    double *__restrict__ pb = a.pbest + rowc * ld;
+    const double *__restrict__ gb = a.gbest;
+    const uint32_t grow = (uint32_t)(a.row0 + rowc);
+    const double w = a.w, c1 = a.c1, c2 = a.c2;
+    const bool shrink = a.constraints != 0;
+    const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
+    const double *r2row = RNG == SX_RNG_HOST ? a.r2 + rowc * (int64_t)n : nullptr;
+
+    // V = w*V + c1*r1*(pbest - X) + c2*r2*(gbest - X)   (cpso/_cpso.py:326)
+    double beta = __builtin_huge_val();
+    U4 wd = {0u, 0u, 0u, 0u};
+    int q = 0;
+    for (int e = lane; e < n; e += kWave, ++q) {
+        const double x = xr[e], v = vr[e];
+        double r1, r2;
+        if (RNG == SX_RNG_PHILOX) {
+            // 32-bit uniforms, one call per 2 steps: words (0,1) -> (r1,r2) of even q, (2,3) of odd q
+            if ((q & 1) == 0)
+                wd = philox4x32_10((uint32_t)(q >> 1) * 64u + (uint32_t)lane, grow, gen, kPurposePsoR1, a.key0, a.key1);
+            r1 = u32((q & 1) ? wd.z : wd.x);
+            r2 = u32((q & 1) ? wd.w : wd.y);
+        } else {
+            r1 = r1row[e];
+            r2 = r2row[e];
+        }
+        const double vn = (w * v + (c1 * r1) * (pb[e] - x)) + (c2 * r2) * (gb[e] - x);
+        Vn[e] = vn;
+        if (shrink) {  // cpso/_constraints.py:22-50: beta = min over violated dims of (bound - x)/v
+            const double xc = x + vn;
+            const double lo = a.lower[e], hi = a.upper[e];
+            if (xc < lo) beta = fmin(beta, (lo - x) / vn);
+            if (xc > hi) beta = fmin(beta, (hi - x) / vn);
+        }
+    }
+    if (shrink) {
+        beta = wave_min(beta);
+        if (beta == __builtin_huge_val()) beta = 1.0;
+    }
+    lds_wave_fence();
+    for (int e = lane; e < n; e += kWave) {
+        double vn = Vn[e];
+        if (shrink) vn = vn * beta;  // V *= beta[:, None]
+        const double xn = xr[e] + vn;
+        U[e] = xn;
+        if (id.active) {
+            vr[e] = vn;
+            xr[e] = xn;
+        }
+    }
+    const double fc = row_objective<FUN>(U, n, plan, lane);
+    const bool better = fc < fold;  // _common.py:127 strict <
+    if (id.active) {
+        if (better)
+            for (int e = lane; e < n; e += kWave) pb[e] = U[e];
+        if (lane == 0) {
+            if (better) a.pbestfit[id.row] = fc;
+            if (a.candfit != nullptr) a.candfit[id.row] = fc;
+        }
+    }
+    block_partial(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+}
+
+typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
+
+template <int RNG>
+pso_kernel_t pick_kernel(int fun_id) {
+    switch (fun_id) {
+        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG>;
+        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG>;
+        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG>;
+        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG>;
+        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG>;
+        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG>;
+    }
+    return nullptr;
+}
+
+int check_args(const sx_pso_args *a) {
+    SX_REQUIRE(a != nullptr, "sx_pso: null args");
+    SX_REQUIRE(a->X && a->V && a->pbest && a->pbestfit && a->gbest && a->state && a->part_f && a->part_i,
+               "sx_pso: null device pointer");
+    SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->ld >= a->n, "sx_pso: bad shape");
+    SX_REQUIRE(a->fun_id >= 0 && a->fun_id < SX_FUN_COUNT, "sx_pso: unknown objective");
+    SX_REQUIRE(a->rng == SX_RNG_HOST || a->rng == SX_RNG_PHILOX, "sx_pso: unknown rng mode");
+    SX_REQUIRE(a->rng != SX_RNG_HOST || (a->r1 && a->r2), "sx_pso: host draws missing");
+    SX_REQUIRE(a->constraints == 0 || (a->lower && a->upper), "sx_pso: bounds missing");
+    return 0;
+}
+
+struct Geometry {
+    unsigned blocks, threads;
+    size_t lds;
+};
+Geometry geometry(int64_t P, int n) {
+    const int rpb = rows_per_block(n);
+    return Geometry{(unsigned)((P + rpb - 1) / rpb), (unsigned)(rpb * kWave),
+                    (size_t)rpb * lds_row_stride(n) * sizeof(double)};
+}
+
+// ---------------------------------------------------------------------------
+// Competitive restart, cpso/_cpso.py:405-426
+// ---------------------------------------------------------------------------
+// per-workgroup max_i ||X_i - gbest||_2  (:410)
+__global__ __launch_bounds__(kMaxRowsPerBlock *kWave) void pso_radius_kernel(const sx_pso_args a,
+                                                                             double *__restrict__ part_r) {
+    __shared__ double sr[kMaxRowsPerBlock];
+    if (a.state->done) return;
+    const RowIds id(a.P);
+    const double *__restrict__ xr = a.X + id.rowc * a.ld;
+    double acc = 0.0;
+    for (int e = id.lane; e < a.n; e += kWave) {
+        const double d = xr[e] - a.gbest[e];
+        acc += d * d;
+    }
+    acc = sqrt(wave_sum(acc));
+    if (id.lane == 0) sr[id.wave] = id.active ? acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = sr[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmax(m, sr[k]);
+        part_r[blockIdx.x] = m;
+    }
+}
+
+// order-preserving map double -> uint64 (larger double <=> larger key)
+__device__ __forceinline__ unsigned long long sort_key(double f) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(f);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+constexpr int kSelThreads = 1024;
+constexpr int kSelPerThread = 32;  // P <= 32768 per GPU for the on-device worst-nw selection
+
+// One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
+// and the nw-th largest pbestfit is found by a 64-step radix descent over keys held in registers.
+// out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
+__global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const sx_pso_args a,
+                                                                         const double *__restrict__ part_r,
+                                                                         int64_t npart, double delta, double gamma,
+                                                                         unsigned long long *__restrict__ out) {
+    __shared__ double smax[kSelThreads / kWave];
+    __shared__ unsigned scount[kSelThreads / kWave];
+    __shared__ unsigned stotal;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (a.state->done) {
+        if (tid == 0) out[0] = 0;
+        return;
+    }
+    double m = 0.0;
+    for (int64_t k = tid; k < npart; k += kSelThreads) m = fmax(m, part_r[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
+    if (lane == 0) smax[wv] = m;
+    __syncthreads();
+    m = smax[0];
+    for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
+    const double radius = m / sqrt(4.0 * (double)a.n);
+    const int64_t it = a.state->it;
+    int64_t nw = 0;
+    if (radius < delta) {
+        const double inorm = (double)it / (double)a.maxiter;
+        nw = (int64_t)(((double)a.P - 1.0) / (1.0 + exp(1.0 / 0.09 * (inorm - gamma + 0.5))));
+    }
+    if (tid == 0) {
+        out[0] = (unsigned long long)(nw > 0 ? nw : 0);
+        out[2] = (unsigned long long)__double_as_longlong(radius);
+    }
+    if (nw <= 0) return;  // uniform
+    unsigned long long key[kSelPerThread];
+#pragma unroll
+    for (int k = 0; k < kSelPerThread; ++k) {
+        const int64_t i = (int64_t)k * kSelThreads + tid;
+        key[k] = i < a.P ? sort_key(a.pbestfit[i]) : 0ull;  // 0 < every real key
+    }
+    unsigned long long prefix = 0ull;
+    for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long cand = prefix | (1ull << bit);
+        unsigned c = 0;
+#pragma unroll
+        for (int k = 0; k < kSelPerThread; ++k) c += (key[k] >= cand) ? 1u : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+        if (lane == 0) scount[wv] = c;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned t = 0;
+            for (int k = 0; k < kSelThreads / kWave; ++k) t += scount[k];
+            stotal = t;
+        }
+        __syncthreads();
+        if ((int64_t)stotal >= nw) prefix = cand;  // at least nw keys are >= cand: the nw-th largest is too
+    }
+    if (tid == 0) out[1] = prefix;
+}
+
+// rows whose pbestfit is among the nw worst: V = 0, X = uniform(lower, upper), pbest = X, pbestfit = 1e30 (:420-424)
+// host_rows != NULL (numpy-legacy): row ids in the reference's descending-fitness order + their new positions
+__global__ __launch_bounds__(kMaxRowsPerBlock *kWave) void pso_restart_apply_kernel(
+    const sx_pso_args a, const unsigned long long *__restrict__ sel, const int64_t *__restrict__ host_rows,
+    const double *__restrict__ host_x, int64_t host_count) {
+    if (a.state->done) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t row;
+    if (host_rows != nullptr) {
+        if (slot >= host_count) return;
+        row = host_rows[slot];
+    } else {
+        if (slot >= a.P || sel[0] == 0) return;
+        row = slot;
+        if (sort_key(a.pbestfit[row]) < sel[1]) return;
+    }
+    const uint32_t gen = (uint32_t)a.state->it;  // the generation that just finished
+    const uint32_t grow = (uint32_t)(a.row0 + row);
+    double *__restrict__ xr = a.X + row * a.ld;
+    double *__restrict__ vr = a.V + row * a.ld;
+    double *__restrict__ pb = a.pbest + row * a.ld;
+    for (int e = lane; e < a.n; e += kWave) {
+        double x;
+        if (host_rows != nullptr)
+            x = host_x[slot * (int64_t)a.n + e];
+        else
+            x = a.lower[e] + (a.upper[e] - a.lower[e]) * philox_u53(e, grow, gen, kPurposePsoRestart, a.key0, a.key1);
+        vr[e] = 0.0;
+        xr[e] = x;
+        pb[e] = x;
+    }
+    if (lane == 0) a.pbestfit[row] = 1.0e30;
+}
+
+}  // namespace
+
+extern "C" int sx_pso_generation(const sx_pso_args *a, int finalize, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a->P, a->n);
+    pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id)
+                                                 : pick_kernel<SX_RNG_HOST>(a->fun_id);
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan);
+    SX_LAUNCH_CHECK();
+    if (finalize)
+        return sx_select_finalize(a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n, a->gbest, a->state,
+                                  a->maxiter, a->xtol, a->ftol, stream);
+    return 0;
+}
+
+extern "C" int sx_pso_radius(const sx_pso_args *a, double *part_r, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(part_r != nullptr, "sx_pso_radius: null scratch");
+    const Geometry g = geometry(a->P, a->n);
+    hipLaunchKernelGGL(pso_radius_kernel, dim3(g.blocks), dim3(g.threads), 0, (hipStream_t)stream, *a, part_r);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_pso_restart_select(const sx_pso_args *a, const double *part_r, double delta, double gamma,
+                                     uint64_t *out3, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(part_r && out3, "sx_pso_restart_select: null pointer");
+    SX_REQUIRE(a->P <= (int64_t)kSelThreads * kSelPerThread, "sx_pso_restart_select: P > 32768 per GPU (select on the host instead)");
+    const Geometry g = geometry(a->P, a->n);
+    hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a, part_r,
+                       (int64_t)g.blocks, delta, gamma, (unsigned long long *)out3);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, const int64_t *host_rows,
+                                    const double *host_x, int64_t host_count, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE((sel3 != nullptr) != (host_rows != nullptr), "sx_pso_restart_apply: give sel3 OR host rows");
+    SX_REQUIRE(host_rows == nullptr || (host_x != nullptr && host_count >= 0), "sx_pso_restart_apply: host rows");
+    SX_REQUIRE(a->lower && a->upper, "sx_pso_restart_apply: bounds missing");
+    const int64_t slots = host_rows ? host_count : a->P;
+    if (slots == 0) return 0;
+    const int rpb = kMaxRowsPerBlock;
+    hipLaunchKernelGGL(pso_restart_apply_kernel, dim3((unsigned)((slots + rpb - 1) / rpb)), dim3(rpb * kWave), 0,
+                       (hipStream_t)stream, *a, (const unsigned long long *)sel3, host_rows, host_x, host_count);
+    SX_LAUNCH_CHECK();
+    return 0;
+}

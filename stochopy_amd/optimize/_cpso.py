@@ -1,0 +1,280 @@
+"""PSO / CPSO front end + generation loop for ``backend="hip"``.
+
+Reference: stochopy/optimize/cpso/_cpso.py:12-179 (``minimize``: signature, defaults,
+validation, sync rule, seeding), :182-321 (``cpso`` loop: init V=0, pbest=X; per-generation
+draw order r1 then r2; return_all; callback; restart after the callback) and
+stochopy/optimize/pso/_pso.py:9-122 (PSO = CPSO with competitivity None).  The
+per-generation work -- mutation (:324-329), Shrink (cpso/_constraints.py:44-53),
+selection_sync and the objective -- is one fused HIP kernel plus the one-workgroup
+best/termination kernel; the competitive restart (:405-426) is three small kernels
+(csrc/sx_pso.hip).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _device, _lib, _rng
+from . import _common
+from ._helpers import OptimizeResult, register
+
+__all__ = ["minimize"]
+
+
+def minimize(
+    fun,
+    bounds,
+    x0=None,
+    args=(),
+    maxiter=100,
+    popsize=10,
+    inertia=0.7298,
+    cognitivity=1.49618,
+    sociability=1.49618,
+    competitivity=1.0,
+    seed=None,
+    xtol=1.0e-8,
+    ftol=1.0e-8,
+    constraints=None,
+    updating="immediate",
+    workers=1,
+    backend=None,
+    return_all=False,
+    verbosity=1.0,
+    callback=None,
+    rng=None,
+):
+    """Minimize an objective function using Competitive PSO on MI355X.
+
+    Parameters are those of the reference (cpso/_cpso.py:12-33) plus ``rng``
+    ("numpy-legacy" default = the reference's stream, or "philox" = in-kernel draws);
+    ``backend`` must be ``"hip"`` and forces synchronous updating (cpso/_cpso.py:147-150).
+    """
+    fun_id = _common.resolve_objective(fun, args)
+    lower, upper = _common.as_bounds(bounds)
+    if x0 is not None:
+        if np.ndim(x0) != 2 or np.shape(x0)[1] != len(bounds):
+            raise ValueError()
+    if popsize < 2:
+        raise ValueError()
+    if x0 is not None and len(x0) != popsize:
+        raise ValueError()
+    if not 0.0 <= inertia <= 1.0:
+        raise ValueError()
+    if not 0.0 <= cognitivity <= 4.0:
+        raise ValueError()
+    if not 0.0 <= sociability <= 4.0:
+        raise ValueError()
+    if competitivity is not None and not 0.0 <= competitivity <= 2.0:
+        raise ValueError()
+    if updating not in {"immediate", "deferred"}:
+        raise ValueError()
+    if constraints not in (None, "Shrink"):
+        raise KeyError(constraints)
+    if callback is not None and not hasattr(callback, "__call__"):
+        raise ValueError()
+    _common.resolve_backend(backend)
+    rng = _common.resolve_rng(rng)
+    workers = _common.resolve_workers(workers)
+    run = _PsoRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(inertia), float(cognitivity),
+                  float(sociability), competitivity, constraints, float(xtol), float(ftol), bool(return_all),
+                  float(verbosity), callback, rng, seed, workers)
+    return run.result()
+
+
+class _PsoRun:
+    CHECK_EVERY = 32  # philox mode: the host reads the device state every this many generations
+
+    def __init__(self, fun_id, lower, upper, x0, maxiter, P, w, c1, c2, gamma, constraints, xtol, ftol, return_all,
+                 verbosity, callback, rng, seed, workers, autorun=True):
+        self.fun_id, self.lower, self.upper = fun_id, lower, upper
+        self.maxiter, self.P, self.n = maxiter, P, len(lower)
+        self.w, self.c1, self.c2, self.gamma, self.constraints = w, c1, c2, gamma, constraints
+        self.xtol, self.ftol = xtol, ftol
+        self.return_all, self.verbosity, self.callback = return_all, verbosity, callback
+        self.rng, self.seed = rng, seed
+        if workers != 1:
+            from ..parallel import require_world
+
+            require_world(workers)
+        self.x0 = x0
+        self.ctx = _device.Context()
+        if autorun:
+            t = _device.torch()
+            with t.cuda.stream(self.ctx.stream):
+                self._run()
+
+    # ------------------------------------------------------------------ setup
+    def _setup(self):
+        ctx, P, n = self.ctx, self.P, self.n
+        t = _device.torch()
+        self.stream = _rng.make_init_stream(self.rng, self.seed)
+        if self.gamma:  # cpso/_cpso.py:215-216 (depends on maxiter)
+            self.delta = np.log(1.0 + 0.003 * P) / np.max((0.2, np.log(0.01 * self.maxiter)))
+        if self.x0 is not None:
+            X0 = np.array(self.x0, dtype=np.float64)
+        else:
+            X0 = self.stream.latin_hypercube(P, n, self.lower, self.upper)
+        self.X = ctx.upload(X0)
+        self.V = ctx.zeros((P, n))
+        self.pbest = self.X.clone()
+        self.pbestfit = ctx.empty((P,))
+        self.candfit = ctx.empty((P,))
+        self.d_lower = ctx.upload(self.lower)
+        self.d_upper = ctx.upload(self.upper)
+        npart = int(ctx.L.sx_num_partials(P, n))
+        self.npart = npart
+        self.part_f = ctx.empty((npart,))
+        self.part_i = ctx.empty((npart,), dtype=t.int64)
+        self.part_r = ctx.empty((npart,))
+        self.sel3 = ctx.zeros((3,), dtype=t.int64)
+        _device.evaluate(ctx, self.fun_id, self.X, n, f=self.pbestfit)
+        self.candfit.copy_(self.pbestfit)
+        out_i = ctx.empty((1,), dtype=t.int64)
+        out_f = ctx.empty((1,))
+        _lib.check(ctx.L.sx_argmin(_device.ptr(self.pbestfit), P, _device.ptr(self.part_f), _device.ptr(self.part_i),
+                                   npart, _device.ptr(out_i), _device.ptr(out_f), ctx.stream_ptr), "sx_argmin")
+        g = int(out_i.cpu()[0])
+        self.gbest = self.X[g].clone()
+        st = _lib.SxState(it=1, gbidx=g, gfit=float(out_f.cpu()[0]), dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
+        self.state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
+        key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
+        a = _lib.SxPsoArgs()
+        a.X, a.V, a.pbest = self.X.data_ptr(), self.V.data_ptr(), self.pbest.data_ptr()
+        a.pbestfit, a.candfit, a.gbest = self.pbestfit.data_ptr(), self.candfit.data_ptr(), self.gbest.data_ptr()
+        a.lower, a.upper, a.state = self.d_lower.data_ptr(), self.d_upper.data_ptr(), self.state.data_ptr()
+        a.part_f, a.part_i = self.part_f.data_ptr(), self.part_i.data_ptr()
+        a.P, a.ld, a.row0, a.n = P, n, 0, n
+        a.fun_id = self.fun_id
+        a.constraints = 1 if self.constraints == "Shrink" else 0
+        a.rng = _lib.SX_RNG_PHILOX if self.rng == "philox" else _lib.SX_RNG_HOST
+        a.maxiter = self.maxiter
+        a.w, a.c1, a.c2, a.xtol, a.ftol = self.w, self.c1, self.c2, self.xtol, self.ftol
+        a.key0, a.key1 = key0, key1
+        self.args = a
+        if self.rng == "numpy-legacy":
+            self.h_r = [t.empty((P, n), dtype=t.float64).pin_memory() for _ in range(2)]
+            self.d_r = [ctx.empty((P, n)) for _ in range(2)]
+            a.r1, a.r2 = self.d_r[0].data_ptr(), self.d_r[1].data_ptr()
+        if self.return_all:
+            self.nout = int(np.ceil(self.verbosity * P))
+            rows = max(self.nout, 1)
+            self.xall = ctx.empty((self.maxiter, rows, n))
+            self.funall = ctx.empty((self.maxiter, rows))
+            if self.nout > 0:
+                self.xall[0].copy_(self.X[: self.nout])
+                self.funall[0].copy_(self.pbestfit[: self.nout])
+            else:
+                self.xall[0, 0].copy_(self.gbest)
+                self.funall[0, 0] = st.gfit
+        self.st = st
+        self.restarts = []
+
+    # --------------------------------------------------------------- helpers
+    def _record(self, it):
+        if not self.return_all:
+            return
+        if self.nout > 0:
+            self.xall[it - 1].copy_(self.X[: self.nout])
+            self.funall[it - 1].copy_(self.candfit[: self.nout])
+        else:
+            k = int(self.candfit.argmin())
+            self.xall[it - 1, 0].copy_(self.X[k])
+            self.funall[it - 1, 0] = self.candfit[k]
+
+    def _partial_result(self, st):
+        res = OptimizeResult(x=self.gbest.cpu().numpy(), fun=st.gfit, nfev=st.it * self.P, nit=st.it)
+        if self.return_all:
+            res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
+        return res
+
+    def _generation(self):
+        ctx = self.ctx
+        if self.rng == "numpy-legacy":  # cpso/_cpso.py:262-263: r1 then r2
+            for h, d in zip(self.h_r, self.d_r):
+                self.stream.random(None, out=h.numpy())
+                d.copy_(h, non_blocking=True)
+        _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_pso_generation")
+
+    def _restart_device(self):
+        """cpso/_cpso.py:405-426 entirely on the device (Philox positions keyed by row)."""
+        ctx, a = self.ctx, C.byref(self.args)
+        _lib.check(ctx.L.sx_pso_radius(a, _device.ptr(self.part_r), ctx.stream_ptr), "sx_pso_radius")
+        _lib.check(ctx.L.sx_pso_restart_select(a, _device.ptr(self.part_r), float(self.delta), float(self.gamma),
+                                               _device.ptr(self.sel3), ctx.stream_ptr), "sx_pso_restart_select")
+        _lib.check(ctx.L.sx_pso_restart_apply(a, _device.ptr(self.sel3), None, None, 0, ctx.stream_ptr),
+                   "sx_pso_restart_apply")
+
+    def _restart_host_order(self, it):
+        """numpy-legacy stream: the new positions are drawn on the host for the rows in the reference's
+        descending-fitness order (cpso/_cpso.py:420-422), so row selection happens on the host too."""
+        ctx, P, n = self.ctx, self.P, self.n
+        _lib.check(ctx.L.sx_pso_radius(C.byref(self.args), _device.ptr(self.part_r), ctx.stream_ptr), "sx_pso_radius")
+        radius = float(self.part_r.max().cpu()) / np.sqrt(4.0 * n)
+        if not radius < self.delta:
+            return
+        inorm = it / self.maxiter
+        nw = int((P - 1.0) / (1.0 + np.exp(1.0 / 0.09 * (inorm - self.gamma + 0.5))))
+        if nw <= 0:
+            return
+        rows = self.pbestfit.cpu().numpy().argsort()[: -nw - 1 : -1]
+        newx = self.stream.uniform_rows(self.lower, self.upper, nw)
+        d_rows = ctx.upload(np.ascontiguousarray(rows, dtype=np.int64))
+        d_newx = ctx.upload(newx)
+        _lib.check(ctx.L.sx_pso_restart_apply(C.byref(self.args), None, _device.ptr(d_rows), _device.ptr(d_newx), nw,
+                                              ctx.stream_ptr), "sx_pso_restart_apply")
+        ctx.sync()  # d_rows / d_newx must outlive the kernel
+        self.restarts.append((it, nw))
+
+    # ------------------------------------------------------------------ loop
+    def _run(self):
+        ctx = self.ctx
+        self._setup()
+        st = self.st
+        if self.callback is not None:
+            self.callback(self.X.cpu().numpy(), self._partial_result(st))
+        stepwise = self.rng == "numpy-legacy" or self.callback is not None or self.return_all
+        while not st.done:
+            if stepwise:
+                self._generation()
+                self._record(st.it + 1)
+                st = ctx.read_state(self.state)
+                if self.callback is not None:
+                    self.callback(self.X.cpu().numpy(), self._partial_result(st))
+                if not st.done and self.gamma:
+                    if self.rng == "numpy-legacy":
+                        self._restart_host_order(st.it)
+                    else:
+                        self._restart_device()
+            else:
+                self.enqueue(min(max(self.maxiter - st.it, 1), self.CHECK_EVERY))
+                st = ctx.read_state(self.state)
+        self.st = st
+        status = int(st.status)
+        res = OptimizeResult(
+            x=self.gbest.cpu().numpy(),
+            success=status >= 0,
+            status=status,
+            message=_common.messages[status],
+            fun=float(st.gfit),
+            nfev=int(st.it) * self.P,
+            nit=int(st.it),
+        )
+        if self.return_all:
+            res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
+        if self.rng == "numpy-legacy":
+            self.stream.sync_back()
+        ctx.sync()
+        self._res = res
+
+    def enqueue(self, ngen):
+        """Enqueue `ngen` generations (and their restarts) without host synchronisation (Philox mode)."""
+        for _ in range(ngen):
+            self._generation()
+            if self.gamma:
+                self._restart_device()
+
+    def result(self):
+        return self._res
+
+
+register("cpso", minimize)
