@@ -224,6 +224,31 @@ int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, const int64
                          int64_t host_count, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * CMA-ES device kernels (fp64 MFMA, v_mfma_f64_16x16x4_f64, LDS-tiled 64x64x32)
+ * sx_cmaes_sample   replaces cmaes/_cmaes.py:232-237:
+ *     arx[i,:] = xmean + sigma * dot(B, D * Z[i,:])          Z (P,n) standard normals
+ * sx_cmaes_recombine replaces cmaes/_cmaes.py:274:
+ *     xmean = dot(w, arx[idx[:mu], :])                        idx DEVICE int64 (mu), best first
+ * sx_cmaes_rank_mu  replaces cmaes/_cmaes.py:290-295 (in place on C, full matrix as the reference):
+ *     artmp = (arx[idx[:mu]] - xold) / sigma
+ *     C = C*(1-c1-cmu) + cmu * artmp^T diag(w) artmp + c1 * outer(pc,pc) + tmp_coef * C_old
+ *     with tmp_coef = 0 when `cond` holds, else c1*cc*(2-cc)  (:291)
+ * sx_cmaes_normals  in-kernel Philox Box-Muller normals (throughput mode of :234)
+ * sx_symmetrize_upper replaces cmaes/_cmaes.py:303: C = triu(C) + triu(C,1).T
+ * All pointers DEVICE.  The eigendecomposition (:304, numpy/LAPACK in the reference) and the
+ * scalar path/step-size/convergence logic stay on the host.
+ * ------------------------------------------------------------------------- */
+int sx_cmaes_sample(const double *xmean, double sigma, const double *B, const double *D, const double *Z, double *arx,
+                    int64_t P, int n, void *stream);
+int sx_cmaes_recombine(const double *arx, const int64_t *idx, const double *w, int mu, int n, double *xmean,
+                       void *stream);
+int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
+                     const double *pc, double c1, double cmu, double tmp_coef, double *C, int n, void *stream);
+int sx_cmaes_normals(double *Z, int64_t P, int n, int64_t row0, uint32_t gen, uint32_t key0, uint32_t key1,
+                     void *stream);
+int sx_symmetrize_upper(double *C, int n, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * numpy-legacy random stream (host): bit-exact MT19937 replica of what the
  * reference draws through np.random.* after np.random.seed(seed)
  * (de/_de.py:148-149, cpso/_cpso.py:153-154, cmaes/_cmaes.py:116-117;

@@ -1,0 +1,267 @@
+"""CMA-ES front end + generation loop for ``backend="hip"``.
+
+Reference: stochopy/optimize/cmaes/_cmaes.py:12-140 (``minimize``) and :143-357 (``cmaes``
+loop), :360-434 (``converge``).  On the device (csrc/sx_cmaes.hip, csrc/sx_core.hip):
+sampling ``arx = xmean + sigma*B*(D o z)`` and the covariance update as fp64 MFMA
+contractions, the objective (fused un-standardisation), the recombination of the
+mean.  On the host, as in the reference: ranking (``np.argsort``), the evolution paths,
+the step size, the ten stopping rules and -- SURVEY.md section 8f rank 1, "next" -- the
+eigendecomposition (``numpy.linalg.eigh`` = LAPACK, the reference's own third-party call),
+which also fixes the eigenvector signs the same-seed parity depends on.
+``constraints="Penalize"`` is outside the hot-path scope.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _device, _lib, _rng
+from . import _common
+from ._helpers import OptimizeResult, register
+
+__all__ = ["minimize"]
+
+
+def minimize(
+    fun,
+    bounds,
+    x0=None,
+    args=(),
+    maxiter=100,
+    popsize=10,
+    sigma=0.1,
+    muperc=0.5,
+    seed=None,
+    xtol=1.0e-8,
+    ftol=1.0e-8,
+    constraints=None,
+    workers=1,
+    backend=None,
+    return_all=False,
+    verbosity=1.0,
+    callback=None,
+    rng=None,
+):
+    """Minimize an objective function using CMA-ES on MI355X (reference cmaes/_cmaes.py:12-30)."""
+    fun_id = _common.resolve_objective(fun, args)
+    lower, upper = _common.as_bounds(bounds)
+    if x0 is not None:
+        if np.ndim(x0) != 1 or len(x0) != len(bounds):
+            raise ValueError()
+    if sigma <= 0.0:
+        raise ValueError()
+    if not 0.0 < muperc <= 1.0:
+        raise ValueError()
+    if constraints is not None:
+        if constraints == "Penalize":
+            raise NotImplementedError("constraints='Penalize' is not on the MI355X hot path; use the reference for it")
+        raise KeyError(constraints)
+    if callback is not None and not hasattr(callback, "__call__"):
+        raise ValueError()
+    _common.resolve_backend(backend)
+    rng = _common.resolve_rng(rng)
+    _common.resolve_workers(workers)
+    run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
+                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed)
+    return run.result()
+
+
+def _stop_status(it, n, maxiter, xmean, xold, besthist, arfit, order, sigma, insigma, ilim, pc, xtol, ftol, diagC, B, D):
+    """The ten ordered stopping rules of cmaes/_cmaes.py:360-434 (including the zero-padded history reads)."""
+    axis = int(np.floor(np.mod(it, n)))
+    sd = np.sqrt(diagC)
+    fbest = arfit[order[0]]
+    if it >= maxiter:
+        return -1
+    if np.linalg.norm(xold - xmean) <= xtol and fbest < ftol:
+        return 0
+    if fbest <= ftol:
+        return 1
+    if (np.abs(0.1 * sigma * B[:, axis] * D[axis]) < 1.0e-10).all():
+        return -2
+    if (0.2 * sigma * sd < 1.0e-10).any():
+        return -3
+    if D.max() > 1.0e7 * D.min():
+        return -4
+    if it >= ilim:
+        window = besthist[it - ilim : it + 1]
+        if window.max() - window.min() < 1.0e-10:
+            return -5
+    if (sigma * sd > 1.0e3 * insigma).any():
+        return -6
+    if it > 2:
+        joined = np.append(arfit, besthist)
+        if joined.max() - joined.min() < 1.0e-12:
+            return -7
+    if (sigma * np.append(np.abs(pc), sd.max()) < 1.0e-11 * insigma).all():
+        return -8
+    return None
+
+
+class _CmaRun:
+    def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, return_all, verbosity,
+                 callback, rng, seed):
+        self.fun_id, self.lower, self.upper, self.x0 = fun_id, lower, upper, x0
+        self.maxiter, self.P, self.n = maxiter, P, len(lower)
+        self.sigma0, self.muperc, self.xtol, self.ftol = sigma, muperc, xtol, ftol
+        self.return_all, self.verbosity, self.callback = return_all, verbosity, callback
+        self.rng, self.seed = rng, seed
+        self.ctx = _device.Context()
+        t = _device.torch()
+        with t.cuda.stream(self.ctx.stream):
+            self._run()
+
+    def _run(self):
+        ctx, L, n, P = self.ctx, self.ctx.L, self.n, self.P
+        t = _device.torch()
+        sp = ctx.stream_ptr
+        ptr = _device.ptr
+        stream = _rng.make_init_stream(self.rng, self.seed)
+        key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
+
+        # standardisation to [-1, 1]^n (cmaes/_cmaes.py:167-173)
+        xm = 0.5 * (self.upper + self.lower)
+        xstd = 0.5 * (self.upper - self.lower)
+
+        def unstd(x):
+            return x * xstd + xm
+
+        d_xm, d_xstd = ctx.upload(xm), ctx.upload(xstd)
+        xmean = stream.uniform(-1.0, 1.0, n) if self.x0 is None else (np.asarray(self.x0, dtype=np.float64) - xm) / xstd
+
+        # strategy parameters (cmaes/_cmaes.py:184-205)
+        mu = int(self.muperc * P)
+        w = np.log(mu + 0.5) - np.log(np.arange(1, mu + 1))
+        w /= w.sum()
+        mueff = w.sum() ** 2 / np.square(w).sum()
+        cc = (4.0 + mueff / n) / (n + 4.0 + 2.0 * mueff / n)
+        cs = (mueff + 2.0) / (n + mueff + 5.0)
+        c1 = 2.0 / ((n + 1.3) ** 2 + mueff)
+        cmu = min(1.0 - c1, 2.0 * (mueff - 2.0 + 1.0 / mueff) / ((n + 2.0) ** 2 + mueff))
+        damps = 1.0 + 2.0 * max(0.0, np.sqrt((mueff - 1.0) / (n + 1.0)) - 1.0) + cs
+        chind = np.sqrt(n) * (1.0 - 1.0 / (4.0 * n) + 1.0 / (21.0 * n**2))
+
+        pc = np.zeros(n)
+        ps = np.zeros(n)
+        B = np.eye(n)
+        D = np.ones(n)
+        invsqrtC = np.eye(n)
+        diagC = np.ones(n)
+        sigma = self.sigma0
+
+        # device state
+        d_w = ctx.upload(w)
+        d_C = ctx.upload(np.eye(n))
+        d_B = ctx.upload(B)
+        d_D = ctx.upload(D)
+        d_Z = ctx.empty((P, n))
+        d_arx = ctx.empty((P, n))
+        d_fit = ctx.empty((P,))
+        d_xmean = ctx.upload(xmean)
+        d_xold = ctx.empty((n,))
+        d_pc = ctx.empty((n,))
+        d_idx = ctx.empty((mu,), dtype=t.int64)
+        h_Z = t.empty((P, n), dtype=t.float64).pin_memory() if self.rng == "numpy-legacy" else None
+
+        if self.return_all:
+            nout = int(np.ceil(self.verbosity * P))
+            xall = np.empty((self.maxiter, max(1, nout), n))
+            funall = np.empty((self.maxiter, max(1, nout)))
+
+        nfev = 0
+        eigeneval = 0
+        besthist = np.zeros(self.maxiter)
+        ilim = int(10.0 + 30.0 * n / P)
+        insigma = sigma
+        it = 0
+        while True:
+            it += 1
+            # ---- sample (device GEMM); normals from the numpy-legacy stream or in-kernel Philox ----
+            if self.rng == "numpy-legacy":
+                stream.randn(None, out=h_Z.numpy())  # P x randn(n), row by row == one block (cmaes/_cmaes.py:234)
+                d_Z.copy_(h_Z, non_blocking=True)
+            else:
+                _lib.check(L.sx_cmaes_normals(ptr(d_Z), P, n, 0, it, key0, key1, sp), "sx_cmaes_normals")
+            _lib.check(L.sx_cmaes_sample(ptr(d_xmean), sigma, ptr(d_B), ptr(d_D), ptr(d_Z), ptr(d_arx), P, n, sp),
+                       "sx_cmaes_sample")
+            # ---- evaluate: fun(unstandardize(x)) fused (cmaes/_cmaes.py:173, 258) ----
+            _device.evaluate(ctx, self.fun_id, d_arx, n, f=d_fit, xm=d_xm, xstd=d_xstd)
+            arfit = d_fit.cpu().numpy()
+            nfev += P
+            if self.return_all:
+                if nout > 0:
+                    xall[it - 1] = unstd(d_arx[:nout].cpu().numpy())
+                    funall[it - 1] = arfit[:nout]
+                else:
+                    k = int(arfit.argmin())
+                    xall[it - 1] = unstd(d_arx[k].cpu().numpy())
+                    funall[it - 1] = arfit[k]
+            # ---- rank and recombine (cmaes/_cmaes.py:272-277) ----
+            order = np.argsort(arfit)
+            d_idx.copy_(t.from_numpy(np.ascontiguousarray(order[:mu], dtype=np.int64)), non_blocking=False)
+            xold = xmean
+            d_xold.copy_(d_xmean)
+            _lib.check(L.sx_cmaes_recombine(ptr(d_arx), ptr(d_idx), ptr(d_w), mu, n, ptr(d_xmean), sp),
+                       "sx_cmaes_recombine")
+            xmean = d_xmean.cpu().numpy()
+            besthist[it - 1] = arfit[order[0]]
+            # ---- evolution paths (cmaes/_cmaes.py:280-287), host vectors ----
+            step = xmean - xold
+            ps = (1.0 - cs) * ps + np.sqrt(cs * (2.0 - cs) * mueff) * np.dot(invsqrtC, step) / sigma
+            cond = np.linalg.norm(ps) / np.sqrt(1.0 - (1.0 - cs) ** (2.0 * nfev / P)) / chind < 1.4 + 2.0 / (n + 1.0)
+            pc *= 1.0 - cc
+            if cond:
+                pc += np.sqrt(cc * (2.0 - cc) * mueff) * step / sigma
+            # ---- covariance update on the device (cmaes/_cmaes.py:290-295) ----
+            d_pc.copy_(t.from_numpy(pc), non_blocking=False)
+            tmp_coef = 0.0 if cond else c1 * cc * (2.0 - cc)
+            _lib.check(L.sx_cmaes_rank_mu(ptr(d_arx), ptr(d_idx), ptr(d_w), mu, ptr(d_xold), sigma, ptr(d_pc), c1, cmu,
+                                          tmp_coef, ptr(d_C), n, sp), "sx_cmaes_rank_mu")
+            # ---- step size (cmaes/_cmaes.py:298) ----
+            sigma *= np.exp((cs / damps) * (np.linalg.norm(ps) / chind - 1.0))
+            # ---- eigendecomposition (cmaes/_cmaes.py:301-309): host LAPACK, as in the reference ----
+            if nfev - eigeneval > P / (c1 + cmu) / n / 10.0:
+                eigeneval = nfev
+                _lib.check(L.sx_symmetrize_upper(ptr(d_C), n, sp), "sx_symmetrize_upper")
+                Ch = d_C.cpu().numpy()
+                D, B = np.linalg.eigh(Ch)
+                o = np.argsort(D)
+                D = D[o]
+                B = B[:, o]
+                D = np.sqrt(D)
+                invsqrtC = np.dot(np.dot(B, np.diag(1.0 / D)), B.T)
+                d_B.copy_(t.from_numpy(np.ascontiguousarray(B)))
+                d_D.copy_(t.from_numpy(np.ascontiguousarray(D)))
+                diagC = np.diag(Ch).copy()
+            else:
+                diagC = d_C.diagonal().cpu().numpy()
+            status = _stop_status(it, n, self.maxiter, xmean, xold, besthist, arfit, order, sigma, insigma, ilim, pc,
+                                  self.xtol, self.ftol, diagC, B, D)
+            if self.callback is not None:
+                res = OptimizeResult(x=unstd(d_arx[int(order[0])].cpu().numpy()), fun=arfit[order[0]], nfev=nfev, nit=it)
+                if self.return_all:
+                    res.update({"xall": xall[:it], "funall": funall[:it]})
+                self.callback(unstd(d_arx.cpu().numpy()), res)
+            if status is not None:
+                break
+
+        res = OptimizeResult(
+            x=unstd(d_arx[int(order[0])].cpu().numpy()),
+            success=status >= 0,
+            status=status,
+            message=_common.messages[status],
+            fun=arfit[order[0]],
+            nfev=nfev,
+            nit=it,
+        )
+        if self.return_all:
+            res.update({"xall": xall[:it], "funall": funall[:it]})
+        if self.rng == "numpy-legacy":
+            stream.sync_back()
+        ctx.sync()
+        self._res = res
+
+    def result(self):
+        return self._res
+
+
+register("cmaes", minimize)
