@@ -57,6 +57,9 @@ int sx_abi_version(void);
 const char *sx_last_error(void);
 /* number of visible HIP devices (<0 on error); used by the loader to fail loudly */
 int sx_device_count(void);
+/* sizeof(sx_state / sx_de_args / sx_pso_args) as compiled: lets a binding check its struct mirror
+ * (which: 0 state, 1 DE args, 2 PSO args; -1 otherwise) */
+int sx_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
  * Summation plan: numpy's pairwise add.reduce order for a length-m vector

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "sx_abi_version": (C.c_int, []),
     "sx_last_error": (C.c_char_p, []),
     "sx_device_count": (C.c_int, []),
+    "sx_struct_size": (C.c_int, [C.c_int]),
     "sx_sum_plan": (C.c_int, [i64, vp, C.c_int]),
     "sx_fun_terms": (i64, [C.c_int, C.c_int]),
     "sx_num_partials": (i64, [i64, C.c_int]),

@@ -21,6 +21,14 @@ using namespace sx;
 
 extern "C" int sx_abi_version(void) { return SX_ABI_VERSION; }
 extern "C" const char *sx_last_error(void) { return g_error.c_str(); }
+extern "C" int sx_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(sx_state);
+        case 1: return (int)sizeof(sx_de_args);
+        case 2: return (int)sizeof(sx_pso_args);
+    }
+    return -1;
+}
 extern "C" int sx_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -1,0 +1,263 @@
+"""CPU-only tests: host RNG replica vs numpy, the C-ABI surface, host-side API logic.
+
+No GPU: these load the shared library (hipcc cross-compiled it) and call only host entry points.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, unhex
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from stochopy_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    """Every function include/stochopy_hip.h declares must resolve in the .so (and be bound in _lib.PROTOTYPES)."""
+    from stochopy_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "stochopy_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sx_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} not exported"
+        assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) <= declared | {"sx_abi_version"}
+    assert lib.sx_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(lib):
+    from stochopy_amd import _lib
+
+    assert C.sizeof(_lib.SxState) == 64 == lib.sx_struct_size(0)
+    assert C.sizeof(_lib.SxDeArgs) == lib.sx_struct_size(1)
+    assert C.sizeof(_lib.SxPsoArgs) == lib.sx_struct_size(2)
+    # field offsets of the scalars that follow the pointer block
+    assert _lib.SxDeArgs.P.offset == 14 * 8 and _lib.SxDeArgs.key0.offset == C.sizeof(_lib.SxDeArgs) - 8
+    assert _lib.SxPsoArgs.P.offset == 13 * 8 and _lib.SxPsoArgs.key0.offset == C.sizeof(_lib.SxPsoArgs) - 8
+
+
+class Stream:
+    def __init__(self, seed):
+        from stochopy_amd import _rng
+
+        state = np.random.get_state()
+        self.s = _rng.LegacyHostStream(seed)
+        np.random.set_state(state)
+
+
+def test_rng_stream_golden(lib):
+    """tests/golden/rng_stream.json: the call sequence captured from numpy's legacy global stream."""
+    g = load_golden("rng_stream.json")
+    s = Stream(g["seed"]).s
+    lo, hi = np.array([-1.0, 0.0, 2.5]), np.array([1.0, 10.0, 2.75])
+    for call in g["calls"]:
+        name = call["call"]
+        if name == "rand(3,4)":
+            got = s.random((3, 4)).ravel()
+        elif name.startswith("permutation(delete"):
+            p = s.permutation(7)
+            got = np.delete(np.arange(8), 3)[p]
+        elif name == "permutation(8)":
+            got = s.permutation(8)
+        elif name == "randint(128,size=10)":
+            got = s.randint(128, 10)
+        elif name == "randint(2)":
+            got = s.randint(2, 1)
+        elif name == "randint(100,size=7)":
+            got = s.randint(100, 7)
+        elif name in ("randn(3)",):
+            got = s.randn((3,))
+        elif name.startswith("uniform(lo,hi,(4,3))"):
+            got = s.uniform_rows(lo, hi, 4).ravel()
+        elif name == "uniform(-1,1,5)":
+            got = s.uniform(-1.0, 1.0, 5)
+        elif name == "uniform(size=(2,3))":
+            got = s.random((2, 3)).ravel()
+        elif name == "uniform(0.25,0.75)":
+            got = s.uniform(0.25, 0.75, 1)
+        elif name == "normal(0,1,4)":
+            got = s.randn((4,))
+        elif name.startswith("randint(2**32"):
+            got = s.randint(4294967296, 4)
+        else:
+            raise AssertionError(name)
+        want = unhex(call["f64"]) if "f64" in call else np.array(call["i64"])
+        assert np.array_equal(np.asarray(got).ravel(), np.asarray(want).ravel()), name
+    for entry in g["long"]:
+        s = Stream(entry["seed"]).s
+        import hashlib
+
+        d = s.random((1000,))
+        assert hashlib.sha256(d.tobytes()).hexdigest() == entry["rand1000_sha"]
+        z = s.randn((1001,))
+        assert hashlib.sha256(z.tobytes()).hexdigest() == entry["randn1001_sha"]
+        assert [int(v) for v in s.permutation(257)] == entry["permutation257"]
+        r = s.randint(1000, 500)
+        assert int(r.sum()) == entry["randint1000x500_sum"]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 42, 2**32 - 1])
+def test_rng_matches_numpy_live(lib, seed):
+    """Same draws as numpy.random.RandomState, incl. the DE donor permutations and LHS."""
+    s = Stream(seed).s
+    rs = np.random.RandomState(seed)
+    assert np.array_equal(s.random((5, 7)), rs.rand(5, 7))
+    P, k = 37, 5
+    don = s.de_donors(P, k)
+    ref = np.transpose([rs.permutation(np.delete(np.arange(P), i)) for i in range(P)])[:k]
+    assert np.array_equal(don, ref)
+    assert np.array_equal(s.randint(13, P), rs.randint(13, size=P))
+    lo, hi = np.linspace(-3, -1, 6), np.linspace(1, 4, 6)
+    assert np.array_equal(s.uniform_rows(lo, hi, 9), rs.uniform(lo, hi, (9, 6)))
+    assert np.array_equal(s.randn((4, 5)), rs.randn(4, 5))  # leaves a cached gaussian
+    assert np.array_equal(s.randn((3,)), rs.randn(3))
+
+
+def test_rng_global_state_interchange(lib):
+    """seed=None continues numpy's global stream; sync_back() hands the advanced state back."""
+    from stochopy_amd import _rng
+
+    np.random.seed(123)
+    a = np.random.rand(3)
+    s = _rng.LegacyHostStream(None)
+    b = s.random((4,))
+    s.sync_back()
+    c = np.random.rand(2)
+    np.random.seed(123)
+    assert np.array_equal(np.concatenate([a, b, c]), np.random.rand(9))
+
+
+def test_lhs_matches_oracle(lib):
+    import oracle
+    from oracle import engine as oe
+
+    lo, hi = np.full(5, -2.0), np.linspace(1, 3, 5)
+    got = Stream(9).s.latin_hypercube(24, 5, lo, hi)
+    want = oe.latin_hypercube(oracle.LegacyStream(9), 24, 5, lo, hi)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("m", [0, 1, 7, 8, 9, 127, 128, 129, 135, 255, 256, 1023, 1024, 6143])
+def test_sum_plan_reproduces_numpy_pairwise(lib, m):
+    """sx_sum_plan drives the kernels' summation order: replay it in Python and compare with ndarray.sum()."""
+    buf = np.zeros(4 + 2 * (m // 64 + 2), dtype=np.int32)
+    got = lib.sx_sum_plan(m, buf.ctypes.data, buf.size)
+    assert got >= 4
+    nleaf, tail, mb, depth = (int(v) for v in buf[:4])
+    assert mb == m // 8 and tail == (m % 8 if m >= 8 else m)
+    a = np.random.RandomState(m).uniform(-1e3, 1e3, m)
+    stack, b0 = [], 0
+    cur = 0.0
+    for t in range(nleaf):
+        b1, merges = int(buf[4 + 2 * t]), int(buf[5 + 2 * t])
+        r = [a[b0 * 8 + j] for j in range(8)]
+        for b in range(b0 + 1, b1):
+            for j in range(8):
+                r[j] = r[j] + a[b * 8 + j]
+        cur = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        if t == nleaf - 1:
+            for k in range(tail):
+                cur = cur + a[b1 * 8 + k]
+        stack.append(cur)
+        assert len(stack) <= depth
+        for _ in range(merges):
+            top = stack.pop()
+            stack[-1] = stack[-1] + top
+        b0 = b1
+    if nleaf == 0:
+        for k in range(tail):
+            cur = cur + a[k]
+        stack = [cur]
+    assert len(stack) == 1
+    assert 0.0 + stack[0] == a.sum()
+
+
+def test_api_surface_and_validation():
+    """Signatures/defaults of the reference (de/_de.py:13-33 etc.) and its bare ValueError/TypeError validation."""
+    import inspect
+
+    import stochopy_amd as sa
+
+    sig = inspect.signature(sa.optimize.minimize)
+    assert list(sig.parameters) == ["fun", "bounds", "x0", "args", "method", "options", "callback"]
+    assert sig.parameters["method"].default == "de"
+    de = inspect.signature(sa.optimize.de).parameters
+    assert (de["maxiter"].default, de["popsize"].default, de["mutation"].default, de["recombination"].default,
+            de["strategy"].default, de["updating"].default, de["xtol"].default) == (100, 10, 0.5, 0.9, "best1bin",
+                                                                                    "immediate", 1e-8)
+    cp = inspect.signature(sa.optimize.cpso).parameters
+    assert (cp["inertia"].default, cp["cognitivity"].default, cp["sociability"].default,
+            cp["competitivity"].default) == (0.7298, 1.49618, 1.49618, 1.0)
+    assert "competitivity" not in inspect.signature(sa.optimize.pso).parameters
+    cm = inspect.signature(sa.optimize.cmaes).parameters
+    assert (cm["sigma"].default, cm["muperc"].default) == (0.1, 0.5) and "updating" not in cm
+    f, b = sa.factory.rosenbrock, [[-5.12, 5.12]] * 2
+    with pytest.raises(TypeError):
+        sa.optimize.minimize(42, b)
+    with pytest.raises(TypeError):  # arbitrary Python callables are refused, never evaluated on the host
+        sa.optimize.minimize(lambda x: float(np.sum(x)), b, options={"backend": "hip"})
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(f, [-1, 1])
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(f, b, options={"popsize": 1})
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(f, b, options={"mutation": 3.0})
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(f, b, method="cpso", options={"inertia": 1.5})
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(f, b, method="cmaes", options={"sigma": 0.0})
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(f, b, options={"backend": "cuda"})
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(f, b, options={"backend": "loky"})
+    with pytest.raises(KeyError):
+        sa.optimize.minimize(f, b, method="na")
+
+
+def test_optimize_result_surface():
+    """stochopy/_common.py:1-35: dict with attribute access; repr sorted, right-justified, hides xall/funall."""
+    from stochopy_amd.optimize import OptimizeResult
+
+    r = OptimizeResult(x=np.array([1.0]), fun=2.0, nit=3, xall=np.zeros(3), funall=np.zeros(3))
+    assert r.fun == 2.0 and r["nit"] == 3 and sorted(dir(r)) == ["fun", "funall", "nit", "x", "xall"]
+    # width = longest key (incl. the hidden ones) + 1, as in the reference
+    assert repr(r).splitlines()[0] == "    fun: 2.0" and "xall" not in repr(r)
+    with pytest.raises(AttributeError):
+        r.missing
+    assert repr(OptimizeResult()) == "OptimizeResult()"
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a ROCm device the product path must raise -- there is no CPU fallback."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    import stochopy_amd as sa
+    from stochopy_amd._device import NoDeviceError
+
+    with pytest.raises(NoDeviceError):
+        sa.optimize.minimize(sa.factory.sphere, [[-1, 1]] * 3, options={"maxiter": 3, "popsize": 8, "seed": 0})
+    with pytest.raises(NoDeviceError):
+        sa.factory.sphere(np.ones(4))
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "stochopy_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
