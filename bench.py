@@ -106,12 +106,9 @@ def main():
     K, W = args.steps, args.warmup
     lower = np.full(n, -5.12)
     upper = np.full(n, 5.12)
-    run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, P, 0.5, 0.9, strategy, None, 0.0, -1.0,
-                     False, 1.0, None, "philox", 1234 + rank, 1, autorun=False)
-    if world > 1:
-        from stochopy_amd import parallel
-
-        run.attach_world(parallel.World(dist, row0=rank * P))
+    # weak scaling: every GPU owns P rows of a global population of world*P (same seed on every rank)
+    run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, world * P, 0.5, 0.9, strategy, None, 0.0,
+                     -1.0, False, 1.0, None, "philox", 1234, world, autorun=False)
     ctx = run.ctx
 
     def barrier():

@@ -166,6 +166,21 @@ int sx_select_finalize(const double *part_f, const int64_t *part_i, int64_t npar
                        double xtol, double ftol, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Multi-GPU (population sharded by rows, one process per GPU): the per-generation exchange that
+ * takes the place of the reference's MPI Bcast/Allreduce (stochopy/optimize/_common.py:58-72).
+ * sx_shard_best: this shard's best of the generation being finalised ->
+ *     record (n+2 doubles) = [ f, (double)(row0 + local row), row[0..n) ]
+ * The caller all-gathers the records of all ranks (RCCL over xGMI) into `records` (world,(n+2)).
+ * sx_gather_finalize: first minimum over the records by (f, global row) = np.argmin over the whole
+ *     population, then the same dx / status / gbest / state update as sx_select_finalize.
+ * ------------------------------------------------------------------------- */
+int sx_shard_best(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                  const double *rows1, int64_t ld, int n, const sx_state *state, int64_t row0, double *record,
+                  void *stream);
+int sx_gather_finalize(const double *records, int world, int n, double *gbest, sx_state *state, int maxiter,
+                       double xtol, double ftol, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * hipGraph of `ngen` identical generations (all per-generation state lives in
  * `state` on the device, so one instantiated graph is replayed).
  * Only valid for SX_RNG_PHILOX (host draws change every generation).

@@ -392,6 +392,38 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
     return _final(unstd(arx[order[0]]), arfit[order[0]], status, nfev, it, hist)
 
 
+def run_de_sharded(fobj, lower, upper, stream, world, maxiter=100, popsize=10, mutation=0.5, recombination=0.9,
+                   strategy="best1bin", xtol=1e-8, ftol=1e-8, constraints=None, **_ignored):
+    """The multi-GPU semantics of the build (NOT a reference algorithm):
+    `world` equal row shards, donors drawn inside the shard, counters keyed by the global row,
+    one global best per generation.  Simulated in one process."""
+    n = len(lower)
+    P = popsize
+    Pl = P // world
+    k = DONORS[strategy]
+    X = latin_hypercube(stream, P, n, lower, upper)
+    fit = fobj(X)
+    g = int(np.argmin(fit))
+    gfit, gbest = fit[g], X[g].copy()
+    trace = [gfit]
+    it = 1
+    while True:
+        it += 1
+        U = np.empty_like(X)
+        for r in range(world):
+            sl = slice(r * Pl, (r + 1) * Pl)
+            draws = stream.de_generation(it, Pl, n, k, (lower, upper) if constraints == "Random" else None,
+                                         row0=r * Pl)
+            U[sl] = de_candidates(X[sl], gbest, draws, mutation, recombination, strategy, lower, upper, constraints)
+        gbest, gfit, status = greedy_select(it, U, fobj(U), gbest, X, fit, maxiter, xtol, ftol)
+        trace.append(gfit)
+        if status is not None:
+            break
+    res = _final(gbest, gfit, status, it * P, it, History(False, 0, 0, 0, 0))
+    res["_trace"] = trace
+    return res
+
+
 RUNNERS = {"de": run_de, "pso": run_pso, "cpso": run_pso, "cmaes": run_cmaes}
 
 

@@ -314,6 +314,101 @@ extern "C" int sx_select_finalize(const double *part_f, const int64_t *part_i, i
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Multi-GPU: shard best -> record, and best-of-generation over the gathered records.
+// record = [ f, (double) global row, row[0..n) ]   (n + 2 doubles)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kFinalThreads) void shard_best_kernel(
+    const double *__restrict__ part_f, const int64_t *__restrict__ part_i, int64_t npart,
+    const double *__restrict__ rows0, const double *__restrict__ rows1, int64_t ld, int n,
+    const sx_state *__restrict__ state, int64_t row0, double *__restrict__ record) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    const int64_t it = state->it + 1;  // the generation being finalised
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int64_t k = threadIdx.x; k < npart; k += kFinalThreads) argmin_combine(bf, bi, part_f[k], part_i[k]);
+    block_argmin(bf, bi, sf, si);
+    const double *src = ((it & 1) ? rows1 : rows0) + bi * ld;
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) record[2 + e] = src[e];
+    if (threadIdx.x == 0) {
+        record[0] = bf;
+        record[1] = (double)(row0 + bi);  // exact below 2^53
+    }
+}
+
+__global__ __launch_bounds__(kFinalThreads) void gather_finalize_kernel(const double *__restrict__ records, int world,
+                                                                        int n, double *__restrict__ gbest,
+                                                                        sx_state *__restrict__ state, int maxiter,
+                                                                        double xtol, double ftol) {
+    __shared__ double sf[kFinalThreads / kWave];
+    if (state->done) return;
+    const int64_t stride = n + 2;
+    // every thread scans the (few) records: first minimum by (f, global row) = np.argmin over the whole population
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    int best = 0;
+    for (int w = 0; w < world; ++w) {
+        const double f = records[w * stride];
+        const int64_t gi = (int64_t)records[w * stride + 1];
+        if (f < bf || (f == bf && gi < bi)) {
+            bf = f;
+            bi = gi;
+            best = w;
+        }
+    }
+    const double *src = records + best * stride + 2;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) {
+        const double d = gbest[e] - src[e];
+        acc += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double ss = 0.0;
+    for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
+    const double dx = sqrt(ss);
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) gbest[e] = src[e];
+    if (threadIdx.x == 0) {
+        const int64_t it = state->it + 1;
+        int status = SX_STATUS_NONE;
+        if (dx <= xtol && bf <= ftol)
+            status = 0;
+        else if (bf <= ftol)
+            status = 1;
+        else if (it >= maxiter)
+            status = -1;
+        state->it = it;
+        state->gbidx = bi;
+        state->gfit = bf;
+        state->dx = dx;
+        state->status = status;
+        state->done = status != SX_STATUS_NONE;
+    }
+}
+
+extern "C" int sx_shard_best(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                             const double *rows1, int64_t ld, int n, const sx_state *state, int64_t row0,
+                             double *record, void *stream) {
+    SX_REQUIRE(part_f && part_i && rows0 && rows1 && state && record && npart >= 1 && n >= 1,
+               "sx_shard_best: bad arguments");
+    hipLaunchKernelGGL(shard_best_kernel, dim3(1), dim3(kFinalThreads), 0, (hipStream_t)stream, part_f, part_i, npart,
+                       rows0, rows1, ld, n, state, row0, record);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_gather_finalize(const double *records, int world, int n, double *gbest, sx_state *state,
+                                  int maxiter, double xtol, double ftol, void *stream) {
+    SX_REQUIRE(records && gbest && state && world >= 1 && n >= 1, "sx_gather_finalize: bad arguments");
+    hipLaunchKernelGGL(gather_finalize_kernel, dim3(1), dim3(kFinalThreads), 0, (hipStream_t)stream, records, world, n,
+                       gbest, state, maxiter, xtol, ftol);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
 namespace sx {
 int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
                       int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,

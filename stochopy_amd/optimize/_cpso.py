@@ -92,10 +92,21 @@ class _PsoRun:
         self.xtol, self.ftol = xtol, ftol
         self.return_all, self.verbosity, self.callback = return_all, verbosity, callback
         self.rng, self.seed = rng, seed
+        self.world = None
+        self.Ptotal = P
+        self.row0 = 0
         if workers != 1:
             from ..parallel import require_world
 
-            require_world(workers)
+            self.world = require_world(workers)
+            if rng != "philox":
+                raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
+            if callback is not None or return_all:
+                raise NotImplementedError("callback / return_all are not available with workers > 1")
+            if gamma:
+                raise NotImplementedError("the competitive restart is single-GPU for now: use method='pso' "
+                                          "or workers=1 (SURVEY.md section 8e lists the extra collectives)")
+            self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
         self.x0 = x0
         self.ctx = _device.Context()
         if autorun:
@@ -113,7 +124,9 @@ class _PsoRun:
         if self.x0 is not None:
             X0 = np.array(self.x0, dtype=np.float64)
         else:
-            X0 = self.stream.latin_hypercube(P, n, self.lower, self.upper)
+            X0 = self.stream.latin_hypercube(self.Ptotal, n, self.lower, self.upper)
+        if self.world is not None:
+            X0 = np.ascontiguousarray(X0[self.row0 : self.row0 + P])
         self.X = ctx.upload(X0)
         self.V = ctx.zeros((P, n))
         self.pbest = self.X.clone()
@@ -134,8 +147,20 @@ class _PsoRun:
         _lib.check(ctx.L.sx_argmin(_device.ptr(self.pbestfit), P, _device.ptr(self.part_f), _device.ptr(self.part_i),
                                    npart, _device.ptr(out_i), _device.ptr(out_f), ctx.stream_ptr), "sx_argmin")
         g = int(out_i.cpu()[0])
+        gfit0 = float(out_f.cpu()[0])
         self.gbest = self.X[g].clone()
-        st = _lib.SxState(it=1, gbidx=g, gfit=float(out_f.cpu()[0]), dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
+        if self.world is not None:  # initial global best: one record exchange, settled on the host
+            from ..parallel import best_of_records
+
+            self.record = ctx.empty((n + 2,))
+            self.records = ctx.empty((self.world.size, n + 2))
+            self.record[0] = gfit0
+            self.record[1] = float(self.row0 + g)
+            self.record[2:].copy_(self.gbest)
+            self.world.all_gather_records(self.record, self.records)
+            wbest, gfit0, g = best_of_records(self.records.cpu().numpy())
+            self.gbest.copy_(self.records[wbest, 2:])
+        st = _lib.SxState(it=1, gbidx=g, gfit=gfit0, dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
         self.state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
         key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
         a = _lib.SxPsoArgs()
@@ -143,7 +168,7 @@ class _PsoRun:
         a.pbestfit, a.candfit, a.gbest = self.pbestfit.data_ptr(), self.candfit.data_ptr(), self.gbest.data_ptr()
         a.lower, a.upper, a.state = self.d_lower.data_ptr(), self.d_upper.data_ptr(), self.state.data_ptr()
         a.part_f, a.part_i = self.part_f.data_ptr(), self.part_i.data_ptr()
-        a.P, a.ld, a.row0, a.n = P, n, 0, n
+        a.P, a.ld, a.row0, a.n = P, n, self.row0, n
         a.fun_id = self.fun_id
         a.constraints = 1 if self.constraints == "Shrink" else 0
         a.rng = _lib.SX_RNG_PHILOX if self.rng == "philox" else _lib.SX_RNG_HOST
@@ -193,7 +218,17 @@ class _PsoRun:
             for h, d in zip(self.h_r, self.d_r):
                 self.stream.random(None, out=h.numpy())
                 d.copy_(h, non_blocking=True)
-        _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_pso_generation")
+        if self.world is None:
+            _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_pso_generation")
+            return
+        # sharded swarm: local generation, then the global-best exchange (parallel.py)
+        p, n = _device.ptr, self.n
+        _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 0, ctx.stream_ptr), "sx_pso_generation")
+        _lib.check(ctx.L.sx_shard_best(p(self.part_f), p(self.part_i), self.npart, p(self.pbest), p(self.pbest), n, n,
+                                       p(self.state), self.row0, p(self.record), ctx.stream_ptr), "sx_shard_best")
+        self.world.all_gather_records(self.record, self.records)
+        _lib.check(ctx.L.sx_gather_finalize(p(self.records), self.world.size, n, p(self.gbest), p(self.state),
+                                            self.maxiter, self.xtol, self.ftol, ctx.stream_ptr), "sx_gather_finalize")
 
     def _restart_device(self):
         """cpso/_cpso.py:405-426 entirely on the device (Philox positions keyed by row)."""
@@ -256,7 +291,7 @@ class _PsoRun:
             status=status,
             message=_common.messages[status],
             fun=float(st.gfit),
-            nfev=int(st.it) * self.P,
+            nfev=int(st.it) * self.Ptotal,
             nit=int(st.it),
         )
         if self.return_all:

@@ -95,10 +95,20 @@ class _DeRun:
         self.return_all, self.verbosity, self.callback = return_all, verbosity, callback
         self.rng, self.seed = rng, seed
         self.k = _lib.DE_DONORS[strategy]
+        self.world = None
+        self.Ptotal = P
+        self.row0 = 0
         if workers != 1:
             from ..parallel import require_world
 
-            require_world(workers)
+            self.world = require_world(workers)
+            if rng != "philox":
+                raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
+            if callback is not None or return_all:
+                raise NotImplementedError("callback / return_all are not available with workers > 1")
+            self.row0, self.P = self.world.shard(P)  # this rank's rows; self.P is the LOCAL population from here on
+            if self.P - 1 < self.k:
+                raise ValueError("shard too small for the strategy")
         self.x0 = x0
         self.ctx = _device.Context()
         self._graph = None
@@ -115,6 +125,18 @@ class _DeRun:
             self.ctx.L.sx_graph_destroy(self._graph)
             self._graph = None
 
+    def _sharded_generation(self):
+        """One generation on this rank's shard + the global-best exchange (parallel.py)."""
+        ctx, a, n = self.ctx, self.args, self.n
+        p = _device.ptr
+        _lib.check(ctx.L.sx_de_generation(C.byref(a), 0, ctx.stream_ptr), "sx_de_generation")
+        _lib.check(ctx.L.sx_shard_best(p(self.part_f), p(self.part_i), self.part_f.numel(), p(self.bufs[0]),
+                                       p(self.bufs[1]), n, n, p(self.state), self.row0, p(self.record),
+                                       ctx.stream_ptr), "sx_shard_best")
+        self.world.all_gather_records(self.record, self.records)
+        _lib.check(ctx.L.sx_gather_finalize(p(self.records), self.world.size, n, p(self.gbest), p(self.state),
+                                            self.maxiter, self.xtol, self.ftol, ctx.stream_ptr), "sx_gather_finalize")
+
     def enqueue(self, ngen):
         """Enqueue `ngen` generations on the engine stream without any host synchronisation.
 
@@ -122,6 +144,10 @@ class _DeRun:
         generation); the remainder is launched eagerly.  Generations after convergence are no-ops.
         """
         ctx = self.ctx
+        if self.world is not None:
+            for _ in range(ngen):
+                self._sharded_generation()
+            return
         while ngen >= self.GRAPH_CHUNK:
             if self._graph is None:
                 g = C.c_void_p()
@@ -141,7 +167,9 @@ class _DeRun:
         if self.x0 is not None:
             X0 = np.array(self.x0, dtype=np.float64)
         else:
-            X0 = self.stream.latin_hypercube(P, n, self.lower, self.upper)
+            X0 = self.stream.latin_hypercube(self.Ptotal, n, self.lower, self.upper)
+        if self.world is not None:  # every rank builds the same global population and keeps its rows
+            X0 = np.ascontiguousarray(X0[self.row0 : self.row0 + P])
         # generation g lives in bufs[g & 1]; the initial population is generation 1
         self.bufs = [ctx.empty((P, n)), ctx.upload(X0)]
         self.fit = ctx.empty((P,))
@@ -159,9 +187,21 @@ class _DeRun:
         _lib.check(ctx.L.sx_argmin(_device.ptr(self.fit), P, _device.ptr(self.part_f), _device.ptr(self.part_i),
                                    npart, _device.ptr(out_i), _device.ptr(out_f), ctx.stream_ptr), "sx_argmin")
         g = int(out_i.cpu()[0])
-        st = _lib.SxState(it=1, gbidx=g, gfit=float(out_f.cpu()[0]), dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
-        self.state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
+        gfit0 = float(out_f.cpu()[0])
         self.gbest = self.bufs[1][g].clone()
+        if self.world is not None:  # initial global best: one record exchange, settled on the host
+            from ..parallel import best_of_records
+
+            self.record = ctx.empty((n + 2,))
+            self.records = ctx.empty((self.world.size, n + 2))
+            self.record[0] = gfit0
+            self.record[1] = float(self.row0 + g)
+            self.record[2:].copy_(self.gbest)
+            self.world.all_gather_records(self.record, self.records)
+            wbest, gfit0, g = best_of_records(self.records.cpu().numpy())
+            self.gbest.copy_(self.records[wbest, 2:])
+        st = _lib.SxState(it=1, gbidx=g, gfit=gfit0, dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
+        self.state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
         key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
         a = _lib.SxDeArgs()
         a.buf0, a.buf1 = self.bufs[0].data_ptr(), self.bufs[1].data_ptr()
@@ -169,7 +209,7 @@ class _DeRun:
         a.lower, a.upper, a.state = self.d_lower.data_ptr(), self.d_upper.data_ptr(), self.state.data_ptr()
         a.part_f, a.part_i = self.part_f.data_ptr(), self.part_i.data_ptr()
         a.gbest = self.gbest.data_ptr()
-        a.P, a.ld, a.row0, a.n = P, n, 0, n
+        a.P, a.ld, a.row0, a.n = P, n, self.row0, n
         a.fun_id, a.strategy = self.fun_id, _lib.DE_STRATEGIES[self.strategy]
         a.constraints = 1 if self.constraints == "Random" else 0
         a.rng = _lib.SX_RNG_PHILOX if self.rng == "philox" else _lib.SX_RNG_HOST
@@ -276,13 +316,13 @@ class _DeRun:
             status=status,
             message=_common.messages[status],
             fun=float(st.gfit),
-            nfev=int(st.it) * self.P,
+            nfev=int(st.it) * self.Ptotal,
             nit=int(st.it),
         )
         if self.return_all:
             res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
         # the reference works in place on x0 (de/_de.py:208 + _common.py:128-129): mirror that
-        if isinstance(self.x0, np.ndarray) and self.x0.dtype == np.float64:
+        if self.world is None and isinstance(self.x0, np.ndarray) and self.x0.dtype == np.float64:
             self.x0[...] = self._population(st.it).cpu().numpy()
         if self.rng == "numpy-legacy":
             self.stream.sync_back()

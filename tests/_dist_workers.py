@@ -1,0 +1,82 @@
+"""Worker entry points for the multi-process tests (spawned; must be importable)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def cpu_exchange_worker(rank, world, port, cfg, out_dir):
+    """CPU-only: each rank advances ITS shard with the oracle's arithmetic and exchanges the global best
+    through stochopy_amd.parallel.World over gloo -- the product's exchange code, real processes."""
+    import torch
+
+    dist = _init(rank, world, port)
+    try:
+        import oracle
+        from oracle import engine as oe
+        from stochopy_amd import parallel
+
+        w = parallel.require_world(world)
+        n, P, gens = cfg["n"], cfg["P"], cfg["gens"]
+        lower, upper = np.full(n, -5.12), np.full(n, 5.12)
+        stream = oracle.PhiloxStream(cfg["seed"])
+        row0, Pl = w.shard(P)
+        fobj = oracle.OBJECTIVES["rosenbrock"]
+        X = oe.latin_hypercube(stream, P, n, lower, upper)[row0 : row0 + Pl].copy()
+        fit = fobj(X)
+
+        def exchange():
+            g = int(np.argmin(fit))
+            rec = torch.from_numpy(np.concatenate([[fit[g], float(row0 + g)], X[g]]))
+            out = torch.empty((world, n + 2), dtype=torch.float64)
+            w.all_gather_records(rec, out)
+            wb, f, gi = parallel.best_of_records(out.numpy())
+            return out[wb, 2:].numpy().copy(), f, gi
+
+        gbest, gfit, _ = exchange()
+        trace = [gfit]
+        for it in range(2, gens + 1):
+            draws = stream.de_generation(it, Pl, n, 2, None, row0=row0)
+            U = oe.de_candidates(X, gbest, draws, 0.5, 0.9, "best1bin", lower, upper, None)
+            cf = fobj(U)
+            better = cf < fit
+            fit[better] = cf[better]
+            X[better] = U[better]
+            gbest, gfit, _ = exchange()
+            trace.append(gfit)
+        assert w.max_over_ranks(rank) == world - 1
+        np.save(os.path.join(out_dir, f"trace_{rank}.npy"), np.array(trace))
+    finally:
+        dist.destroy_process_group()
+
+
+def gpu_minimize_worker(rank, world, port, cfg, out_dir):
+    """Two ranks share the one GPU of the test box (gloo, host-staged records): the sharded HIP path end to end."""
+    dist = _init(rank, world, port)
+    try:
+        import torch
+
+        torch.cuda.set_device(0)
+        import stochopy_amd as sa
+
+        n = cfg["n"]
+        opts = dict(cfg["options"], backend="hip", rng="philox", workers=world)
+        res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), [[-5.12, 5.12]] * n, method=cfg["method"],
+                                   options=opts)
+        np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
+        np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))
+    finally:
+        dist.destroy_process_group()
