@@ -126,21 +126,20 @@ def main():
         ctx.sync()
         barrier()
         t1 = time.perf_counter()
-        st = ctx.read_state(run.state)
+        st = run.read_state()
         assert st.it == 1 + W + K, (st.it, W, K)
 
-        # dominant kernel: HIP events on the engine stream around back-to-back launches of the
-        # fused generation kernel alone (finalize=0), average per launch
-        nl = args.kernel_timing_launches
+        # dominant kernel: HIP events on the engine stream around a replayed hipGraph of generation
+        # kernels (real generations, nothing else on the stream), average per launch
+        nl = (args.kernel_timing_launches // run.GRAPH_CHUNK) * run.GRAPH_CHUNK
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
-        for _ in range(20):
-            _lib.check(ctx.L.sx_de_generation(run.args, 0, ctx.stream_ptr), "sx_de_generation")
+        run.enqueue(run.GRAPH_CHUNK)
         ev0.record(ctx.stream)
-        for _ in range(nl):
-            _lib.check(ctx.L.sx_de_generation(run.args, 0, ctx.stream_ptr), "sx_de_generation")
+        run.enqueue(nl)
         ev1.record(ctx.stream)
         ctx.sync()
+        kernels_per_gen = 1 if run.chain else (2 if world == 1 else 3)
         kern_ms = ev0.elapsed_time(ev1) / nl
     run.close()
 
@@ -190,7 +189,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_us": kern_ms * 1e3,
-                "timing": "HIP events on the engine stream around %d back-to-back launches" % nl,
+                "timing": "HIP events on the engine stream around %d generations (%d kernel(s) each)" % (nl, kernels_per_gen),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

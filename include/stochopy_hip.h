@@ -187,6 +187,16 @@ int sx_gather_finalize(const double *records, int world, int n, double *gbest, s
  * ------------------------------------------------------------------------- */
 typedef struct sx_graph sx_graph;
 int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out);
+/* Chained finalize (single GPU, SX_RNG_PHILOX): ONE kernel per generation.  a->state must point to
+ * sx_state[3] and a->part_f / a->part_i to [2][sx_num_partials(P,n)].  Launch L uses parity L & 1: every
+ * workgroup first re-reduces the records its predecessor wrote to part[parity] (the best-of-generation /
+ * termination step of _common.py:131-158, published in state[1-parity] by workgroup 0) and then produces
+ * the next generation with records in part[1-parity].  finalize_only: just that first half, result in
+ * state[2] (what the host reads).  The kernel stops on fun <= ftol with status 1; status 0 (xtol) is settled
+ * by the caller from state.reserved[0] = the previous best row.  Start: state[0] = {it 0, gbidx}, part[0] =
+ * {(f_best, row_best), +inf...}, generation 1 in buf1. */
+int sx_de_chain_launch(const sx_de_args *a, int parity, int finalize_only, void *stream);
+int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start_parity, sx_graph **out);
 int sx_graph_launch(sx_graph *g, void *stream);
 int sx_graph_destroy(sx_graph *g);
 

@@ -86,17 +86,80 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
     irand = (int)__umulhi(a.x, (uint32_t)n);
 }
 
-template <int FUN, int RNG>
+// CHAIN = false: a.state is ONE sx_state, the best/termination step is a separate kernel.
+// CHAIN = true ("chained finalize", single GPU + Philox): a.state is sx_state[3], a.part_f/part_i are
+// [2][npart].  Launch L (parity p = L & 1) first finalises the generation its predecessor produced --
+// EVERY workgroup reduces the npart records part[p] (written before the kernel boundary, so plainly
+// visible) and derives the same best / status; workgroup 0 publishes it in state[1-p] -- and then
+// produces the next generation, writing records to part[1-p].  No second kernel, no atomics.
+// mode 1 = finalise only (one workgroup), result to state[2] for the host.  dx (xtol) only separates
+// status 0 from 1, both of which stop: the host derives it from state.reserved[0] (previous best row).
+template <int FUN, int RNG, bool CHAIN>
 __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void de_generation_kernel(const sx_de_args a,
-                                                                                 const PlanArg plan) {
+                                                                                 const PlanArg plan,
+                                                                                 const int chain_p, const int mode,
+                                                                                 const int64_t npart) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
     SX_TP(0);
-    const sx_state *st = a.state;
-    if (st->done) return;
-    const int64_t it = st->it;  // generations completed; this launch produces it+1
-    const int64_t gbidx = st->gbidx;
+    int64_t it, gbidx;
+    double *part_f_out = a.part_f;
+    int64_t *part_i_out = a.part_i;
+    if (CHAIN) {
+        const sx_state *sin = a.state + chain_p;
+        const double *pf = a.part_f + (int64_t)chain_p * npart;
+        const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
+        if (sin->done) {
+            if (mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
+            return;
+        }
+        // wave 0 reduces the records (contiguous slices per lane keep np.argmin's first-minimum rule);
+        // the other waves of the workgroup pick the result up from LDS
+        if (threadIdx.x < kWave) {
+            double bf = __builtin_huge_val();
+            int64_t bi = INT64_MAX;
+            const int64_t per = (npart + kWave - 1) / kWave;
+            const int64_t k0 = (int64_t)threadIdx.x * per;
+            for (int64_t kk = k0; kk < k0 + per && kk < npart; ++kk) argmin_combine(bf, bi, pf[kk], pi[kk]);
+            wave_argmin_all(bf, bi);
+            if (threadIdx.x == 0) {
+                sf[0] = bf;
+                si[0] = bi;
+            }
+        }
+        __syncthreads();
+        const double bf = sf[0];
+        const int64_t bi = si[0];
+        __syncthreads();  // sf/si are reused at the end of the kernel
+        it = sin->it + 1;  // the generation just finalised
+        int status = SX_STATUS_NONE;
+        if (it >= 2) {  // the reference does not test the initial population (de/_de.py:212-218)
+            if (bf <= a.ftol)
+                status = 1;
+            else if (it >= a.maxiter)
+                status = -1;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            sx_state *so = a.state + (mode == 1 ? 2 : 1 - chain_p);
+            so->it = it;
+            so->gbidx = bi;
+            so->gfit = bf;
+            so->dx = 0.0;
+            so->status = status;
+            so->done = status != SX_STATUS_NONE;
+            so->reserved[0] = sin->gbidx;
+        }
+        if (status != SX_STATUS_NONE || mode == 1) return;
+        gbidx = bi;
+        part_f_out = a.part_f + (int64_t)(1 - chain_p) * npart;
+        part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
+    } else {
+        const sx_state *st = a.state;
+        if (st->done) return;
+        it = st->it;  // generations completed; this launch produces it+1
+        gbidx = st->gbidx;
+    }
     SX_TP(6);
     const uint32_t gen = (uint32_t)(it + 1);
     const double *__restrict__ cur = (it & 1) ? a.buf1 : a.buf0;
@@ -188,22 +251,22 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void de_generation_kern
         }
     }
     SX_TP(4);
-    block_partial(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+    block_partial(better ? fc : fold, id, sf, si, part_f_out, part_i_out);
     SX_TP(5);
 }
 
-typedef void (*de_kernel_t)(const sx_de_args, const PlanArg);
+typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t);
 
-template <int RNG>
+template <int RNG, bool CHAIN>
 de_kernel_t pick_kernel(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG>;
-        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG>;
-        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG>;
-        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG>;
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, CHAIN>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, CHAIN>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, CHAIN>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, CHAIN>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, CHAIN>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, CHAIN>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, CHAIN>;
     }
     return nullptr;
 }
@@ -225,7 +288,8 @@ int check_args(const sx_de_args *a) {
 }
 
 de_kernel_t kernel_for(const sx_de_args *a) {
-    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id) : pick_kernel<SX_RNG_HOST>(a->fun_id);
+    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, false>(a->fun_id)
+                                   : pick_kernel<SX_RNG_HOST, false>(a->fun_id);
 }
 
 struct Geometry {
@@ -246,7 +310,7 @@ extern "C" int sx_de_generation(const sx_de_args *a, int finalize, void *stream)
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan);
+    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan, 0, 0, (int64_t)g.blocks);
     SX_LAUNCH_CHECK();
     if (finalize) {
         SX_REQUIRE(a->gbest != nullptr, "sx_de_generation: the separate finalize kernel needs the gbest buffer");
@@ -275,7 +339,9 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
     sx_graph *gr = new sx_graph();
     SX_HIP(hipGraphCreate(&gr->graph, 0));
     sx_de_args args = *a;
-    void *kargs[] = {&args, &plan};
+    int zero = 0;
+    int64_t npart = g.blocks;
+    void *kargs[] = {&args, &plan, &zero, &zero, &npart};
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
         hipKernelNodeParams kp = {};
@@ -291,6 +357,61 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
         if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->buf0, a->buf1, a->ld, a->n,
                                        a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
             return rc;
+    }
+    SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
+    *out = gr;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Chained finalize (single GPU, Philox): one kernel per generation.
+// ---------------------------------------------------------------------------
+static int check_chain(const sx_de_args *a) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_de_chain: needs in-kernel (Philox) draws");
+    return 0;
+}
+
+extern "C" int sx_de_chain_launch(const sx_de_args *a, int parity, int finalize_only, void *stream) {
+    if (int rc = check_chain(a)) return rc;
+    SX_REQUIRE(parity == 0 || parity == 1, "sx_de_chain_launch: parity must be 0 or 1");
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a);
+    de_kernel_t kern = pick_kernel<SX_RNG_PHILOX, true>(a->fun_id);
+    const unsigned blocks = finalize_only ? 1u : g.blocks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream, *a, plan, parity,
+                       finalize_only ? 1 : 0, (int64_t)g.blocks);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start_parity, sx_graph **out) {
+    if (int rc = check_chain(a)) return rc;
+    SX_REQUIRE(out != nullptr && ngen >= 1 && (start_parity == 0 || start_parity == 1),
+               "sx_de_chain_graph_create: bad arguments");
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a);
+    sx_graph *gr = new sx_graph();
+    SX_HIP(hipGraphCreate(&gr->graph, 0));
+    sx_de_args args = *a;
+    int mode = 0;
+    int64_t npart = g.blocks;
+    hipGraphNode_t prev = nullptr;
+    for (int i = 0; i < ngen; ++i) {
+        int parity = (start_parity + i) & 1;
+        void *kargs[] = {&args, &plan, &parity, &mode, &npart};
+        hipKernelNodeParams kp = {};
+        kp.func = (void *)pick_kernel<SX_RNG_PHILOX, true>(a->fun_id);
+        kp.gridDim = dim3(g.blocks);
+        kp.blockDim = dim3(g.threads);
+        kp.sharedMemBytes = (unsigned)g.lds;
+        kp.kernelParams = kargs;
+        kp.extra = nullptr;
+        hipGraphNode_t node;
+        SX_HIP(hipGraphAddKernelNode(&node, gr->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+        prev = node;
     }
     SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
     *out = gr;

@@ -20,14 +20,20 @@ namespace sx {
 
 constexpr int kGroup = 8;     // numpy's 8 running accumulators
 constexpr int kWave = 64;     // gfx950 wavefront = one individual
-constexpr int kMaxRowsPerBlock = 4;
+constexpr int kMaxRowsPerBlock = 16;
 constexpr int kMaxLeaf = 96;  // leaves carried in kernel arguments (n up to ~6k..12k)
 constexpr int kMaxDim = 6144; // LDS staging: 3 arrays of n doubles per wave (< 160 KiB)
 
-// rows (= waves) per workgroup: 4 while the LDS staging of a workgroup stays <= 32 KiB
-__host__ __device__ inline int rows_per_block(int n) { return n <= 256 ? 4 : (n <= 640 ? 2 : 1); }
 // doubles of LDS per wave: U[n+8] | A[n] | B[n] | stack[24]
 __host__ __device__ inline int lds_row_stride(int n) { return 3 * n + 8 + 24; }
+// rows (= waves) per workgroup: the largest power of two <= 16 whose LDS staging stays <= 64 KiB.
+// n <= 128 -> 16 rows (P = 4096 is exactly one 1024-thread workgroup per CU), 256 -> 8, 512 -> 4, 1024 -> 2.
+__host__ __device__ inline int rows_per_block(int n) {
+    const int fit = (64 * 1024) / (8 * lds_row_stride(n));
+    int r = 1;
+    while (r < kMaxRowsPerBlock && 2 * r <= fit) r *= 2;
+    return r;
+}
 
 // numpy pairwise-summation plan for an m-term row sum, passed BY VALUE as a kernel argument
 struct PlanArg {

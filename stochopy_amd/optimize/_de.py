@@ -110,8 +110,16 @@ class _DeRun:
             if self.P - 1 < self.k:
                 raise ValueError("shard too small for the strategy")
         self.x0 = x0
+        # single GPU + in-kernel draws + nothing to report per generation: one kernel per generation
+        # ("chained finalize", include/stochopy_hip.h sx_de_chain_launch)
+        # -- every workgroup re-reduces the per-workgroup records, so only while those are few
+        npart = int(_lib.lib().sx_num_partials(self.P, self.n))
+        self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
+                      and npart <= 1024)
+        self.launches = 0
         self.ctx = _device.Context()
         self._graph = None
+        self._chain_graphs = {}
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
@@ -124,6 +132,35 @@ class _DeRun:
         if self._graph is not None:
             self.ctx.L.sx_graph_destroy(self._graph)
             self._graph = None
+        for g in self._chain_graphs.values():
+            self.ctx.L.sx_graph_destroy(g)
+        self._chain_graphs = {}
+
+    def read_state(self):
+        """Host view of the run: (chained mode) finalise the last generation into state[2], then read it."""
+        ctx = self.ctx
+        if not self.chain:
+            return ctx.read_state(self.state)
+        _lib.check(ctx.L.sx_de_chain_launch(C.byref(self.args), self.launches & 1, 1, ctx.stream_ptr),
+                   "sx_de_chain_launch")
+        return ctx.read_state(self.state[16:24])
+
+    def _enqueue_chain(self, ngen):
+        ctx = self.ctx
+        while ngen >= self.GRAPH_CHUNK:
+            par = self.launches & 1
+            if par not in self._chain_graphs:
+                g = C.c_void_p()
+                _lib.check(ctx.L.sx_de_chain_graph_create(C.byref(self.args), self.GRAPH_CHUNK, par, C.byref(g)),
+                           "sx_de_chain_graph_create")
+                self._chain_graphs[par] = g
+            _lib.check(ctx.L.sx_graph_launch(self._chain_graphs[par], ctx.stream_ptr), "sx_graph_launch")
+            self.launches += self.GRAPH_CHUNK
+            ngen -= self.GRAPH_CHUNK
+        for _ in range(ngen):
+            _lib.check(ctx.L.sx_de_chain_launch(C.byref(self.args), self.launches & 1, 0, ctx.stream_ptr),
+                       "sx_de_chain_launch")
+            self.launches += 1
 
     def _sharded_generation(self):
         """One generation on this rank's shard + the global-best exchange (parallel.py)."""
@@ -147,6 +184,9 @@ class _DeRun:
         if self.world is not None:
             for _ in range(ngen):
                 self._sharded_generation()
+            return
+        if self.chain:
+            self._enqueue_chain(ngen)
             return
         while ngen >= self.GRAPH_CHUNK:
             if self._graph is None:
@@ -201,14 +241,26 @@ class _DeRun:
             wbest, gfit0, g = best_of_records(self.records.cpu().numpy())
             self.gbest.copy_(self.records[wbest, 2:])
         st = _lib.SxState(it=1, gbidx=g, gfit=gfit0, dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
-        self.state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
+        if self.chain:
+            # state[3] + records[2][npart]: launch 0 (parity 0) first "finalises" generation 1 from records[0]
+            s0 = _lib.SxState(it=0, gbidx=g, gfit=gfit0, dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
+            raw = np.frombuffer(bytes(s0) + bytes(st) + bytes(st), dtype=np.int64).copy()
+            self.state = ctx.upload(raw)
+            pf = np.full((2, npart), np.inf)
+            pi = np.full((2, npart), np.iinfo(np.int64).max, dtype=np.int64)
+            pf[0, 0], pi[0, 0] = gfit0, g
+            self.part_f = ctx.upload(pf)
+            self.part_i = ctx.upload(pi)
+        else:
+            self.state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
         key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
         a = _lib.SxDeArgs()
         a.buf0, a.buf1 = self.bufs[0].data_ptr(), self.bufs[1].data_ptr()
         a.fit, a.candfit = self.fit.data_ptr(), self.candfit.data_ptr()
         a.lower, a.upper, a.state = self.d_lower.data_ptr(), self.d_upper.data_ptr(), self.state.data_ptr()
         a.part_f, a.part_i = self.part_f.data_ptr(), self.part_i.data_ptr()
-        a.gbest = self.gbest.data_ptr()
+        # chained mode reads the best row straight from the population (row state.gbidx): no copy to maintain
+        a.gbest = None if self.chain else self.gbest.data_ptr()
         a.P, a.ld, a.row0, a.n = P, n, self.row0, n
         a.fun_id, a.strategy = self.fun_id, _lib.DE_STRATEGIES[self.strategy]
         a.constraints = 1 if self.constraints == "Random" else 0
@@ -264,7 +316,19 @@ class _DeRun:
 
     def _best_row(self, st):
         """The best individual of generation st.it (host copy)."""
+        if self.chain:
+            return self._population(st.it)[st.gbidx].cpu().numpy()
         return self.gbest.cpu().numpy()
+
+    def _settle_status(self, st):
+        """Chained mode stops on `fun <= ftol` with status 1; _common.py:135-140 calls it 0 when the best moved
+        by <= xtol.  Both generations are still resident (nothing is produced after `done`)."""
+        status = int(st.status)
+        if self.chain and status == 1:
+            prev = self._population(st.it - 1)[st.reserved[0]].cpu().numpy()
+            if np.linalg.norm(prev - self._best_row(st)) <= self.xtol:
+                status = 0
+        return status
 
     def _partial_result(self, st):
         res = OptimizeResult(x=self._best_row(st), fun=st.gfit, nfev=st.it * self.P, nit=st.it)
@@ -307,9 +371,9 @@ class _DeRun:
             else:
                 # termination is tested on the device every generation; the host looks every <=4 chunks
                 self.enqueue(min(remaining, 4 * self.GRAPH_CHUNK))
-                st = ctx.read_state(self.state)
+                st = self.read_state()
         self.st = st
-        status = int(st.status)
+        status = self._settle_status(st)
         res = OptimizeResult(
             x=self._best_row(st),
             success=status >= 0,

@@ -1,11 +1,11 @@
 """Debug helper: build a -DSX_TRACE variant of the library, run a few DE generations, print checkpoint deltas."""
-import ctypes as C, os, subprocess, sys
+import ctypes as C, glob, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "stochopy_amd", "csrc")
 out = "/tmp/libsx_trace.so"
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-DSX_TRACE",
-                "-shared", "-x", "hip", src + "/sx_core.hip", src + "/sx_de.hip", src + "/sx_mt19937.cpp", "-o", out], check=True)
+                "-shared", "-x", "hip"] + sorted(glob.glob(src + "/*.hip") + glob.glob(src + "/*.cpp")) + ["-o", out], check=True)
 from stochopy_amd import _lib
 _lib.LIB_PATH = out
 _lib.PROTOTYPES["sx_trace_read"] = (C.c_int, [C.c_void_p])
@@ -21,6 +21,7 @@ with torch.cuda.stream(run.ctx.stream):
     buf = np.zeros(1024 * 8, dtype=np.uint64)
     run.ctx.L.sx_trace_read(buf.ctypes.data)
 b = buf.reshape(1024, 8).astype(np.int64)
+print('chain', run.chain)
 nb = min(1024, int(run.ctx.L.sx_num_partials(P, n)))
 b = b[:nb]
 t0 = b[:, 0].min()
