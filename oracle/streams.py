@@ -116,11 +116,12 @@ class PhiloxStream:
     """Counter-based draws, identical to the HIP kernels' device generator.
 
     key = (seed & 0xffffffff, seed >> 32); counter = (slot, row, gen, purpose).
-    Element e of a row belongs to lane l = e & 63 of the row's wavefront at step q = e >> 6.
+    A row is owned by LPR = 16 / 32 / 64 lanes (n <= 64 / <= 128 / larger); element e belongs to
+    lane l = e % LPR at step q = e // LPR.
     53-bit uniforms: one call yields d0 = u53(w0, w1), d1 = u53(w2, w3);
-    slot = (q >> 1) * 64 + l, half = q & 1.
+    slot = (q >> 1) * LPR + l, half = q & 1.
     32-bit uniforms (DE crossover decisions): word * 2^-32 with
-    slot = (q >> 2) * 64 + l, word = q & 3.
+    slot = (q >> 2) * LPR + l, word = q & 3.
     Initial population / initial mean: the legacy stream (host-side init step).
     """
 
@@ -141,16 +142,22 @@ class PhiloxStream:
         return self.init.cma_initial_mean(n)
 
     @staticmethod
-    def _lanes(n):
-        """Element e sits in lane l = e & 63 of its row's wavefront at step q = e >> 6."""
+    def lanes_per_row(n):
+        """LPR lanes of a wavefront own one row (csrc/sx_device.hpp lanes_per_row)."""
+        return 16 if n <= 64 else (32 if n <= 128 else 64)
+
+    @classmethod
+    def _lanes(cls, n):
+        """Element e sits in lane l = e % LPR of its row at step q = e // LPR."""
+        lpr = np.uint64(cls.lanes_per_row(n))
         e = np.arange(n, dtype=np.uint64)[None, :]
-        return e >> np.uint64(6), e & np.uint64(63)
+        return e // lpr, e % lpr
 
     def _uniform_block(self, rows, n, gen, purpose):
         """53-bit uniforms: slot = (q >> 1) * 64 + l, half = q & 1."""
         rows = np.asarray(rows, dtype=np.uint64)[:, None]
         q, l = self._lanes(n)
-        slot = (q >> np.uint64(1)) * np.uint64(64) + l
+        slot = (q >> np.uint64(1)) * np.uint64(self.lanes_per_row(n)) + l
         half = (q & np.uint64(1)).astype(bool)
         w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, purpose, self.k0, self.k1)
         return np.where(half, u53(w2, w3), u53(w0, w1))
@@ -159,7 +166,7 @@ class PhiloxStream:
         """32-bit uniforms word * 2^-32: slot = (q >> 2) * 64 + l, word = q & 3."""
         rows = np.asarray(rows, dtype=np.uint64)[:, None]
         q, l = self._lanes(n)
-        slot = (q >> np.uint64(2)) * np.uint64(64) + l
+        slot = (q >> np.uint64(2)) * np.uint64(self.lanes_per_row(n)) + l
         wi = (q & np.uint64(3)).astype(np.int64)
         w = philox4x32_10(slot, rows, gen, purpose, self.k0, self.k1)
         pick = np.choose(np.broadcast_to(wi, w[0].shape), w)
@@ -193,7 +200,7 @@ class PhiloxStream:
         words (0, 1) -> (r1, r2) for even q, words (2, 3) for odd q."""
         rows = (np.arange(P, dtype=np.uint64) + np.uint64(row0))[:, None]
         q, l = self._lanes(n)
-        slot = (q >> np.uint64(1)) * np.uint64(64) + l
+        slot = (q >> np.uint64(1)) * np.uint64(self.lanes_per_row(n)) + l
         odd = np.broadcast_to((q & np.uint64(1)).astype(bool), (P, n))
         w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, PURPOSE_PSO_R1, self.k0, self.k1)
         r1 = np.where(odd, w2, w0).astype(np.float64) / 4294967296.0
@@ -208,7 +215,7 @@ class PhiloxStream:
         """Box-Muller on the two doubles of a call: half 0 -> cos branch, half 1 -> sin branch."""
         rows = (np.arange(P, dtype=np.uint64) + np.uint64(row0))[:, None]
         q, l = self._lanes(n)
-        slot = (q >> np.uint64(1)) * np.uint64(64) + l
+        slot = (q >> np.uint64(1)) * np.uint64(self.lanes_per_row(n)) + l
         half = (q & np.uint64(1)).astype(bool)
         w0, w1, w2, w3 = philox4x32_10(slot, rows, gen, PURPOSE_CMA_NORMAL, self.k0, self.k1)
         d0 = u53(w0, w1)

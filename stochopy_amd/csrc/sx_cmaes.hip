@@ -195,9 +195,10 @@ __global__ __launch_bounds__(256) void cma_normals_kernel(double *__restrict__ Z
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= P) return;
     const uint32_t grow = (uint32_t)(row0 + row);
+    const uint32_t lpr = (uint32_t)lanes_per_row(n);  // same element -> (slot, half) layout as the row kernels
     for (int e = lane; e < n; e += kWave) {
-        const uint32_t q = (uint32_t)e >> 6;
-        const U4 w = philox4x32_10((q >> 1) * 64u + (uint32_t)lane, grow, gen, kPurposeCmaNormal, k0, k1);
+        const uint32_t q = (uint32_t)e / lpr, l = (uint32_t)e & (lpr - 1u);
+        const U4 w = philox4x32_10((q >> 1) * lpr + l, grow, gen, kPurposeCmaNormal, k0, k1);
         const double d0 = u53(w.x, w.y), d1 = u53(w.z, w.w);
         const double rad = sqrt(-2.0 * log(1.0 - d0));
         const double ang = 6.283185307179586 * d1;

@@ -96,15 +96,12 @@ extern "C" int64_t sx_fun_terms(int fun_id, int n) {
     return n;
 }
 
-extern "C" int64_t sx_num_partials(int64_t P, int n) {
-    const int rpb = rows_per_block(n);
-    return (P + rpb - 1) / rpb;
-}
+extern "C" int64_t sx_num_partials(int64_t P, int n) { return (int64_t)row_geometry(P, n).blocks; }
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out) {
     if (n > kMaxDim) {
-        set_error("dimension above the LDS staging limit (n <= 6144)");
+        set_error("dimension above the LDS staging limit (n <= 2560)");
         return -1;
     }
     const int64_t m = sx_fun_terms(fun_id, n);
@@ -129,36 +126,34 @@ int make_plan_arg(int fun_id, int n, PlanArg *out) {
 // ---------------------------------------------------------------------------
 // Batched evaluation kernel: one wavefront per individual.
 // ---------------------------------------------------------------------------
-template <int FUN>
-__global__ __launch_bounds__(kMaxRowsPerBlock *kWave) void eval_kernel(
+template <int FUN, int LPR>
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const double *__restrict__ X, int64_t P, int n, int64_t ldx, const double *__restrict__ xm,
     const double *__restrict__ xstd, double *__restrict__ f, const PlanArg plan, double *__restrict__ part_f,
     int64_t *__restrict__ part_i) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
-    const RowIds id(P);
-    double *U = lds + id.wave * lds_row_stride(n);
+    const RowIds<LPR> id(P);
+    double *U = lds + id.slot * lds_row_stride(n);
     const double *xr = X + id.rowc * ldx;
     const bool affine = xm != nullptr;
-    for (int e = id.lane; e < n; e += kWave) {
+    for (int e = id.l; e < n; e += LPR) {
         double v = xr[e];
         if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
         U[e] = v;
     }
-    const double val = row_objective<FUN>(U, n, plan, id.lane);
-    if (id.active && id.lane == 0) f[id.row] = val;
-    if (part_f != nullptr) block_partial(val, id, sf, si, part_f, part_i);
+    const double val = row_objective<FUN, LPR>(U, n, plan, id.l);
+    if (id.active && id.l == 0) f[id.row] = val;
+    if (part_f != nullptr) block_partial<LPR>(val, id, sf, si, part_f, part_i);
 }
 
 template <int FUN>
 static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
                        const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s) {
-    const int rpb = rows_per_block(n);
-    const int64_t nblk = (P + rpb - 1) / rpb;
-    const size_t lds = (size_t)rpb * lds_row_stride(n) * sizeof(double);
-    hipLaunchKernelGGL(eval_kernel<FUN>, dim3((unsigned)nblk), dim3(rpb * kWave), lds, s, X, P, n, ldx, xm, xstd, f,
-                       plan, part_f, part_i);
+    const Geometry g = row_geometry(P, n);
+    SX_DISPATCH_LPR(n, hipLaunchKernelGGL((eval_kernel<FUN, LPR>), dim3(g.blocks), dim3(g.threads), g.lds, s, X, P, n,
+                                          ldx, xm, xstd, f, plan, part_f, part_i))
     SX_LAUNCH_CHECK();
     return 0;
 }

@@ -29,13 +29,16 @@ using namespace sx;
 
 #ifdef SX_TRACE
 // debug build only: per-workgroup checkpoints (s_memrealtime, 100 MHz) of the generation kernel
-__device__ unsigned long long sx_trace_buf[1024 * 8];
+__device__ unsigned long long sx_trace_buf[1024 * 16];
 #define SX_TP(k)                                                                              \
     do {                                                                                      \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) sx_trace_buf[blockIdx.x * 8 + (k)] = wall_clock64(); \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                          \
+            sx_trace_buf[blockIdx.x * 16 + (k)] = wall_clock64();                             \
+            sx_trace_buf[blockIdx.x * 16 + 8 + (k)] = clock64();                              \
+        }                                                                                     \
     } while (0)
 extern "C" int sx_trace_read(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sx_trace_buf), sizeof(unsigned long long) * 1024 * 8);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sx_trace_buf), sizeof(unsigned long long) * 1024 * 16);
 }
 #else
 #define SX_TP(k) do {} while (0)
@@ -89,13 +92,15 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
 // CHAIN = false: a.state is ONE sx_state, the best/termination step is a separate kernel.
 // CHAIN = true ("chained finalize", single GPU + Philox): a.state is sx_state[3], a.part_f/part_i are
 // [2][npart].  Launch L (parity p = L & 1) first finalises the generation its predecessor produced --
-// EVERY workgroup reduces the npart records part[p] (written before the kernel boundary, so plainly
-// visible) and derives the same best / status; workgroup 0 publishes it in state[1-p] -- and then
+// EVERY wavefront reduces the npart (<= 512) records part[p] (written before the kernel boundary, so
+// plainly visible) and derives the same best / status; workgroup 0 publishes it in state[1-p] -- and then
 // produces the next generation, writing records to part[1-p].  No second kernel, no atomics.
 // mode 1 = finalise only (one workgroup), result to state[2] for the host.  dx (xtol) only separates
 // status 0 from 1, both of which stop: the host derives it from state.reserved[0] (previous best row).
-template <int FUN, int RNG, bool CHAIN>
-__global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void de_generation_kernel(const sx_de_args a,
+constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its loads in flight together
+
+template <int FUN, int RNG, bool CHAIN, int LPR>
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_de_args a,
                                                                                  const PlanArg plan,
                                                                                  const int chain_p, const int mode,
                                                                                  const int64_t npart) {
@@ -103,36 +108,114 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void de_generation_kern
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
     SX_TP(0);
-    int64_t it, gbidx;
+    const int n = a.n;
+    const int64_t P = a.P, ld = a.ld;
+    const RowIds<LPR> id(P);
+    const int l = id.l;  // lane within the row
+    const int64_t rowc = id.rowc;
+    double *U = lds + id.slot * lds_row_stride(n);
+
+    // ---- A. which generation?  (CHAIN) every wave fetches the predecessor's records right away (their
+    //      addresses do not depend on the state word) and keeps them in registers until stage C
+    const sx_state *sin = CHAIN ? a.state + chain_p : a.state;
+    constexpr int kRecPerLane = 8;  // npart <= 512 in chained mode
+    double pfv[kRecPerLane];
+    int64_t piv[kRecPerLane];
+    if (CHAIN) {
+        const double *pf = a.part_f + (int64_t)chain_p * npart;
+        const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
+        const int per = (int)((npart + kWave - 1) / kWave);  // contiguous slice per lane: first-minimum rule
+        const int64_t k0 = (int64_t)id.lane * per;
+#pragma unroll
+        for (int u = 0; u < kRecPerLane; ++u) {
+            const bool in = u < per && k0 + u < npart;
+            pfv[u] = in ? pf[k0 + u] : __builtin_huge_val();
+            piv[u] = in ? pi[k0 + u] : INT64_MAX;
+        }
+    }
+    if (sin->done) {
+        if (CHAIN && mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
+        return;
+    }
+    const int64_t it = CHAIN ? sin->it + 1 : sin->it;  // the generation the population holds; we produce it+1
+    SX_TP(6);
+
+    // ---- B. everything that only needs `it`: donors, the first batch of row loads, the first Philox call
+    const uint32_t gen = (uint32_t)(it + 1);
+    const double *__restrict__ cur = (it & 1) ? a.buf1 : a.buf0;
+    double *__restrict__ nxt = (it & 1) ? a.buf0 : a.buf1;
+    const double fold = a.fit[rowc];
+    const double *__restrict__ xi = cur + rowc * ld;
+    const uint32_t grow = (uint32_t)(a.row0 + rowc);
+    const int strategy = a.strategy;
+    const int k = donors_of(strategy);
+    const bool repair = a.constraints != 0;
+    const bool use_best = strategy == SX_DE_BEST1BIN || strategy == SX_DE_BEST2BIN;
+
+    int64_t d[kMaxDonors];
+    int irand;
+    if (RNG == SX_RNG_PHILOX) {
+        philox_donors(P, k, rowc, grow, gen, a.key0, a.key1, n, d, irand);
+    } else {
+#pragma unroll
+        for (int t = 0; t < kMaxDonors; ++t) d[t] = t < k ? (int64_t)a.donors[(int64_t)t * P + rowc] : 0;
+        irand = a.irand[rowc];
+    }
+    SX_TP(1);
+    const double *pd[kMaxDonors];
+#pragma unroll
+    for (int t = 0; t < kMaxDonors; ++t) pd[t] = cur + d[t] * ld;
+    const double F = a.F, CR = a.CR;
+    const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
+    const double *rsrow = (RNG == SX_RNG_HOST && repair) ? a.resample + rowc * (int64_t)n : nullptr;
+
+    double bx[kStep], bd[kMaxDonors][kStep], br[kStep], brs[kStep];
+    auto load_batch = [&](int q0) {
+#pragma unroll
+        for (int t = 0; t < kStep; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            const bool in = e < n;
+            bx[t] = in ? xi[e] : 0.0;
+#pragma unroll
+            for (int s = 0; s < kMaxDonors; ++s) bd[s][t] = (s < k && in) ? pd[s][e] : 0.0;
+            br[t] = 2.0;
+            brs[t] = 0.0;
+            if (RNG == SX_RNG_HOST && in) {
+                br[t] = r1row[e];
+                if (repair) brs[t] = rsrow[e];
+            }
+        }
+        if (RNG == SX_RNG_PHILOX) {
+            // 32-bit crossover uniforms: one call per 4 steps (slot = (q>>2)*LPR + l, word = q&3)
+            const U4 w = philox4x32_10((uint32_t)(q0 >> 2) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposeDeCross,
+                                       a.key0, a.key1);
+            br[0] = u32(w.x);
+            br[1] = u32(w.y);
+            br[2] = u32(w.z);
+            br[3] = u32(w.w);
+            if (repair) {
+#pragma unroll
+                for (int t = 0; t < kStep; ++t) {
+                    const int e = (q0 + t) * LPR + l;
+                    if (e < n)  // np.random.uniform(lo, hi): lo + (hi-lo)*double
+                        brs[t] = a.lower[e] + (a.upper[e] - a.lower[e]) *
+                                                  philox_u53(e, LPR, grow, gen, kPurposeDeResample, a.key0, a.key1);
+                }
+            }
+        }
+    };
+    load_batch(0);
+
+    // ---- C. (CHAIN) best of the predecessor generation, status, publication
+    int64_t gbidx;
     double *part_f_out = a.part_f;
     int64_t *part_i_out = a.part_i;
     if (CHAIN) {
-        const sx_state *sin = a.state + chain_p;
-        const double *pf = a.part_f + (int64_t)chain_p * npart;
-        const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
-        if (sin->done) {
-            if (mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
-            return;
-        }
-        // wave 0 reduces the records (contiguous slices per lane keep np.argmin's first-minimum rule);
-        // the other waves of the workgroup pick the result up from LDS
-        if (threadIdx.x < kWave) {
-            double bf = __builtin_huge_val();
-            int64_t bi = INT64_MAX;
-            const int64_t per = (npart + kWave - 1) / kWave;
-            const int64_t k0 = (int64_t)threadIdx.x * per;
-            for (int64_t kk = k0; kk < k0 + per && kk < npart; ++kk) argmin_combine(bf, bi, pf[kk], pi[kk]);
-            wave_argmin_all(bf, bi);
-            if (threadIdx.x == 0) {
-                sf[0] = bf;
-                si[0] = bi;
-            }
-        }
-        __syncthreads();
-        const double bf = sf[0];
-        const int64_t bi = si[0];
-        __syncthreads();  // sf/si are reused at the end of the kernel
-        it = sin->it + 1;  // the generation just finalised
+        double bf = pfv[0];
+        int64_t bi = piv[0];
+#pragma unroll
+        for (int u = 1; u < kRecPerLane; ++u) argmin_combine(bf, bi, pfv[u], piv[u]);
+        wave_argmin_ordered(bf, bi);  // every wave on its own: no LDS, no workgroup barrier
         int status = SX_STATUS_NONE;
         if (it >= 2) {  // the reference does not test the initial population (de/_de.py:212-218)
             if (bf <= a.ftol)
@@ -155,120 +238,90 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void de_generation_kern
         part_f_out = a.part_f + (int64_t)(1 - chain_p) * npart;
         part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
     } else {
-        const sx_state *st = a.state;
-        if (st->done) return;
-        it = st->it;  // generations completed; this launch produces it+1
-        gbidx = st->gbidx;
+        gbidx = sin->gbidx;
     }
-    SX_TP(6);
-    const uint32_t gen = (uint32_t)(it + 1);
-    const double *__restrict__ cur = (it & 1) ? a.buf1 : a.buf0;
-    double *__restrict__ nxt = (it & 1) ? a.buf0 : a.buf1;
-    const int n = a.n;
-    const int64_t P = a.P, ld = a.ld;
-    const RowIds id(P);
-    const int lane = id.lane;
-    const int64_t rowc = id.rowc;
-    double *U = lds + id.wave * lds_row_stride(n);
-
-    const double fold = a.fit[rowc];
-    const double *__restrict__ xi = cur + rowc * ld;
-    const uint32_t grow = (uint32_t)(a.row0 + rowc);
-    const int strategy = a.strategy;
-    const int k = donors_of(strategy);
-    const bool repair = a.constraints != 0;
-
-    int64_t d[kMaxDonors];
-    int irand;
-    if (RNG == SX_RNG_PHILOX) {
-        philox_donors(P, k, rowc, grow, gen, a.key0, a.key1, n, d, irand);
-    } else {
-#pragma unroll
-        for (int t = 0; t < kMaxDonors; ++t) d[t] = t < k ? (int64_t)a.donors[(int64_t)t * P + rowc] : 0;
-        irand = a.irand[rowc];
-    }
-    SX_TP(1);
-    const double *__restrict__ p0 = cur + d[0] * ld;
-    const double *__restrict__ p1 = cur + d[1] * ld;
-    const double *__restrict__ p2 = cur + d[2] * ld;
-    const double *__restrict__ p3 = cur + d[3] * ld;
-    const double *__restrict__ p4 = cur + d[4] * ld;
     // best row: the caller's copy (multi-GPU: it may come from another shard) or row gbidx of this generation
     const double *__restrict__ gb = a.gbest != nullptr ? a.gbest : cur + gbidx * ld;
-    const double F = a.F, CR = a.CR;
-    const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
-    const double *rsrow = (RNG == SX_RNG_HOST && repair) ? a.resample + rowc * (int64_t)n : nullptr;
 
-    // ---- trial vector: mutation (de/_strategy.py, same association), crossover
-    //      (de/_de.py:344 forced index OR r <= CR), Random repair (de/_constraints.py:21-26) -> LDS
-    U4 w = {0u, 0u, 0u, 0u};
-    int q = 0;
-    for (int e = lane; e < n; e += kWave, ++q) {
-        const double x = xi[e];
-        double v;
-        if (strategy == SX_DE_BEST1BIN)
-            v = gb[e] + F * (p0[e] - p1[e]);
-        else if (strategy == SX_DE_RAND1BIN)
-            v = p0[e] + F * (p1[e] - p2[e]);
-        else if (strategy == SX_DE_BEST2BIN)
-            v = gb[e] + F * (((p0[e] + p1[e]) - p2[e]) - p3[e]);
-        else
-            v = p0[e] + F * (((p1[e] + p2[e]) - p3[e]) - p4[e]);
-        double r, rs = 0.0;
-        if (RNG == SX_RNG_PHILOX) {
-            // 32-bit crossover uniforms: one call per 4 steps (slot = (q>>2)*64 + lane, word = q&3)
-            if ((q & 3) == 0)
-                w = philox4x32_10((uint32_t)(q >> 2) * 64u + (uint32_t)lane, grow, gen, kPurposeDeCross, a.key0,
-                                  a.key1);
-            const int wi = q & 3;
-            r = u32(wi == 0 ? w.x : wi == 1 ? w.y : wi == 2 ? w.z : w.w);
-            if (repair)  // np.random.uniform(lo, hi): lo + (hi-lo)*double
-                rs = a.lower[e] + (a.upper[e] - a.lower[e]) *
-                                      philox_u53(e, grow, gen, kPurposeDeResample, a.key0, a.key1);
-        } else {
-            r = r1row[e];
-            if (repair) rs = rsrow[e];
+    // ---- D. trial vector: mutation (de/_strategy.py, same association), crossover (de/_de.py:344 forced
+    //      index OR r <= CR), Random repair (de/_constraints.py:21-26) -> LDS
+    const int nq = (n + LPR - 1) / LPR;
+    for (int q0 = 0; q0 < nq; q0 += kStep) {
+        if (q0 > 0) load_batch(q0);
+        double g[kStep];
+#pragma unroll
+        for (int t = 0; t < kStep; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            g[t] = (use_best && e < n) ? gb[e] : 0.0;
         }
-        double cand = (e == irand || r <= CR) ? v : x;
-        if (repair && (cand < a.lower[e] || cand > a.upper[e])) cand = rs;
-        U[e] = cand;
+#pragma unroll
+        for (int t = 0; t < kStep; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            if (e < n) {
+                double v;
+                if (strategy == SX_DE_BEST1BIN)
+                    v = g[t] + F * (bd[0][t] - bd[1][t]);
+                else if (strategy == SX_DE_RAND1BIN)
+                    v = bd[0][t] + F * (bd[1][t] - bd[2][t]);
+                else if (strategy == SX_DE_BEST2BIN)
+                    v = g[t] + F * (((bd[0][t] + bd[1][t]) - bd[2][t]) - bd[3][t]);
+                else
+                    v = bd[0][t] + F * (((bd[1][t] + bd[2][t]) - bd[3][t]) - bd[4][t]);
+                double cand = (e == irand || br[t] <= CR) ? v : bx[t];
+                if (repair && (cand < a.lower[e] || cand > a.upper[e])) cand = brs[t];
+                U[e] = cand;
+            }
+        }
     }
 
     SX_TP(2);
-    const double fc = row_objective<FUN>(U, n, plan, lane);
+    const double fc = row_objective<FUN, LPR>(U, n, plan, l);
     SX_TP(3);
     const bool better = fc < fold;  // _common.py:127 strict <
     if (id.active) {
         double *__restrict__ xo = nxt + id.row * ld;
-        if (better) {
-            for (int e = lane; e < n; e += kWave) xo[e] = U[e];
-        } else {
-            for (int e = lane; e < n; e += kWave) xo[e] = xi[e];
+        const double *__restrict__ src = better ? U : xi;  // LDS or global: generic loads
+        for (int e0 = l; e0 < n; e0 += kStep * LPR) {
+            double v[kStep];
+#pragma unroll
+            for (int t = 0; t < kStep; ++t) v[t] = (e0 + t * LPR < n) ? src[e0 + t * LPR] : 0.0;
+#pragma unroll
+            for (int t = 0; t < kStep; ++t)
+                if (e0 + t * LPR < n) xo[e0 + t * LPR] = v[t];
         }
-        if (lane == 0) {
+        if (l == 0) {
             if (better) a.fit[id.row] = fc;
             if (a.candfit != nullptr) a.candfit[id.row] = fc;
         }
     }
     SX_TP(4);
-    block_partial(better ? fc : fold, id, sf, si, part_f_out, part_i_out);
+    block_partial<LPR>(better ? fc : fold, id, sf, si, part_f_out, part_i_out);
     SX_TP(5);
 }
 
 typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t);
 
-template <int RNG, bool CHAIN>
-de_kernel_t pick_kernel(int fun_id) {
+template <int RNG, bool CHAIN, int LPR>
+de_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, CHAIN>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, CHAIN>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, CHAIN>;
-        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, CHAIN>;
-        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, CHAIN>;
-        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, CHAIN>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, CHAIN>;
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, CHAIN, LPR>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, CHAIN, LPR>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, CHAIN, LPR>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, CHAIN, LPR>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, CHAIN, LPR>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, CHAIN, LPR>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, CHAIN, LPR>;
     }
     return nullptr;
+}
+
+template <int RNG, bool CHAIN>
+de_kernel_t pick_kernel(int fun_id, int n) {
+    switch (lanes_per_row(n)) {
+        case 16: return pick_kernel_lpr<RNG, CHAIN, 16>(fun_id);
+        case 32: return pick_kernel_lpr<RNG, CHAIN, 32>(fun_id);
+    }
+    return pick_kernel_lpr<RNG, CHAIN, 64>(fun_id);
 }
 
 int check_args(const sx_de_args *a) {
@@ -288,19 +341,11 @@ int check_args(const sx_de_args *a) {
 }
 
 de_kernel_t kernel_for(const sx_de_args *a) {
-    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, false>(a->fun_id)
-                                   : pick_kernel<SX_RNG_HOST, false>(a->fun_id);
+    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, false>(a->fun_id, a->n)
+                                   : pick_kernel<SX_RNG_HOST, false>(a->fun_id, a->n);
 }
 
-struct Geometry {
-    unsigned blocks, threads;
-    size_t lds;
-};
-Geometry geometry(const sx_de_args *a) {
-    const int rpb = rows_per_block(a->n);
-    return Geometry{(unsigned)((a->P + rpb - 1) / rpb), (unsigned)(rpb * kWave),
-                    (size_t)rpb * lds_row_stride(a->n) * sizeof(double)};
-}
+Geometry geometry(const sx_de_args *a) { return row_geometry(a->P, a->n); }
 
 }  // namespace
 
@@ -369,6 +414,7 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
 static int check_chain(const sx_de_args *a) {
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_de_chain: needs in-kernel (Philox) draws");
+    SX_REQUIRE(sx_num_partials(a->P, a->n) <= 512, "sx_de_chain: more than 512 workgroup records (use the two-kernel path)");
     return 0;
 }
 
@@ -378,7 +424,7 @@ extern "C" int sx_de_chain_launch(const sx_de_args *a, int parity, int finalize_
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    de_kernel_t kern = pick_kernel<SX_RNG_PHILOX, true>(a->fun_id);
+    de_kernel_t kern = pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n);
     const unsigned blocks = finalize_only ? 1u : g.blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream, *a, plan, parity,
                        finalize_only ? 1 : 0, (int64_t)g.blocks);
@@ -403,7 +449,7 @@ extern "C" int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start
         int parity = (start_parity + i) & 1;
         void *kargs[] = {&args, &plan, &parity, &mode, &npart};
         hipKernelNodeParams kp = {};
-        kp.func = (void *)pick_kernel<SX_RNG_PHILOX, true>(a->fun_id);
+        kp.func = (void *)pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n);
         kp.gridDim = dim3(g.blocks);
         kp.blockDim = dim3(g.threads);
         kp.sharedMemBytes = (unsigned)g.lds;

@@ -1,15 +1,16 @@
 // Device-side building blocks shared by the generation kernels (gfx950, wave64).
 //
-// Thread layout: ONE WAVEFRONT PER INDIVIDUAL.  Lane l holds elements e = 64*q + l of
-// the row, so every vector load/store of a row is one fully coalesced 512-byte
-// access.  The trial vector U and the per-element objective terms are staged in
-// LDS; the row sum is then taken from LDS in numpy's pairwise add.reduce order
-// (8 running accumulators over blocks of 8, combined as
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), recursion above 128 terms; SURVEY.md
-// App. C): lane j&7 walks chain j, the 8-lane tree is three DPP steps.  Fitness
-// values therefore reproduce the reference's `.sum()` bit for bit for +,-,*
-// objectives.  The leaf table of the recursion travels in the kernel arguments
-// (scalar loads, uniform control flow).
+// Thread layout: an individual (row) is owned by LPR = 16, 32 or 64 adjacent lanes of a
+// wavefront (lanes_per_row(n): 16 up to n = 64, 32 up to 128, else the whole wave), so a
+// wave carries 4, 2 or 1 rows.  Lane l of a row holds elements e = LPR*q + l: every row
+// access is a coalesced run of >= 128 bytes, and the fixed per-wave work (state, donors,
+// Philox calls, reduction control) is shared by up to 4 rows.  The trial vector U and the
+// per-element objective terms are staged in LDS; the row sum is then taken from LDS in
+// numpy's pairwise add.reduce order (8 running accumulators over blocks of 8, combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), recursion above 128 terms): lane
+// l&7 of the row walks chain l&7, the 8-lane tree is three DPP steps.  Fitness values
+// therefore reproduce the reference's `.sum()` bit for bit for +,-,* objectives.  The leaf
+// table of the recursion travels in the kernel arguments (scalar loads, uniform control flow).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,19 +22,25 @@ namespace sx {
 constexpr int kGroup = 8;     // numpy's 8 running accumulators
 constexpr int kWave = 64;     // gfx950 wavefront = one individual
 constexpr int kMaxRowsPerBlock = 16;
+constexpr int kMaxWavesPerBlock = 8;
 constexpr int kMaxLeaf = 96;  // leaves carried in kernel arguments (n up to ~6k..12k)
-constexpr int kMaxDim = 6144; // LDS staging: 3 arrays of n doubles per wave (< 160 KiB)
+constexpr int kMaxDim = 2560; // LDS staging: 3 arrays of n doubles per row, <= 64 KiB per workgroup
 
 // doubles of LDS per wave: U[n+8] | A[n] | B[n] | stack[24]
 __host__ __device__ inline int lds_row_stride(int n) { return 3 * n + 8 + 24; }
-// rows (= waves) per workgroup: the largest power of two <= 16 whose LDS staging stays <= 64 KiB.
-// n <= 128 -> 16 rows (P = 4096 is exactly one 1024-thread workgroup per CU), 256 -> 8, 512 -> 4, 1024 -> 2.
-__host__ __device__ inline int rows_per_block(int n) {
-    const int fit = (64 * 1024) / (8 * lds_row_stride(n));
-    int r = 1;
-    while (r < kMaxRowsPerBlock && 2 * r <= fit) r *= 2;
-    return r;
+// lanes that own one row
+// (the smallest of 16/32/64 that covers the row in one batch of 4 steps, else the whole wave)
+__host__ __device__ inline int lanes_per_row(int n) { return n <= 64 ? 16 : (n <= 128 ? 32 : 64); }
+// waves per workgroup: the largest power of two with <= 16 rows and <= 64 KiB of LDS staging.
+// n <= 128 -> 4 waves x 4 rows (P = 4096 is exactly one workgroup per CU), 256 -> 2 x 4, 512 -> 2 x 2, 1024 -> 2 x 1.
+__host__ __device__ inline int waves_per_block(int n) {
+    const int rpw = kWave / lanes_per_row(n);
+    const int fit = (64 * 1024) / (8 * lds_row_stride(n) * rpw);
+    int w = 1;
+    while (2 * w <= fit && 2 * w * rpw <= kMaxRowsPerBlock && 2 * w <= kMaxWavesPerBlock) w *= 2;
+    return w;
 }
+__host__ __device__ inline int rows_per_block(int n) { return waves_per_block(n) * (kWave / lanes_per_row(n)); }
 
 // numpy pairwise-summation plan for an m-term row sum, passed BY VALUE as a kernel argument
 struct PlanArg {
@@ -117,21 +124,13 @@ enum : uint32_t {
     kPurposeCmaNormal = 6,
 };
 
-// Element e of a row sits in lane l = e & 63 at step q = e >> 6.
-// 53-bit uniform: slot = (q >> 1) * 64 + l, half = q & 1   (two per call)
-__device__ __forceinline__ double philox_u53(int e, uint32_t row, uint32_t gen, uint32_t purpose, uint32_t k0,
-                                             uint32_t k1) {
-    const uint32_t q = (uint32_t)e >> 6, l = (uint32_t)e & 63u;
-    const U4 w = philox4x32_10((q >> 1) * 64u + l, row, gen, purpose, k0, k1);
+// Element e of a row sits in lane l = e % LPR of the row's lanes at step q = e / LPR (LPR a power of two).
+// 53-bit uniform: slot = (q >> 1) * LPR + l, half = q & 1   (two per call)
+__device__ __forceinline__ double philox_u53(int e, int lpr, uint32_t row, uint32_t gen, uint32_t purpose,
+                                             uint32_t k0, uint32_t k1) {
+    const uint32_t l = (uint32_t)e & (uint32_t)(lpr - 1), q = (uint32_t)e / (uint32_t)lpr;
+    const U4 w = philox4x32_10((q >> 1) * (uint32_t)lpr + l, row, gen, purpose, k0, k1);
     return (q & 1u) ? u53(w.z, w.w) : u53(w.x, w.y);
-}
-// 32-bit uniform: slot = (q >> 2) * 64 + l, word = q & 3   (four per call)
-__device__ __forceinline__ double philox_u32(int e, uint32_t row, uint32_t gen, uint32_t purpose, uint32_t k0,
-                                             uint32_t k1) {
-    const uint32_t q = (uint32_t)e >> 6, l = (uint32_t)e & 63u;
-    const U4 w = philox4x32_10((q >> 2) * 64u + l, row, gen, purpose, k0, k1);
-    const uint32_t wi = q & 3u;
-    return u32(wi == 0 ? w.x : wi == 1 ? w.y : wi == 2 ? w.z : w.w);
 }
 
 // ---------------------------------------------------------------------------
@@ -324,6 +323,35 @@ __device__ __forceinline__ void argmin_combine(double &f, int64_t &i, double f2,
         f = f2;
         i = i2;
     }
+}
+
+constexpr int kDppRowMirror = 0x140;  // row_mirror: lane i <-> 15-i inside each 16 lanes
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// minimum over the 64 lanes, returned to every lane: four DPP steps + four readlanes (no LDS traffic)
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = fmin(v, dpp_f64<kDppXor1>(v));
+    v = fmin(v, dpp_f64<kDppXor2>(v));
+    v = fmin(v, dpp_f64<kDppHalfMirror>(v));
+    v = fmin(v, dpp_f64<kDppRowMirror>(v));  // every 16-lane row is uniform now
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
+// (min f, its index) over the wave when LOWER LANES HOLD LOWER INDICES: the first lane that holds the
+// minimum wins = np.argmin's first-minimum rule.  Result in every lane.
+__device__ __forceinline__ void wave_argmin_ordered(double &f, int64_t &i) {
+    const double m = wave_min_f64(f);
+    const unsigned long long mask = __ballot(f == m);
+    const int src = (int)__ffsll((long long)mask) - 1;
+    const int lo = __builtin_amdgcn_readlane((int)(i & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(i >> 32), src);
+    f = m;
+    i = ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
 }
 
 __device__ __forceinline__ void wave_argmin_all(double &f, int64_t &i) {

@@ -22,20 +22,9 @@ using namespace sx;
 
 namespace {
 
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, kWave));
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
-
-template <int FUN, int RNG>
-__global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void pso_generation_kernel(const sx_pso_args a,
-                                                                                  const PlanArg plan) {
+template <int FUN, int RNG, int LPR>
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
+                                                                                const PlanArg plan) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
@@ -44,10 +33,10 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void pso_generation_ker
     const uint32_t gen = (uint32_t)(st->it + 1);
     const int n = a.n;
     const int64_t P = a.P, ld = a.ld;
-    const RowIds id(P);
-    const int lane = id.lane;
+    const RowIds<LPR> id(P);
+    const int l = id.l;  // lane within the row
     const int64_t rowc = id.rowc;
-    double *U = lds + id.wave * lds_row_stride(n);
+    double *U = lds + id.slot * lds_row_stride(n);
     double *Vn = U + n + 8;  // staging for the new velocity (the objective's A region, free until then)
 
     const double fold = a.pbestfit[rowc];
@@ -65,13 +54,14 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void pso_generation_ker
     double beta = __builtin_huge_val();
     U4 wd = {0u, 0u, 0u, 0u};
     int q = 0;
-    for (int e = lane; e < n; e += kWave, ++q) {
+    for (int e = l; e < n; e += LPR, ++q) {
         const double x = xr[e], v = vr[e];
         double r1, r2;
         if (RNG == SX_RNG_PHILOX) {
             // 32-bit uniforms, one call per 2 steps: words (0,1) -> (r1,r2) of even q, (2,3) of odd q
             if ((q & 1) == 0)
-                wd = philox4x32_10((uint32_t)(q >> 1) * 64u + (uint32_t)lane, grow, gen, kPurposePsoR1, a.key0, a.key1);
+                wd = philox4x32_10((uint32_t)(q >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR1, a.key0,
+                                   a.key1);
             r1 = u32((q & 1) ? wd.z : wd.x);
             r2 = u32((q & 1) ? wd.w : wd.y);
         } else {
@@ -88,11 +78,11 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void pso_generation_ker
         }
     }
     if (shrink) {
-        beta = wave_min(beta);
+        beta = row_min<LPR>(beta);
         if (beta == __builtin_huge_val()) beta = 1.0;
     }
     lds_wave_fence();
-    for (int e = lane; e < n; e += kWave) {
+    for (int e = l; e < n; e += LPR) {
         double vn = Vn[e];
         if (shrink) vn = vn * beta;  // V *= beta[:, None]
         const double xn = xr[e] + vn;
@@ -102,33 +92,42 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave, 4) void pso_generation_ker
             xr[e] = xn;
         }
     }
-    const double fc = row_objective<FUN>(U, n, plan, lane);
+    const double fc = row_objective<FUN, LPR>(U, n, plan, l);
     const bool better = fc < fold;  // _common.py:127 strict <
     if (id.active) {
         if (better)
-            for (int e = lane; e < n; e += kWave) pb[e] = U[e];
-        if (lane == 0) {
+            for (int e = l; e < n; e += LPR) pb[e] = U[e];
+        if (l == 0) {
             if (better) a.pbestfit[id.row] = fc;
             if (a.candfit != nullptr) a.candfit[id.row] = fc;
         }
     }
-    block_partial(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+    block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
 }
 
 typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
 
-template <int RNG>
-pso_kernel_t pick_kernel(int fun_id) {
+template <int RNG, int LPR>
+pso_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG>;
-        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG>;
-        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG>;
-        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG>;
-        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG>;
-        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG>;
+        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR>;
+        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR>;
+        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR>;
+        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR>;
+        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR>;
+        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR>;
     }
     return nullptr;
+}
+
+template <int RNG>
+pso_kernel_t pick_kernel(int fun_id, int n) {
+    switch (lanes_per_row(n)) {
+        case 16: return pick_kernel_lpr<RNG, 16>(fun_id);
+        case 32: return pick_kernel_lpr<RNG, 32>(fun_id);
+    }
+    return pick_kernel_lpr<RNG, 64>(fun_id);
 }
 
 int check_args(const sx_pso_args *a) {
@@ -143,37 +142,31 @@ int check_args(const sx_pso_args *a) {
     return 0;
 }
 
-struct Geometry {
-    unsigned blocks, threads;
-    size_t lds;
-};
-Geometry geometry(int64_t P, int n) {
-    const int rpb = rows_per_block(n);
-    return Geometry{(unsigned)((P + rpb - 1) / rpb), (unsigned)(rpb * kWave),
-                    (size_t)rpb * lds_row_stride(n) * sizeof(double)};
-}
+Geometry geometry(int64_t P, int n) { return row_geometry(P, n); }
 
 // ---------------------------------------------------------------------------
 // Competitive restart, cpso/_cpso.py:405-426
 // ---------------------------------------------------------------------------
 // per-workgroup max_i ||X_i - gbest||_2  (:410)
-__global__ __launch_bounds__(kMaxRowsPerBlock *kWave) void pso_radius_kernel(const sx_pso_args a,
-                                                                             double *__restrict__ part_r) {
+template <int LPR>
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(const sx_pso_args a,
+                                                                              double *__restrict__ part_r) {
     __shared__ double sr[kMaxRowsPerBlock];
     if (a.state->done) return;
-    const RowIds id(a.P);
+    const RowIds<LPR> id(a.P);
     const double *__restrict__ xr = a.X + id.rowc * a.ld;
     double acc = 0.0;
-    for (int e = id.lane; e < a.n; e += kWave) {
+    for (int e = id.l; e < a.n; e += LPR) {
         const double d = xr[e] - a.gbest[e];
         acc += d * d;
     }
-    acc = sqrt(wave_sum(acc));
-    if (id.lane == 0) sr[id.wave] = id.active ? acc : 0.0;
+    acc = sqrt(row_sum<LPR>(acc));
+    if (id.l == 0) sr[id.slot] = id.active ? acc : 0.0;
     __syncthreads();
     if (threadIdx.x == 0) {
         double m = sr[0];
-        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmax(m, sr[k]);
+        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+        for (int k = 1; k < rows_in_block; ++k) m = fmax(m, sr[k]);
         part_r[blockIdx.x] = m;
     }
 }
@@ -251,7 +244,7 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 
 // rows whose pbestfit is among the nw worst: V = 0, X = uniform(lower, upper), pbest = X, pbestfit = 1e30 (:420-424)
 // host_rows != NULL (numpy-legacy): row ids in the reference's descending-fitness order + their new positions
-__global__ __launch_bounds__(kMaxRowsPerBlock *kWave) void pso_restart_apply_kernel(
+__global__ __launch_bounds__(256) void pso_restart_apply_kernel(
     const sx_pso_args a, const unsigned long long *__restrict__ sel, const int64_t *__restrict__ host_rows,
     const double *__restrict__ host_x, int64_t host_count) {
     if (a.state->done) return;
@@ -276,7 +269,8 @@ __global__ __launch_bounds__(kMaxRowsPerBlock *kWave) void pso_restart_apply_ker
         if (host_rows != nullptr)
             x = host_x[slot * (int64_t)a.n + e];
         else
-            x = a.lower[e] + (a.upper[e] - a.lower[e]) * philox_u53(e, grow, gen, kPurposePsoRestart, a.key0, a.key1);
+            x = a.lower[e] + (a.upper[e] - a.lower[e]) *
+                                 philox_u53(e, lanes_per_row(a.n), grow, gen, kPurposePsoRestart, a.key0, a.key1);
         vr[e] = 0.0;
         xr[e] = x;
         pb[e] = x;
@@ -292,8 +286,8 @@ extern "C" int sx_pso_generation(const sx_pso_args *a, int finalize, void *strea
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a->P, a->n);
-    pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id)
-                                                 : pick_kernel<SX_RNG_HOST>(a->fun_id);
+    pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n)
+                                                 : pick_kernel<SX_RNG_HOST>(a->fun_id, a->n);
     hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan);
     SX_LAUNCH_CHECK();
     if (finalize)
@@ -306,7 +300,8 @@ extern "C" int sx_pso_radius(const sx_pso_args *a, double *part_r, void *stream)
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(part_r != nullptr, "sx_pso_radius: null scratch");
     const Geometry g = geometry(a->P, a->n);
-    hipLaunchKernelGGL(pso_radius_kernel, dim3(g.blocks), dim3(g.threads), 0, (hipStream_t)stream, *a, part_r);
+    SX_DISPATCH_LPR(a->n, hipLaunchKernelGGL(pso_radius_kernel<LPR>, dim3(g.blocks), dim3(g.threads), 0,
+                                             (hipStream_t)stream, *a, part_r))
     SX_LAUNCH_CHECK();
     return 0;
 }
@@ -331,7 +326,7 @@ extern "C" int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, 
     SX_REQUIRE(a->lower && a->upper, "sx_pso_restart_apply: bounds missing");
     const int64_t slots = host_rows ? host_count : a->P;
     if (slots == 0) return 0;
-    const int rpb = kMaxRowsPerBlock;
+    const int rpb = 4;
     hipLaunchKernelGGL(pso_restart_apply_kernel, dim3((unsigned)((slots + rpb - 1) / rpb)), dim3(rpb * kWave), 0,
                        (hipStream_t)stream, *a, (const unsigned long long *)sel3, host_rows, host_x, host_count);
     SX_LAUNCH_CHECK();

@@ -1,23 +1,41 @@
 // Row-level device routines shared by the evaluation / DE / PSO kernels:
-// wave-per-individual indexing, LDS-staged objective evaluation, per-workgroup best.
+// row <-> lane indexing, LDS-staged objective evaluation, per-workgroup best.
 #pragma once
 #include "sx_device.hpp"
 
 namespace sx {
 
+// LPR lanes own one row; a wave carries RPW = 64 / LPR rows.
+template <int LPR>
 struct RowIds {
-    int wave, lane;
+    static constexpr int RPW = kWave / LPR;
+    int wave, lane;  // wave in workgroup, lane in wave
+    int l;           // lane within the row
+    int slot;        // row slot within the workgroup
     int64_t row, rowc;
     bool active;
     __device__ __forceinline__ explicit RowIds(int64_t P) {
         wave = (int)(threadIdx.x >> 6);
         lane = (int)(threadIdx.x & 63);
-        const int rpb = (int)(blockDim.x >> 6);
-        row = (int64_t)blockIdx.x * rpb + wave;
+        l = lane & (LPR - 1);
+        slot = wave * RPW + lane / LPR;
+        const int rows_in_block = (int)(blockDim.x >> 6) * RPW;
+        row = (int64_t)blockIdx.x * rows_in_block + slot;
         active = row < P;
-        rowc = active ? row : P - 1;  // padding waves shadow the last row and store nothing
+        rowc = active ? row : P - 1;  // padding rows shadow the last row and store nothing
     }
 };
+
+struct Geometry {
+    unsigned blocks, threads;
+    size_t lds;
+};
+inline Geometry row_geometry(int64_t P, int n) {
+    const int wpb = waves_per_block(n);
+    const int rpb = rows_per_block(n);
+    return Geometry{(unsigned)((P + rpb - 1) / rpb), (unsigned)(wpb * kWave),
+                    (size_t)rpb * lds_row_stride(n) * sizeof(double)};
+}
 
 // LDS traffic of one wavefront is processed in issue order, so data a lane wrote is
 // visible to the other lanes of the SAME wave once the write has been issued; this
@@ -28,45 +46,88 @@ __device__ __forceinline__ void lds_wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Objective of the row staged in LDS at U[0..n): terms by all 64 lanes -> A/B (behind U),
-// then the numpy-order row sums.  Each wave works on its own LDS slice (no workgroup barrier).
-template <int FUN>
-__device__ __forceinline__ double row_objective(double *U, int n, const PlanArg &plan, int lane) {
+// reductions over the LPR lanes of a row (LPR is a power of two, rows are LPR-aligned)
+template <int LPR>
+__device__ __forceinline__ double row_min(double v) {
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) v = fmin(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ double row_sum(double v) {
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Objective of the row staged in LDS at U[0..n): terms by the row's LPR lanes -> A/B (behind U),
+// then the numpy-order row sums (lanes l >= 8 repeat the chains of lanes l & 7: LDS broadcasts, same bits).
+// Every lane of the row returns the value.  Each row works on its own LDS slice (no workgroup barrier).
+template <int FUN, int LPR>
+__device__ __forceinline__ double row_objective(double *U, int n, const PlanArg &plan, int l) {
     using O = Obj<FUN>;
     double *A = U + n + 8;
     double *B = A + n;
     const int m = O::NEXT ? n - 1 : n;
     lds_wave_fence();  // U complete (written and read by this wave only)
-    for (int e = lane; e < m; e += kWave) {
-        const double x = U[e];
-        const double xn = O::NEXT ? U[e + 1] : 0.0;
-        double a, b;
-        O::term(x, xn, e, a, b);
-        A[e] = a;
-        if (O::TWO) B[e] = b;
+    for (int e0 = l; e0 < m; e0 += 4 * LPR) {  // 4 steps per trip: the LDS reads of a trip are independent
+        double x[4], xn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = e0 + t * LPR;
+            x[t] = e < m ? U[e] : 0.0;
+            xn[t] = (O::NEXT && e < m) ? U[e + 1] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = e0 + t * LPR;
+            if (e < m) {
+                double a, b;
+                O::term(x[t], xn[t], e, a, b);
+                A[e] = a;
+                if (O::TWO) B[e] = b;
+            }
+        }
     }
     lds_wave_fence();  // terms complete
     double sa, sb;
-    row_reduce2<O::TWO, O::BMUL>(A, B, B + n, plan, lane, sa, sb);
+    row_reduce2<O::TWO, O::BMUL>(A, B, B + n, plan, l, sa, sb);
     return O::finish(sa, sb, n);
 }
 
-// one (min f, first row) record per workgroup for the best-of-generation kernel
-__device__ __forceinline__ void block_partial(double val, const RowIds &id, double *sf, int64_t *si,
+// one (min f, first row) record per workgroup for the best-of-generation step
+template <int LPR>
+__device__ __forceinline__ void block_partial(double val, const RowIds<LPR> &id, double *sf, int64_t *si,
                                               double *__restrict__ part_f, int64_t *__restrict__ part_i) {
-    if (id.lane == 0) {
-        sf[id.wave] = id.active ? val : __builtin_huge_val();
-        si[id.wave] = id.active ? id.row : INT64_MAX;
+    if (id.l == 0) {
+        sf[id.slot] = id.active ? val : __builtin_huge_val();
+        si[id.slot] = id.active ? id.row : INT64_MAX;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double bf = sf[0];
-        int64_t bi = si[0];
-        const int rpb = (int)(blockDim.x >> 6);
-        for (int k = 1; k < rpb; ++k) argmin_combine(bf, bi, sf[k], si[k]);
+        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+        double vf[kMaxRowsPerBlock];
+        int64_t vi[kMaxRowsPerBlock];
+#pragma unroll
+        for (int k = 0; k < kMaxRowsPerBlock; ++k) {  // all LDS reads in flight at once
+            vf[k] = k < rows_in_block ? sf[k] : __builtin_huge_val();
+            vi[k] = k < rows_in_block ? si[k] : INT64_MAX;
+        }
+        double bf = vf[0];
+        int64_t bi = vi[0];
+#pragma unroll
+        for (int k = 1; k < kMaxRowsPerBlock; ++k) argmin_combine(bf, bi, vf[k], vi[k]);
         part_f[blockIdx.x] = bf;
         part_i[blockIdx.x] = bi;
     }
 }
+
+// run `body(std::integral_constant<int, LPR>)` for the LPR that lanes_per_row(n) prescribes
+#define SX_DISPATCH_LPR(n, CALL)            \
+    switch (lanes_per_row(n)) {             \
+        case 16: { constexpr int LPR = 16; CALL; } break; \
+        case 32: { constexpr int LPR = 32; CALL; } break; \
+        default: { constexpr int LPR = 64; CALL; } break; \
+    }
 
 }  // namespace sx

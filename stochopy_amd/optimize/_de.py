@@ -112,10 +112,10 @@ class _DeRun:
         self.x0 = x0
         # single GPU + in-kernel draws + nothing to report per generation: one kernel per generation
         # ("chained finalize", include/stochopy_hip.h sx_de_chain_launch)
-        # -- every workgroup re-reduces the per-workgroup records, so only while those are few
+        # -- every wavefront re-reduces the per-workgroup records, so only while those are few (<= 512)
         npart = int(_lib.lib().sx_num_partials(self.P, self.n))
         self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
-                      and npart <= 1024)
+                      and npart <= 512)
         self.launches = 0
         self.ctx = _device.Context()
         self._graph = None

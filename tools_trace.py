@@ -18,9 +18,11 @@ with torch.cuda.stream(run.ctx.stream):
     run._setup()
     run.enqueue(30)
     run.ctx.sync()
-    buf = np.zeros(1024 * 8, dtype=np.uint64)
+    buf = np.zeros(1024 * 16, dtype=np.uint64)
     run.ctx.L.sx_trace_read(buf.ctypes.data)
-b = buf.reshape(1024, 8).astype(np.int64)
+full = buf.reshape(1024, 16).astype(np.int64)
+b = full[:, :8]
+clk = full[:, 8:]
 print('chain', run.chain)
 nb = min(1024, int(run.ctx.L.sx_num_partials(P, n)))
 b = b[:nb]
@@ -33,4 +35,6 @@ print("6 -> 1 (donors):", (b[:, 1] - b[:, 6]).mean())
 for k in range(2, 6):
     d = b[:, k] - b[:, k - 1]
     print(f"phase {k-1}->{k}: mean {d.mean():.1f} min {d.min()} max {d.max()}")
+cyc = (clk[:nb, 5] - clk[:nb, 0]).mean(); wall = (b[:, 5] - b[:, 0]).mean()
+print("shader cycles per block %.0f over %.0f ticks -> %.2f GHz" % (cyc, wall, cyc / (wall * 10.0)))
 print("per-block total: mean", (b[:, 5] - b[:, 0]).mean(), "max", (b[:, 5] - b[:, 0]).max())
