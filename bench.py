@@ -118,6 +118,7 @@ def main():
 
     with torch.cuda.stream(ctx.stream):
         run._setup()
+        run.prepare_graphs()
         run.enqueue(W)
         ctx.sync()
         barrier()

@@ -115,9 +115,19 @@ int make_plan_arg(int fun_id, int n, PlanArg *out) {
     out->tail = buf[1];
     out->mb = buf[2];
     out->depth = buf[3];
+    std::vector<int> stack;  // slots (leaf indices) of the pending partial sums
+    int nm = 0;
     for (int t = 0; t < buf[0]; ++t) {
-        out->end[t] = (uint16_t)buf[4 + 2 * t];
-        out->merges[t] = (uint8_t)buf[5 + 2 * t];
+        out->end[t] = buf[4 + 2 * t];
+        out->merges[t] = buf[5 + 2 * t];
+        stack.push_back(t);
+        for (int k = 0; k < buf[5 + 2 * t]; ++k) {
+            const int right = stack.back();
+            stack.pop_back();
+            out->mleft[nm] = stack.back();
+            out->mright[nm] = right;
+            ++nm;
+        }
     }
     return 0;
 }

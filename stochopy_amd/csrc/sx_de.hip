@@ -99,7 +99,9 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
 // status 0 from 1, both of which stop: the host derives it from state.reserved[0] (previous best row).
 constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its loads in flight together
 
-template <int FUN, int RNG, bool CHAIN, int LPR>
+// FULL: n is a whole number of batches (n % (kStep*LPR) == 0) and P a whole number of workgroups, so
+// every bounds test folds away (the P = 4096, n = 128 headline shape).
+template <int FUN, int RNG, bool CHAIN, int LPR, bool FULL>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_de_args a,
                                                                                  const PlanArg plan,
                                                                                  const int chain_p, const int mode,
@@ -169,12 +171,19 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
     const double *rsrow = (RNG == SX_RNG_HOST && repair) ? a.resample + rowc * (int64_t)n : nullptr;
 
-    double bx[kStep], bd[kMaxDonors][kStep], br[kStep], brs[kStep];
-    auto load_batch = [&](int q0) {
+    struct Batch {
+        double x[kStep], d[kMaxDonors][kStep], r[kStep], rs[kStep];
+    };
+    Batch B0, B1;  // two batches in flight: the loads of the next one overlap the arithmetic of this one
+    auto load_batch = [&](int q0, Batch &bt) {
+        double(&bx)[kStep] = bt.x;
+        double(&bd)[kMaxDonors][kStep] = bt.d;
+        double(&br)[kStep] = bt.r;
+        double(&brs)[kStep] = bt.rs;
 #pragma unroll
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
-            const bool in = e < n;
+            const bool in = FULL || e < n;
             bx[t] = in ? xi[e] : 0.0;
 #pragma unroll
             for (int s = 0; s < kMaxDonors; ++s) bd[s][t] = (s < k && in) ? pd[s][e] : 0.0;
@@ -197,14 +206,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
 #pragma unroll
                 for (int t = 0; t < kStep; ++t) {
                     const int e = (q0 + t) * LPR + l;
-                    if (e < n)  // np.random.uniform(lo, hi): lo + (hi-lo)*double
+                    if (FULL || e < n)  // np.random.uniform(lo, hi): lo + (hi-lo)*double
                         brs[t] = a.lower[e] + (a.upper[e] - a.lower[e]) *
                                                   philox_u53(e, LPR, grow, gen, kPurposeDeResample, a.key0, a.key1);
                 }
             }
         }
     };
-    load_batch(0);
+    load_batch(0, B0);
 
     // ---- C. (CHAIN) best of the predecessor generation, status, publication
     int64_t gbidx;
@@ -246,18 +255,21 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     // ---- D. trial vector: mutation (de/_strategy.py, same association), crossover (de/_de.py:344 forced
     //      index OR r <= CR), Random repair (de/_constraints.py:21-26) -> LDS
     const int nq = (n + LPR - 1) / LPR;
-    for (int q0 = 0; q0 < nq; q0 += kStep) {
-        if (q0 > 0) load_batch(q0);
+    auto trial_batch = [&](int q0, const Batch &bt) {
+        const double(&bx)[kStep] = bt.x;
+        const double(&bd)[kMaxDonors][kStep] = bt.d;
+        const double(&br)[kStep] = bt.r;
+        const double(&brs)[kStep] = bt.rs;
         double g[kStep];
 #pragma unroll
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
-            g[t] = (use_best && e < n) ? gb[e] : 0.0;
+            g[t] = (use_best && (FULL || e < n)) ? gb[e] : 0.0;
         }
 #pragma unroll
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
-            if (e < n) {
+            if (FULL || e < n) {
                 double v;
                 if (strategy == SX_DE_BEST1BIN)
                     v = g[t] + F * (bd[0][t] - bd[1][t]);
@@ -272,22 +284,31 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
                 U[e] = cand;
             }
         }
+    };
+    for (int q0 = 0; q0 < nq; q0 += 2 * kStep) {
+        const bool more1 = q0 + kStep < nq, more2 = q0 + 2 * kStep < nq;
+        if (more1) load_batch(q0 + kStep, B1);
+        trial_batch(q0, B0);
+        if (more1) {
+            if (more2) load_batch(q0 + 2 * kStep, B0);
+            trial_batch(q0 + kStep, B1);
+        }
     }
 
     SX_TP(2);
-    const double fc = row_objective<FUN, LPR>(U, n, plan, l);
+    const double fc = row_objective<FUN, LPR, FULL>(U, n, plan, l);
     SX_TP(3);
     const bool better = fc < fold;  // _common.py:127 strict <
-    if (id.active) {
+    if (FULL || id.active) {
         double *__restrict__ xo = nxt + id.row * ld;
         const double *__restrict__ src = better ? U : xi;  // LDS or global: generic loads
         for (int e0 = l; e0 < n; e0 += kStep * LPR) {
             double v[kStep];
 #pragma unroll
-            for (int t = 0; t < kStep; ++t) v[t] = (e0 + t * LPR < n) ? src[e0 + t * LPR] : 0.0;
+            for (int t = 0; t < kStep; ++t) v[t] = (FULL || e0 + t * LPR < n) ? src[e0 + t * LPR] : 0.0;
 #pragma unroll
             for (int t = 0; t < kStep; ++t)
-                if (e0 + t * LPR < n) xo[e0 + t * LPR] = v[t];
+                if (FULL || e0 + t * LPR < n) xo[e0 + t * LPR] = v[t];
         }
         if (l == 0) {
             if (better) a.fit[id.row] = fc;
@@ -301,27 +322,30 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
 
 typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t);
 
-template <int RNG, bool CHAIN, int LPR>
+template <int RNG, bool CHAIN, int LPR, bool FULL>
 de_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, CHAIN, LPR>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, CHAIN, LPR>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, CHAIN, LPR>;
-        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, CHAIN, LPR>;
-        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, CHAIN, LPR>;
-        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, CHAIN, LPR>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, CHAIN, LPR>;
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, CHAIN, LPR, FULL>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, CHAIN, LPR, FULL>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, CHAIN, LPR, FULL>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, CHAIN, LPR, FULL>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, CHAIN, LPR, FULL>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, CHAIN, LPR, FULL>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, CHAIN, LPR, FULL>;
     }
     return nullptr;
 }
 
+// bounds-test-free variant only for the chained (throughput) kernels, to keep the build small
 template <int RNG, bool CHAIN>
-de_kernel_t pick_kernel(int fun_id, int n) {
-    switch (lanes_per_row(n)) {
-        case 16: return pick_kernel_lpr<RNG, CHAIN, 16>(fun_id);
-        case 32: return pick_kernel_lpr<RNG, CHAIN, 32>(fun_id);
+de_kernel_t pick_kernel(int fun_id, int n, int64_t P) {
+    const int lpr = lanes_per_row(n);
+    const bool full = CHAIN && n % (kStep * lpr) == 0 && P % rows_per_block(n) == 0;
+    switch (lpr) {
+        case 16: return full ? pick_kernel_lpr<RNG, CHAIN, 16, CHAIN>(fun_id) : pick_kernel_lpr<RNG, CHAIN, 16, false>(fun_id);
+        case 32: return full ? pick_kernel_lpr<RNG, CHAIN, 32, CHAIN>(fun_id) : pick_kernel_lpr<RNG, CHAIN, 32, false>(fun_id);
     }
-    return pick_kernel_lpr<RNG, CHAIN, 64>(fun_id);
+    return full ? pick_kernel_lpr<RNG, CHAIN, 64, CHAIN>(fun_id) : pick_kernel_lpr<RNG, CHAIN, 64, false>(fun_id);
 }
 
 int check_args(const sx_de_args *a) {
@@ -341,8 +365,8 @@ int check_args(const sx_de_args *a) {
 }
 
 de_kernel_t kernel_for(const sx_de_args *a) {
-    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, false>(a->fun_id, a->n)
-                                   : pick_kernel<SX_RNG_HOST, false>(a->fun_id, a->n);
+    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, false>(a->fun_id, a->n, a->P)
+                                   : pick_kernel<SX_RNG_HOST, false>(a->fun_id, a->n, a->P);
 }
 
 Geometry geometry(const sx_de_args *a) { return row_geometry(a->P, a->n); }
@@ -424,7 +448,7 @@ extern "C" int sx_de_chain_launch(const sx_de_args *a, int parity, int finalize_
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    de_kernel_t kern = pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n);
+    de_kernel_t kern = pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n, a->P);
     const unsigned blocks = finalize_only ? 1u : g.blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream, *a, plan, parity,
                        finalize_only ? 1 : 0, (int64_t)g.blocks);
@@ -449,7 +473,7 @@ extern "C" int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start
         int parity = (start_parity + i) & 1;
         void *kargs[] = {&args, &plan, &parity, &mode, &npart};
         hipKernelNodeParams kp = {};
-        kp.func = (void *)pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n);
+        kp.func = (void *)pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n, a->P);
         kp.gridDim = dim3(g.blocks);
         kp.blockDim = dim3(g.threads);
         kp.sharedMemBytes = (unsigned)g.lds;

@@ -23,11 +23,12 @@ constexpr int kGroup = 8;     // numpy's 8 running accumulators
 constexpr int kWave = 64;     // gfx950 wavefront = one individual
 constexpr int kMaxRowsPerBlock = 16;
 constexpr int kMaxWavesPerBlock = 8;
-constexpr int kMaxLeaf = 96;  // leaves carried in kernel arguments (n up to ~6k..12k)
+constexpr int kMaxLeaf = 48;  // leaves carried in kernel arguments (n <= kMaxDim has at most 40)
 constexpr int kMaxDim = 2560; // LDS staging: 3 arrays of n doubles per row, <= 64 KiB per workgroup
 
-// doubles of LDS per wave: U[n+8] | A[n] | B[n] | stack[24]
-__host__ __device__ inline int lds_row_stride(int n) { return 3 * n + 8 + 24; }
+// doubles of LDS per row: U[n+8] | A[n] | B[n] | stack[24] | leaf sums [2][n/64+2]
+__host__ __device__ inline int leaf_cap(int n) { return n / 64 + 2; }
+__host__ __device__ inline int lds_row_stride(int n) { return 3 * n + 8 + 24 + 2 * leaf_cap(n); }
 // lanes that own one row
 // (the smallest of 16/32/64 that covers the row in one batch of 4 steps, else the whole wave)
 __host__ __device__ inline int lanes_per_row(int n) { return n <= 64 ? 16 : (n <= 128 ? 32 : 64); }
@@ -48,8 +49,11 @@ struct PlanArg {
     int32_t tail;   // m % 8: terms added one by one after the last leaf's tree
     int32_t mb;     // m / 8
     int32_t depth;  // stack depth of the recursion
-    uint16_t end[kMaxLeaf];    // end block (exclusive) of leaf t
-    uint8_t merges[kMaxLeaf];  // stack merges after leaf t
+    // 32-bit entries: a uniform, run-time-indexed read of a kernel-argument array is then one s_load_dword
+    int32_t end[kMaxLeaf];     // end block (exclusive) of leaf t
+    int32_t merges[kMaxLeaf];  // stack merges after leaf t
+    int32_t mleft[kMaxLeaf];   // merge m adds slot mright[m] into slot mleft[m] (slots = leaf indices;
+    int32_t mright[kMaxLeaf];  //  the recursion's combines in order; the total ends in slot 0)
 };
 
 // ---------------------------------------------------------------------------
@@ -65,6 +69,12 @@ __device__ __forceinline__ double dpp_f64(double v) {
 constexpr int kDppXor1 = 0xB1;        // quad_perm:[1,0,3,2]
 constexpr int kDppXor2 = 0x4E;        // quad_perm:[2,3,0,1]
 constexpr int kDppHalfMirror = 0x141; // row_half_mirror: lane i <-> 7-i inside each 8 lanes
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 
 template <bool MUL>
 __device__ __forceinline__ double combine(double a, double b) {
@@ -317,6 +327,93 @@ __device__ __forceinline__ void row_reduce2(const double *A, const double *B, do
     sb = (TWO && !BMUL) ? 0.0 + curB : curB;
 }
 
+// value held by lane `idx` of this lane's row (idx uniform).  A whole-wave row can use v_readlane.
+template <int LPR>
+__device__ __forceinline__ double row_lane_value(double v, int idx, int l) {
+    if (LPR == kWave) return readlane_f64(v, idx);
+    return __shfl(v, (int)(threadIdx.x & 63) - l + idx, kWave);
+}
+
+// Rows with several leaves (n > 128): the leaves of numpy's recursion are independent, so the LPR/8
+// 8-lane groups of the row take one leaf each (chain + tree [+ tail]); the leaf sums meet in LDS and are
+// then merged in recursion order.  L: 2*leaf_cap doubles of LDS scratch (leaf sums), S: the merge stack.
+template <bool TWO, bool BMUL, int LPR>
+__device__ __forceinline__ void row_reduce_leaves(const double *A, const double *B, double *S, double *L, int lcap,
+                                                  const PlanArg &p, int l, double &sa, double &sb) {
+    constexpr int NG = LPR / kGroup;
+    const int j = l & (kGroup - 1), grp = l >> 3;
+    const double identB = BMUL ? 1.0 : 0.0;
+    const int t0 = p.mb * kGroup;
+    for (int leaf0 = 0; leaf0 < p.nleaf; leaf0 += NG) {
+        // this group's leaf: block range via uniform (scalar) plan reads + selects
+        int b0 = 0, b1 = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int lf = leaf0 + g;
+            const int e1 = lf < p.nleaf ? (int)p.end[lf] : 0;
+            const int e0 = (lf > 0 && lf <= p.nleaf) ? (int)p.end[lf - 1] : 0;
+            if (grp == g) {
+                b0 = e0;
+                b1 = e1;
+            }
+        }
+        const int leaf = leaf0 + grp;
+        const int cnt = b1 - b0;  // 0 for groups beyond the last leaf
+        double chA = 0.0, chB = identB;
+#pragma unroll
+        for (int h = 0; h < kLeafBlocks; h += 8) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool in = h + t < cnt;
+                va[t] = in ? A[(b0 + h + t) * kGroup + j] : 0.0;
+                vb[t] = (TWO && in) ? B[(b0 + h + t) * kGroup + j] : identB;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (h + t == 0) {
+                    chA = va[0];
+                    chB = vb[0];
+                } else if (h + t < cnt) {
+                    chA = chA + va[t];
+                    if (TWO) chB = combine<BMUL>(chB, vb[t]);
+                }
+            }
+        }
+        double curA = group_tree<false>(chA);
+        double curB = TWO ? group_tree<BMUL>(chB) : identB;
+        if (leaf == p.nleaf - 1) {
+            for (int k = 0; k < p.tail; ++k) {
+                curA = curA + A[t0 + k];
+                if (TWO) curB = combine<BMUL>(curB, B[t0 + k]);
+            }
+        }
+        if (cnt > 0 && j == 0) {
+            L[leaf] = curA;
+            if (TWO) L[lcap + leaf] = curB;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // merge in recursion order: leaf t's sums sit in lane t; the host-built program (pair[m] = left, right
+    // slot) is replayed with one readlane + one add per merge -- no LDS round trips.  Result in slot 0.
+    double vA = l < p.nleaf ? L[l] : 0.0;
+    double vB = (TWO && l < p.nleaf) ? L[lcap + l] : identB;
+    for (int m = 0; m + 1 < p.nleaf; ++m) {
+        const int left = (int)p.mleft[m], right = (int)p.mright[m];  // uniform (scalar loads)
+        const double rA = row_lane_value<LPR>(vA, right, l);
+        const double rB = TWO ? row_lane_value<LPR>(vB, right, l) : identB;
+        if (l == left) {
+            vA = vA + rA;
+            if (TWO) vB = combine<BMUL>(vB, rB);
+        }
+    }
+    sa = 0.0 + row_lane_value<LPR>(vA, 0, l);
+    const double rb = TWO ? row_lane_value<LPR>(vB, 0, l) : identB;
+    sb = (TWO && !BMUL) ? 0.0 + rb : rb;
+}
+
 // lexicographic (value, index) minimum = np.argmin's first-minimum rule
 __device__ __forceinline__ void argmin_combine(double &f, int64_t &i, double f2, int64_t i2) {
     if (f2 < f || (f2 == f && i2 < i)) {
@@ -326,12 +423,6 @@ __device__ __forceinline__ void argmin_combine(double &f, int64_t &i, double f2,
 }
 
 constexpr int kDppRowMirror = 0x140;  // row_mirror: lane i <-> 15-i inside each 16 lanes
-
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
 
 // minimum over the 64 lanes, returned to every lane: four DPP steps + four readlanes (no LDS traffic)
 __device__ __forceinline__ double wave_min_f64(double v) {

@@ -63,7 +63,7 @@ __device__ __forceinline__ double row_sum(double v) {
 // Objective of the row staged in LDS at U[0..n): terms by the row's LPR lanes -> A/B (behind U),
 // then the numpy-order row sums (lanes l >= 8 repeat the chains of lanes l & 7: LDS broadcasts, same bits).
 // Every lane of the row returns the value.  Each row works on its own LDS slice (no workgroup barrier).
-template <int FUN, int LPR>
+template <int FUN, int LPR, bool FULL = false>
 __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg &plan, int l) {
     using O = Obj<FUN>;
     double *A = U + n + 8;
@@ -75,8 +75,9 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = e0 + t * LPR;
-            x[t] = e < m ? U[e] : 0.0;
-            xn[t] = (O::NEXT && e < m) ? U[e + 1] : 0.0;
+            // FULL: rows are whole batches, U[n..n+7] is padding, so the reads need no guard
+            x[t] = (FULL || e < m) ? U[e] : 0.0;
+            xn[t] = (O::NEXT && (FULL || e < m)) ? U[e + 1] : 0.0;
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -91,7 +92,10 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     }
     lds_wave_fence();  // terms complete
     double sa, sb;
-    row_reduce2<O::TWO, O::BMUL>(A, B, B + n, plan, l, sa, sb);
+    if (plan.nleaf > 1)  // uniform: n > 128, leaves reduced in parallel by the row's 8-lane groups
+        row_reduce_leaves<O::TWO, O::BMUL, LPR>(A, B, B + n, B + n + 24, leaf_cap(n), plan, l, sa, sb);
+    else
+        row_reduce2<O::TWO, O::BMUL>(A, B, B + n, plan, l, sa, sb);
     return O::finish(sa, sb, n);
 }
 

@@ -145,16 +145,31 @@ class _DeRun:
                    "sx_de_chain_launch")
         return ctx.read_state(self.state[16:24])
 
+    def _chain_graph(self, par):
+        if par not in self._chain_graphs:
+            g = C.c_void_p()
+            _lib.check(self.ctx.L.sx_de_chain_graph_create(C.byref(self.args), self.GRAPH_CHUNK, par, C.byref(g)),
+                       "sx_de_chain_graph_create")
+            self._chain_graphs[par] = g
+        return self._chain_graphs[par]
+
+    def prepare_graphs(self):
+        """Instantiate the hipGraph(s) up front (otherwise the first full chunk pays for it)."""
+        if self.world is not None:
+            return
+        if self.chain:
+            self._chain_graph(0)  # GRAPH_CHUNK is even: replays always start at parity 0 unless eager launches intervene
+        elif self.rng == "philox" and self._graph is None:
+            g = C.c_void_p()
+            _lib.check(self.ctx.L.sx_de_graph_create(C.byref(self.args), self.GRAPH_CHUNK, C.byref(g)),
+                       "sx_de_graph_create")
+            self._graph = g
+
     def _enqueue_chain(self, ngen):
         ctx = self.ctx
         while ngen >= self.GRAPH_CHUNK:
             par = self.launches & 1
-            if par not in self._chain_graphs:
-                g = C.c_void_p()
-                _lib.check(ctx.L.sx_de_chain_graph_create(C.byref(self.args), self.GRAPH_CHUNK, par, C.byref(g)),
-                           "sx_de_chain_graph_create")
-                self._chain_graphs[par] = g
-            _lib.check(ctx.L.sx_graph_launch(self._chain_graphs[par], ctx.stream_ptr), "sx_graph_launch")
+            _lib.check(ctx.L.sx_graph_launch(self._chain_graph(par), ctx.stream_ptr), "sx_graph_launch")
             self.launches += self.GRAPH_CHUNK
             ngen -= self.GRAPH_CHUNK
         for _ in range(ngen):
