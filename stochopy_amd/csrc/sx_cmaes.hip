@@ -171,20 +171,40 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
     }
 }
 
-// xmean[e] = sum_k w[k] * arx[idx[k]][e]   (one workgroup per 64 columns, 4 k-slices)
-__global__ __launch_bounds__(256) void cma_recombine_kernel(const double *__restrict__ arx,
-                                                            const int64_t *__restrict__ idx,
-                                                            const double *__restrict__ w, int mu, int n,
-                                                            double *__restrict__ xmean) {
-    __shared__ double part[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+// xmean[e] = sum_k w[k] * arx[idx[k]][e]   (one workgroup per 64 columns; 16 k-slices of 64 lanes each,
+// 4 rows in flight per thread, fixed combination order => reproducible)
+constexpr int kRecSlices = 16;
+__global__ __launch_bounds__(64 * kRecSlices) void cma_recombine_kernel(const double *__restrict__ arx,
+                                                                        const int64_t *__restrict__ idx,
+                                                                        const double *__restrict__ w, int mu, int n,
+                                                                        double *__restrict__ xmean) {
+    __shared__ double part[kRecSlices][64];
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 64 + lane;
     const int slice = threadIdx.x >> 6;
     double acc = 0.0;
-    if (col < n)
-        for (int k = slice; k < mu; k += 4) acc += w[k] * arx[idx[k] * (int64_t)n + col];
-    part[slice][threadIdx.x & 63] = acc;
+    if (col < n) {
+        for (int k0 = slice; k0 < mu; k0 += 4 * kRecSlices) {
+            double v[4], ww[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * kRecSlices;
+                const bool in = k < mu;
+                ww[u] = in ? w[k] : 0.0;
+                v[u] = in ? arx[idx[k] * (int64_t)n + col] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += ww[u] * v[u];
+        }
+    }
+    part[slice][lane] = acc;
     __syncthreads();
-    if (slice == 0 && col < n) xmean[col] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (slice == 0 && col < n) {
+        double s = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < kRecSlices; ++k) s += part[k][lane];
+        xmean[col] = s;
+    }
 }
 
 // Z[i][e] ~ N(0,1): Box-Muller on the two 53-bit uniforms of a call, half 0 -> cos, half 1 -> sin
@@ -240,7 +260,7 @@ extern "C" int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const dou
 extern "C" int sx_cmaes_recombine(const double *arx, const int64_t *idx, const double *w, int mu, int n,
                                   double *xmean, void *stream) {
     SX_REQUIRE(arx && idx && w && xmean && mu >= 1 && n >= 1, "sx_cmaes_recombine: bad arguments");
-    hipLaunchKernelGGL(cma_recombine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, arx, idx,
+    hipLaunchKernelGGL(cma_recombine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * kRecSlices), 0, (hipStream_t)stream, arx, idx,
                        w, mu, n, xmean);
     SX_LAUNCH_CHECK();
     return 0;

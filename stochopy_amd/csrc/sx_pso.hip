@@ -181,15 +181,13 @@ constexpr int kSelThreads = 1024;
 constexpr int kSelPerThread = 32;  // P <= 32768 per GPU for the on-device worst-nw selection
 
 // One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
-// and the nw-th largest pbestfit is found by a 64-step radix descent over keys held in registers.
+// and the nw-th largest pbestfit is found by an 8-step (one byte per step) radix descent over keys held in registers.
 // out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
 __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const sx_pso_args a,
                                                                          const double *__restrict__ part_r,
                                                                          int64_t npart, double delta, double gamma,
                                                                          unsigned long long *__restrict__ out) {
     __shared__ double smax[kSelThreads / kWave];
-    __shared__ unsigned scount[kSelThreads / kWave];
-    __shared__ unsigned stotal;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.state->done) {
         if (tid == 0) out[0] = 0;
@@ -221,23 +219,51 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         const int64_t i = (int64_t)k * kSelThreads + tid;
         key[k] = i < a.P ? sort_key(a.pbestfit[i]) : 0ull;  // 0 < every real key
     }
+    // radix descent, 8 bits per step: histogram (LDS atomics) of the next byte over the keys that match the
+    // prefix found so far; the byte of the `remaining`-th largest of them is where the suffix count crosses it
+    __shared__ unsigned bins[256];
+    __shared__ unsigned s_digit, s_above;
     unsigned long long prefix = 0ull;
-    for (int bit = 63; bit >= 0; --bit) {
-        const unsigned long long cand = prefix | (1ull << bit);
-        unsigned c = 0;
-#pragma unroll
-        for (int k = 0; k < kSelPerThread; ++k) c += (key[k] >= cand) ? 1u : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
-        if (lane == 0) scount[wv] = c;
+    unsigned remaining = (unsigned)nw;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (tid < 256) bins[tid] = 0u;
         __syncthreads();
-        if (tid == 0) {
-            unsigned t = 0;
-            for (int k = 0; k < kSelThreads / kWave; ++k) t += scount[k];
-            stotal = t;
+        const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+#pragma unroll
+        for (int k = 0; k < kSelPerThread; ++k) {
+            const int64_t i = (int64_t)k * kSelThreads + tid;
+            if (i < a.P && (key[k] & himask) == prefix) atomicAdd(&bins[(unsigned)(key[k] >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if ((int64_t)stotal >= nw) prefix = cand;  // at least nw keys are >= cand: the nw-th largest is too
+        if (tid < kWave) {  // wave 0: lane l owns bins 4l..4l+3; suffix sums locate the crossing byte
+            const unsigned c0 = bins[4 * lane], c1 = bins[4 * lane + 1], c2 = bins[4 * lane + 2], c3 = bins[4 * lane + 3];
+            const unsigned mine = c0 + c1 + c2 + c3;
+            unsigned suf = mine;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const unsigned o = __shfl_down(suf, off, kWave);
+                if (lane + off < kWave) suf += o;
+            }
+            const unsigned above = suf - mine;  // keys in bins of higher lanes
+            if (above < remaining && suf >= remaining) {  // exactly one lane
+                unsigned acc = above, digit = 4u * lane + 3u;
+                if (acc + c3 >= remaining) {
+                    digit = 4u * lane + 3u;
+                } else if ((acc += c3) + c2 >= remaining) {
+                    digit = 4u * lane + 2u;
+                } else if ((acc += c2) + c1 >= remaining) {
+                    digit = 4u * lane + 1u;
+                } else {
+                    acc += c1;
+                    digit = 4u * lane;
+                }
+                s_digit = digit;
+                s_above = acc;  // keys (matching the prefix) with a larger byte than `digit`
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)s_digit << shift;
+        remaining -= s_above;
     }
     if (tid == 0) out[1] = prefix;
 }
