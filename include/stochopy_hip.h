@@ -271,7 +271,8 @@ int sx_cmaes_sample(const double *xmean, double sigma, const double *B, const do
 int sx_cmaes_recombine(const double *arx, const int64_t *idx, const double *w, int mu, int n, double *xmean,
                        void *stream);
 int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
-                     const double *pc, double c1, double cmu, double tmp_coef, double *C, int n, void *stream);
+                     const double *pc, double c1, double cmu, double tmp_coef, double *C, double *ws_y, int n,
+                     void *stream); /* ws_y: DEVICE scratch (mu,n) for artmp */
 int sx_cmaes_normals(double *Z, int64_t P, int n, int64_t row0, uint32_t gen, uint32_t key0, uint32_t key1,
                      void *stream);
 int sx_symmetrize_upper(double *C, int n, void *stream);

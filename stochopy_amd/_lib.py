@@ -84,7 +84,7 @@ PROTOTYPES = {
     "sx_pso_restart_apply": (C.c_int, [C.POINTER(SxPsoArgs), vp, vp, vp, i64, vp]),
     "sx_cmaes_sample": (C.c_int, [vp, f64, vp, vp, vp, vp, i64, C.c_int, vp]),
     "sx_cmaes_recombine": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
-    "sx_cmaes_rank_mu": (C.c_int, [vp, vp, vp, C.c_int, vp, f64, vp, f64, f64, f64, vp, C.c_int, vp]),
+    "sx_cmaes_rank_mu": (C.c_int, [vp, vp, vp, C.c_int, vp, f64, vp, f64, f64, f64, vp, vp, C.c_int, vp]),
     "sx_cmaes_normals": (C.c_int, [vp, i64, C.c_int, i64, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "sx_symmetrize_upper": (C.c_int, [vp, C.c_int, vp]),
     "sx_mt_create": (vp, [C.c_uint32]),

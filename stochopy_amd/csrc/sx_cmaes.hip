@@ -11,7 +11,8 @@
 // MFMA: v_mfma_f64_16x16x4_f64.  Operand layout (cdna_hip_programming.md section 3):
 //   A (16x4): lane l holds A[l & 15][l >> 4];  B (4x16): lane l holds B[l >> 4][l & 15];
 //   C/D: 4 doubles per lane, col = l & 15, row = (l >> 4) + 4 * reg.
-// Workgroup tile 64x64, four waves in a 2x2 grid of 32x32 (2x2 MFMA tiles each), K chunk 32.
+// Workgroup tiles 64x64 / 32x64 / 32x32 (chosen so the small CMA-ES shapes still give >= 256 workgroups),
+// four waves in a 2x2 grid, K chunk 32 staged through LDS with register prefetch of the next chunk.
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 
@@ -21,9 +22,8 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, KC = 32;
+constexpr int KC = 32;        // K chunk
 constexpr int LDA = KC + 2;   // A tile [BM][LDA]: row stride 34 doubles -> conflict-free ds_read_b64 of a column slab
-constexpr int LDB = BN + 16;  // B tile [KC][LDB]: the two k-groups of a 32-lane half land 32 banks apart
 constexpr int kGemmThreads = 256;
 
 struct SampleOp {  // arx = xmean + sigma * (Z o D) * B^T
@@ -37,116 +37,143 @@ struct SampleOp {  // arx = xmean + sigma * (Z o D) * B^T
     int n;
 };
 
-struct RankMuOp {  // C = (1-c1-cmu)*C + cmu * Y^T diag(w) Y + c1 * pc pc^T + tmpc * C_old,  Y[k] = (arx[idx[k]] - xold)/sigma
-    const double *arx;    // (P,n)
-    const int64_t *idx;   // (mu) selected rows, best first
+struct RankMuOp {  // C = (1-c1-cmu)*C + cmu * Y^T diag(w) Y + c1 * pc pc^T + tmpc * C_old
+    const double *Y;      // (mu,n)  Y[k] = (arx[idx[k]] - xold)/sigma  (cma_y_kernel)
     const double *w;      // (mu)
-    const double *xold;   // (n)
     const double *pc;     // (n)
     double *C;            // (n,n) in place
-    double sigma, decay, cmu, c1, tmpc;
+    double decay, cmu, c1, tmpc;
     int mu, n;
 };
 
+// Y[k][:] = (arx[idx[k]][:] - xold) / sigma   (cmaes/_cmaes.py:290), once per generation
+__global__ __launch_bounds__(256) void cma_y_kernel(const double *__restrict__ arx, const int64_t *__restrict__ idx,
+                                                    const double *__restrict__ xold, double sigma, int mu, int n,
+                                                    double *__restrict__ Y) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)mu * n) return;
+    const int k = (int)(t / n), e = (int)(t % n);
+    Y[t] = (arx[idx[k] * (int64_t)n + e] - xold[e]) / sigma;
+}
+
 // MODE 0: M = P rows, N = n, K = n.   MODE 1: M = N = n, K = mu.
-template <int MODE, class Op>
+// Workgroup tile BM x BN, four waves in a 2x2 grid, wave tile (BM/2) x (BN/2) of 16x16 MFMA tiles.
+// The global loads of chunk k+1 are issued into registers before the MFMAs of chunk k.
+template <int MODE, int BM, int BN, class Op>
 __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
+    constexpr int LDB = BN + 16;  // B tile [KC][LDB]: the two k-groups of a 32-lane half land 32 banks apart
+    constexpr int TM = BM / 32, TN = BN / 32;  // MFMA tiles per wave
+    constexpr int NA = BM * KC / kGemmThreads, NB = BN * KC / kGemmThreads;  // staged elements per thread
     __shared__ __attribute__((aligned(16))) double As[BM * LDA];
     __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;  // wave tile origin inside the workgroup tile
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int64_t m0 = (int64_t)blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
     int64_t M;
     int N, K;
     if (MODE == 0) {
         const SampleOp &o = (const SampleOp &)op;
-        M = o.P;
-        N = o.n;
-        K = o.n;
+        M = o.P, N = o.n, K = o.n;
     } else {
         const RankMuOp &o = (const RankMuOp &)op;
-        M = o.n;
-        N = o.n;
-        K = o.mu;
+        M = o.n, N = o.n, K = o.mu;
     }
-    v4d acc[2][2];
+    v4d acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        // ---- stage the A tile As[i][k] and the B tile Bs[k][j] ----
+    double ra[NA], rb[NB];
+    // thread -> staged elements.  MODE 0: A row i = tid / (KC/NA), NA contiguous k; B row j = tid / (KC/NB), NB contiguous k.
+    //                             MODE 1: k = tid / 8 for both; NA contiguous i, NB contiguous j.
+    auto fetch = [&](int k0) {
         if (MODE == 0) {
             const SampleOp &o = (const SampleOp &)op;
-            // A[i][k] = Z[m0+i][k0+k] * D[k0+k]: thread -> row tid/4, 8 contiguous k
             {
-                const int i = tid >> 2, kk = (tid & 3) * 8;
+                const int i = tid / (KC / NA), kk = (tid % (KC / NA)) * NA;
                 const int64_t gi = m0 + i;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < NA; ++u) {
                     const int gk = k0 + kk + u;
-                    double v = 0.0;
-                    if (gi < M && gk < K) v = o.D[gk] * o.Z[gi * (int64_t)o.n + gk];  // D * z  (:234)
-                    As[i * LDA + kk + u] = v;
+                    ra[u] = (gi < M && gk < K) ? o.D[gk] * o.Z[gi * (int64_t)o.n + gk] : 0.0;  // D * z (:234)
                 }
             }
-            // B[k][j] = Bm[n0+j][k0+k]: thread -> row j = tid/4, 8 contiguous k, transposed store
             {
-                const int j = tid >> 2, kk = (tid & 3) * 8;
+                const int j = tid / (KC / NB), kk = (tid % (KC / NB)) * NB;
                 const int gj = n0 + j;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < NB; ++u) {
                     const int gk = k0 + kk + u;
-                    double v = 0.0;
-                    if (gj < N && gk < K) v = o.Bm[(int64_t)gj * o.n + gk];
-                    Bs[(kk + u) * LDB + j] = v;
+                    rb[u] = (gj < N && gk < K) ? o.Bm[(int64_t)gj * o.n + gk] : 0.0;
                 }
             }
         } else {
             const RankMuOp &o = (const RankMuOp &)op;
-            // selected row k: y = (arx[idx[k]] - xold) / sigma (:290); A[i][k] = y[m0+i] * w[k]; B[k][j] = y[n0+j]
-            // thread -> k = tid/8 (0..31), 8 contiguous columns starting at (tid&7)*8
-            const int kk = tid >> 3, c0 = (tid & 7) * 8;
-            const int gk = k0 + kk;
+            const int kk = tid >> 3, gk = k0 + kk;
             const bool kin = gk < K;
-            const int64_t row = kin ? o.idx[gk] : 0;
             const double wk = kin ? o.w[gk] : 0.0;
-            const double *xr = o.arx + row * (int64_t)o.n;
+            const double *yr = o.Y + (int64_t)(kin ? gk : 0) * o.n;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int ci = c0 + u;
-                const int64_t gi = m0 + ci;
-                const int gj = n0 + ci;
-                double ya = 0.0, yb = 0.0;
-                if (kin && gi < M) ya = ((xr[gi] - o.xold[gi]) / o.sigma) * wk;  // artmp.T @ diag(w)
-                if (kin && gj < N) yb = (xr[gj] - o.xold[gj]) / o.sigma;
-                As[ci * LDA + kk] = ya;
-                Bs[kk * LDB + ci] = yb;
+            for (int u = 0; u < NA; ++u) {
+                const int64_t gi = m0 + (tid & 7) * NA + u;
+                ra[u] = (kin && gi < M) ? yr[gi] * wk : 0.0;  // artmp.T @ diag(w)
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int gj = n0 + (tid & 7) * NB + u;
+                rb[u] = (kin && gj < N) ? yr[gj] : 0.0;
             }
         }
+    };
+    auto stage = [&]() {
+        if (MODE == 0) {
+            {
+                const int i = tid / (KC / NA), kk = (tid % (KC / NA)) * NA;
+#pragma unroll
+                for (int u = 0; u < NA; ++u) As[i * LDA + kk + u] = ra[u];
+            }
+            {
+                const int j = tid / (KC / NB), kk = (tid % (KC / NB)) * NB;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) Bs[(kk + u) * LDB + j] = rb[u];
+            }
+        } else {
+            const int kk = tid >> 3;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) As[((tid & 7) * NA + u) * LDA + kk] = ra[u];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) Bs[kk * LDB + (tid & 7) * NB + u] = rb[u];
+        }
+    };
+
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        stage();
         __syncthreads();
-        // ---- 8 k-steps of 4: 2 A fragments x 2 B fragments -> 4 MFMAs per step ----
+        if (k0 + KC < K) fetch(k0 + KC);  // in flight while the MFMAs below run
 #pragma unroll
         for (int ks = 0; ks < KC; ks += 4) {
             const int kq = ks + (lane >> 4);
-            const double a0 = As[(wm + (lane & 15)) * LDA + kq];
-            const double a1 = As[(wm + 16 + (lane & 15)) * LDA + kq];
-            const double b0 = Bs[kq * LDB + wn + (lane & 15)];
-            const double b1 = Bs[kq * LDB + wn + 16 + (lane & 15)];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            double af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[(wm + i * 16 + (lane & 15)) * LDA + kq];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[kq * LDB + wn + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
     // ---- epilogue: C/D element (row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile ----
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < TM; ++ti) {
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
+        for (int tj = 0; tj < TN; ++tj) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t gi = m0 + wm + ti * 16 + (lane >> 4) + 4 * r;
@@ -160,10 +187,10 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
                     const RankMuOp &o = (const RankMuOp &)op;
                     double *cp = o.C + gi * (int64_t)o.n + gj;
                     const double cold = *cp;
-                    double c = cold * o.decay;           // C *= 1 - c1 - cmu
-                    c = c + o.cmu * g;                   // C += cmu * A^T diag(w) A
+                    double c = cold * o.decay;             // C *= 1 - c1 - cmu
+                    c = c + o.cmu * g;                     // C += cmu * A^T diag(w) A
                     c = c + o.c1 * (o.pc[gi] * o.pc[gj]);  // C += c1 * outer(pc, pc)
-                    c = c + o.tmpc * cold;               // C += tmp  (tmp = c1*cc*(2-cc)*C_old, or 0)
+                    c = c + o.tmpc * cold;                 // C += tmp  (tmp = c1*cc*(2-cc)*C_old, or 0)
                     *cp = c;
                 }
             }
@@ -236,23 +263,40 @@ __global__ __launch_bounds__(256) void symmetrize_upper_kernel(double *__restric
 
 }  // namespace
 
+// tile choice: enough workgroups to cover the 256 CUs on the (small) CMA-ES shapes
 extern "C" int sx_cmaes_sample(const double *xmean, double sigma, const double *B, const double *D, const double *Z,
                                double *arx, int64_t P, int n, void *stream) {
     SX_REQUIRE(xmean && B && D && Z && arx && P >= 1 && n >= 1, "sx_cmaes_sample: bad arguments");
     SampleOp op{Z, B, D, xmean, arx, sigma, P, n};
-    dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((P + BM - 1) / BM));
-    hipLaunchKernelGGL((cma_gemm_kernel<0, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    const int64_t big = ((P + 63) / 64) * ((n + 63) / 64);
+    if (big >= 512) {
+        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((P + 63) / 64));
+        hipLaunchKernelGGL((cma_gemm_kernel<0, 64, 64, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    } else {
+        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((P + 31) / 32));
+        hipLaunchKernelGGL((cma_gemm_kernel<0, 32, 64, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    }
     SX_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold,
                                 double sigma, const double *pc, double c1, double cmu, double tmp_coef, double *C,
-                                int n, void *stream) {
-    SX_REQUIRE(arx && idx && w && xold && pc && C && mu >= 1 && n >= 1, "sx_cmaes_rank_mu: bad arguments");
-    RankMuOp op{arx, idx, w, xold, pc, C, sigma, 1.0 - c1 - cmu, cmu, c1, tmp_coef, mu, n};
-    dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((n + BM - 1) / BM));
-    hipLaunchKernelGGL((cma_gemm_kernel<1, RankMuOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+                                double *ws_y, int n, void *stream) {
+    SX_REQUIRE(arx && idx && w && xold && pc && C && ws_y && mu >= 1 && n >= 1, "sx_cmaes_rank_mu: bad arguments");
+    const int64_t total = (int64_t)mu * n;
+    hipLaunchKernelGGL(cma_y_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, arx, idx,
+                       xold, sigma, mu, n, ws_y);
+    SX_LAUNCH_CHECK();
+    RankMuOp op{ws_y, w, pc, C, 1.0 - c1 - cmu, cmu, c1, tmp_coef, mu, n};
+    const int64_t big = ((int64_t)(n + 63) / 64) * ((n + 63) / 64);
+    if (big >= 512) {
+        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
+        hipLaunchKernelGGL((cma_gemm_kernel<1, 64, 64, RankMuOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    } else {
+        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32));
+        hipLaunchKernelGGL((cma_gemm_kernel<1, 32, 32, RankMuOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    }
     SX_LAUNCH_CHECK();
     return 0;
 }

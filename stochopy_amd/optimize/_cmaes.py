@@ -40,8 +40,15 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
+    eigh="host",
 ):
-    """Minimize an objective function using CMA-ES on MI355X (reference cmaes/_cmaes.py:12-30)."""
+    """Minimize an objective function using CMA-ES on MI355X (reference cmaes/_cmaes.py:12-30).
+
+    ``eigh="host"`` (default) decomposes C with numpy/LAPACK exactly like the reference
+    (cmaes/_cmaes.py:304), which also pins the eigenvector signs that same-seed parity depends on;
+    ``eigh="device"`` keeps C on the GPU and uses rocSOLVER through ``torch.linalg.eigh`` -- the
+    SURVEY.md section 8f "next" step: a different (equally valid) eigenbasis, no 2 x n^2 PCIe trip.
+    """
     fun_id = _common.resolve_objective(fun, args)
     lower, upper = _common.as_bounds(bounds)
     if x0 is not None:
@@ -60,8 +67,10 @@ def minimize(
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
     _common.resolve_workers(workers)
+    if eigh not in ("host", "device"):
+        raise ValueError("eigh must be 'host' or 'device'")
     run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
-                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed)
+                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh)
     return run.result()
 
 
@@ -99,7 +108,8 @@ def _stop_status(it, n, maxiter, xmean, xold, besthist, arfit, order, sigma, ins
 
 class _CmaRun:
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, return_all, verbosity,
-                 callback, rng, seed):
+                 callback, rng, seed, eigh="host"):
+        self.eigh = eigh
         self.fun_id, self.lower, self.upper, self.x0 = fun_id, lower, upper, x0
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.sigma0, self.muperc, self.xtol, self.ftol = sigma, muperc, xtol, ftol
@@ -160,6 +170,7 @@ class _CmaRun:
         d_xold = ctx.empty((n,))
         d_pc = ctx.empty((n,))
         d_idx = ctx.empty((mu,), dtype=t.int64)
+        d_Y = ctx.empty((mu, n))  # artmp scratch of the covariance update
         h_Z = t.empty((P, n), dtype=t.float64).pin_memory() if self.rng == "numpy-legacy" else None
 
         if self.return_all:
@@ -206,7 +217,11 @@ class _CmaRun:
             besthist[it - 1] = arfit[order[0]]
             # ---- evolution paths (cmaes/_cmaes.py:280-287), host vectors ----
             step = xmean - xold
-            ps = (1.0 - cs) * ps + np.sqrt(cs * (2.0 - cs) * mueff) * np.dot(invsqrtC, step) / sigma
+            if self.eigh == "device":  # C^(-1/2) v = B ((B^T v) / D): no n^3 product on the host
+                isc_step = np.dot(B, np.dot(B.T, step) / D)
+            else:
+                isc_step = np.dot(invsqrtC, step)
+            ps = (1.0 - cs) * ps + np.sqrt(cs * (2.0 - cs) * mueff) * isc_step / sigma
             cond = np.linalg.norm(ps) / np.sqrt(1.0 - (1.0 - cs) ** (2.0 * nfev / P)) / chind < 1.4 + 2.0 / (n + 1.0)
             pc *= 1.0 - cc
             if cond:
@@ -215,13 +230,31 @@ class _CmaRun:
             d_pc.copy_(t.from_numpy(pc), non_blocking=False)
             tmp_coef = 0.0 if cond else c1 * cc * (2.0 - cc)
             _lib.check(L.sx_cmaes_rank_mu(ptr(d_arx), ptr(d_idx), ptr(d_w), mu, ptr(d_xold), sigma, ptr(d_pc), c1, cmu,
-                                          tmp_coef, ptr(d_C), n, sp), "sx_cmaes_rank_mu")
+                                          tmp_coef, ptr(d_C), ptr(d_Y), n, sp), "sx_cmaes_rank_mu")
             # ---- step size (cmaes/_cmaes.py:298) ----
             sigma *= np.exp((cs / damps) * (np.linalg.norm(ps) / chind - 1.0))
             # ---- eigendecomposition (cmaes/_cmaes.py:301-309): host LAPACK, as in the reference ----
             if nfev - eigeneval > P / (c1 + cmu) / n / 10.0:
                 eigeneval = nfev
                 _lib.check(L.sx_symmetrize_upper(ptr(d_C), n, sp), "sx_symmetrize_upper")
+                if self.eigh == "device":
+                    Dt, Bt = t.linalg.eigh(d_C)  # rocSOLVER, ascending eigenvalues, eigenvectors in columns
+                    d_D.copy_(t.sqrt(Dt))
+                    d_B.copy_(Bt)
+                    D = d_D.cpu().numpy()
+                    B = d_B.cpu().numpy()
+                    diagC = d_C.diagonal().cpu().numpy()
+                    status = _stop_status(it, n, self.maxiter, xmean, xold, besthist, arfit, order, sigma, insigma,
+                                          ilim, pc, self.xtol, self.ftol, diagC, B, D)
+                    if self.callback is not None:
+                        res = OptimizeResult(x=unstd(d_arx[int(order[0])].cpu().numpy()), fun=arfit[order[0]],
+                                             nfev=nfev, nit=it)
+                        if self.return_all:
+                            res.update({"xall": xall[:it], "funall": funall[:it]})
+                        self.callback(unstd(d_arx.cpu().numpy()), res)
+                    if status is not None:
+                        break
+                    continue
                 Ch = d_C.cpu().numpy()
                 D, B = np.linalg.eigh(Ch)
                 o = np.argsort(D)

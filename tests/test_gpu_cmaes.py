@@ -71,8 +71,9 @@ def test_rank_mu_and_recombine_vs_numpy(sa, ctx, shape, cond):
     d_arx, d_w, d_xold, d_pc, d_C = (ctx.upload(v) for v in (arx, w, xold, pc, C0))
     d_idx = ctx.upload(np.ascontiguousarray(order[:mu], dtype=np.int64))
     tmp = 0.0 if cond else c1 * cc * (2.0 - cc)
-    _lib.check(ctx.L.sx_cmaes_rank_mu(p(d_arx), p(d_idx), p(d_w), mu, p(d_xold), sigma, p(d_pc), c1, cmu, tmp, p(d_C), n,
-                                      ctx.stream_ptr))
+    d_Y = ctx.empty((mu, n))
+    _lib.check(ctx.L.sx_cmaes_rank_mu(p(d_arx), p(d_idx), p(d_w), mu, p(d_xold), sigma, p(d_pc), c1, cmu, tmp, p(d_C),
+                                      p(d_Y), n, ctx.stream_ptr))
     d_mean = ctx.empty((n,))
     _lib.check(ctx.L.sx_cmaes_recombine(p(d_arx), p(d_idx), p(d_w), mu, n, p(d_mean), ctx.stream_ptr))
     ctx.sync()
@@ -152,3 +153,14 @@ def test_cmaes_philox_vs_oracle(sa):
     sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"),
                          callback=lambda X, r: t_got.append(r.fun))
     assert np.allclose(t_got, t_ref, rtol=1e-6)
+
+
+def test_cmaes_device_eigensolver_converges(sa):
+    """eigh="device" (rocSOLVER): a different eigenbasis, so no same-seed parity -- the run must still
+    behave like CMA-ES: converge on the sphere with status 1, and on the reference-suite problem."""
+    res = sa.optimize.minimize(sa.factory.sphere, [[-5.12, 5.12]] * 12, method="cmaes",
+                               options={"maxiter": 600, "popsize": 32, "seed": 3, "eigh": "device"})
+    assert res.status == 1 and res.fun <= 1e-8 and np.abs(res.x).max() < 1e-3
+    res = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * 2, method="cmaes",
+                               options={"maxiter": 300, "popsize": 10, "seed": 0, "eigh": "device", "rng": "philox"})
+    assert res.success and np.allclose(res.x, [1.0, 1.0], atol=1e-3)

@@ -22,3 +22,5 @@ for method in ("pso", "cpso"):
 b512 = [[-5.12, 5.12]] * 512
 o = {"popsize": 1024, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0}
 timed("C4 cmaes rosenbrock n512 P1024", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m)), 4, 14)
+o = {"popsize": 1024, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "eigh": "device"}
+timed("C4 cmaes rosenbrock n512 P1024 eigh=device", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m)), 4, 14)
