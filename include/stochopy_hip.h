@@ -179,6 +179,8 @@ int sx_shard_best(const double *part_f, const int64_t *part_i, int64_t npart, co
                   void *stream);
 int sx_gather_finalize(const double *records, int world, int n, double *gbest, sx_state *state, int maxiter,
                        double xtol, double ftol, void *stream);
+/* sx_de_generation(a, 0) + sx_shard_best in one host call (fewer launches' worth of host time per generation) */
+int sx_de_shard_generation(const struct sx_de_args *a, double *record, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * hipGraph of `ngen` identical generations (all per-generation state lives in

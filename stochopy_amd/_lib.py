@@ -73,6 +73,7 @@ PROTOTYPES = {
     "sx_select_finalize": (C.c_int, [vp, vp, i64, vp, vp, i64, C.c_int, vp, vp, C.c_int, f64, f64, vp]),
     "sx_shard_best": (C.c_int, [vp, vp, i64, vp, vp, i64, C.c_int, vp, i64, vp, vp]),
     "sx_gather_finalize": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, f64, f64, vp]),
+    "sx_de_shard_generation": (C.c_int, [C.POINTER(SxDeArgs), vp, vp]),
     "sx_de_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.POINTER(vp)]),
     "sx_de_chain_launch": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.c_int, vp]),
     "sx_de_chain_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.c_int, C.POINTER(vp)]),

@@ -432,6 +432,15 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
     return 0;
 }
 
+// Multi-GPU: this shard's generation + its best-of-generation record, one host call (the caller then
+// all-gathers the records and calls sx_gather_finalize).
+extern "C" int sx_de_shard_generation(const sx_de_args *a, double *record, void *stream) {
+    SX_REQUIRE(record != nullptr, "sx_de_shard_generation: null record");
+    if (int rc = sx_de_generation(a, 0, stream)) return rc;
+    return sx_shard_best(a->part_f, a->part_i, (int64_t)geometry(a).blocks, a->buf0, a->buf1, a->ld, a->n, a->state,
+                         a->row0, record, stream);
+}
+
 // ---------------------------------------------------------------------------
 // Chained finalize (single GPU, Philox): one kernel per generation.
 // ---------------------------------------------------------------------------

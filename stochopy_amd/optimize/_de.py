@@ -9,6 +9,7 @@ objective -- is ONE fused HIP kernel (csrc/sx_de.hip) plus a one-workgroup
 best/termination kernel.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -98,8 +99,8 @@ class _DeRun:
         self.world = None
         self.Ptotal = P
         self.row0 = 0
-        if workers != 1:
-            from ..parallel import require_world
+        if workers != 1 or os.environ.get("SX_FORCE_SHARDED") == "1":  # the env switch lets a 1-rank group
+            from ..parallel import require_world                         # exercise the exchange path (tests)
 
             self.world = require_world(workers)
             if rng != "philox":
@@ -120,6 +121,7 @@ class _DeRun:
         self.ctx = _device.Context()
         self._graph = None
         self._chain_graphs = {}
+        self._shard_calls = None
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
@@ -178,16 +180,19 @@ class _DeRun:
             self.launches += 1
 
     def _sharded_generation(self):
-        """One generation on this rank's shard + the global-best exchange (parallel.py)."""
-        ctx, a, n = self.ctx, self.args, self.n
-        p = _device.ptr
-        _lib.check(ctx.L.sx_de_generation(C.byref(a), 0, ctx.stream_ptr), "sx_de_generation")
-        _lib.check(ctx.L.sx_shard_best(p(self.part_f), p(self.part_i), self.part_f.numel(), p(self.bufs[0]),
-                                       p(self.bufs[1]), n, n, p(self.state), self.row0, p(self.record),
-                                       ctx.stream_ptr), "sx_shard_best")
+        """One generation on this rank's shard + the global-best exchange (parallel.py): two host calls into
+        the library around one all-gather."""
+        ctx, L = self.ctx, self.ctx.L
+        if self._shard_calls is None:  # argument objects built once: the loop below is host-bound
+            p = _device.ptr
+            self._shard_calls = (C.byref(self.args), p(self.record), p(self.records), p(self.gbest), p(self.state),
+                                 ctx.stream_ptr)
+        a, rec, recs, gb, st, sp = self._shard_calls
+        if L.sx_de_shard_generation(a, rec, sp) != 0:
+            _lib.check(-1, "sx_de_shard_generation")
         self.world.all_gather_records(self.record, self.records)
-        _lib.check(ctx.L.sx_gather_finalize(p(self.records), self.world.size, n, p(self.gbest), p(self.state),
-                                            self.maxiter, self.xtol, self.ftol, ctx.stream_ptr), "sx_gather_finalize")
+        if L.sx_gather_finalize(recs, self.world.size, self.n, gb, st, self.maxiter, self.xtol, self.ftol, sp) != 0:
+            _lib.check(-1, "sx_gather_finalize")
 
     def enqueue(self, ngen):
         """Enqueue `ngen` generations on the engine stream without any host synchronisation.

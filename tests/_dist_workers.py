@@ -80,3 +80,25 @@ def gpu_minimize_worker(rank, world, port, cfg, out_dir):
         np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))
     finally:
         dist.destroy_process_group()
+
+
+def nccl_single_rank_worker(rank, world, port, cfg, out_dir):
+    """One rank, backend nccl (= RCCL): the production exchange path (all_gather_into_tensor on the device)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SX_FORCE_SHARDED"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import stochopy_amd as sa
+
+        n = cfg["n"]
+        opts = dict(cfg["options"], backend="hip", rng="philox", workers=1)
+        res = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="de", options=opts)
+        np.save(os.path.join(out_dir, "x_0.npy"), res.x)
+        np.save(os.path.join(out_dir, "meta_0.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))
+    finally:
+        dist.destroy_process_group()

@@ -81,3 +81,17 @@ def test_sharded_pso_on_gpu_is_exact():
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
         assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+
+
+@pytest.mark.gpu
+def test_sharded_path_over_rccl_single_rank():
+    """backend "nccl" (RCCL) with one rank: the device-side all_gather_into_tensor exchange used in production."""
+    from _dist_workers import nccl_single_rank_worker
+
+    cfg = {"n": 24, "P": 128, "gens": 9, "seed": 2024,
+           "options": {"maxiter": 9, "popsize": 128, "seed": 2024, "ftol": -1.0, "xtol": 0.0}}
+    out = _spawn(nccl_single_rank_worker, 1, cfg)
+    ref = _sharded_oracle(cfg, 1)
+    fun, nit, nfev, status = np.load(os.path.join(out, "meta_0.npy"))
+    assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+    assert np.array_equal(np.load(os.path.join(out, "x_0.npy")), ref.x)
