@@ -1,0 +1,112 @@
+"""GPU edge cases the reference's own tests touch (tests/helpers.py, tests/test_optimize.py) or imply:
+x0 handling, verbosity=0 history, maxiter <= 1, callback count, ragged / tiny / large dimensions."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import stochopy_amd
+
+    return stochopy_amd
+
+
+B2 = [[-5.12, 5.12]] * 2
+
+
+@pytest.mark.parametrize("method", ["de", "pso", "cpso", "cmaes"])
+def test_callback_count_equals_maxiter(sa, method):
+    """reference tests/test_optimize.py:135-152: the callback fires exactly maxiter times."""
+    for maxiter in (2, 5, 9):
+        count = []
+        sa.optimize.minimize(sa.factory.rosenbrock, B2, method=method, options={"maxiter": maxiter, "seed": 1},
+                             callback=lambda X, s: count.append(X.shape))
+        assert len(count) == maxiter
+        assert all(shape == (10, 2) for shape in count)
+
+
+@pytest.mark.parametrize("method", ["de", "pso"])
+def test_x0_population_and_inplace_semantics(sa, method):
+    rs = np.random.RandomState(3)
+    x0 = rs.uniform(-5, 5, (16, 3))
+    keep = x0.copy()
+    opts = {"maxiter": 12, "popsize": 16, "seed": 4, "updating": "deferred"}
+    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 3, x0=keep.copy(), method=method, options=dict(opts))
+    got = sa.optimize.minimize(sa.factory.sphere, [[-5.12, 5.12]] * 3, x0=x0, method=method, options=dict(opts, backend="hip"))
+    assert got.fun == ref.fun and np.array_equal(got.x, ref.x) and got.nit == ref.nit
+    if method == "de":  # the reference works in place on x0 (de/_de.py:208): the final population comes back in it
+        assert not np.array_equal(x0, keep)
+    else:               # sync PSO rebinds X (cpso/_constraints.py:8): x0 untouched
+        assert np.array_equal(x0, keep)
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(sa.factory.sphere, [[-5.12, 5.12]] * 3, x0=keep[:5], method=method, options=opts)
+
+
+@pytest.mark.parametrize("method", ["de", "pso", "cmaes"])
+@pytest.mark.parametrize("verbosity", [0.0, 0.3, 1.0])
+def test_return_all_shapes_and_values(sa, method, verbosity):
+    opts = {"maxiter": 7, "popsize": 10, "seed": 2, "return_all": True, "verbosity": verbosity, "updating": "deferred"}
+    if method == "cmaes":
+        opts.pop("updating")
+    ref = oracle.minimize("rosenbrock", B2, method=method, options=dict(opts))
+    got = sa.optimize.minimize(sa.factory.rosenbrock, B2, method=method, options=dict(opts, backend="hip"))
+    rows = max(int(np.ceil(verbosity * 10)), 1)
+    assert got.xall.shape == (got.nit, rows, 2) and got.funall.shape == (got.nit, rows)
+    if method == "cmaes":  # MFMA vs BLAS summation order: north-star tolerance instead of bit equality
+        assert np.allclose(got.xall, ref.xall, rtol=1e-6, atol=1e-9) and np.allclose(got.funall, ref.funall, rtol=1e-6)
+    else:
+        assert np.array_equal(got.xall, ref.xall) and np.array_equal(got.funall, ref.funall)
+
+
+@pytest.mark.parametrize("method", ["de", "pso"])
+def test_maxiter_one_still_runs_a_generation(sa, method):
+    """`it` starts at 1 and is incremented before the test `it >= maxiter` (de/_de.py:245-247)."""
+    r = sa.optimize.minimize(sa.factory.sphere, B2, method=method, options={"maxiter": 1, "popsize": 8, "seed": 0})
+    assert r.nit == 2 and r.nfev == 16 and r.status == -1 and r.success is False
+    for rng in ("numpy-legacy", "philox"):
+        r = sa.optimize.minimize(sa.factory.sphere, B2, method=method,
+                                 options={"maxiter": 2, "popsize": 8, "seed": 0, "rng": rng})
+        assert r.nit == 2 and r.status == -1
+
+
+def test_early_termination_statuses_match_oracle_in_philox_mode(sa):
+    """ftol / xtol ladder (status 1 and 0) in the one-kernel-per-generation path, where the host settles 0 vs 1."""
+    b = [[-5.12, 5.12]] * 4
+    for xtol, want in ((1e-3, None), (10.0, 0)):
+        opts = {"maxiter": 400, "popsize": 64, "seed": 9, "ftol": 1e-6, "xtol": xtol, "updating": "deferred"}
+        ref = oracle.minimize("sphere", b, method="de", options=dict(opts), rng="philox")
+        got = sa.optimize.minimize(sa.factory.sphere, b, method="de", options=dict(opts, backend="hip", rng="philox"))
+        assert (got.nit, got.status, got.fun, got.message) == (ref.nit, ref.status, ref.fun, ref.message)
+        assert np.array_equal(got.x, ref.x)
+        if want is not None:
+            assert got.status == want
+
+
+@pytest.mark.parametrize("n,P", [(1, 8), (2, 6), (65, 33), (129, 70), (257, 40), (1000, 24), (2560, 12)])
+def test_ragged_shapes_philox_de_and_pso(sa, n, P):
+    b = [[-3.0, 3.0]] * n
+    for method in ("de", "pso"):
+        opts = {"maxiter": 5, "popsize": P, "seed": 5 + n, "updating": "deferred", "constraints": None}
+        ref = oracle.minimize("rosenbrock", b, method=method, options=dict(opts), rng="philox")
+        got = sa.optimize.minimize(sa.factory.rosenbrock, b, method=method, options=dict(opts, backend="hip", rng="philox"))
+        assert got.fun == ref.fun and np.array_equal(got.x, ref.x), (method, n, P)
+
+
+def test_dimension_limit_is_loud(sa):
+    from stochopy_amd._lib import HipLibraryError
+
+    with pytest.raises(HipLibraryError):
+        sa.optimize.minimize(sa.factory.sphere, [[-1.0, 1.0]] * 2561, method="de", options={"maxiter": 2, "popsize": 8, "seed": 0})
+
+
+def test_result_surface(sa):
+    r = sa.optimize.minimize(sa.factory.rosenbrock, B2, method="cmaes", options={"maxiter": 100, "popsize": 10, "seed": 0})
+    # README example of the reference (README.rst:93-105): nit 49, nfev 490, status 1
+    assert (r.nit, r.nfev, r.status, r.success) == (49, 490, 1, True)
+    assert np.allclose(r.x, [0.99997096, 0.99993643]) and np.isclose(r.fun, 3.862267664744548e-09, rtol=1e-6)
+    assert sorted(r.keys()) == ["fun", "message", "nfev", "nit", "status", "success", "x"]
+    assert r.message == "best solution value is lower than ftol"
