@@ -50,46 +50,71 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
     const double *r2row = RNG == SX_RNG_HOST ? a.r2 + rowc * (int64_t)n : nullptr;
 
-    // V = w*V + c1*r1*(pbest - X) + c2*r2*(gbest - X)   (cpso/_cpso.py:326)
+    // V = w*V + c1*r1*(pbest - X) + c2*r2*(gbest - X)   (cpso/_cpso.py:326), four row steps per batch so
+    // the 16 loads of a batch are in flight together.  Without Shrink the new position follows at once;
+    // with Shrink the raw velocity waits in LDS for the row-wide beta.
+    constexpr int kStep = 4;
     double beta = __builtin_huge_val();
-    U4 wd = {0u, 0u, 0u, 0u};
-    int q = 0;
-    for (int e = l; e < n; e += LPR, ++q) {
-        const double x = xr[e], v = vr[e];
-        double r1, r2;
+    const int nq = (n + LPR - 1) / LPR;
+    for (int q0 = 0; q0 < nq; q0 += kStep) {
+        double x[kStep], v[kStep], p[kStep], g[kStep], r1[kStep], r2[kStep];
+#pragma unroll
+        for (int t = 0; t < kStep; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            const bool in = e < n;
+            x[t] = in ? xr[e] : 0.0;
+            v[t] = in ? vr[e] : 0.0;
+            p[t] = in ? pb[e] : 0.0;
+            g[t] = in ? gb[e] : 0.0;
+            r1[t] = (RNG == SX_RNG_HOST && in) ? r1row[e] : 0.0;
+            r2[t] = (RNG == SX_RNG_HOST && in) ? r2row[e] : 0.0;
+        }
         if (RNG == SX_RNG_PHILOX) {
             // 32-bit uniforms, one call per 2 steps: words (0,1) -> (r1,r2) of even q, (2,3) of odd q
-            if ((q & 1) == 0)
-                wd = philox4x32_10((uint32_t)(q >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR1, a.key0,
-                                   a.key1);
-            r1 = u32((q & 1) ? wd.z : wd.x);
-            r2 = u32((q & 1) ? wd.w : wd.y);
-        } else {
-            r1 = r1row[e];
-            r2 = r2row[e];
+#pragma unroll
+            for (int t = 0; t < kStep; t += 2) {
+                const U4 wd = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen,
+                                            kPurposePsoR1, a.key0, a.key1);
+                r1[t] = u32(wd.x);
+                r2[t] = u32(wd.y);
+                r1[t + 1] = u32(wd.z);
+                r2[t + 1] = u32(wd.w);
+            }
         }
-        const double vn = (w * v + (c1 * r1) * (pb[e] - x)) + (c2 * r2) * (gb[e] - x);
-        Vn[e] = vn;
-        if (shrink) {  // cpso/_constraints.py:22-50: beta = min over violated dims of (bound - x)/v
-            const double xc = x + vn;
-            const double lo = a.lower[e], hi = a.upper[e];
-            if (xc < lo) beta = fmin(beta, (lo - x) / vn);
-            if (xc > hi) beta = fmin(beta, (hi - x) / vn);
+#pragma unroll
+        for (int t = 0; t < kStep; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            if (e < n) {
+                const double vn = (w * v[t] + (c1 * r1[t]) * (p[t] - x[t])) + (c2 * r2[t]) * (g[t] - x[t]);
+                if (shrink) {  // cpso/_constraints.py:22-50: beta = min over violated dims of (bound - x)/v
+                    Vn[e] = vn;
+                    const double xc = x[t] + vn;
+                    const double lo = a.lower[e], hi = a.upper[e];
+                    if (xc < lo) beta = fmin(beta, (lo - x[t]) / vn);
+                    if (xc > hi) beta = fmin(beta, (hi - x[t]) / vn);
+                } else {  // cpso/_constraints.py:4-10: X + V
+                    const double xn = x[t] + vn;
+                    U[e] = xn;
+                    if (id.active) {
+                        vr[e] = vn;
+                        xr[e] = xn;
+                    }
+                }
+            }
         }
     }
     if (shrink) {
         beta = row_min<LPR>(beta);
         if (beta == __builtin_huge_val()) beta = 1.0;
-    }
-    lds_wave_fence();
-    for (int e = l; e < n; e += LPR) {
-        double vn = Vn[e];
-        if (shrink) vn = vn * beta;  // V *= beta[:, None]
-        const double xn = xr[e] + vn;
-        U[e] = xn;
-        if (id.active) {
-            vr[e] = vn;
-            xr[e] = xn;
+        lds_wave_fence();
+        for (int e = l; e < n; e += LPR) {
+            const double vn = Vn[e] * beta;  // V *= beta[:, None]
+            const double xn = xr[e] + vn;
+            U[e] = xn;
+            if (id.active) {
+                vr[e] = vn;
+                xr[e] = xn;
+            }
         }
     }
     const double fc = row_objective<FUN, LPR>(U, n, plan, l);
