@@ -142,6 +142,7 @@ def main():
         ctx.sync()
         kernels_per_gen = 1 if run.chain else (2 if run.world is None else 3)
         kern_ms = ev0.elapsed_time(ev1) / nl
+    barrier()  # no rank frees its exchange buffer while a peer may still write into it
     run.close()
 
     dt = t1 - t0
@@ -178,7 +179,11 @@ def main():
                 "workload": args.workload,
                 "method": "de", "strategy": strategy, "objective": objective, "dim": n,
                 "popsize_per_gpu": P, "popsize_total": world * P, "rng": "philox", "F": 0.5, "CR": 0.9,
-                "exchange": "none" if run.world is None else "global best per generation (RCCL all_gather of an (n+2)-double record)",
+                "exchange": ("none" if run.world is None else
+                             "global best per generation, peer writes over xGMI inside the generation kernel "
+                             "(tagged (n+2)-double record per rank)" if run.exchange == "p2p" else
+                             "global best per generation (RCCL all_gather of an (n+2)-double record)"),
+                "exchange_note": getattr(run, "exchange_note", None),
             },
             "roofline": {
                 "bound": "hbm",

@@ -57,8 +57,8 @@ int sx_abi_version(void);
 const char *sx_last_error(void);
 /* number of visible HIP devices (<0 on error); used by the loader to fail loudly */
 int sx_device_count(void);
-/* sizeof(sx_state / sx_de_args / sx_pso_args) as compiled: lets a binding check its struct mirror
- * (which: 0 state, 1 DE args, 2 PSO args; -1 otherwise) */
+/* sizeof(sx_state / sx_de_args / sx_pso_args / sx_xchg_args) as compiled: lets a binding check its struct
+ * mirror (which: 0 state, 1 DE args, 2 PSO args, 3 exchange args; -1 otherwise) */
 int sx_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
@@ -201,6 +201,45 @@ int sx_de_chain_launch(const sx_de_args *a, int parity, int finalize_only, void 
 int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start_parity, sx_graph **out);
 int sx_graph_launch(sx_graph *g, void *stream);
 int sx_graph_destroy(sx_graph *g);
+
+/* ------------------------------------------------------------------------- *
+ * Multi-GPU, peer exchange over xGMI (one process per GPU; population sharded by rows)
+ * replaces: the per-generation MPI traffic of stochopy/optimize/_common.py:58-72 (Bcast + Allreduce)
+ *           for the global best of _common.py:131-133.
+ * Every rank owns an exchange buffer in its HBM (uncached, IPC-shareable) that all peers map.  It holds
+ * slots[2][world][2*(n+2)] 64-bit words: the record [f, global row, best row] of each rank, each 32-bit
+ * half carried with a 32-bit generation tag in one 8-byte store (arrival is detected on the data itself,
+ * no separate flag, no fence).  sx_de_p2p_* = the chained kernel of sx_de_chain_* where, per generation,
+ * workgroup 0 writes this shard's record straight into every peer's slot and every wavefront picks the
+ * global best out of its own rank's slots as they arrive: still ONE kernel per generation and no
+ * collective call on the data path.  A rank that waits longer than `timeout_ticks` (100 MHz ticks) sets
+ * *error and the kernels become no-ops (the caller raises).
+ * Start as for sx_de_chain_launch with a->gbest = NULL; afterwards the best row of the last generation is
+ * slot[parity][state.reserved[1]] (decode with sx_xchg_read_record), the previous one is in the other parity.
+ * ------------------------------------------------------------------------- */
+#define SX_MAX_PEERS 8
+#define SX_IPC_HANDLE_BYTES 64
+typedef struct sx_xchg_args {
+    uint64_t *peer[SX_MAX_PEERS]; /* DEVICE: exchange buffer of rank r as mapped in this process (peer[rank] = own) */
+    int32_t world, rank;
+    int64_t timeout_ticks;        /* per wait, in 100 MHz ticks (1e8 = 1 s) */
+    int32_t *error;               /* DEVICE: 0, set to 1 on timeout */
+} sx_xchg_args;
+/* bytes of one exchange buffer for `world` ranks and rows of n doubles (includes the probe area) */
+int64_t sx_xchg_bytes(int world, int n);
+/* allocate + zero an exchange buffer on the current device and export it (handle: 64 bytes) */
+int sx_xchg_alloc(int64_t bytes, void **ptr, void *handle);
+int sx_xchg_free(void *ptr);
+/* map a peer's buffer from the handle it exported / unmap it */
+int sx_xchg_open(const void *handle, void **ptr);
+int sx_xchg_close(void *ptr);
+/* transport self-test: `rounds` tagged all-to-all writes + waits through the probe area of the buffers;
+ * returns 0 = every word of every round arrived, 1 = timeout or corrupt word (synchronises the stream) */
+int sx_xchg_probe(const sx_xchg_args *x, int n, int rounds, void *stream);
+/* decode slot[parity][src] of the own buffer into record[n+2] (host memory); synchronises the stream */
+int sx_xchg_read_record(const sx_xchg_args *x, int n, int parity, int src, double *record, void *stream);
+int sx_de_p2p_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, int finalize_only, void *stream);
+int sx_de_p2p_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ngen, int start_parity, sx_graph **out);
 
 /* ------------------------------------------------------------------------- *
  * PSO / CPSO, synchronous generation

@@ -58,6 +58,14 @@ class SxPsoArgs(C.Structure):
     ]
 
 
+SX_MAX_PEERS = 8
+SX_IPC_HANDLE_BYTES = 64
+
+
+class SxXchgArgs(C.Structure):
+    _fields_ = [("peer", vp * SX_MAX_PEERS), ("world", i32), ("rank", i32), ("timeout_ticks", i64), ("error", vp)]
+
+
 # name -> (restype, argtypes); every symbol include/stochopy_hip.h declares
 PROTOTYPES = {
     "sx_abi_version": (C.c_int, []),
@@ -77,6 +85,16 @@ PROTOTYPES = {
     "sx_de_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.POINTER(vp)]),
     "sx_de_chain_launch": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.c_int, vp]),
     "sx_de_chain_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.c_int, C.POINTER(vp)]),
+    "sx_xchg_bytes": (i64, [C.c_int, C.c_int]),
+    "sx_xchg_alloc": (C.c_int, [i64, C.POINTER(vp), vp]),
+    "sx_xchg_free": (C.c_int, [vp]),
+    "sx_xchg_open": (C.c_int, [vp, C.POINTER(vp)]),
+    "sx_xchg_close": (C.c_int, [vp]),
+    "sx_xchg_probe": (C.c_int, [C.POINTER(SxXchgArgs), C.c_int, C.c_int, vp]),
+    "sx_xchg_read_record": (C.c_int, [C.POINTER(SxXchgArgs), C.c_int, C.c_int, C.c_int, vp, vp]),
+    "sx_de_p2p_launch": (C.c_int, [C.POINTER(SxDeArgs), C.POINTER(SxXchgArgs), C.c_int, C.c_int, vp]),
+    "sx_de_p2p_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.POINTER(SxXchgArgs), C.c_int, C.c_int,
+                                         C.POINTER(vp)]),
     "sx_graph_launch": (C.c_int, [vp, vp]),
     "sx_graph_destroy": (C.c_int, [vp]),
     "sx_pso_generation": (C.c_int, [C.POINTER(SxPsoArgs), C.c_int, vp]),

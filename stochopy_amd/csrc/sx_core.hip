@@ -26,6 +26,7 @@ extern "C" int sx_struct_size(int which) {
         case 0: return (int)sizeof(sx_state);
         case 1: return (int)sizeof(sx_de_args);
         case 2: return (int)sizeof(sx_pso_args);
+        case 3: return (int)sizeof(sx_xchg_args);
     }
     return -1;
 }

@@ -18,12 +18,14 @@
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 #include "sx_rowops.hpp"
+#include "sx_xchg.hpp"
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out);
 int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
                       int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,
                       sx_state *state, int maxiter, double xtol, double ftol);
+int check_xchg_args(const sx_xchg_args *x);
 }
 using namespace sx;
 
@@ -89,30 +91,85 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
     irand = (int)__umulhi(a.x, (uint32_t)n);
 }
 
-// CHAIN = false: a.state is ONE sx_state, the best/termination step is a separate kernel.
-// CHAIN = true ("chained finalize", single GPU + Philox): a.state is sx_state[3], a.part_f/part_i are
+// XM = 0: a.state is ONE sx_state, the best/termination step is a separate kernel.
+// XM = 1 ("chained finalize", single GPU + Philox): a.state is sx_state[3], a.part_f/part_i are
 // [2][npart].  Launch L (parity p = L & 1) first finalises the generation its predecessor produced --
 // EVERY wavefront reduces the npart (<= 512) records part[p] (written before the kernel boundary, so
 // plainly visible) and derives the same best / status; workgroup 0 publishes it in state[1-p] -- and then
 // produces the next generation, writing records to part[1-p].  No second kernel, no atomics.
 // mode 1 = finalise only (one workgroup), result to state[2] for the host.  dx (xtol) only separates
 // status 0 from 1, both of which stop: the host derives it from state.reserved[0] (previous best row).
+// XM = 2 (multi-GPU, peer exchange; sx_xchg.hpp): as XM = 1, but the population is this rank's shard.
+// Workgroup 0 is a service workgroup: it reduces the shard's records, writes [f, global row, row] with
+// the generation tag into every peer's exchange buffer (one wavefront per peer) and publishes the state;
+// the row workgroups (blockIdx 1..) wait for the tagged headers of all ranks in their OWN rank's buffer,
+// pick the global best and read its row from there.  Still one kernel per generation; the only
+// cross-GPU dependency is "all ranks have reached this generation".
+// XM = 2, workgroup 0: shard best -> peers, global best -> state.  Returns nothing; sets *x.error on timeout.
+__device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_args &x, int chain_p, int mode,
+                                            int64_t npart, int64_t it, const sx_state *sin) {
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), nw = (int)(blockDim.x >> 6);
+    const double *pf = a.part_f + (int64_t)chain_p * npart;
+    const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
+    const int per = (int)((npart + kWave - 1) / kWave);  // contiguous slice per lane: first-minimum rule
+    const int64_t k0 = (int64_t)lane * per;
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int u = 0; u < per; ++u)
+        if (k0 + u < npart) argmin_combine(bf, bi, pf[k0 + u], pi[k0 + u]);
+    wave_argmin_ordered(bf, bi);
+    const uint32_t tag = (uint32_t)(it + 1);
+    const double *row = ((it & 1) ? a.buf1 : a.buf0) + bi * a.ld;
+    for (int r = wave; r < x.world; r += nw)
+        xchg_push_record(x.peer[r] + xchg_slot_offset(a.n, chain_p, x.rank), bf, a.row0 + bi, row, a.n, tag, lane);
+    if (wave != 0) return;
+    double gf;
+    int64_t gi;
+    int winner;
+    if (!xchg_wait_best(x.peer[x.rank] + xchg_slot_offset(a.n, chain_p, 0), a.n, x.world, tag, x.timeout_ticks, lane,
+                        gf, gi, winner)) {
+        if (lane == 0) atomicExch(x.error, 1);
+        return;
+    }
+    if (lane == 0) {
+        int status = SX_STATUS_NONE;
+        if (it >= 2) {
+            if (gf <= a.ftol)
+                status = 1;
+            else if (it >= a.maxiter)
+                status = -1;
+        }
+        sx_state *so = a.state + (mode == 1 ? 2 : 1 - chain_p);
+        so->it = it;
+        so->gbidx = gi;  // GLOBAL row
+        so->gfit = gf;
+        so->dx = 0.0;
+        so->status = status;
+        so->done = status != SX_STATUS_NONE;
+        so->reserved[0] = sin->reserved[1];  // rank that held the previous best row
+        so->reserved[1] = winner;
+    }
+}
+
 constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its loads in flight together
 
 // FULL: n is a whole number of batches (n % (kStep*LPR) == 0) and P a whole number of workgroups, so
 // every bounds test folds away (the P = 4096, n = 128 headline shape).
-template <int FUN, int RNG, bool CHAIN, int LPR, bool FULL>
+template <int FUN, int RNG, int XM, int LPR, bool FULL>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_de_args a,
                                                                                  const PlanArg plan,
                                                                                  const int chain_p, const int mode,
-                                                                                 const int64_t npart) {
+                                                                                 const int64_t npart,
+                                                                                 const sx_xchg_args x) {
+    constexpr bool CHAIN = XM >= 1;  // finalise the predecessor's generation in the prologue
+    constexpr bool P2P = XM == 2;    // ... over all ranks, through the peer exchange buffers
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
     SX_TP(0);
     const int n = a.n;
     const int64_t P = a.P, ld = a.ld;
-    const RowIds<LPR> id(P);
+    const RowIds<LPR> id(P, P2P ? 1 : 0);
     const int l = id.l;  // lane within the row
     const int64_t rowc = id.rowc;
     double *U = lds + id.slot * lds_row_stride(n);
@@ -123,7 +180,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     constexpr int kRecPerLane = 8;  // npart <= 512 in chained mode
     double pfv[kRecPerLane];
     int64_t piv[kRecPerLane];
-    if (CHAIN) {
+    if (CHAIN && !P2P) {
         const double *pf = a.part_f + (int64_t)chain_p * npart;
         const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
         const int per = (int)((npart + kWave - 1) / kWave);  // contiguous slice per lane: first-minimum rule
@@ -139,8 +196,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         if (CHAIN && mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
         return;
     }
+    if (P2P && *x.error) return;  // an earlier wait timed out: the run is dead, the host raises
     const int64_t it = CHAIN ? sin->it + 1 : sin->it;  // the generation the population holds; we produce it+1
     SX_TP(6);
+    if (P2P && blockIdx.x == 0) {
+        p2p_service(a, x, chain_p, mode, npart, it, sin);
+        return;
+    }
 
     // ---- B. everything that only needs `it`: donors, the first batch of row loads, the first Philox call
     const uint32_t gen = (uint32_t)(it + 1);
@@ -216,10 +278,26 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     load_batch(0, B0);
 
     // ---- C. (CHAIN) best of the predecessor generation, status, publication
-    int64_t gbidx;
+    int64_t gbidx = 0;
     double *part_f_out = a.part_f;
     int64_t *part_i_out = a.part_i;
-    if (CHAIN) {
+    const uint32_t xtag = (uint32_t)(it + 1);
+    const uint64_t *gbw = nullptr;  // P2P: the winner's row as tagged words
+    if (P2P) {
+        double bf;
+        int64_t bi;
+        int winner;
+        if (!xchg_wait_best(x.peer[x.rank] + xchg_slot_offset(n, chain_p, 0), n, x.world, xtag, x.timeout_ticks,
+                            id.lane, bf, bi, winner)) {
+            if (id.lane == 0) atomicExch(x.error, 1);
+            return;
+        }
+        if (it >= 2 && (bf <= a.ftol || it >= a.maxiter)) return;  // same rule as the service workgroup
+        gbidx = bi;
+        gbw = x.peer[x.rank] + xchg_slot_offset(n, chain_p, winner) + 4;
+        part_f_out = a.part_f + (int64_t)(1 - chain_p) * npart;
+        part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
+    } else if (CHAIN) {
         double bf = pfv[0];
         int64_t bi = piv[0];
 #pragma unroll
@@ -250,7 +328,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         gbidx = sin->gbidx;
     }
     // best row: the caller's copy (multi-GPU: it may come from another shard) or row gbidx of this generation
-    const double *__restrict__ gb = a.gbest != nullptr ? a.gbest : cur + gbidx * ld;
+    const double *__restrict__ gb = P2P ? cur : a.gbest != nullptr ? a.gbest : cur + gbidx * ld;
 
     // ---- D. trial vector: mutation (de/_strategy.py, same association), crossover (de/_de.py:344 forced
     //      index OR r <= CR), Random repair (de/_constraints.py:21-26) -> LDS
@@ -261,10 +339,41 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         const double(&br)[kStep] = bt.r;
         const double(&brs)[kStep] = bt.rs;
         double g[kStep];
+        if (P2P) {
+            if (use_best) {  // tagged words from the exchange buffer; a word not yet there is simply re-read
+                const uint64_t t0 = wall_clock64();
+                for (;;) {
+                    uint64_t lo[kStep], hi[kStep];
+                    bool ok = true;
 #pragma unroll
-        for (int t = 0; t < kStep; ++t) {
-            const int e = (q0 + t) * LPR + l;
-            g[t] = (use_best && (FULL || e < n)) ? gb[e] : 0.0;
+                    for (int t = 0; t < kStep; ++t) {
+                        const int e = (q0 + t) * LPR + l;
+                        const bool in = FULL || e < n;
+                        lo[t] = in ? ll_load(gbw + 2 * e) : 0;
+                        hi[t] = in ? ll_load(gbw + 2 * e + 1) : 0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < kStep; ++t) {
+                        const int e = (q0 + t) * LPR + l;
+                        if (FULL || e < n) ok = ok && ll_ok(lo[t], xtag) && ll_ok(hi[t], xtag);
+                        g[t] = ll_join_f64(lo[t], hi[t]);
+                    }
+                    if (ok) break;
+                    if ((int64_t)(wall_clock64() - t0) > x.timeout_ticks) {
+                        atomicExch(x.error, 1);
+                        break;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < kStep; ++t) g[t] = 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < kStep; ++t) {
+                const int e = (q0 + t) * LPR + l;
+                g[t] = (use_best && (FULL || e < n)) ? gb[e] : 0.0;
+            }
         }
 #pragma unroll
         for (int t = 0; t < kStep; ++t) {
@@ -320,32 +429,34 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     SX_TP(5);
 }
 
-typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t);
+typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t,
+                            const sx_xchg_args);
 
-template <int RNG, bool CHAIN, int LPR, bool FULL>
+template <int RNG, int XM, int LPR, bool FULL>
 de_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, CHAIN, LPR, FULL>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, CHAIN, LPR, FULL>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, CHAIN, LPR, FULL>;
-        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, CHAIN, LPR, FULL>;
-        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, CHAIN, LPR, FULL>;
-        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, CHAIN, LPR, FULL>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, CHAIN, LPR, FULL>;
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL>;
     }
     return nullptr;
 }
 
 // bounds-test-free variant only for the chained (throughput) kernels, to keep the build small
-template <int RNG, bool CHAIN>
+template <int RNG, int XM>
 de_kernel_t pick_kernel(int fun_id, int n, int64_t P) {
+    constexpr bool CH = XM >= 1;
     const int lpr = lanes_per_row(n);
-    const bool full = CHAIN && n % (kStep * lpr) == 0 && P % rows_per_block(n) == 0;
+    const bool full = CH && n % (kStep * lpr) == 0 && P % rows_per_block(n) == 0;
     switch (lpr) {
-        case 16: return full ? pick_kernel_lpr<RNG, CHAIN, 16, CHAIN>(fun_id) : pick_kernel_lpr<RNG, CHAIN, 16, false>(fun_id);
-        case 32: return full ? pick_kernel_lpr<RNG, CHAIN, 32, CHAIN>(fun_id) : pick_kernel_lpr<RNG, CHAIN, 32, false>(fun_id);
+        case 16: return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 16, false>(fun_id);
+        case 32: return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 32, false>(fun_id);
     }
-    return full ? pick_kernel_lpr<RNG, CHAIN, 64, CHAIN>(fun_id) : pick_kernel_lpr<RNG, CHAIN, 64, false>(fun_id);
+    return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 64, false>(fun_id);
 }
 
 int check_args(const sx_de_args *a) {
@@ -365,8 +476,8 @@ int check_args(const sx_de_args *a) {
 }
 
 de_kernel_t kernel_for(const sx_de_args *a) {
-    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, false>(a->fun_id, a->n, a->P)
-                                   : pick_kernel<SX_RNG_HOST, false>(a->fun_id, a->n, a->P);
+    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, 0>(a->fun_id, a->n, a->P)
+                                   : pick_kernel<SX_RNG_HOST, 0>(a->fun_id, a->n, a->P);
 }
 
 Geometry geometry(const sx_de_args *a) { return row_geometry(a->P, a->n); }
@@ -379,7 +490,8 @@ extern "C" int sx_de_generation(const sx_de_args *a, int finalize, void *stream)
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan, 0, 0, (int64_t)g.blocks);
+    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan, 0, 0, (int64_t)g.blocks,
+                       sx_xchg_args{});
     SX_LAUNCH_CHECK();
     if (finalize) {
         SX_REQUIRE(a->gbest != nullptr, "sx_de_generation: the separate finalize kernel needs the gbest buffer");
@@ -410,7 +522,8 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
     sx_de_args args = *a;
     int zero = 0;
     int64_t npart = g.blocks;
-    void *kargs[] = {&args, &plan, &zero, &zero, &npart};
+    sx_xchg_args nox = {};
+    void *kargs[] = {&args, &plan, &zero, &zero, &npart, &nox};
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
         hipKernelNodeParams kp = {};
@@ -451,21 +564,23 @@ static int check_chain(const sx_de_args *a) {
     return 0;
 }
 
-extern "C" int sx_de_chain_launch(const sx_de_args *a, int parity, int finalize_only, void *stream) {
+// x == nullptr: single GPU (XM = 1); otherwise the peer-exchange kernel (XM = 2, one service workgroup in front)
+static int chain_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, int finalize_only, void *stream) {
     if (int rc = check_chain(a)) return rc;
     SX_REQUIRE(parity == 0 || parity == 1, "sx_de_chain_launch: parity must be 0 or 1");
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    de_kernel_t kern = pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n, a->P);
-    const unsigned blocks = finalize_only ? 1u : g.blocks;
+    de_kernel_t kern = x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P)
+                         : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P);
+    const unsigned blocks = finalize_only ? 1u : g.blocks + (x ? 1u : 0u);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream, *a, plan, parity,
-                       finalize_only ? 1 : 0, (int64_t)g.blocks);
+                       finalize_only ? 1 : 0, (int64_t)g.blocks, x ? *x : sx_xchg_args{});
     SX_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start_parity, sx_graph **out) {
+static int chain_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ngen, int start_parity, sx_graph **out) {
     if (int rc = check_chain(a)) return rc;
     SX_REQUIRE(out != nullptr && ngen >= 1 && (start_parity == 0 || start_parity == 1),
                "sx_de_chain_graph_create: bad arguments");
@@ -475,15 +590,17 @@ extern "C" int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start
     sx_graph *gr = new sx_graph();
     SX_HIP(hipGraphCreate(&gr->graph, 0));
     sx_de_args args = *a;
+    sx_xchg_args xa = x ? *x : sx_xchg_args{};
     int mode = 0;
     int64_t npart = g.blocks;
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
         int parity = (start_parity + i) & 1;
-        void *kargs[] = {&args, &plan, &parity, &mode, &npart};
+        void *kargs[] = {&args, &plan, &parity, &mode, &npart, &xa};
         hipKernelNodeParams kp = {};
-        kp.func = (void *)pick_kernel<SX_RNG_PHILOX, true>(a->fun_id, a->n, a->P);
-        kp.gridDim = dim3(g.blocks);
+        kp.func = (void *)(x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P)
+                             : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P));
+        kp.gridDim = dim3(g.blocks + (x ? 1u : 0u));
         kp.blockDim = dim3(g.threads);
         kp.sharedMemBytes = (unsigned)g.lds;
         kp.kernelParams = kargs;
@@ -495,6 +612,27 @@ extern "C" int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start
     SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
     *out = gr;
     return 0;
+}
+
+extern "C" int sx_de_chain_launch(const sx_de_args *a, int parity, int finalize_only, void *stream) {
+    return chain_launch(a, nullptr, parity, finalize_only, stream);
+}
+extern "C" int sx_de_chain_graph_create(const sx_de_args *a, int ngen, int start_parity, sx_graph **out) {
+    return chain_graph_create(a, nullptr, ngen, start_parity, out);
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU, peer exchange: the chained kernel on this rank's shard (a->P rows from global row a->row0)
+// ---------------------------------------------------------------------------
+extern "C" int sx_de_p2p_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, int finalize_only,
+                                void *stream) {
+    if (int rc = check_xchg_args(x)) return rc;
+    return chain_launch(a, x, parity, finalize_only, stream);
+}
+extern "C" int sx_de_p2p_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ngen, int start_parity,
+                                      sx_graph **out) {
+    if (int rc = check_xchg_args(x)) return rc;
+    return chain_graph_create(a, x, ngen, start_parity, out);
 }
 
 extern "C" int sx_graph_launch(sx_graph *g, void *stream) {

@@ -12,15 +12,17 @@ struct RowIds {
     int wave, lane;  // wave in workgroup, lane in wave
     int l;           // lane within the row
     int slot;        // row slot within the workgroup
+    int block;       // row workgroup index (blockIdx.x minus the leading service workgroups)
     int64_t row, rowc;
     bool active;
-    __device__ __forceinline__ explicit RowIds(int64_t P) {
+    __device__ __forceinline__ explicit RowIds(int64_t P, int first_block = 0) {
         wave = (int)(threadIdx.x >> 6);
         lane = (int)(threadIdx.x & 63);
         l = lane & (LPR - 1);
         slot = wave * RPW + lane / LPR;
         const int rows_in_block = (int)(blockDim.x >> 6) * RPW;
-        row = (int64_t)blockIdx.x * rows_in_block + slot;
+        block = (int)blockIdx.x - first_block;
+        row = (int64_t)block * rows_in_block + slot;
         active = row < P;
         rowc = active ? row : P - 1;  // padding rows shadow the last row and store nothing
     }
@@ -121,8 +123,8 @@ __device__ __forceinline__ void block_partial(double val, const RowIds<LPR> &id,
         int64_t bi = vi[0];
 #pragma unroll
         for (int k = 1; k < kMaxRowsPerBlock; ++k) argmin_combine(bf, bi, vf[k], vi[k]);
-        part_f[blockIdx.x] = bf;
-        part_i[blockIdx.x] = bi;
+        part_f[id.block] = bf;
+        part_i[id.block] = bi;
     }
 }
 

@@ -41,6 +41,7 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
+    exchange=None,
 ):
     """Minimize an objective function using Differential Evolution on MI355X.
 
@@ -49,7 +50,10 @@ def minimize(
     random-draw source: ``"numpy-legacy"`` (default; the reference's stream, so the
     same seed gives the reference's result) or ``"philox"`` (in-kernel counter-based
     draws, the throughput mode).  As in the reference, choosing a parallel backend
-    forces ``updating="deferred"`` (de/_de.py:142-145).
+    forces ``updating="deferred"`` (de/_de.py:142-145).  ``exchange`` (``workers > 1`` only) picks how the
+    per-generation global best travels between GPUs: ``"p2p"`` (the generation kernel writes its shard's
+    record straight into the peers' HBM over xGMI), ``"rccl"`` (one all-gather per generation) or ``None`` /
+    ``"auto"`` (p2p if its self-test passes on every rank, else rccl); both give identical results.
     """
     fun_id = _common.resolve_objective(fun, args)
     lower, upper = _common.as_bounds(bounds)
@@ -80,7 +84,7 @@ def minimize(
 
     run = _DeRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(mutation), float(recombination),
                  strategy, constraints, float(xtol), float(ftol), bool(return_all), float(verbosity), callback, rng,
-                 seed, workers)
+                 seed, workers, exchange=exchange)
     return run.result()
 
 
@@ -88,7 +92,7 @@ class _DeRun:
     GRAPH_CHUNK = 50
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, F, CR, strategy, constraints, xtol, ftol, return_all,
-                 verbosity, callback, rng, seed, workers, autorun=True):
+                 verbosity, callback, rng, seed, workers, autorun=True, exchange=None):
         self.fun_id, self.lower, self.upper = fun_id, lower, upper
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.F, self.CR, self.strategy, self.constraints = F, CR, strategy, constraints
@@ -119,6 +123,26 @@ class _DeRun:
                       and npart <= 512)
         self.launches = 0
         self.ctx = _device.Context()
+        # multi-GPU: the chained kernel with the peer exchange in its prologue, if the transport checks out
+        self.px = None
+        self.exchange = None
+        if self.world is not None:
+            exchange = exchange or os.environ.get("SX_EXCHANGE") or "auto"
+            if exchange not in ("auto", "p2p", "rccl"):
+                raise ValueError('exchange must be "auto", "p2p" or "rccl"')
+            self.exchange, self.exchange_note = "rccl", None
+            if exchange != "rccl":
+                if npart <= 512:
+                    from ..parallel import PeerExchange
+
+                    timeout = float(os.environ.get("SX_XCHG_TIMEOUT_S", "20"))
+                    self.px, self.exchange_note = PeerExchange.negotiate(self.ctx, self.world, self.n, timeout)
+                else:
+                    self.exchange_note = "more than 512 workgroup records per shard"
+                if self.px is not None:
+                    self.exchange, self.chain = "p2p", True
+                elif exchange == "p2p":
+                    raise RuntimeError(f'exchange="p2p" is not available: {self.exchange_note}')
         self._graph = None
         self._chain_graphs = {}
         self._shard_calls = None
@@ -137,27 +161,48 @@ class _DeRun:
         for g in self._chain_graphs.values():
             self.ctx.L.sx_graph_destroy(g)
         self._chain_graphs = {}
+        if self.px is not None:
+            self.ctx.sync()
+            self.px.close()
+            self.px = None
 
     def read_state(self):
         """Host view of the run: (chained mode) finalise the last generation into state[2], then read it."""
         ctx = self.ctx
         if not self.chain:
             return ctx.read_state(self.state)
-        _lib.check(ctx.L.sx_de_chain_launch(C.byref(self.args), self.launches & 1, 1, ctx.stream_ptr),
-                   "sx_de_chain_launch")
-        return ctx.read_state(self.state[16:24])
+        self._chain_launch(self.launches & 1, 1)
+        st = ctx.read_state(self.state[16:24])
+        if self.px is not None and self.px.failed():
+            raise RuntimeError("peer exchange timed out: a rank did not reach the generation the others "
+                               "were waiting for (SX_XCHG_TIMEOUT_S)")
+        return st
+
+    def _chain_launch(self, parity, finalize_only):
+        ctx = self.ctx
+        if self.px is not None:
+            _lib.check(ctx.L.sx_de_p2p_launch(C.byref(self.args), C.byref(self.px.args), parity, finalize_only,
+                                              ctx.stream_ptr), "sx_de_p2p_launch")
+        else:
+            _lib.check(ctx.L.sx_de_chain_launch(C.byref(self.args), parity, finalize_only, ctx.stream_ptr),
+                       "sx_de_chain_launch")
 
     def _chain_graph(self, par):
         if par not in self._chain_graphs:
             g = C.c_void_p()
-            _lib.check(self.ctx.L.sx_de_chain_graph_create(C.byref(self.args), self.GRAPH_CHUNK, par, C.byref(g)),
-                       "sx_de_chain_graph_create")
+            if self.px is not None:
+                _lib.check(self.ctx.L.sx_de_p2p_graph_create(C.byref(self.args), C.byref(self.px.args),
+                                                             self.GRAPH_CHUNK, par, C.byref(g)),
+                           "sx_de_p2p_graph_create")
+            else:
+                _lib.check(self.ctx.L.sx_de_chain_graph_create(C.byref(self.args), self.GRAPH_CHUNK, par,
+                                                               C.byref(g)), "sx_de_chain_graph_create")
             self._chain_graphs[par] = g
         return self._chain_graphs[par]
 
     def prepare_graphs(self):
         """Instantiate the hipGraph(s) up front (otherwise the first full chunk pays for it)."""
-        if self.world is not None:
+        if self.world is not None and not self.chain:
             return
         if self.chain:
             self._chain_graph(0)  # GRAPH_CHUNK is even: replays always start at parity 0 unless eager launches intervene
@@ -175,8 +220,7 @@ class _DeRun:
             self.launches += self.GRAPH_CHUNK
             ngen -= self.GRAPH_CHUNK
         for _ in range(ngen):
-            _lib.check(ctx.L.sx_de_chain_launch(C.byref(self.args), self.launches & 1, 0, ctx.stream_ptr),
-                       "sx_de_chain_launch")
+            self._chain_launch(self.launches & 1, 0)
             self.launches += 1
 
     def _sharded_generation(self):
@@ -201,12 +245,12 @@ class _DeRun:
         generation); the remainder is launched eagerly.  Generations after convergence are no-ops.
         """
         ctx = self.ctx
+        if self.chain:
+            self._enqueue_chain(ngen)
+            return
         if self.world is not None:
             for _ in range(ngen):
                 self._sharded_generation()
-            return
-        if self.chain:
-            self._enqueue_chain(ngen)
             return
         while ngen >= self.GRAPH_CHUNK:
             if self._graph is None:
@@ -249,7 +293,7 @@ class _DeRun:
         g = int(out_i.cpu()[0])
         gfit0 = float(out_f.cpu()[0])
         self.gbest = self.bufs[1][g].clone()
-        if self.world is not None:  # initial global best: one record exchange, settled on the host
+        if self.world is not None and self.px is None:  # initial global best: one record exchange, settled on the host
             from ..parallel import best_of_records
 
             self.record = ctx.empty((n + 2,))
@@ -336,6 +380,8 @@ class _DeRun:
 
     def _best_row(self, st):
         """The best individual of generation st.it (host copy)."""
+        if self.px is not None:  # generation `it` was finalised from the records in slot parity (it-1)&1
+            return self.px.read_record((st.it - 1) & 1, int(st.reserved[1]))[2]
         if self.chain:
             return self._population(st.it)[st.gbidx].cpu().numpy()
         return self.gbest.cpu().numpy()
@@ -345,7 +391,10 @@ class _DeRun:
         by <= xtol.  Both generations are still resident (nothing is produced after `done`)."""
         status = int(st.status)
         if self.chain and status == 1:
-            prev = self._population(st.it - 1)[st.reserved[0]].cpu().numpy()
+            if self.px is not None:  # the previous generation's records sit in the other parity
+                prev = self.px.read_record(st.it & 1, int(st.reserved[0]))[2]
+            else:
+                prev = self._population(st.it - 1)[st.reserved[0]].cpu().numpy()
             if np.linalg.norm(prev - self._best_row(st)) <= self.xtol:
                 status = 0
         return status
@@ -411,6 +460,8 @@ class _DeRun:
         if self.rng == "numpy-legacy":
             self.stream.sync_back()
         ctx.sync()
+        if self.px is not None:
+            self.world.barrier()  # no rank frees its exchange buffer while a peer may still write into it
         self._res = res
 
     def result(self):

@@ -64,6 +64,19 @@ class World:
         self.dist.all_gather(gathered, host, group=self.group)
         out.copy_(torch.stack(gathered).to(out.device))
 
+    def all_gather_object(self, obj):
+        """Small host objects (set-up only: IPC handles, flags)."""
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+    def all_agree(self, flag):
+        """True iff `flag` is true on every rank."""
+        return all(self.all_gather_object(bool(flag)))
+
     def max_over_ranks(self, value):
         import torch
 
@@ -72,6 +85,112 @@ class World:
             t = t.cuda()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
+
+
+class PeerExchange:
+    """Exchange buffers for the peer-exchange generation kernels (include/stochopy_hip.h, sx_xchg_*).
+
+    Every rank allocates one uncached buffer in its HBM, exports it (HIP IPC), maps every peer's buffer and
+    runs the transport self-test.  The process group is only used here, at set-up, to pass the 64-byte handles
+    around and to agree on the outcome; afterwards the generation kernels write into the peers' memory
+    themselves.  ``negotiate`` never leaves ranks in different modes: either all of them get a working
+    exchange or all of them get ``None`` (and the reason), and the caller falls back to the RCCL path.
+    """
+
+    def __init__(self):
+        self.own = None
+        self.opened = []
+        self.args = None
+        self.error = None
+
+    @classmethod
+    def negotiate(cls, ctx, world, n, timeout_s=20.0, probe_rounds=8, probe_timeout_s=3.0):
+        import ctypes as C
+
+        from . import _lib
+
+        L = ctx.L
+        px = cls()
+        px.ctx, px.world, px.n = ctx, world, n
+        why = None
+        handle = None
+        if world.size > _lib.SX_MAX_PEERS:
+            why = f"more than {_lib.SX_MAX_PEERS} ranks"
+        else:
+            own = C.c_void_p()
+            hbuf = C.create_string_buffer(_lib.SX_IPC_HANDLE_BYTES)
+            if L.sx_xchg_alloc(L.sx_xchg_bytes(world.size, n), C.byref(own), hbuf) == 0:
+                px.own = own
+                handle = hbuf.raw
+            else:
+                why = "alloc: " + L.sx_last_error().decode()
+        handles = world.all_gather_object(handle)
+        if any(h is None for h in handles):
+            px.close()
+            return None, why or "a peer could not allocate / export its exchange buffer"
+        # map the peers
+        a = _lib.SxXchgArgs()
+        a.world, a.rank = world.size, world.rank
+        ok = True
+        for r, h in enumerate(handles):
+            if r == world.rank:
+                a.peer[r] = px.own.value
+                continue
+            p = C.c_void_p()
+            if L.sx_xchg_open(h, C.byref(p)) != 0:
+                ok, why = False, "open: " + L.sx_last_error().decode()
+                break
+            px.opened.append(p)
+            a.peer[r] = p.value
+        t = ctx.zeros((1,), dtype=_torch_int32())
+        px.error = t
+        a.error = t.data_ptr()
+        if not world.all_agree(ok):
+            px.close()
+            return None, why or "a peer could not map this rank's exchange buffer"
+        # transport self-test (short timeout), then the run's own timeout
+        a.timeout_ticks = int(probe_timeout_s * 1e8)
+        rc = L.sx_xchg_probe(C.byref(a), n, probe_rounds, ctx.stream_ptr)
+        if not world.all_agree(rc == 0):
+            px.close()
+            return None, ("probe: words did not arrive intact" if rc == 1 else
+                          "probe failed on a peer" if rc == 0 else "probe: " + L.sx_last_error().decode())
+        a.timeout_ticks = int(timeout_s * 1e8)
+        px.args = a
+        return px, None
+
+    def failed(self):
+        """True if a wait inside a kernel timed out (synchronises)."""
+        self.ctx.sync()
+        return bool(int(self.error.cpu()[0]))
+
+    def read_record(self, parity, src):
+        """Host copy of slot[parity][src] of this rank's buffer: (f, global row, row)."""
+        import ctypes as C
+
+        from . import _lib
+
+        rec = np.empty(self.n + 2)
+        _lib.check(self.ctx.L.sx_xchg_read_record(C.byref(self.args), self.n, parity, src,
+                                                  rec.ctypes.data_as(C.c_void_p), self.ctx.stream_ptr),
+                   "sx_xchg_read_record")
+        return float(rec[0]), int(rec[1:2].view(np.int64)[0]), rec[2:].copy()
+
+    def close(self):
+        L = self.ctx.L
+        for p in self.opened:
+            L.sx_xchg_close(p)
+        self.opened = []
+        if self.own is not None:
+            L.sx_xchg_free(self.own)
+            self.own = None
+        self.args = None
+
+
+def _torch_int32():
+    import torch
+
+    return torch.int32
 
 
 def best_of_records(records):

@@ -63,21 +63,82 @@ def cpu_exchange_worker(rank, world, port, cfg, out_dir):
         dist.destroy_process_group()
 
 
+def _spy_on_de_runs():
+    """Record the _DeRun objects minimize() creates (to see which exchange a run ended up with)."""
+    from stochopy_amd.optimize import _de
+
+    runs = []
+    orig = _de._DeRun.__init__
+
+    def spy(self, *a, **k):
+        runs.append(self)
+        orig(self, *a, **k)
+
+    _de._DeRun.__init__ = spy
+    return runs
+
+
+def _minimize_and_save(rank, world, cfg, out_dir):
+    import stochopy_amd as sa
+
+    runs = _spy_on_de_runs()
+    n = cfg["n"]
+    opts = dict(cfg["options"], backend="hip", rng="philox", workers=world)
+    res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), [[-5.12, 5.12]] * n, method=cfg["method"],
+                               options=opts)
+    np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
+    np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))
+    if runs:
+        with open(os.path.join(out_dir, f"exchange_{rank}.txt"), "w") as f:
+            f.write(str(runs[-1].exchange))
+
+
 def gpu_minimize_worker(rank, world, port, cfg, out_dir):
-    """Two ranks share the one GPU of the test box (gloo, host-staged records): the sharded HIP path end to end."""
+    """Ranks share the one GPU of the test box (gloo for the process group): the sharded HIP path end to end."""
+    dist = _init(rank, world, port)
+    try:
+        import torch
+
+        torch.cuda.set_device(0)
+        _minimize_and_save(rank, world, cfg, out_dir)
+    finally:
+        dist.destroy_process_group()
+
+
+def gpu_p2p_straggler_worker(rank, world, port, cfg, out_dir):
+    """Rank 1 sets the exchange up and then never launches a generation; rank 0 must time out and raise."""
+    import time
+
+    os.environ["SX_XCHG_TIMEOUT_S"] = "1"
     dist = _init(rank, world, port)
     try:
         import torch
 
         torch.cuda.set_device(0)
         import stochopy_amd as sa
+        from stochopy_amd import _lib
+        from stochopy_amd.optimize import _de
 
-        n = cfg["n"]
-        opts = dict(cfg["options"], backend="hip", rng="philox", workers=world)
-        res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), [[-5.12, 5.12]] * n, method=cfg["method"],
-                                   options=opts)
-        np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
-        np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))
+        n, o = cfg["n"], cfg["options"]
+        run = _de._DeRun(_lib.FUN_IDS[cfg["objective"]], np.full(n, -5.12), np.full(n, 5.12), None, o["maxiter"],
+                         o["popsize"], 0.5, 0.9, "best1bin", None, 0.0, -1.0, False, 1.0, None, "philox", o["seed"],
+                         world, autorun=False, exchange="p2p")
+        assert run.exchange == "p2p"
+        with torch.cuda.stream(run.ctx.stream):
+            run._setup()
+            if rank == 0:
+                run.enqueue(3)
+                try:
+                    run.read_state()
+                    msg = "no error"
+                except RuntimeError as e:
+                    msg = str(e)
+                with open(os.path.join(out_dir, "err_0.txt"), "w") as f:
+                    f.write(msg)
+            else:
+                time.sleep(0.5)
+        dist.barrier()
+        run.close()
     finally:
         dist.destroy_process_group()
 
@@ -93,12 +154,6 @@ def nccl_single_rank_worker(rank, world, port, cfg, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     try:
-        import stochopy_amd as sa
-
-        n = cfg["n"]
-        opts = dict(cfg["options"], backend="hip", rng="philox", workers=1)
-        res = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="de", options=opts)
-        np.save(os.path.join(out_dir, "x_0.npy"), res.x)
-        np.save(os.path.join(out_dir, "meta_0.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))
+        _minimize_and_save(rank, 1, cfg, out_dir)
     finally:
         dist.destroy_process_group()

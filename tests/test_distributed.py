@@ -52,20 +52,64 @@ def test_world_exchange_two_ranks_gloo_cpu():
         assert np.array_equal(np.load(os.path.join(out, f"trace_{r}.npy")), np.array(ref["_trace"]))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_de_on_gpu_matches_oracle(world):
-    """Ranks share the single test GPU (gloo); sharded HIP DE == oracle.run_de_sharded bit for bit."""
+def _de_reference(cfg, world):
+    o = dict(cfg["options"])
+    n = cfg["n"]
+    seed = o.pop("seed")
+    o.pop("exchange", None)
+    return oe.run_de_sharded(oracle.OBJECTIVES[cfg["objective"]], np.full(n, -5.12), np.full(n, 5.12),
+                             oracle.PhiloxStream(seed), world, **o)
+
+
+def _check_sharded_de(world, cfg, worker=None):
     from _dist_workers import gpu_minimize_worker
 
-    cfg = {"n": 24, "P": 128, "gens": 9, "seed": 2024, "objective": "rosenbrock", "method": "de",
-           "options": {"maxiter": 9, "popsize": 128, "seed": 2024, "ftol": -1.0, "xtol": 0.0}}
-    out = _spawn(gpu_minimize_worker, world, cfg)
-    ref = _sharded_oracle(cfg, world)
+    out = _spawn(worker or gpu_minimize_worker, world, cfg)
+    ref = _de_reference(cfg, world)
     for r in range(world):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
-        assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+        assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status), (r, fun, nit, status, ref)
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+        assert open(os.path.join(out, f"exchange_{r}.txt")).read() == cfg["options"]["exchange"]
+
+
+def _de_cfg(n, P, gens, seed, exchange, objective="rosenbrock", **more):
+    opts = {"maxiter": gens, "popsize": P, "seed": seed, "ftol": -1.0, "xtol": 0.0, "exchange": exchange}
+    opts.update(more)
+    return {"n": n, "objective": objective, "method": "de", "options": opts}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_de_on_gpu_matches_oracle(world, exchange):
+    """Ranks share the single test GPU (gloo for set-up); sharded HIP DE == oracle.run_de_sharded bit for bit,
+    with the record exchange staged through the process group ("rccl" path) and with the generation kernels
+    writing into each other's IPC-mapped exchange buffers ("p2p")."""
+    _check_sharded_de(world, _de_cfg(24, 128, 9, 2024, exchange))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    dict(n=128, P=64, gens=130, seed=5),                                   # bounds-test-free kernel, graph replays
+    dict(n=300, P=36, gens=60, seed=6),                                    # whole wave per row, several leaves
+    dict(n=10, P=40, gens=30, seed=7, strategy="rand1bin"),                # the row of the record is never read
+    dict(n=33, P=48, gens=25, seed=8, strategy="best2bin", constraints="Random"),
+    dict(n=16, P=64, gens=400, seed=9, objective="sphere", ftol=1e-3, xtol=1e-8),   # stops on ftol (status 0/1)
+])
+def test_p2p_exchange_cases(case):
+    case = dict(case)
+    cfg = _de_cfg(case.pop("n"), case.pop("P"), case.pop("gens"), case.pop("seed"), "p2p", **case)
+    _check_sharded_de(2, cfg)
+
+
+@pytest.mark.gpu
+def test_p2p_exchange_timeout_is_reported():
+    """A rank that never shows up: the others give up after the timeout and raise (no hang)."""
+    from _dist_workers import gpu_p2p_straggler_worker
+
+    out = _spawn(gpu_p2p_straggler_worker, 2, _de_cfg(24, 128, 9, 2024, "p2p"))
+    assert "timed out" in open(os.path.join(out, "err_0.txt")).read()
 
 
 @pytest.mark.gpu
@@ -88,10 +132,12 @@ def test_sharded_path_over_rccl_single_rank():
     """backend "nccl" (RCCL) with one rank: the device-side all_gather_into_tensor exchange used in production."""
     from _dist_workers import nccl_single_rank_worker
 
-    cfg = {"n": 24, "P": 128, "gens": 9, "seed": 2024,
-           "options": {"maxiter": 9, "popsize": 128, "seed": 2024, "ftol": -1.0, "xtol": 0.0}}
-    out = _spawn(nccl_single_rank_worker, 1, cfg)
-    ref = _sharded_oracle(cfg, 1)
-    fun, nit, nfev, status = np.load(os.path.join(out, "meta_0.npy"))
-    assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
-    assert np.array_equal(np.load(os.path.join(out, "x_0.npy")), ref.x)
+    _check_sharded_de(1, _de_cfg(24, 128, 9, 2024, "rccl"), worker=nccl_single_rank_worker)
+
+
+@pytest.mark.gpu
+def test_p2p_path_single_rank_nccl_setup():
+    """Same with the peer exchange (handles and agreement travel over the RCCL group, the kernels write locally)."""
+    from _dist_workers import nccl_single_rank_worker
+
+    _check_sharded_de(1, _de_cfg(24, 128, 9, 2024, "p2p"), worker=nccl_single_rank_worker)
