@@ -10,7 +10,7 @@
 //   stochopy/optimize/_common.py:123-130  selection (strict <, in place)
 //   stochopy/factory/benchmark.py         objective, fused
 //
-// One wavefront per individual; the population is double-buffered: generation g
+// 16/32/64 lanes per individual (sx_rowops.hpp); the population is double-buffered: generation g
 // lives in buf[g & 1], its successor is written to the other buffer (winner or
 // unchanged row), so donor reads never race with selection writes.
 #include <vector>

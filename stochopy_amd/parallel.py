@@ -3,9 +3,11 @@
 Takes the place of the reference's MPI backend (stochopy/optimize/_common.py:45-72: every
 rank runs the optimiser, rank 0's candidates are broadcast, fitness is summed with Allreduce).
 Here each GPU owns ``popsize / world`` rows for the whole run; per generation the only traffic is
-ONE all-gather of an (n+2)-double record per rank -- [best f, global row, best row] -- over RCCL
-(``torch.distributed`` backend "nccl" on ROCm = RCCL over xGMI), after which every rank finalises
-the same global best locally.  The population never moves.
+an (n+2)-double record per rank -- [best f, global row, best row] -- after which every rank finalises
+the same global best locally.  The population never moves.  Two transports with identical results:
+``World.all_gather_records`` (ONE all-gather over RCCL; ``torch.distributed`` backend "nccl" on ROCm =
+RCCL over xGMI) and ``PeerExchange`` (DE: the generation kernel writes the record into the peers'
+IPC-mapped HBM itself; the process group is only used at set-up).
 
 Semantics with ``workers > 1`` (documented deviation): DE donors are drawn
 from the rank's own shard (an island model with a shared global best); PSO is exact.  Random draws
