@@ -32,6 +32,10 @@ WORKLOADS = {
     "de_rastrigin_n128_p4096": ("rastrigin", 128, 4096, "best1bin"),
     "de_rosenbrock_n1024_p16384": ("rosenbrock", 1024, 16384, "best1bin"),
     "de_rosenbrock_n1024_p131072": ("rosenbrock", 1024, 131072, "best1bin"),
+    "de_rosenbrock_n256_p4096": ("rosenbrock", 256, 4096, "best1bin"),
+    "de_rosenbrock_n512_p8192": ("rosenbrock", 512, 8192, "best1bin"),
+    "de_rastrigin_n1024_p16384": ("rastrigin", 1024, 16384, "best1bin"),
+    "de_rosenbrock_n2048_p16384": ("rosenbrock", 2048, 16384, "best1bin"),
 }
 
 

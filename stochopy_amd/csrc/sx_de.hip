@@ -394,13 +394,21 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
             }
         }
     };
-    for (int q0 = 0; q0 < nq; q0 += 2 * kStep) {
-        const bool more1 = q0 + kStep < nq, more2 = q0 + 2 * kStep < nq;
-        if (more1) load_batch(q0 + kStep, B1);
-        trial_batch(q0, B0);
-        if (more1) {
-            if (more2) load_batch(q0 + 2 * kStep, B0);
-            trial_batch(q0 + kStep, B1);
+    if (LPR < kWave) {  // short rows: two batches in flight cover the latency at 2 waves per SIMD
+        for (int q0 = 0; q0 < nq; q0 += 2 * kStep) {
+            const bool more1 = q0 + kStep < nq, more2 = q0 + 2 * kStep < nq;
+            if (more1) load_batch(q0 + kStep, B1);
+            trial_batch(q0, B0);
+            if (more1) {
+                if (more2) load_batch(q0 + 2 * kStep, B0);
+                trial_batch(q0 + kStep, B1);
+            }
+        }
+    } else {  // whole-wave rows (n > 128): one batch and half the registers -- twice the waves hide it better
+        trial_batch(0, B0);
+        for (int q0 = kStep; q0 < nq; q0 += kStep) {
+            load_batch(q0, B0);
+            trial_batch(q0, B0);
         }
     }
 

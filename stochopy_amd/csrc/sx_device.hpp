@@ -24,16 +24,24 @@ constexpr int kWave = 64;     // gfx950 wavefront = one individual
 constexpr int kMaxRowsPerBlock = 16;
 constexpr int kMaxWavesPerBlock = 8;
 constexpr int kMaxLeaf = 48;  // leaves carried in kernel arguments (n <= kMaxDim has at most 40)
-constexpr int kMaxDim = 2560; // LDS staging: 3 arrays of n doubles per row, <= 64 KiB per workgroup
+constexpr int kMaxDim = 2560; // leaf table (kMaxLeaf) and LDS staging (<= 64 KiB per workgroup) are sized for this
 
-// doubles of LDS per row: U[n+8] | A[n] | B[n] | stack[24] | leaf sums [2][n/64+2]
+// Rows of more than 256 elements form their objective terms inside the reduction (row_reduce_leaves_fused:
+// one leaf of <= 128 terms per 8-lane group, so >= 3 of the 8 groups are busy); shorter rows have too few
+// leaves for that and stage the terms, computed by all lanes, in LDS first.
+__host__ __device__ inline bool fused_terms(int n) { return n > 256; }
+// doubles of LDS per row.  staged: U[n+8] | A[n] | B[n] | stack[24] | leaf sums [2][n/64+2];
+// fused: U[n+8] | leaf sums [2][n/64+2]
 __host__ __device__ inline int leaf_cap(int n) { return n / 64 + 2; }
-__host__ __device__ inline int lds_row_stride(int n) { return 3 * n + 8 + 24 + 2 * leaf_cap(n); }
+__host__ __device__ inline int lds_row_stride(int n) {
+    return fused_terms(n) ? n + 8 + 2 * leaf_cap(n) : 3 * n + 8 + 24 + 2 * leaf_cap(n);
+}
 // lanes that own one row
 // (the smallest of 16/32/64 that covers the row in one batch of 4 steps, else the whole wave)
 __host__ __device__ inline int lanes_per_row(int n) { return n <= 64 ? 16 : (n <= 128 ? 32 : 64); }
 // waves per workgroup: the largest power of two with <= 16 rows and <= 64 KiB of LDS staging.
-// n <= 128 -> 4 waves x 4 rows (P = 4096 is exactly one workgroup per CU), 256 -> 2 x 4, 512 -> 2 x 2, 1024 -> 2 x 1.
+// n <= 64 -> 4 waves x 4 rows, 128 -> 8 x 2 (P = 4096 is exactly one workgroup per CU), 256 and 512 -> 8 x 1,
+// 1024 -> 4 x 1, 2048 -> 2 x 1.
 __host__ __device__ inline int waves_per_block(int n) {
     const int rpw = kWave / lanes_per_row(n);
     const int fit = (64 * 1024) / (8 * lds_row_stride(n) * rpw);
@@ -402,6 +410,94 @@ __device__ __forceinline__ void row_reduce_leaves(const double *A, const double 
     double vB = (TWO && l < p.nleaf) ? L[lcap + l] : identB;
     for (int m = 0; m + 1 < p.nleaf; ++m) {
         const int left = (int)p.mleft[m], right = (int)p.mright[m];  // uniform (scalar loads)
+        const double rA = row_lane_value<LPR>(vA, right, l);
+        const double rB = TWO ? row_lane_value<LPR>(vB, right, l) : identB;
+        if (l == left) {
+            vA = vA + rA;
+            if (TWO) vB = combine<BMUL>(vB, rB);
+        }
+    }
+    sa = 0.0 + row_lane_value<LPR>(vA, 0, l);
+    const double rb = TWO ? row_lane_value<LPR>(vB, 0, l) : identB;
+    sb = (TWO && !BMUL) ? 0.0 + rb : rb;
+}
+
+// The same for whole-wave rows (n > 128), with the objective terms computed on the way: the chain lane that
+// adds term e reads U[e] (and U[e+1]) from LDS and forms the term itself -- every lane still handles m/64
+// terms, but no term array is written or staged, so a row needs n+8 doubles of LDS instead of 3n+8 (3x the
+// rows per CU at n = 1024).  Same operations on the same values: same bits as the staged form.
+template <int FUN, int LPR>
+__device__ __forceinline__ void row_reduce_leaves_fused(const double *U, double *L, int lcap, int m, const PlanArg &p,
+                                                        int l, double &sa, double &sb) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    constexpr int NG = LPR / kGroup;
+    const int j = l & (kGroup - 1), grp = l >> 3;
+    const double identB = BMUL ? 1.0 : 0.0;
+    const int t0 = p.mb * kGroup;
+    for (int leaf0 = 0; leaf0 < p.nleaf; leaf0 += NG) {
+        int b0 = 0, b1 = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int lf = leaf0 + g;
+            const int e1 = lf < p.nleaf ? (int)p.end[lf] : 0;
+            const int e0 = (lf > 0 && lf <= p.nleaf) ? (int)p.end[lf - 1] : 0;
+            if (grp == g) {
+                b0 = e0;
+                b1 = e1;
+            }
+        }
+        const int leaf = leaf0 + grp;
+        const int cnt = b1 - b0;  // 0 for groups beyond the last leaf
+        double chA = 0.0, chB = identB;
+#pragma unroll
+        for (int h = 0; h < kLeafBlocks; h += 8) {
+            double x[8], xn[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool in = h + t < cnt;
+                const int e = (b0 + h + t) * kGroup + j;
+                x[t] = in ? U[e] : 0.0;
+                xn[t] = (O::NEXT && in) ? U[e + 1] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (h + t < cnt) {
+                    double a, b;
+                    O::term(x[t], xn[t], (b0 + h + t) * kGroup + j, a, b);
+                    if (h + t == 0) {
+                        chA = a;
+                        chB = b;
+                    } else {
+                        chA = chA + a;
+                        if (TWO) chB = combine<BMUL>(chB, b);
+                    }
+                }
+            }
+        }
+        double curA = group_tree<false>(chA);
+        double curB = TWO ? group_tree<BMUL>(chB) : identB;
+        if (leaf == p.nleaf - 1) {
+            for (int k = 0; k < p.tail; ++k) {
+                double a, b;
+                O::term(U[t0 + k], O::NEXT ? U[t0 + k + 1] : 0.0, t0 + k, a, b);
+                curA = curA + a;
+                if (TWO) curB = combine<BMUL>(curB, b);
+            }
+        }
+        if (cnt > 0 && j == 0) {
+            L[leaf] = curA;
+            if (TWO) L[lcap + leaf] = curB;
+        }
+    }
+    (void)m;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double vA = l < p.nleaf ? L[l] : 0.0;
+    double vB = (TWO && l < p.nleaf) ? L[lcap + l] : identB;
+    for (int mm = 0; mm + 1 < p.nleaf; ++mm) {
+        const int left = (int)p.mleft[mm], right = (int)p.mright[mm];  // uniform (scalar loads)
         const double rA = row_lane_value<LPR>(vA, right, l);
         const double rB = TWO ? row_lane_value<LPR>(vB, right, l) : identB;
         if (l == left) {

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     const int l = id.l;  // lane within the row
     const int64_t rowc = id.rowc;
     double *U = lds + id.slot * lds_row_stride(n);
-    double *Vn = U + n + 8;  // staging for the new velocity (the objective's A region, free until then)
+    double *Vn = U;  // Shrink: the raw velocity waits in U[e] until the owning lane replaces it by the position
 
     const double fold = a.pbestfit[rowc];
     double *__restrict__ xr = a.X + rowc * ld;

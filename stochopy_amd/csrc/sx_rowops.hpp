@@ -68,10 +68,15 @@ __device__ __forceinline__ double row_sum(double v) {
 template <int FUN, int LPR, bool FULL = false>
 __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg &plan, int l) {
     using O = Obj<FUN>;
-    double *A = U + n + 8;
-    double *B = A + n;
     const int m = O::NEXT ? n - 1 : n;
     lds_wave_fence();  // U complete (written and read by this wave only)
+    if (LPR == kWave && fused_terms(n)) {  // terms are formed inside the reduction, nothing else is staged
+        double sa, sb;
+        row_reduce_leaves_fused<FUN, LPR>(U, U + n + 8, leaf_cap(n), m, plan, l, sa, sb);
+        return O::finish(sa, sb, n);
+    }
+    double *A = U + n + 8;
+    double *B = A + n;
     for (int e0 = l; e0 < m; e0 += 4 * LPR) {  // 4 steps per trip: the LDS reads of a trip are independent
         double x[4], xn[4];
 #pragma unroll
