@@ -13,6 +13,7 @@
 // 16/32/64 lanes per individual (sx_rowops.hpp); the population is double-buffered: generation g
 // lives in buf[g & 1], its successor is written to the other buffer (winner or
 // unchanged row), so donor reads never race with selection writes.
+#include <type_traits>
 #include <vector>
 
 #include "sx_device.hpp"
@@ -179,7 +180,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const sx_state *sin = CHAIN ? a.state + chain_p : a.state;
     constexpr int kRecPerLane = 8;  // npart <= 512 in chained mode
     double pfv[kRecPerLane];
-    int64_t piv[kRecPerLane];
+    // whole-wave rows keep the record rows as 32 bits (rows < 2^31, check_args): 8 registers less is what
+    // lets that kernel run 4 waves per SIMD; the short-row kernels are faster with the 64-bit form
+    using rec_t = typename std::conditional<LPR == kWave, int32_t, int64_t>::type;
+    constexpr rec_t kNoRec = LPR == kWave ? (rec_t)INT32_MAX : (rec_t)INT64_MAX;
+    rec_t piv[kRecPerLane];
     if (CHAIN && !P2P) {
         const double *pf = a.part_f + (int64_t)chain_p * npart;
         const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         for (int u = 0; u < kRecPerLane; ++u) {
             const bool in = u < per && k0 + u < npart;
             pfv[u] = in ? pf[k0 + u] : __builtin_huge_val();
-            piv[u] = in ? pi[k0 + u] : INT64_MAX;
+            piv[u] = in ? (rec_t)pi[k0 + u] : kNoRec;
         }
     }
     if (sin->done) {
@@ -299,9 +304,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
     } else if (CHAIN) {
         double bf = pfv[0];
-        int64_t bi = piv[0];
+        rec_t br = piv[0];
 #pragma unroll
-        for (int u = 1; u < kRecPerLane; ++u) argmin_combine(bf, bi, pfv[u], piv[u]);
+        for (int u = 1; u < kRecPerLane; ++u)
+            if (pfv[u] < bf || (pfv[u] == bf && piv[u] < br)) {
+                bf = pfv[u];
+                br = piv[u];
+            }
+        int64_t bi = br == kNoRec ? INT64_MAX : (int64_t)br;
         wave_argmin_ordered(bf, bi);  // every wave on its own: no LDS, no workgroup barrier
         int status = SX_STATUS_NONE;
         if (it >= 2) {  // the reference does not test the initial population (de/_de.py:212-218)
