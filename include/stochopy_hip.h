@@ -291,6 +291,12 @@ int sx_pso_restart_select(const sx_pso_args *a, const double *part_r, double del
                           void *stream);
 int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, const int64_t *host_rows, const double *host_x,
                          int64_t host_count, void *stream);
+/* Sharded swarm (one process per GPU, a->P rows each): the same selection over the WHOLE swarm.
+ * gathered DEVICE (world, a->P + sx_num_partials(a->P, n)): row r = rank r's [pbestfit | part_r] after one
+ * all-gather per generation (the allreduce(max) of the radius and the fitness all-gather of SURVEY.md
+ * section 8e in one message).  Every rank computes the same {nw, threshold, radius}; world * a->P <= 32768. */
+int sx_pso_restart_select_gathered(const sx_pso_args *a, const double *gathered, int world, double delta,
+                                   double gamma, uint64_t *out3, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * CMA-ES device kernels (fp64 MFMA, v_mfma_f64_16x16x4_f64, LDS-tiled 64x64x32)

@@ -208,10 +208,15 @@ constexpr int kSelPerThread = 32;  // P <= 32768 per GPU for the on-device worst
 // One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
 // and the nw-th largest pbestfit is found by an 8-step (one byte per step) radix descent over keys held in registers.
 // out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
+// The swarm is `nseg` segments (one per rank; 1 on a single GPU) of `seg_len` fitness values followed by
+// `seg_npart` partial radii, `seg_stride` doubles apart: fit = base, part_r = base + seg_len.
 __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const sx_pso_args a,
+                                                                         const double *__restrict__ fit,
                                                                          const double *__restrict__ part_r,
-                                                                         int64_t npart, double delta, double gamma,
+                                                                         int nseg, int64_t seg_len, int64_t seg_npart,
+                                                                         int64_t seg_stride, double delta, double gamma,
                                                                          unsigned long long *__restrict__ out) {
+    const int64_t Ptot = (int64_t)nseg * seg_len, npart = (int64_t)nseg * seg_npart;
     __shared__ double smax[kSelThreads / kWave];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.state->done) {
@@ -219,7 +224,8 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         return;
     }
     double m = 0.0;
-    for (int64_t k = tid; k < npart; k += kSelThreads) m = fmax(m, part_r[k]);
+    for (int64_t k = tid; k < npart; k += kSelThreads)
+        m = fmax(m, part_r[(k / seg_npart) * seg_stride + k % seg_npart]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
     if (lane == 0) smax[wv] = m;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
     int64_t nw = 0;
     if (radius < delta) {
         const double inorm = (double)it / (double)a.maxiter;
-        nw = (int64_t)(((double)a.P - 1.0) / (1.0 + exp(1.0 / 0.09 * (inorm - gamma + 0.5))));
+        nw = (int64_t)(((double)Ptot - 1.0) / (1.0 + exp(1.0 / 0.09 * (inorm - gamma + 0.5))));
     }
     if (tid == 0) {
         out[0] = (unsigned long long)(nw > 0 ? nw : 0);
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 #pragma unroll
     for (int k = 0; k < kSelPerThread; ++k) {
         const int64_t i = (int64_t)k * kSelThreads + tid;
-        key[k] = i < a.P ? sort_key(a.pbestfit[i]) : 0ull;  // 0 < every real key
+        key[k] = i < Ptot ? sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]) : 0ull;  // 0 < every real key
     }
     // radix descent, 8 bits per step: histogram (LDS atomics) of the next byte over the keys that match the
     // prefix found so far; the byte of the `remaining`-th largest of them is where the suffix count crosses it
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 #pragma unroll
         for (int k = 0; k < kSelPerThread; ++k) {
             const int64_t i = (int64_t)k * kSelThreads + tid;
-            if (i < a.P && (key[k] & himask) == prefix) atomicAdd(&bins[(unsigned)(key[k] >> shift) & 255u], 1u);
+            if (i < Ptot && (key[k] & himask) == prefix) atomicAdd(&bins[(unsigned)(key[k] >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (tid < kWave) {  // wave 0: lane l owns bins 4l..4l+3; suffix sums locate the crossing byte
@@ -363,8 +369,24 @@ extern "C" int sx_pso_restart_select(const sx_pso_args *a, const double *part_r,
     SX_REQUIRE(part_r && out3, "sx_pso_restart_select: null pointer");
     SX_REQUIRE(a->P <= (int64_t)kSelThreads * kSelPerThread, "sx_pso_restart_select: P > 32768 per GPU (select on the host instead)");
     const Geometry g = geometry(a->P, a->n);
-    hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a, part_r,
-                       (int64_t)g.blocks, delta, gamma, (unsigned long long *)out3);
+    hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a,
+                       (const double *)a->pbestfit, part_r, 1, a->P, (int64_t)g.blocks, a->P, delta, gamma,
+                       (unsigned long long *)out3);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// Sharded swarm: `gathered` = (world, P_local + npart) doubles, row r = rank r's [pbestfit | partial radii]
+// (one all-gather per generation); every rank derives the same radius / nw / threshold for the WHOLE swarm.
+extern "C" int sx_pso_restart_select_gathered(const sx_pso_args *a, const double *gathered, int world, double delta,
+                                              double gamma, uint64_t *out3, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(gathered && out3 && world >= 1, "sx_pso_restart_select_gathered: bad arguments");
+    SX_REQUIRE(a->P * world <= (int64_t)kSelThreads * kSelPerThread,
+               "sx_pso_restart_select_gathered: more than 32768 particles in total");
+    const int64_t npart = (int64_t)geometry(a->P, a->n).blocks;
+    hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a, gathered,
+                       gathered + a->P, world, a->P, npart, a->P + npart, delta, gamma, (unsigned long long *)out3);
     SX_LAUNCH_CHECK();
     return 0;
 }

@@ -48,6 +48,12 @@ def minimize(
     (cmaes/_cmaes.py:304), which also pins the eigenvector signs that same-seed parity depends on;
     ``eigh="device"`` keeps C on the GPU and uses rocSOLVER through ``torch.linalg.eigh`` -- the
     SURVEY.md section 8f "next" step: a different (equally valid) eigenbasis, no 2 x n^2 PCIe trip.
+
+    ``workers > 1`` (one process per GPU) shards what the reference's parallel backends shard -- the
+    candidates: every rank samples and evaluates ``popsize / workers`` rows (same draws: the legacy stream is
+    replicated on the hosts, Philox normals are keyed by the global row), one all-gather per generation
+    returns all candidates and fitness values to every rank, and the O(n^2)/O(n^3) model update is replicated.
+    Same result as ``workers=1`` on every rank.
     """
     fun_id = _common.resolve_objective(fun, args)
     lower, upper = _common.as_bounds(bounds)
@@ -66,11 +72,11 @@ def minimize(
         raise ValueError()
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
-    _common.resolve_workers(workers)
+    workers = _common.resolve_workers(workers)
     if eigh not in ("host", "device"):
         raise ValueError("eigh must be 'host' or 'device'")
     run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
-                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh)
+                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh, workers)
     return run.result()
 
 
@@ -108,8 +114,14 @@ def _stop_status(it, n, maxiter, xmean, xold, besthist, arfit, order, sigma, ins
 
 class _CmaRun:
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, return_all, verbosity,
-                 callback, rng, seed, eigh="host"):
+                 callback, rng, seed, eigh="host", workers=1):
         self.eigh = eigh
+        self.world = None
+        if workers != 1:
+            from ..parallel import require_world
+
+            self.world = require_world(workers)
+            self.world.shard(P)  # popsize must divide evenly
         self.fun_id, self.lower, self.upper, self.x0 = fun_id, lower, upper, x0
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.sigma0, self.muperc, self.xtol, self.ftol = sigma, muperc, xtol, ftol
@@ -163,9 +175,13 @@ class _CmaRun:
         d_C = ctx.upload(np.eye(n))
         d_B = ctx.upload(B)
         d_D = ctx.upload(D)
-        d_Z = ctx.empty((P, n))
         d_arx = ctx.empty((P, n))
         d_fit = ctx.empty((P,))
+        # this rank's candidates: rows [row0, row0 + Pl) of the generation (all of them on one GPU)
+        row0, Pl = (0, P) if self.world is None else self.world.shard(P)
+        d_Z = ctx.empty((Pl, n))
+        d_arx_loc = d_arx if self.world is None else ctx.empty((Pl, n))
+        d_fit_loc = d_fit if self.world is None else ctx.empty((Pl,))
         d_xmean = ctx.upload(xmean)
         d_xold = ctx.empty((n,))
         d_pc = ctx.empty((n,))
@@ -189,13 +205,16 @@ class _CmaRun:
             # ---- sample (device GEMM); normals from the numpy-legacy stream or in-kernel Philox ----
             if self.rng == "numpy-legacy":
                 stream.randn(None, out=h_Z.numpy())  # P x randn(n), row by row == one block (cmaes/_cmaes.py:234)
-                d_Z.copy_(h_Z, non_blocking=True)
+                d_Z.copy_(h_Z[row0 : row0 + Pl], non_blocking=True)
             else:
-                _lib.check(L.sx_cmaes_normals(ptr(d_Z), P, n, 0, it, key0, key1, sp), "sx_cmaes_normals")
-            _lib.check(L.sx_cmaes_sample(ptr(d_xmean), sigma, ptr(d_B), ptr(d_D), ptr(d_Z), ptr(d_arx), P, n, sp),
+                _lib.check(L.sx_cmaes_normals(ptr(d_Z), Pl, n, row0, it, key0, key1, sp), "sx_cmaes_normals")
+            _lib.check(L.sx_cmaes_sample(ptr(d_xmean), sigma, ptr(d_B), ptr(d_D), ptr(d_Z), ptr(d_arx_loc), Pl, n, sp),
                        "sx_cmaes_sample")
             # ---- evaluate: fun(unstandardize(x)) fused (cmaes/_cmaes.py:173, 258) ----
-            _device.evaluate(ctx, self.fun_id, d_arx, n, f=d_fit, xm=d_xm, xstd=d_xstd)
+            _device.evaluate(ctx, self.fun_id, d_arx_loc, n, f=d_fit_loc, xm=d_xm, xstd=d_xstd)
+            if self.world is not None:  # every rank gets all candidates and fitness values back
+                self.world.all_gather_rows(d_arx_loc, d_arx)
+                self.world.all_gather_rows(d_fit_loc, d_fit)
             arfit = d_fit.cpu().numpy()
             nfev += P
             if self.return_all:

@@ -103,9 +103,9 @@ class _PsoRun:
                 raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
             if callback is not None or return_all:
                 raise NotImplementedError("callback / return_all are not available with workers > 1")
-            if gamma:
-                raise NotImplementedError("the competitive restart is single-GPU for now: use method='pso' "
-                                          "or workers=1 (SURVEY.md section 8e lists the extra collectives)")
+            if gamma and P > 32768:
+                raise NotImplementedError("competitive restart with workers > 1: at most 32768 particles in total "
+                                          "(the worst-nw selection runs in one workgroup over the gathered fitness)")
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
         self.x0 = x0
         self.ctx = _device.Context()
@@ -119,8 +119,8 @@ class _PsoRun:
         ctx, P, n = self.ctx, self.P, self.n
         t = _device.torch()
         self.stream = _rng.make_init_stream(self.rng, self.seed)
-        if self.gamma:  # cpso/_cpso.py:215-216 (depends on maxiter)
-            self.delta = np.log(1.0 + 0.003 * P) / np.max((0.2, np.log(0.01 * self.maxiter)))
+        if self.gamma:  # cpso/_cpso.py:215-216 (depends on maxiter; the whole swarm's size)
+            self.delta = np.log(1.0 + 0.003 * self.Ptotal) / np.max((0.2, np.log(0.01 * self.maxiter)))
         if self.x0 is not None:
             X0 = np.array(self.x0, dtype=np.float64)
         else:
@@ -130,15 +130,19 @@ class _PsoRun:
         self.X = ctx.upload(X0)
         self.V = ctx.zeros((P, n))
         self.pbest = self.X.clone()
-        self.pbestfit = ctx.empty((P,))
+        npart = int(ctx.L.sx_num_partials(P, n))
+        self.npart = npart
+        # [pbestfit | partial radii] in one buffer: with workers > 1 the restart all-gathers exactly this
+        self.fit_radius = ctx.empty((P + npart,))
+        self.pbestfit = self.fit_radius[:P]
+        self.part_r = self.fit_radius[P:]
+        if self.world is not None and self.gamma:
+            self.fit_radius_all = ctx.empty((self.world.size, P + npart))
         self.candfit = ctx.empty((P,))
         self.d_lower = ctx.upload(self.lower)
         self.d_upper = ctx.upload(self.upper)
-        npart = int(ctx.L.sx_num_partials(P, n))
-        self.npart = npart
         self.part_f = ctx.empty((npart,))
         self.part_i = ctx.empty((npart,), dtype=t.int64)
-        self.part_r = ctx.empty((npart,))
         self.sel3 = ctx.zeros((3,), dtype=t.int64)
         _device.evaluate(ctx, self.fun_id, self.X, n, f=self.pbestfit)
         self.candfit.copy_(self.pbestfit)
@@ -234,8 +238,17 @@ class _PsoRun:
         """cpso/_cpso.py:405-426 entirely on the device (Philox positions keyed by row)."""
         ctx, a = self.ctx, C.byref(self.args)
         _lib.check(ctx.L.sx_pso_radius(a, _device.ptr(self.part_r), ctx.stream_ptr), "sx_pso_radius")
-        _lib.check(ctx.L.sx_pso_restart_select(a, _device.ptr(self.part_r), float(self.delta), float(self.gamma),
-                                               _device.ptr(self.sel3), ctx.stream_ptr), "sx_pso_restart_select")
+        if self.world is None:
+            _lib.check(ctx.L.sx_pso_restart_select(a, _device.ptr(self.part_r), float(self.delta), float(self.gamma),
+                                                   _device.ptr(self.sel3), ctx.stream_ptr), "sx_pso_restart_select")
+        else:
+            # the swarm radius is a max and the worst-nw rule a rank over ALL particles: one all-gather of
+            # [pbestfit | partial radii] per generation, then every rank derives the same threshold
+            self.world.all_gather_records(self.fit_radius, self.fit_radius_all)
+            _lib.check(ctx.L.sx_pso_restart_select_gathered(a, _device.ptr(self.fit_radius_all), self.world.size,
+                                                            float(self.delta), float(self.gamma),
+                                                            _device.ptr(self.sel3), ctx.stream_ptr),
+                       "sx_pso_restart_select_gathered")
         _lib.check(ctx.L.sx_pso_restart_apply(a, _device.ptr(self.sel3), None, None, 0, ctx.stream_ptr),
                    "sx_pso_restart_apply")
 

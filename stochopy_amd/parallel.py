@@ -66,6 +66,18 @@ class World:
         self.dist.all_gather(gathered, host, group=self.group)
         out.copy_(torch.stack(gathered).to(out.device))
 
+    def all_gather_rows(self, local, out):
+        """out[(world * rows, ...)] <- every rank's local[(rows, ...)] in rank order (CMA-ES candidates / fitness)."""
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=self.group)
+            return
+        import torch
+
+        host = local.detach().cpu().reshape(-1)
+        gathered = [torch.empty_like(host) for _ in range(self.size)]
+        self.dist.all_gather(gathered, host, group=self.group)
+        out.view(-1).copy_(torch.cat(gathered).to(out.device))
+
     def all_gather_object(self, obj):
         """Small host objects (set-up only: IPC handles, flags)."""
         out = [None] * self.size

@@ -63,6 +63,31 @@ def cpu_exchange_worker(rank, world, port, cfg, out_dir):
         dist.destroy_process_group()
 
 
+def cpu_rows_worker(rank, world, port, cfg, out_dir):
+    """CPU-only: World.all_gather_rows / all_gather_object / all_agree / barrier over gloo."""
+    import torch
+
+    dist = _init(rank, world, port)
+    try:
+        from stochopy_amd import parallel
+
+        w = parallel.require_world(world)
+        rows, n = cfg["rows"], cfg["n"]
+        local = torch.arange(rows * n, dtype=torch.float64).reshape(rows, n) + 1000.0 * rank
+        out = torch.empty((world * rows, n), dtype=torch.float64)
+        w.all_gather_rows(local, out)
+        fit = torch.empty((world * rows,), dtype=torch.float64)
+        w.all_gather_rows(local[:, 0].contiguous(), fit)
+        objs = w.all_gather_object({"rank": rank})
+        assert [o["rank"] for o in objs] == list(range(world))
+        assert w.all_agree(True) and not w.all_agree(rank != 1)
+        w.barrier()
+        np.save(os.path.join(out_dir, f"rows_{rank}.npy"), out.numpy())
+        np.save(os.path.join(out_dir, f"fit_{rank}.npy"), fit.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
 def _spy_on_de_runs():
     """Record the _DeRun objects minimize() creates (to see which exchange a run ended up with)."""
     from stochopy_amd.optimize import _de
@@ -83,7 +108,8 @@ def _minimize_and_save(rank, world, cfg, out_dir):
 
     runs = _spy_on_de_runs()
     n = cfg["n"]
-    opts = dict(cfg["options"], backend="hip", rng="philox", workers=world)
+    opts = dict(cfg["options"], backend="hip", workers=world)
+    opts.setdefault("rng", "philox")
     res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), [[-5.12, 5.12]] * n, method=cfg["method"],
                                options=opts)
     np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)

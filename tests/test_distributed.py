@@ -52,6 +52,17 @@ def test_world_exchange_two_ranks_gloo_cpu():
         assert np.array_equal(np.load(os.path.join(out, f"trace_{r}.npy")), np.array(ref["_trace"]))
 
 
+def test_world_row_gather_and_agreement_gloo_cpu():
+    """The set-up / CMA-ES plumbing of parallel.World with real processes (world_size 2, CPU)."""
+    from _dist_workers import cpu_rows_worker
+
+    out = _spawn(cpu_rows_worker, 2, {"rows": 3, "n": 4})
+    want = np.concatenate([np.arange(12.0).reshape(3, 4) + 1000.0 * r for r in range(2)])
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(out, f"rows_{r}.npy")), want)
+        assert np.array_equal(np.load(os.path.join(out, f"fit_{r}.npy")), want[:, 0])
+
+
 def _de_reference(cfg, world):
     o = dict(cfg["options"])
     n = cfg["n"]
@@ -125,6 +136,44 @@ def test_sharded_pso_on_gpu_is_exact():
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
         assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_cpso_restart_is_exact(world):
+    """Competitive restart over a sharded swarm: the radius (a max) and the worst-nw rule (a rank) span ALL
+    particles -- one all-gather of [pbestfit | partial radii] per generation -- and the new positions are keyed
+    by the global row, so the shards reproduce the unsharded run.  Restarts must actually fire."""
+    from _dist_workers import gpu_minimize_worker
+
+    opts = {"maxiter": 30, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
+    cfg = {"n": 16, "objective": "sphere", "method": "cpso", "options": opts}
+    out = _spawn(gpu_minimize_worker, world, cfg)
+    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method="cpso", options=dict(opts), rng="philox")
+    assert len(ref["_restarts"]) > 0
+    for r in range(world):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rng", ["philox", "numpy-legacy"])
+def test_sharded_cmaes_matches_single_gpu(rng):
+    """CMA-ES with workers=2: candidates sampled / evaluated by shards, model update replicated == workers=1."""
+    import stochopy_amd as sa
+    from _dist_workers import gpu_minimize_worker
+
+    n = 20
+    opts = {"maxiter": 40, "popsize": 48, "seed": 11, "rng": rng}
+    cfg = {"n": n, "objective": "rosenbrock", "method": "cmaes", "options": opts, "rng": rng}
+    one = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="cmaes",
+                               options=dict(opts, backend="hip"))
+    out = _spawn(gpu_minimize_worker, 2, cfg)
+    for r in range(2):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (one.fun, one.nit, one.nfev, one.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), one.x)
 
 
 @pytest.mark.gpu
