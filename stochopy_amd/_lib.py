@@ -102,6 +102,7 @@ PROTOTYPES = {
     "sx_pso_restart_select": (C.c_int, [C.POINTER(SxPsoArgs), vp, f64, f64, vp, vp]),
     "sx_pso_restart_apply": (C.c_int, [C.POINTER(SxPsoArgs), vp, vp, vp, i64, vp]),
     "sx_pso_restart_select_gathered": (C.c_int, [C.POINTER(SxPsoArgs), vp, C.c_int, f64, f64, vp, vp]),
+    "sx_pso_graph_create": (C.c_int, [C.POINTER(SxPsoArgs), C.c_int, vp, f64, f64, vp, C.POINTER(vp)]),
     "sx_cmaes_sample": (C.c_int, [vp, f64, vp, vp, vp, vp, i64, C.c_int, vp]),
     "sx_cmaes_recombine": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "sx_cmaes_rank_mu": (C.c_int, [vp, vp, vp, C.c_int, vp, f64, vp, f64, f64, f64, vp, vp, C.c_int, vp]),

@@ -263,26 +263,55 @@ extern "C" int sx_argmin(const double *f, int64_t P, double *ws_f, int64_t *ws_i
 // ---------------------------------------------------------------------------
 // Best-of-generation + termination (stochopy/optimize/_common.py:131-158)
 // ---------------------------------------------------------------------------
+// best of the per-workgroup records, 8 records per thread and trip so their loads overlap
+__device__ __forceinline__ void scan_records(const double *__restrict__ part_f, const int64_t *__restrict__ part_i,
+                                             int64_t npart, double &bf, int64_t &bi) {
+    constexpr int kScan = 8;
+    for (int64_t k0 = threadIdx.x; k0 < npart; k0 += (int64_t)kFinalThreads * kScan) {
+        double f[kScan];
+        int64_t i[kScan];
+#pragma unroll
+        for (int u = 0; u < kScan; ++u) {
+            const int64_t k = k0 + (int64_t)u * kFinalThreads;
+            f[u] = k < npart ? part_f[k] : __builtin_huge_val();
+            i[u] = k < npart ? part_i[k] : INT64_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < kScan; ++u) argmin_combine(bf, bi, f[u], i[u]);
+    }
+}
+
 __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
     const double *__restrict__ part_f, const int64_t *__restrict__ part_i, int64_t npart,
     const double *__restrict__ rows0, const double *__restrict__ rows1, int64_t ld, int n,
     double *__restrict__ gbest, sx_state *__restrict__ state, int maxiter, double xtol, double ftol) {
     __shared__ double sf[kFinalThreads / kWave];
     __shared__ int64_t si[kFinalThreads / kWave];
-    if (state->done) return;
-    const int64_t it = state->it + 1;  // the generation being finalised
     double bf = __builtin_huge_val();
     int64_t bi = INT64_MAX;
-    for (int64_t k = threadIdx.x; k < npart; k += kFinalThreads) argmin_combine(bf, bi, part_f[k], part_i[k]);
+    scan_records(part_f, part_i, npart, bf, bi);  // the loads do not depend on the state word: issue them first
+    if (state->done) return;
+    const int64_t it = state->it + 1;  // the generation being finalised
     block_argmin(bf, bi, sf, si);
 
     // generation g lives in rows[g & 1] (double-buffered populations); rows0 == rows1 for in-place state
     const double *src = ((it & 1) ? rows1 : rows0) + bi * ld;
-    // dx = ||xbest_prev - x[k]||_2 (np.linalg.norm, _common.py:135)
+    // dx = ||xbest_prev - x[k]||_2 (np.linalg.norm, _common.py:135); all loads of a thread in flight together
+    constexpr int kPer = (kMaxDim + kFinalThreads - 1) / kFinalThreads;
+    double gv[kPer], sv[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = threadIdx.x + u * kFinalThreads;
+        gv[u] = e < n ? gbest[e] : 0.0;
+        sv[u] = e < n ? src[e] : 0.0;
+    }
     double acc = 0.0;
-    for (int e = threadIdx.x; e < n; e += kFinalThreads) {
-        const double d = gbest[e] - src[e];
-        acc += d * d;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        if (threadIdx.x + u * kFinalThreads < n) {
+            const double d = gv[u] - sv[u];
+            acc += d * d;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
@@ -291,7 +320,9 @@ __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
     double ss = 0.0;
     for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
     const double dx = sqrt(ss);
-    for (int e = threadIdx.x; e < n; e += kFinalThreads) gbest[e] = src[e];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u)
+        if (threadIdx.x + u * kFinalThreads < n) gbest[threadIdx.x + u * kFinalThreads] = sv[u];
     if (threadIdx.x == 0) {
         int status = SX_STATUS_NONE;
         if (dx <= xtol && bf <= ftol)
@@ -330,10 +361,10 @@ __global__ __launch_bounds__(kFinalThreads) void shard_best_kernel(
     const sx_state *__restrict__ state, int64_t row0, double *__restrict__ record) {
     __shared__ double sf[kFinalThreads / kWave];
     __shared__ int64_t si[kFinalThreads / kWave];
-    const int64_t it = state->it + 1;  // the generation being finalised
     double bf = __builtin_huge_val();
     int64_t bi = INT64_MAX;
-    for (int64_t k = threadIdx.x; k < npart; k += kFinalThreads) argmin_combine(bf, bi, part_f[k], part_i[k]);
+    scan_records(part_f, part_i, npart, bf, bi);
+    const int64_t it = state->it + 1;  // the generation being finalised
     block_argmin(bf, bi, sf, si);
     const double *src = ((it & 1) ? rows1 : rows0) + bi * ld;
     for (int e = threadIdx.x; e < n; e += kFinalThreads) record[2 + e] = src[e];

@@ -523,11 +523,6 @@ extern "C" int sx_de_generation(const sx_de_args *a, int finalize, void *stream)
 // hipGraph of ngen generations: 2*ngen kernel nodes in a chain, every node
 // identical (per-generation state is read from a.state on the device).
 // ---------------------------------------------------------------------------
-struct sx_graph {
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-};
-
 extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out) {
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(out != nullptr && ngen >= 1 && a->gbest != nullptr, "sx_de_graph_create: bad arguments");

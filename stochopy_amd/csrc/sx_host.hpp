@@ -18,6 +18,12 @@ inline int hip_fail(hipError_t e, const char *what, const char *file, int line) 
 
 }  // namespace sx
 
+// an instantiated hipGraph of generations (opaque in the C ABI)
+struct sx_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
 #define SX_HIP(call)                                                          \
     do {                                                                      \
         hipError_t e__ = (call);                                              \

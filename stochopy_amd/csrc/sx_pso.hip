@@ -405,3 +405,92 @@ extern "C" int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, 
     SX_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// hipGraph of `ngen` generations (single GPU, Philox draws): per generation the generation kernel, the
+// best/termination kernel and -- CPSO (part_r != NULL) -- the three restart kernels, all reading the
+// generation counter and the done flag from the device, so one instantiated graph is replayed.
+// ---------------------------------------------------------------------------
+namespace {
+int add_kernel_node(hipGraph_t graph, hipGraphNode_t *prev, void *func, dim3 grid, dim3 block, unsigned lds,
+                    void **kargs) {
+    hipKernelNodeParams kp = {};
+    kp.func = func;
+    kp.gridDim = grid;
+    kp.blockDim = block;
+    kp.sharedMemBytes = lds;
+    kp.kernelParams = kargs;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    SX_HIP(hipGraphAddKernelNode(&node, graph, *prev ? prev : nullptr, *prev ? 1 : 0, &kp));
+    *prev = node;
+    return 0;
+}
+
+template <int LPR>
+void *radius_kernel_ptr() {
+    return (void *)pso_radius_kernel<LPR>;
+}
+}  // namespace
+
+namespace sx {
+int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
+                      int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,
+                      sx_state *state, int maxiter, double xtol, double ftol);
+}
+
+extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_r, double delta, double gamma,
+                                   uint64_t *sel3, sx_graph **out) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(out != nullptr && ngen >= 1, "sx_pso_graph_create: bad arguments");
+    SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_pso_graph_create: graphs need in-kernel (Philox) draws");
+    SX_REQUIRE((part_r == nullptr) == (sel3 == nullptr), "sx_pso_graph_create: restart needs part_r AND sel3");
+    SX_REQUIRE(part_r == nullptr || a->P <= (int64_t)kSelThreads * kSelPerThread,
+               "sx_pso_graph_create: P > 32768 (restart selection)");
+    SX_REQUIRE(part_r == nullptr || (a->lower && a->upper), "sx_pso_graph_create: bounds missing");
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a->P, a->n);
+    sx_graph *gr = new sx_graph();
+    SX_HIP(hipGraphCreate(&gr->graph, 0));
+    sx_pso_args args = *a;
+    void *gen_args[] = {&args, &plan};
+    // restart kernels' arguments
+    const double *fit = a->pbestfit;
+    const double *pr = part_r;
+    int one = 1;
+    int64_t P = a->P, npart = g.blocks;
+    unsigned long long *sel = (unsigned long long *)sel3;
+    void *rad_args[] = {&args, &part_r};
+    void *sel_args[] = {&args, &fit, &pr, &one, &P, &npart, &P, &delta, &gamma, &sel};
+    const int64_t *no_rows = nullptr;
+    const double *no_x = nullptr;
+    int64_t zero = 0;
+    const unsigned long long *csel = sel;
+    void *app_args[] = {&args, &csel, &no_rows, &no_x, &zero};
+    void *radius_fn = nullptr;
+    SX_DISPATCH_LPR(a->n, radius_fn = radius_kernel_ptr<LPR>())
+    hipGraphNode_t prev = nullptr;
+    for (int i = 0; i < ngen; ++i) {
+        if (int rc = add_kernel_node(gr->graph, &prev, (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n),
+                                     dim3(g.blocks), dim3(g.threads), (unsigned)g.lds, gen_args))
+            return rc;
+        if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n,
+                                       a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
+            return rc;
+        if (part_r != nullptr) {
+            if (int rc = add_kernel_node(gr->graph, &prev, radius_fn, dim3(g.blocks), dim3(g.threads), 0, rad_args))
+                return rc;
+            if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_select_kernel, dim3(1), dim3(kSelThreads),
+                                         0, sel_args))
+                return rc;
+            const int rpb = 4;
+            if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_apply_kernel,
+                                         dim3((unsigned)((a->P + rpb - 1) / rpb)), dim3(rpb * kWave), 0, app_args))
+                return rc;
+        }
+    }
+    SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
+    *out = gr;
+    return 0;
+}

@@ -83,6 +83,7 @@ def minimize(
 
 class _PsoRun:
     CHECK_EVERY = 32  # philox mode: the host reads the device state every this many generations
+    GRAPH_CHUNK = 16  # generations per hipGraph replay (2 or 5 kernel nodes each)
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, w, c1, c2, gamma, constraints, xtol, ftol, return_all,
                  verbosity, callback, rng, seed, workers, autorun=True):
@@ -109,10 +110,20 @@ class _PsoRun:
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
         self.x0 = x0
         self.ctx = _device.Context()
+        self._graph = None
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
-                self._run()
+                try:
+                    self._run()
+                finally:
+                    self.close()
+
+    def close(self):
+        if self._graph is not None:
+            self.ctx.sync()
+            self.ctx.L.sx_graph_destroy(self._graph)
+            self._graph = None
 
     # ------------------------------------------------------------------ setup
     def _setup(self):
@@ -315,7 +326,21 @@ class _PsoRun:
         self._res = res
 
     def enqueue(self, ngen):
-        """Enqueue `ngen` generations (and their restarts) without host synchronisation (Philox mode)."""
+        """Enqueue `ngen` generations (and their restarts) without host synchronisation (Philox mode).
+        Single GPU: full chunks replay one instantiated hipGraph of the loop body."""
+        ctx = self.ctx
+        if self.world is None and (not self.gamma or self.P <= 32768):
+            while ngen >= self.GRAPH_CHUNK:
+                if self._graph is None:
+                    g = C.c_void_p()
+                    restart = bool(self.gamma)
+                    _lib.check(ctx.L.sx_pso_graph_create(
+                        C.byref(self.args), self.GRAPH_CHUNK, _device.ptr(self.part_r) if restart else None,
+                        float(self.delta) if restart else 0.0, float(self.gamma) if restart else 0.0,
+                        _device.ptr(self.sel3) if restart else None, C.byref(g)), "sx_pso_graph_create")
+                    self._graph = g
+                _lib.check(ctx.L.sx_graph_launch(self._graph, ctx.stream_ptr), "sx_graph_launch")
+                ngen -= self.GRAPH_CHUNK
         for _ in range(ngen):
             self._generation()
             if self.gamma:
