@@ -96,6 +96,45 @@ def test_ragged_shapes_philox_de_and_pso(sa, n, P):
         assert got.fun == ref.fun and np.array_equal(got.x, ref.x), (method, n, P)
 
 
+@pytest.mark.parametrize("objective", ["rosenbrock", "rastrigin", "griewank"])
+@pytest.mark.parametrize("n,P", [(513, 40), (1024, 64), (2048, 24)])
+def test_long_rows_fused_reduction(sa, objective, n, P):
+    """n > 256: the objective terms are formed inside the numpy-order reduction (no term arrays in LDS);
+    DE (two-kernel path, Shrink-free PSO, Shrink PSO) must still follow the oracle: bit for bit for +,-,*
+    objectives, best-f within 1e-12 rel where cos/sqrt are involved."""
+    b = [[-3.0, 3.0]] * n
+    for method, cons in (("de", None), ("de", "Random"), ("pso", None), ("pso", "Shrink")):
+        opts = {"maxiter": 6, "popsize": P, "seed": 11 + n, "updating": "deferred", "constraints": cons}
+        ref = oracle.minimize(objective, b, method=method, options=dict(opts), rng="philox")
+        got = sa.optimize.minimize(getattr(sa.factory, objective), b, method=method,
+                                   options=dict(opts, backend="hip", rng="philox"))
+        if objective == "rosenbrock":
+            assert got.fun == ref.fun and np.array_equal(got.x, ref.x), (method, cons)
+        else:
+            assert np.isclose(got.fun, ref.fun, rtol=1e-12, atol=0), (method, cons, got.fun, ref.fun)
+
+
+def test_c5_shard_shape_three_generations(sa):
+    """BASELINE config 5's per-GPU shard (DE, n=1024, P=16384) at full size: three generations on the device
+    == the oracle, population rows included (bit-exact; Rosenbrock is +,-,* only)."""
+    n, P = 1024, 16384
+    b = [[-5.12, 5.12]] * n
+    opts = {"maxiter": 4, "popsize": P, "seed": 3, "updating": "deferred", "ftol": -1.0, "xtol": 0.0}
+    t_ref, t_got = [], []
+    pick = np.array([0, 1, 4095, 8192, 16383])
+    ref = oracle.minimize("rosenbrock", b, method="de", options=dict(opts), rng="philox",
+                          callback=lambda X, r: t_ref.append((r.fun, X[pick].copy())))
+    got = sa.optimize.minimize(sa.factory.rosenbrock, b, method="de", options=dict(opts, backend="hip", rng="philox"),
+                               callback=lambda X, r: t_got.append((r.fun, X[pick].copy())))
+    assert len(t_ref) == len(t_got) == 4
+    for (fa, Xa), (fb, Xb) in zip(t_ref, t_got):
+        assert fa == fb and np.array_equal(Xa, Xb)
+    assert got.fun == ref.fun and np.array_equal(got.x, ref.x) and got.nfev == ref.nfev == 4 * P
+    # and the asynchronous (no callback) path at the same size
+    fast = sa.optimize.minimize(sa.factory.rosenbrock, b, method="de", options=dict(opts, backend="hip", rng="philox"))
+    assert fast.fun == ref.fun and np.array_equal(fast.x, ref.x)
+
+
 def test_dimension_limit_is_loud(sa):
     from stochopy_amd._lib import HipLibraryError
 
