@@ -146,6 +146,8 @@ class _DeRun:
         self._graph = None
         self._chain_graphs = {}
         self._shard_calls = None
+        self._rccl_graph = None
+        self._rccl_graph_note = None
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
@@ -155,6 +157,9 @@ class _DeRun:
                     self.close()
 
     def close(self):
+        if self._rccl_graph is not None:
+            self.ctx.sync()
+            self._rccl_graph = None
         if self._graph is not None:
             self.ctx.L.sx_graph_destroy(self._graph)
             self._graph = None
@@ -238,6 +243,29 @@ class _DeRun:
         if L.sx_gather_finalize(recs, self.world.size, self.n, gb, st, self.maxiter, self.xtol, self.ftol, sp) != 0:
             _lib.check(-1, "sx_gather_finalize")
 
+    def _capture_sharded_chunk(self):
+        """Capture GRAPH_CHUNK generations of the "rccl" transport (kernels + all-gathers) into one graph.
+        False when that is not possible (gloo staging goes through the host; SX_RCCL_GRAPH=0; a failed capture):
+        the caller then launches generation by generation -- the same sequence of collectives either way, so
+        ranks need not agree on which form they use."""
+        if self._rccl_graph is not None:
+            return True
+        if (self._rccl_graph_note is not None or self.world.backend != "nccl"
+                or os.environ.get("SX_RCCL_GRAPH") == "0"):
+            return False
+        t = _device.torch()
+        try:
+            self.ctx.sync()
+            g = t.cuda.CUDAGraph()
+            with t.cuda.graph(g, stream=self.ctx.stream):
+                for _ in range(self.GRAPH_CHUNK):
+                    self._sharded_generation()
+            self._rccl_graph = g
+            return True
+        except Exception as e:  # capture is an optimisation, never a requirement
+            self._rccl_graph_note = f"graph capture of the rccl path failed: {e}"
+            return False
+
     def enqueue(self, ngen):
         """Enqueue `ngen` generations on the engine stream without any host synchronisation.
 
@@ -249,6 +277,11 @@ class _DeRun:
             self._enqueue_chain(ngen)
             return
         if self.world is not None:
+            # "rccl" transport: kernels + the all-gather of a chunk of generations captured once into a graph
+            # (RCCL collectives are capturable) and replayed, so the host is off the per-generation path
+            while ngen >= self.GRAPH_CHUNK and self._capture_sharded_chunk():
+                self._rccl_graph.replay()
+                ngen -= self.GRAPH_CHUNK
             for _ in range(ngen):
                 self._sharded_generation()
             return

@@ -185,6 +185,14 @@ def test_sharded_path_over_rccl_single_rank():
 
 
 @pytest.mark.gpu
+def test_rccl_path_graph_capture_single_rank():
+    """130 generations: two replays of the captured 50-generation graph (kernels + RCCL all-gathers) + 29 eager."""
+    from _dist_workers import nccl_single_rank_worker
+
+    _check_sharded_de(1, _de_cfg(24, 128, 130, 77, "rccl"), worker=nccl_single_rank_worker)
+
+
+@pytest.mark.gpu
 def test_p2p_path_single_rank_nccl_setup():
     """Same with the peer exchange (handles and agreement travel over the RCCL group, the kernels write locally)."""
     from _dist_workers import nccl_single_rank_worker
