@@ -36,6 +36,7 @@ WORKLOADS = {
     "de_rosenbrock_n512_p8192": ("rosenbrock", 512, 8192, "best1bin"),
     "de_rastrigin_n1024_p16384": ("rastrigin", 1024, 16384, "best1bin"),
     "de_rosenbrock_n2048_p16384": ("rosenbrock", 2048, 16384, "best1bin"),
+    "de_rand1bin_n1024_p16384": ("rosenbrock", 1024, 16384, "rand1bin"),
 }
 
 

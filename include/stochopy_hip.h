@@ -224,9 +224,14 @@ typedef struct sx_xchg_args {
     int32_t world, rank;
     int64_t timeout_ticks;        /* per wait, in 100 MHz ticks (1e8 = 1 s) */
     int32_t *error;               /* DEVICE: 0, set to 1 on timeout */
+    uint64_t *relay;              /* DEVICE, ordinary (cacheable) memory, sx_xchg_relay_bytes(n), zeroed: rows of
+                                     more than 128 elements are read from here after workgroup 0 has copied the
+                                     winning record out of the uncached exchange buffer (once per generation,
+                                     instead of once per wavefront) */
 } sx_xchg_args;
 /* bytes of one exchange buffer for `world` ranks and rows of n doubles (includes the probe area) */
 int64_t sx_xchg_bytes(int world, int n);
+int64_t sx_xchg_relay_bytes(int n);
 /* allocate + zero an exchange buffer on the current device and export it (handle: 64 bytes) */
 int sx_xchg_alloc(int64_t bytes, void **ptr, void *handle);
 int sx_xchg_free(void *ptr);

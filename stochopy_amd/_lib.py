@@ -63,7 +63,8 @@ SX_IPC_HANDLE_BYTES = 64
 
 
 class SxXchgArgs(C.Structure):
-    _fields_ = [("peer", vp * SX_MAX_PEERS), ("world", i32), ("rank", i32), ("timeout_ticks", i64), ("error", vp)]
+    _fields_ = [("peer", vp * SX_MAX_PEERS), ("world", i32), ("rank", i32), ("timeout_ticks", i64), ("error", vp),
+                ("relay", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/stochopy_hip.h declares
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "sx_de_chain_launch": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.c_int, vp]),
     "sx_de_chain_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.c_int, C.c_int, C.POINTER(vp)]),
     "sx_xchg_bytes": (i64, [C.c_int, C.c_int]),
+    "sx_xchg_relay_bytes": (i64, [C.c_int]),
     "sx_xchg_alloc": (C.c_int, [i64, C.POINTER(vp), vp]),
     "sx_xchg_free": (C.c_int, [vp]),
     "sx_xchg_open": (C.c_int, [vp, C.POINTER(vp)]),

@@ -108,22 +108,58 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
 // cross-GPU dependency is "all ranks have reached this generation".
 // XM = 2, workgroup 0: shard best -> peers, global best -> state.  Returns nothing; sets *x.error on timeout.
 __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_args &x, int chain_p, int mode,
-                                            int64_t npart, int64_t it, const sx_state *sin) {
+                                            int64_t npart, int64_t it, const sx_state *sin, bool relay) {
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), nw = (int)(blockDim.x >> 6);
     const double *pf = a.part_f + (int64_t)chain_p * npart;
     const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
-    const int per = (int)((npart + kWave - 1) / kWave);  // contiguous slice per lane: first-minimum rule
-    const int64_t k0 = (int64_t)lane * per;
+    // shard best = lexicographic (f, row) minimum of the records: the whole workgroup scans them (8 records per
+    // thread and trip, loads overlapping), waves meet in LDS; every wave ends up with the same pair
+    __shared__ double svc_f[kMaxWavesPerBlock];
+    __shared__ int64_t svc_i[kMaxWavesPerBlock];
     double bf = __builtin_huge_val();
     int64_t bi = INT64_MAX;
-    for (int u = 0; u < per; ++u)
-        if (k0 + u < npart) argmin_combine(bf, bi, pf[k0 + u], pi[k0 + u]);
-    wave_argmin_ordered(bf, bi);
+    if (npart <= 8 * kWave) {
+        // few records (the latency-critical small shards): every wave scans all of them on its own, lane-
+        // contiguous slices + the DPP minimum -- no LDS, no barrier (as the single-GPU chained kernel does)
+        const int per = (int)((npart + kWave - 1) / kWave);
+        const int64_t k0 = (int64_t)lane * per;
+        double f[8];
+        int64_t i[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = u < per && k0 + u < npart;
+            f[u] = in ? pf[k0 + u] : __builtin_huge_val();
+            i[u] = in ? pi[k0 + u] : INT64_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) argmin_combine(bf, bi, f[u], i[u]);
+        wave_argmin_ordered(bf, bi);
+    } else {
+    for (int64_t k0 = threadIdx.x; k0 < npart; k0 += (int64_t)blockDim.x * 8) {
+        double f[8];
+        int64_t i[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t k = k0 + (int64_t)u * blockDim.x;
+            f[u] = k < npart ? pf[k] : __builtin_huge_val();
+            i[u] = k < npart ? pi[k] : INT64_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) argmin_combine(bf, bi, f[u], i[u]);
+    }
+    wave_argmin_all(bf, bi);
+    if (lane == 0) {
+        svc_f[wave] = bf;
+        svc_i[wave] = bi;
+    }
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) argmin_combine(bf, bi, svc_f[w], svc_i[w]);
+    }
     const uint32_t tag = (uint32_t)(it + 1);
     const double *row = ((it & 1) ? a.buf1 : a.buf0) + bi * a.ld;
     for (int r = wave; r < x.world; r += nw)
         xchg_push_record(x.peer[r] + xchg_slot_offset(a.n, chain_p, x.rank), bf, a.row0 + bi, row, a.n, tag, lane);
-    if (wave != 0) return;
+    if (wave != 0 && !relay) return;
     double gf;
     int64_t gi;
     int winner;
@@ -131,6 +167,45 @@ __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_a
                         gf, gi, winner)) {
         if (lane == 0) atomicExch(x.error, 1);
         return;
+    }
+    if (relay) {
+        // long rows: every row wavefront reading the winner's 16(n+2) bytes from uncached memory would cost
+        // more than the generation's own traffic, so this workgroup copies the record once into ordinary
+        // (L2-cacheable) memory, still as tagged words; device-scope stores, the readers verify the tags
+        const uint64_t *src = x.peer[x.rank] + xchg_slot_offset(a.n, chain_p, winner);
+        uint64_t *dst = x.relay + (int64_t)chain_p * xchg_relay_stride(a.n);
+        const uint64_t t0 = wall_clock64();
+        bool lost = false;
+        const int nwords = 2 * (a.n + 2);
+        for (int j0 = (int)threadIdx.x; j0 < nwords && !lost; j0 += (int)blockDim.x * 8) {
+            uint64_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // 8 words per thread in flight; a late word is re-read on its own
+                const int j = j0 + u * (int)blockDim.x;
+                w[u] = j < nwords ? ll_load(src + j) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * (int)blockDim.x;
+                if (j >= nwords) continue;
+                while (!ll_ok(w[u], tag)) {
+                    if ((int64_t)(wall_clock64() - t0) > x.timeout_ticks) {
+                        atomicExch(x.error, 1);
+                        lost = true;
+                        break;
+                    }
+                    w[u] = ll_load(src + j);
+                }
+                __hip_atomic_store(dst + j, w[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // all words written through, then the "ready" word: readers poll it past the caches and only then
+        // touch the row with cacheable loads, so no cache ever holds a line from before the copy
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(dst + xchg_slot_words(a.n), (uint64_t)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave != 0) return;
     }
     if (lane == 0) {
         int status = SX_STATUS_NONE;
@@ -205,7 +280,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const int64_t it = CHAIN ? sin->it + 1 : sin->it;  // the generation the population holds; we produce it+1
     SX_TP(6);
     if (P2P && blockIdx.x == 0) {
-        p2p_service(a, x, chain_p, mode, npart, it, sin);
+        p2p_service(a, x, chain_p, mode, npart, it, sin, LPR == kWave);
         return;
     }
 
@@ -299,7 +374,27 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         }
         if (it >= 2 && (bf <= a.ftol || it >= a.maxiter)) return;  // same rule as the service workgroup
         gbidx = bi;
-        gbw = x.peer[x.rank] + xchg_slot_offset(n, chain_p, winner) + 4;
+        // short rows read the winner's row straight from the exchange buffer; whole-wave rows from the relay
+        if (LPR == kWave) {
+            const uint64_t *rel = x.relay + (int64_t)chain_p * xchg_relay_stride(n);
+            if (use_best) {
+                // wait (past the caches) until workgroup 0 has published this generation's copy.  Relaxed: the
+                // ready word only keeps early readers from caching lines of the previous copy; every word read
+                // afterwards is verified by its own tag, so no acquire (= L2 invalidate) is needed
+                const uint64_t t0 = wall_clock64();
+                while (__hip_atomic_load(rel + xchg_slot_words(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                       (uint64_t)xtag) {
+                    if ((int64_t)(wall_clock64() - t0) > x.timeout_ticks) {
+                        if (id.lane == 0) atomicExch(x.error, 1);
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            gbw = rel + 4;
+        } else {
+            gbw = x.peer[x.rank] + xchg_slot_offset(n, chain_p, winner) + 4;
+        }
         part_f_out = a.part_f + (int64_t)(1 - chain_p) * npart;
         part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
     } else if (CHAIN) {
@@ -352,15 +447,28 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         if (P2P) {
             if (use_best) {  // tagged words from the exchange buffer; a word not yet there is simply re-read
                 const uint64_t t0 = wall_clock64();
-                for (;;) {
+                for (int attempt = 0;; ++attempt) {
                     uint64_t lo[kStep], hi[kStep];
                     bool ok = true;
+                    // relay (LPR = 64): first an ordinary, cacheable load -- a stale or not yet written word
+                    // fails the tag test and is then re-read past the caches (device scope) until it is there
+                    const bool cached = LPR == kWave && attempt == 0;
 #pragma unroll
                     for (int t = 0; t < kStep; ++t) {
                         const int e = (q0 + t) * LPR + l;
                         const bool in = FULL || e < n;
-                        lo[t] = in ? ll_load(gbw + 2 * e) : 0;
-                        hi[t] = in ? ll_load(gbw + 2 * e + 1) : 0;
+                        if (cached) {  // both tagged halves of a double in one 16-byte load
+                            const ulonglong2 w2 =
+                                in ? *reinterpret_cast<const ulonglong2 *>(gbw + 2 * e) : make_ulonglong2(0, 0);
+                            lo[t] = w2.x;
+                            hi[t] = w2.y;
+                        } else if (LPR == kWave) {
+                            lo[t] = in ? __hip_atomic_load(gbw + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                            hi[t] = in ? __hip_atomic_load(gbw + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                        } else {
+                            lo[t] = in ? ll_load(gbw + 2 * e) : 0;
+                            hi[t] = in ? ll_load(gbw + 2 * e + 1) : 0;
+                        }
                     }
 #pragma unroll
                     for (int t = 0; t < kStep; ++t) {
@@ -570,16 +678,19 @@ extern "C" int sx_de_shard_generation(const sx_de_args *a, double *record, void 
 // ---------------------------------------------------------------------------
 // Chained finalize (single GPU, Philox): one kernel per generation.
 // ---------------------------------------------------------------------------
-static int check_chain(const sx_de_args *a) {
+// every wavefront of the single-GPU chained kernel re-reduces the workgroup records, so only while those are
+// few; in the peer-exchange kernel only the service workgroup reads them (any number)
+static int check_chain(const sx_de_args *a, bool peer_exchange) {
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_de_chain: needs in-kernel (Philox) draws");
-    SX_REQUIRE(sx_num_partials(a->P, a->n) <= 512, "sx_de_chain: more than 512 workgroup records (use the two-kernel path)");
+    SX_REQUIRE(peer_exchange || sx_num_partials(a->P, a->n) <= 512,
+               "sx_de_chain: more than 512 workgroup records (use the two-kernel path)");
     return 0;
 }
 
 // x == nullptr: single GPU (XM = 1); otherwise the peer-exchange kernel (XM = 2, one service workgroup in front)
 static int chain_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, int finalize_only, void *stream) {
-    if (int rc = check_chain(a)) return rc;
+    if (int rc = check_chain(a, x != nullptr)) return rc;
     SX_REQUIRE(parity == 0 || parity == 1, "sx_de_chain_launch: parity must be 0 or 1");
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
@@ -594,7 +705,7 @@ static int chain_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, 
 }
 
 static int chain_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ngen, int start_parity, sx_graph **out) {
-    if (int rc = check_chain(a)) return rc;
+    if (int rc = check_chain(a, x != nullptr)) return rc;
     SX_REQUIRE(out != nullptr && ngen >= 1 && (start_parity == 0 || start_parity == 1),
                "sx_de_chain_graph_create: bad arguments");
     PlanArg plan;

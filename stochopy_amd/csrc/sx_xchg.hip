@@ -64,6 +64,11 @@ extern "C" int64_t sx_xchg_bytes(int world, int n) {
     return xchg_total_words(n) * (int64_t)sizeof(uint64_t);
 }
 
+extern "C" int64_t sx_xchg_relay_bytes(int n) {
+    if (n < 1) return -1;
+    return 2 * xchg_relay_stride(n) * (int64_t)sizeof(uint64_t);
+}
+
 extern "C" int sx_xchg_alloc(int64_t bytes, void **ptr, void *handle) {
     SX_REQUIRE(ptr != nullptr && handle != nullptr && bytes > 0, "sx_xchg_alloc: bad arguments");
     static_assert(sizeof(hipIpcMemHandle_t) == SX_IPC_HANDLE_BYTES, "IPC handle size");
@@ -111,7 +116,8 @@ static int check_xchg(const sx_xchg_args *x, const char *who) {
     SX_REQUIRE(x != nullptr, "sx_xchg: null exchange arguments");
     SX_REQUIRE(x->world >= 1 && x->world <= SX_MAX_PEERS && x->rank >= 0 && x->rank < x->world,
                "sx_xchg: bad world / rank (at most 8 ranks)");
-    SX_REQUIRE(x->error != nullptr && x->timeout_ticks > 0, "sx_xchg: error word / timeout missing");
+    SX_REQUIRE(x->error != nullptr && x->timeout_ticks > 0 && x->relay != nullptr,
+               "sx_xchg: error word / timeout / relay buffer missing");
     for (int r = 0; r < x->world; ++r) SX_REQUIRE(x->peer[r] != nullptr, "sx_xchg: unmapped peer buffer");
     (void)who;
     return 0;

@@ -21,6 +21,8 @@ __host__ __device__ inline int64_t xchg_probe_offset(int n, int src) {
     return ((int64_t)2 * SX_MAX_PEERS + src) * xchg_slot_words(n);
 }
 __host__ __device__ inline int64_t xchg_total_words(int n) { return (int64_t)3 * SX_MAX_PEERS * xchg_slot_words(n); }
+// relay (ordinary memory): per generation parity one record as tagged words, then the "ready" word (its own line)
+__host__ __device__ inline int64_t xchg_relay_stride(int n) { return xchg_slot_words(n) + 16; }
 
 __device__ __forceinline__ void ll_store(uint64_t *p, uint32_t data, uint32_t tag) {
     __hip_atomic_store(p, ((uint64_t)tag << 32) | (uint64_t)data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -41,9 +43,18 @@ __device__ __forceinline__ bool ll_ok(uint64_t w, uint32_t tag) { return (uint32
 // One wavefront writes this rank's record for generation tag `tag` into dst (a peer's slot for this rank).
 __device__ __forceinline__ void xchg_push_record(uint64_t *dst, double f, int64_t grow, const double *__restrict__ row,
                                                  int n, uint32_t tag, int lane) {
-    for (int j = lane; j < n + 2; j += kWave) {
-        const double v = j == 0 ? f : j == 1 ? __longlong_as_double((long long)grow) : row[j - 2];
-        ll_store_f64(dst + 2 * j, v, tag);
+    for (int j0 = lane; j0 < n + 2; j0 += 8 * kWave) {  // 8 row loads in flight per trip, then their stores
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * kWave;
+            v[u] = j == 0 ? f : j == 1 ? __longlong_as_double((long long)grow) : j < n + 2 ? row[j - 2] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * kWave;
+            if (j < n + 2) ll_store_f64(dst + 2 * j, v[u], tag);
+        }
     }
 }
 

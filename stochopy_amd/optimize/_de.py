@@ -132,13 +132,10 @@ class _DeRun:
                 raise ValueError('exchange must be "auto", "p2p" or "rccl"')
             self.exchange, self.exchange_note = "rccl", None
             if exchange != "rccl":
-                if npart <= 512:
-                    from ..parallel import PeerExchange
+                from ..parallel import PeerExchange
 
-                    timeout = float(os.environ.get("SX_XCHG_TIMEOUT_S", "20"))
-                    self.px, self.exchange_note = PeerExchange.negotiate(self.ctx, self.world, self.n, timeout)
-                else:
-                    self.exchange_note = "more than 512 workgroup records per shard"
+                timeout = float(os.environ.get("SX_XCHG_TIMEOUT_S", "20"))
+                self.px, self.exchange_note = PeerExchange.negotiate(self.ctx, self.world, self.n, timeout)
                 if self.px is not None:
                     self.exchange, self.chain = "p2p", True
                 elif exchange == "p2p":

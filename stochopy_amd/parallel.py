@@ -159,6 +159,8 @@ class PeerExchange:
         t = ctx.zeros((1,), dtype=_torch_int32())
         px.error = t
         a.error = t.data_ptr()
+        px.relay = ctx.zeros((int(L.sx_xchg_relay_bytes(n)) // 8,))  # ordinary HBM (zero = no tag yet)
+        a.relay = px.relay.data_ptr()
         if not world.all_agree(ok):
             px.close()
             return None, why or "a peer could not map this rank's exchange buffer"

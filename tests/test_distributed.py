@@ -107,6 +107,7 @@ def test_sharded_de_on_gpu_matches_oracle(world, exchange):
     dict(n=10, P=40, gens=30, seed=7, strategy="rand1bin"),                # the row of the record is never read
     dict(n=33, P=48, gens=25, seed=8, strategy="best2bin", constraints="Random"),
     dict(n=16, P=64, gens=400, seed=9, objective="sphere", ftol=1e-3, xtol=1e-8),   # stops on ftol (status 0/1)
+    dict(n=2048, P=2200, gens=5, seed=10),                                 # 550 workgroup records per shard (> 512)
 ])
 def test_p2p_exchange_cases(case):
     case = dict(case)
