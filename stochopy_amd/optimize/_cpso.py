@@ -96,7 +96,9 @@ class _PsoRun:
         self.world = None
         self.Ptotal = P
         self.row0 = 0
-        if workers != 1:
+        import os
+
+        if workers != 1 or os.environ.get("SX_FORCE_SHARDED") == "1":  # env switch: a 1-rank group (tests)
             from ..parallel import require_world
 
             self.world = require_world(workers)
@@ -111,6 +113,8 @@ class _PsoRun:
         self.x0 = x0
         self.ctx = _device.Context()
         self._graph = None
+        self._rccl_graph = None
+        self._rccl_graph_note = None
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
@@ -120,6 +124,9 @@ class _PsoRun:
                     self.close()
 
     def close(self):
+        if self._rccl_graph is not None:
+            self.ctx.sync()
+            self._rccl_graph = None
         if self._graph is not None:
             self.ctx.sync()
             self.ctx.L.sx_graph_destroy(self._graph)
@@ -341,10 +348,39 @@ class _PsoRun:
                     self._graph = g
                 _lib.check(ctx.L.sx_graph_launch(self._graph, ctx.stream_ptr), "sx_graph_launch")
                 ngen -= self.GRAPH_CHUNK
+        elif self.world is not None:
+            # sharded swarm: kernels + the RCCL all-gathers of a chunk of generations captured once and replayed
+            while ngen >= self.GRAPH_CHUNK and self._capture_sharded_chunk():
+                self._rccl_graph.replay()
+                ngen -= self.GRAPH_CHUNK
         for _ in range(ngen):
             self._generation()
             if self.gamma:
                 self._restart_device()
+
+    def _capture_sharded_chunk(self):
+        """GRAPH_CHUNK sharded generations (kernels + all-gathers) as one graph; False if that is not possible
+        (gloo stages through the host; SX_RCCL_GRAPH=0; a failed capture) -- same collectives either way."""
+        import os
+
+        if self._rccl_graph is not None:
+            return True
+        if self._rccl_graph_note is not None or self.world.backend != "nccl" or os.environ.get("SX_RCCL_GRAPH") == "0":
+            return False
+        t = _device.torch()
+        try:
+            self.ctx.sync()
+            g = t.cuda.CUDAGraph()
+            with t.cuda.graph(g, stream=self.ctx.stream):
+                for _ in range(self.GRAPH_CHUNK):
+                    self._generation()
+                    if self.gamma:
+                        self._restart_device()
+            self._rccl_graph = g
+            return True
+        except Exception as e:  # capture is an optimisation, never a requirement
+            self._rccl_graph_note = f"graph capture of the rccl path failed: {e}"
+            return False
 
     def result(self):
         return self._res

@@ -194,6 +194,22 @@ def test_rccl_path_graph_capture_single_rank():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["pso", "cpso"])
+def test_sharded_pso_rccl_graph_capture_single_rank(method):
+    """PSO / CPSO over RCCL with one rank, 70 generations: replays of the captured 16-generation graph
+    (generation, shard best, all-gather, finalise [, radius, all-gather, select, apply]) == the oracle."""
+    from _dist_workers import nccl_single_rank_worker
+
+    opts = {"maxiter": 70, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
+    cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts}
+    out = _spawn(nccl_single_rank_worker, 1, cfg)
+    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts), rng="philox")
+    fun, nit, nfev, status = np.load(os.path.join(out, "meta_0.npy"))
+    assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+    assert np.array_equal(np.load(os.path.join(out, "x_0.npy")), ref.x)
+
+
+@pytest.mark.gpu
 def test_p2p_path_single_rank_nccl_setup():
     """Same with the peer exchange (handles and agreement travel over the RCCL group, the kernels write locally)."""
     from _dist_workers import nccl_single_rank_worker
