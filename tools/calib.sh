@@ -1,7 +1,7 @@
 #!/bin/bash
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_calib
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python $GRAFT_REPO_ROOT/tools_calib.py > $OUT/log.txt 2>&1 < /dev/null
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python $GRAFT_REPO_ROOT/tools/calib.py > $OUT/log.txt 2>&1 < /dev/null
 echo rc=$?; grep calib $OUT/log.txt
 python - <<PY
 import csv, glob, collections

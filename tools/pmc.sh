@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <bench args...>  -> gpurun_out/pmc_<tag>/{sq,sq2,fetch,write}/  (separate --pmc passes, no tracing domains)
+# usage: tools/pmc.sh <tag> <bench args...>  -> gpurun_out/pmc_<tag>/{sq,sq2,fetch,write}/  (separate --pmc passes, no tracing domains)
 set -u
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> <bench args...>   -> gpurun_out/prof_<tag>/ (kernel trace + stats, csv)
+# usage: tools/prof.sh <tag> <bench args...>   -> gpurun_out/prof_<tag>/ (kernel trace + stats, csv)
 set -u
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG

@@ -1,7 +1,7 @@
 """Debug helper: build a -DSX_TRACE variant of the library, run a few DE generations, print checkpoint deltas."""
 import ctypes as C, glob, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "stochopy_amd", "csrc")
 out = "/tmp/libsx_trace.so"
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-DSX_TRACE",
