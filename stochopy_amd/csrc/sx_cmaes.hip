@@ -272,9 +272,12 @@ extern "C" int sx_cmaes_sample(const double *xmean, double sigma, const double *
     if (big >= 512) {
         dim3 grid((unsigned)((n + 63) / 64), (unsigned)((P + 63) / 64));
         hipLaunchKernelGGL((cma_gemm_kernel<0, 64, 64, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
-    } else {
+    } else if (big >= 256) {
         dim3 grid((unsigned)((n + 63) / 64), (unsigned)((P + 31) / 32));
         hipLaunchKernelGGL((cma_gemm_kernel<0, 32, 64, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    } else {  // small problems: more, smaller workgroups (2+ waves per SIMD hide the per-chunk latency)
+        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((P + 31) / 32));
+        hipLaunchKernelGGL((cma_gemm_kernel<0, 32, 32, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
     }
     SX_LAUNCH_CHECK();
     return 0;
