@@ -298,9 +298,20 @@ class _PsoRun:
         st = self.st
         if self.callback is not None:
             self.callback(self.X.cpu().numpy(), self._partial_result(st))
-        stepwise = self.rng == "numpy-legacy" or self.callback is not None or self.return_all
+        # return_all with in-kernel draws: history copies (cpso/_cpso.py:283-295) are device-side and ordered on
+        # the engine stream, so the host need not look at every generation
+        record_async = (self.return_all and self.rng == "philox" and self.callback is None and self.nout > 0
+                        and self.maxiter > 1)
+        stepwise = (self.rng == "numpy-legacy" or self.callback is not None or self.return_all) and not record_async
         while not st.done:
-            if stepwise:
+            if record_async:
+                for j in range(min(max(self.maxiter - st.it, 1), self.CHECK_EVERY)):
+                    self._generation()
+                    self._record(st.it + 1 + j)  # generations after convergence are no-ops; their slots are cut off
+                    if self.gamma:
+                        self._restart_device()
+                st = ctx.read_state(self.state)
+            elif stepwise:
                 self._generation()
                 self._record(st.it + 1)
                 st = ctx.read_state(self.state)

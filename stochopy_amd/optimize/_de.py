@@ -455,11 +455,20 @@ class _DeRun:
         st = self.st
         if self.callback is not None:
             self.callback(self._population(1).cpu().numpy(), self._partial_result(st))
-        stepwise = self.rng == "numpy-legacy" or self.callback is not None or self.return_all
+        # return_all with in-kernel draws: the per-generation history copies (de/_de.py:270-278) are device-side
+        # and ordered on the engine stream, so the host need not look at every generation
+        record_async = (self.return_all and self.rng == "philox" and self.callback is None and self.nout > 0
+                        and self.maxiter > 1)
+        stepwise = (self.rng == "numpy-legacy" or self.callback is not None or self.return_all) and not record_async
         while not st.done:
             # maxiter <= 1: the reference still runs one generation before it tests `it >= maxiter`
             remaining = max(self.maxiter - st.it, 1)
-            if stepwise:
+            if record_async:
+                for j in range(min(remaining, 32)):
+                    _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")
+                    self._record(st.it + 1 + j)  # generations after convergence are no-ops; their slots are cut off
+                st = ctx.read_state(self.state)
+            elif stepwise:
                 if self.rng == "numpy-legacy":
                     self._host_draws()
                 _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")

@@ -62,6 +62,24 @@ def test_return_all_shapes_and_values(sa, method, verbosity):
         assert np.array_equal(got.xall, ref.xall) and np.array_equal(got.funall, ref.funall)
 
 
+@pytest.mark.parametrize("method,objective,gens", [("de", "rosenbrock", 75), ("pso", "rosenbrock", 75),
+                                                   ("cpso", "sphere", 45), ("de", "sphere", 400)])
+def test_return_all_philox_streams_history_without_host_round_trips(sa, method, objective, gens):
+    """Philox draws + return_all: the history slabs are copied device-side on the engine stream and the host
+    looks at the state every 32 generations only -- same xall / funall / nit as the oracle, including runs that
+    converge between two looks (DE on Sphere stops on ftol) and CPSO restarts."""
+    n, P = 12, 64
+    b = [[-5.12, 5.12]] * n
+    opts = {"maxiter": gens, "popsize": P, "seed": 21, "return_all": True, "verbosity": 0.5, "updating": "deferred",
+            "ftol": 1e-6 if objective == "sphere" and method == "de" else -1.0}
+    ref = oracle.minimize(objective, b, method=method, options=dict(opts), rng="philox")
+    got = sa.optimize.minimize(getattr(sa.factory, objective), b, method=method,
+                               options=dict(opts, backend="hip", rng="philox"))
+    assert (got.nit, got.status, got.fun) == (ref.nit, ref.status, ref.fun)
+    assert got.xall.shape == (ref.nit, P // 2, n)
+    assert np.array_equal(got.xall, ref.xall) and np.array_equal(got.funall, ref.funall)
+
+
 @pytest.mark.parametrize("method", ["de", "pso"])
 def test_maxiter_one_still_runs_a_generation(sa, method):
     """`it` starts at 1 and is incremented before the test `it >= maxiter` (de/_de.py:245-247)."""
