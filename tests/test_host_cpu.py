@@ -186,6 +186,22 @@ def test_sum_plan_reproduces_numpy_pairwise(lib, m):
     assert 0.0 + stack[0] == a.sum()
 
 
+def test_exchange_buffer_geometry(lib):
+    """Host side of the peer exchange: slots[2][8][w] + probe[8][w] words of 8 bytes, w = 2(n+2) rounded up to
+    whole 128-byte lines; the relay holds two records + their ready lines; bad arguments are refused."""
+    for n in (1, 2, 6, 7, 128, 1024, 2560):
+        w = -(-2 * (n + 2) // 16) * 16
+        assert lib.sx_xchg_bytes(8, n) == 3 * 8 * w * 8 == lib.sx_xchg_bytes(1, n)
+        assert lib.sx_xchg_relay_bytes(n) == 2 * (w + 16) * 8
+    assert lib.sx_xchg_bytes(9, 8) == -1 and lib.sx_xchg_bytes(0, 8) == -1 and lib.sx_xchg_bytes(2, 0) == -1
+    assert lib.sx_xchg_relay_bytes(0) == -1
+    from stochopy_amd import _lib
+
+    x = _lib.SxXchgArgs()
+    x.world, x.rank = 2, 5  # rank outside the world
+    assert lib.sx_xchg_probe(C.byref(x), 8, 1, None) != 0 and b"world / rank" in lib.sx_last_error()
+
+
 def test_api_surface_and_validation():
     """Signatures/defaults of the reference (de/_de.py:13-33 etc.) and its bare ValueError/TypeError validation."""
     import inspect
