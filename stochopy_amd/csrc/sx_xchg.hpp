@@ -43,17 +43,20 @@ __device__ __forceinline__ bool ll_ok(uint64_t w, uint32_t tag) { return (uint32
 // One wavefront writes this rank's record for generation tag `tag` into dst (a peer's slot for this rank).
 __device__ __forceinline__ void xchg_push_record(uint64_t *dst, double f, int64_t grow, const double *__restrict__ row,
                                                  int n, uint32_t tag, int lane) {
-    for (int j0 = lane; j0 < n + 2; j0 += 8 * kWave) {  // 8 row loads in flight per trip, then their stores
+    // the header goes first: the readers learn the winner while the row is still being fetched here (they
+    // re-read any row word that has not arrived yet)
+    if (lane < 2) ll_store_f64(dst + 2 * lane, lane == 0 ? f : __longlong_as_double((long long)grow), tag);
+    for (int j0 = lane; j0 < n; j0 += 8 * kWave) {  // 8 row loads in flight per trip, then their stores
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = j0 + u * kWave;
-            v[u] = j == 0 ? f : j == 1 ? __longlong_as_double((long long)grow) : j < n + 2 ? row[j - 2] : 0.0;
+            v[u] = j < n ? row[j] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = j0 + u * kWave;
-            if (j < n + 2) ll_store_f64(dst + 2 * j, v[u], tag);
+            if (j < n) ll_store_f64(dst + 2 * (j + 2), v[u], tag);
         }
     }
 }
