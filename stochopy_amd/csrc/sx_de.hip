@@ -108,8 +108,14 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
 // cross-GPU dependency is "all ranks have reached this generation".
 // XM = 2, workgroup 0: shard best -> peers, global best -> state.  Returns nothing; sets *x.error on timeout.
 __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_args &x, int chain_p, int mode,
-                                            int64_t npart, int64_t it, const sx_state *sin, bool relay) {
+                                            int64_t npart, const sx_state *sin, bool relay) {
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), nw = (int)(blockDim.x >> 6);
+    // the state word and the records do not depend on each other: fetch the state first (relaxed atomics pin
+    // the loads here), scan the records, and only then look at it
+    const int done0 = __atomic_load_n(&sin->done, __ATOMIC_RELAXED);
+    const int64_t it0 = __atomic_load_n(&sin->it, __ATOMIC_RELAXED);
+    const int64_t prev_winner = __atomic_load_n(&sin->reserved[1], __ATOMIC_RELAXED);
+    const int err0 = __atomic_load_n(x.error, __ATOMIC_RELAXED);
     const double *pf = a.part_f + (int64_t)chain_p * npart;
     const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
     // shard best = lexicographic (f, row) minimum of the records: the whole workgroup scans them (8 records per
@@ -155,6 +161,12 @@ __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_a
     __syncthreads();
     for (int w = 0; w < nw; ++w) argmin_combine(bf, bi, svc_f[w], svc_i[w]);
     }
+    if (done0) {
+        if (mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
+        return;
+    }
+    if (err0) return;  // an earlier wait timed out: the run is dead, the host raises
+    const int64_t it = it0 + 1;  // the generation the population holds
     const uint32_t tag = (uint32_t)(it + 1);
     const double *row = ((it & 1) ? a.buf1 : a.buf0) + bi * a.ld;
     for (int r = wave; r < x.world; r += nw)
@@ -222,7 +234,7 @@ __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_a
         so->dx = 0.0;
         so->status = status;
         so->done = status != SX_STATUS_NONE;
-        so->reserved[0] = sin->reserved[1];  // rank that held the previous best row
+        so->reserved[0] = prev_winner;        // rank that held the previous best row
         so->reserved[1] = winner;
     }
 }
@@ -272,6 +284,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
             piv[u] = in ? (rec_t)pi[k0 + u] : kNoRec;
         }
     }
+    if (P2P && blockIdx.x == 0) {  // reads the state word itself, after it has issued its record loads
+        p2p_service(a, x, chain_p, mode, npart, sin, LPR == kWave);
+        return;
+    }
     if (sin->done) {
         if (CHAIN && mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
         return;
@@ -279,10 +295,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     if (P2P && *x.error) return;  // an earlier wait timed out: the run is dead, the host raises
     const int64_t it = CHAIN ? sin->it + 1 : sin->it;  // the generation the population holds; we produce it+1
     SX_TP(6);
-    if (P2P && blockIdx.x == 0) {
-        p2p_service(a, x, chain_p, mode, npart, it, sin, LPR == kWave);
-        return;
-    }
 
     // ---- B. everything that only needs `it`: donors, the first batch of row loads, the first Philox call
     const uint32_t gen = (uint32_t)(it + 1);
