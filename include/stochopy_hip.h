@@ -333,6 +333,14 @@ int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const double *w, int
 int sx_cmaes_normals(double *Z, int64_t P, int n, int64_t row0, uint32_t gen, uint32_t key0, uint32_t key1,
                      void *stream);
 int sx_symmetrize_upper(double *C, int n, void *stream);
+/* CMA-ES box-constraint handling "Penalize", device part.
+ * replaces: cmaes/_constraints.py:29-31 (candidates clipped to the standardised box [-1,1]^n, then the objective)
+ *           and :79 (arfitness += dot((arxvalid - arx)**2, bnd_weights / bnd_scale)); the scalar bookkeeping
+ *           of :33-76 (percentiles, weight history) stays on the host as in the reference.
+ * X DEVICE (P,n) standardised candidates; xm/xstd DEVICE (n); v DEVICE (n) = bnd_weights / bnd_scale or NULL;
+ * f_raw DEVICE (P) = fun(unstandardise(clip(X))); pen DEVICE (P) = sum_j (clip(x_ij) - x_ij)^2 v_j (NULL with v). */
+int sx_cmaes_eval_penalized(int fun_id, const double *X, int64_t P, int n, const double *xm, const double *xstd,
+                            const double *v, double *f_raw, double *pen, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * numpy-legacy random stream (host): bit-exact MT19937 replica of what the

@@ -331,10 +331,54 @@ def cma_covariance(C, arx_sel, xold, sigma, w, pc, cond, c1, cmu, cc):
     return C
 
 
+class PenalizeState:
+    """CMA-ES box-constraint handling "Penalize" (cmaes/_constraints.py:4-82), restated.  State carried over
+    generations (cmaes/_cmaes.py:213-215, 230-231): boundary weights, the history of fitness-spread estimates,
+    and the two phase flags."""
+
+    def __init__(self, n):
+        self.weights = np.zeros(n)
+        self.dfithist = np.ones(1)
+        self.validfitval = False
+        self.iniphase = True
+
+    def apply(self, arx, xmean, xold, sigma, diagC, mueff, it, fun):
+        P, n = arx.shape
+        valid = np.clip(arx, -1.0, 1.0)                      # :29-31
+        fit = fun(valid)
+        q25, q75 = np.percentile(fit, [25.0, 75.0])          # :34-35
+        delta = (q75 - q25) / n / diagC.mean() / sigma**2
+        if delta == 0:                                       # :38-42
+            delta = self.dfithist[self.dfithist > 0.0].min()
+        elif not self.validfitval:
+            self.dfithist = np.empty(0)
+            self.validfitval = True
+        if self.dfithist.size < 20 + (3.0 * n) / P:          # :45-48 (sliding window)
+            self.dfithist = np.append(self.dfithist, delta)
+        else:
+            self.dfithist = np.append(self.dfithist[1:], delta)
+        outside = (xmean < -1.0) | (xmean > 1.0)             # :51
+        # :52-53 -- the second assignment overwrites the first, so only the UPPER side is clipped here
+        tx = np.where(xmean > 1.0, 1.0, xmean)
+        if self.iniphase and outside.any():                  # :56-59
+            self.weights = np.full(n, 2.0002 * np.median(self.dfithist))
+            if self.validfitval and it > 2:
+                self.iniphase = False
+        if outside.any():                                    # :61-73
+            tx = xmean - tx
+            grow = outside & (np.abs(tx) > 3.0 * max(1.0, np.sqrt(n / mueff)) * sigma * np.sqrt(diagC))
+            grow &= np.sign(tx) == np.sign(xmean - xold)
+            self.weights = np.where(grow, self.weights * 1.2 ** min(1.0, mueff / 10.0 / n), self.weights)
+        scale = np.exp(0.9 * (np.log(diagC) - np.log(diagC).mean()))   # :76
+        fit = fit + np.dot((valid - arx) ** 2, self.weights / scale)   # :79
+        return fit, valid
+
+
 def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, sigma=0.1, muperc=0.5,
               xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, **_ignored):
-    if constraints is not None:
-        raise NotImplementedError("Penalize is outside the hot-path scope (SURVEY.md section 2 row 10)")
+    if constraints not in (None, "Penalize"):
+        raise KeyError(constraints)
+    pen = PenalizeState(len(lower)) if constraints == "Penalize" else None
     n = len(lower)
     P = popsize
     xm = 0.5 * (upper + lower)
@@ -361,9 +405,13 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
         it += 1
         Z = stream.cma_normals(it, P, n)
         arx = cma_sample(xmean, sigma, B, D, Z)
-        arfit = fobj(unstd(arx))
+        arxvalid = arx
+        if pen is None:
+            arfit = fobj(unstd(arx))
+        else:  # cmaes/_cmaes.py:238-256: the valid (clipped) points are what the caller sees, arx drives the model
+            arfit, arxvalid = pen.apply(arx, xmean, xold, sigma, np.diag(C), mueff, it, lambda x: fobj(unstd(x)))
         nfev += P
-        hist.put(it - 1, unstd(arx), arfit)
+        hist.put(it - 1, unstd(arxvalid), arfit)
         order = np.argsort(arfit)
         xold = xmean.copy()
         xmean = np.dot(w, arx[order[:mu], :])
@@ -386,10 +434,10 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
         status = cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, insigma, ilim, pc,
                           xtol, ftol, np.diag(C), B, D)
         if callback is not None:
-            callback(unstd(arx), Result(x=unstd(arx[order[0]]), fun=arfit[order[0]], nfev=nfev, nit=it))
+            callback(unstd(arxvalid), Result(x=unstd(arxvalid[order[0]]), fun=arfit[order[0]], nfev=nfev, nit=it))
         if status is not None:
             break
-    return _final(unstd(arx[order[0]]), arfit[order[0]], status, nfev, it, hist)
+    return _final(unstd(arxvalid[order[0]]), arfit[order[0]], status, nfev, it, hist)
 
 
 def run_de_sharded(fobj, lower, upper, stream, world, maxiter=100, popsize=10, mutation=0.5, recombination=0.9,

@@ -141,7 +141,7 @@ template <int FUN, int LPR>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const double *__restrict__ X, int64_t P, int n, int64_t ldx, const double *__restrict__ xm,
     const double *__restrict__ xstd, double *__restrict__ f, const PlanArg plan, double *__restrict__ part_f,
-    int64_t *__restrict__ part_i) {
+    int64_t *__restrict__ part_i, const int clip, const double *__restrict__ pen_v, double *__restrict__ pen_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
@@ -149,10 +149,20 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     double *U = lds + id.slot * lds_row_stride(n);
     const double *xr = X + id.rowc * ldx;
     const bool affine = xm != nullptr;
+    double pacc = 0.0;
     for (int e = id.l; e < n; e += LPR) {
         double v = xr[e];
+        if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
+            const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+            if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
+            v = c;
+        }
         if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
         U[e] = v;
+    }
+    if (pen_out != nullptr) {
+        pacc = row_sum<LPR>(pacc);
+        if (id.active && id.l == 0) pen_out[id.row] = pacc;
     }
     const double val = row_objective<FUN, LPR>(U, n, plan, id.l);
     if (id.active && id.l == 0) f[id.row] = val;
@@ -161,10 +171,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
 
 template <int FUN>
 static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
-                       const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s) {
+                       const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s, int clip = 0,
+                       const double *pen_v = nullptr, double *pen_out = nullptr) {
     const Geometry g = row_geometry(P, n);
     SX_DISPATCH_LPR(n, hipLaunchKernelGGL((eval_kernel<FUN, LPR>), dim3(g.blocks), dim3(g.threads), g.lds, s, X, P, n,
-                                          ldx, xm, xstd, f, plan, part_f, part_i))
+                                          ldx, xm, xstd, f, plan, part_f, part_i, clip, pen_v, pen_out))
     SX_LAUNCH_CHECK();
     return 0;
 }
@@ -183,6 +194,34 @@ extern "C" int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ld
 #define SX_CASE(ID) \
     case ID:        \
         return launch_eval<ID>(X, P, n, ldx, xm, xstd, f, plan, part_f, part_i, s);
+        SX_CASE(SX_FUN_ACKLEY)
+        SX_CASE(SX_FUN_GRIEWANK)
+        SX_CASE(SX_FUN_QUARTIC)
+        SX_CASE(SX_FUN_RASTRIGIN)
+        SX_CASE(SX_FUN_ROSENBROCK)
+        SX_CASE(SX_FUN_SPHERE)
+        SX_CASE(SX_FUN_STYBLINSKI_TANG)
+#undef SX_CASE
+    }
+    return -1;
+}
+
+// CMA-ES "Penalize" boundary handling (cmaes/_constraints.py:4-82), device part: candidates are clipped to the
+// standardised box [-1, 1]^n before the objective (f_raw), and pen[i] = sum_j (clip(x_ij) - x_ij)^2 * v[j]
+// (v = bnd_weights / bnd_scale from the host; NULL = no penalty term wanted).  One kernel.
+extern "C" int sx_cmaes_eval_penalized(int fun_id, const double *X, int64_t P, int n, const double *xm,
+                                       const double *xstd, const double *v, double *f_raw, double *pen, void *stream) {
+    SX_REQUIRE(X && f_raw && xm && xstd, "sx_cmaes_eval_penalized: null pointer");
+    SX_REQUIRE(P >= 1 && n >= 1, "sx_cmaes_eval_penalized: bad shape");
+    SX_REQUIRE(fun_id >= 0 && fun_id < SX_FUN_COUNT, "sx_cmaes_eval_penalized: unknown fun_id");
+    SX_REQUIRE((v == nullptr) == (pen == nullptr), "sx_cmaes_eval_penalized: v and pen must be given together");
+    hipStream_t s = (hipStream_t)stream;
+    PlanArg plan;
+    if (make_plan_arg(fun_id, n, &plan)) return -1;
+    switch (fun_id) {
+#define SX_CASE(ID) \
+    case ID:        \
+        return launch_eval<ID>(X, P, n, n, xm, xstd, f_raw, plan, nullptr, nullptr, s, 1, v, pen);
         SX_CASE(SX_FUN_ACKLEY)
         SX_CASE(SX_FUN_GRIEWANK)
         SX_CASE(SX_FUN_QUARTIC)

@@ -8,7 +8,9 @@ mean.  On the host, as in the reference: ranking (``np.argsort``), the evolution
 the step size, the ten stopping rules and -- SURVEY.md section 8f rank 1, "next" -- the
 eigendecomposition (``numpy.linalg.eigh`` = LAPACK, the reference's own third-party call),
 which also fixes the eigenvector signs the same-seed parity depends on.
-``constraints="Penalize"`` is outside the hot-path scope.
+``constraints="Penalize"`` (cmaes/_constraints.py:4-82): the clipping of the
+candidates, the objective and the weighted squared excess run in one device kernel
+(``sx_cmaes_eval_penalized``); the scalar bookkeeping of the boundary weights stays on the host.
 """
 import ctypes as C
 
@@ -64,9 +66,7 @@ def minimize(
         raise ValueError()
     if not 0.0 < muperc <= 1.0:
         raise ValueError()
-    if constraints is not None:
-        if constraints == "Penalize":
-            raise NotImplementedError("constraints='Penalize' is not on the MI355X hot path; use the reference for it")
+    if constraints not in (None, "Penalize"):
         raise KeyError(constraints)
     if callback is not None and not hasattr(callback, "__call__"):
         raise ValueError()
@@ -76,8 +76,48 @@ def minimize(
     if eigh not in ("host", "device"):
         raise ValueError("eigh must be 'host' or 'device'")
     run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
-                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh, workers)
+                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh, workers,
+                  penalize=constraints == "Penalize")
     return run.result()
+
+
+class _BoundaryWeights:
+    """Host bookkeeping of constraints="Penalize" (cmaes/_constraints.py:33-76; state created at
+    cmaes/_cmaes.py:213-215, 230-231): per-dimension penalty weights, the sliding history of fitness-spread
+    estimates they are initialised from, and the two phase flags.  ``update`` takes the RAW fitness of the
+    clipped candidates and returns ``weights / scale`` -- the vector the device multiplies the squared excess by."""
+
+    def __init__(self, n):
+        self.weights = np.zeros(n)
+        self.spreads = np.ones(1)
+        self.have_spread = False
+        self.initial_phase = True
+
+    def update(self, fit_raw, xmean, xold, sigma, diagC, mueff, it, P):
+        n = xmean.size
+        q25, q75 = np.percentile(fit_raw, [25.0, 75.0])
+        spread = (q75 - q25) / n / diagC.mean() / sigma**2
+        if spread == 0:
+            spread = self.spreads[self.spreads > 0.0].min()
+        elif not self.have_spread:
+            self.spreads = np.empty(0)
+            self.have_spread = True
+        keep = self.spreads if self.spreads.size < 20 + (3.0 * n) / P else self.spreads[1:]
+        self.spreads = np.append(keep, spread)
+        outside = (xmean < -1.0) | (xmean > 1.0)
+        if outside.any():
+            if self.initial_phase:
+                self.weights = np.full(n, 2.0002 * np.median(self.spreads))
+                if self.have_spread and it > 2:
+                    self.initial_phase = False
+            # the reference measures the excess against a mean clipped on the UPPER side only (:52-53: the
+            # second np.where starts again from xmean), so weights only ever grow for dimensions above +1
+            excess = xmean - np.where(xmean > 1.0, 1.0, xmean)
+            limit = 3.0 * max(1.0, np.sqrt(n / mueff)) * sigma * np.sqrt(diagC)
+            grow = outside & (np.abs(excess) > limit) & (np.sign(excess) == np.sign(xmean - xold))
+            self.weights = np.where(grow, self.weights * 1.2 ** min(1.0, mueff / 10.0 / n), self.weights)
+        logd = np.log(diagC)
+        return self.weights / np.exp(0.9 * (logd - logd.mean()))
 
 
 def _stop_status(it, n, maxiter, xmean, xold, besthist, arfit, order, sigma, insigma, ilim, pc, xtol, ftol, diagC, B, D):
@@ -114,8 +154,9 @@ def _stop_status(it, n, maxiter, xmean, xold, besthist, arfit, order, sigma, ins
 
 class _CmaRun:
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, return_all, verbosity,
-                 callback, rng, seed, eigh="host", workers=1):
+                 callback, rng, seed, eigh="host", workers=1, penalize=False):
         self.eigh = eigh
+        self.penalize = penalize
         self.world = None
         if workers != 1:
             from ..parallel import require_world
@@ -188,6 +229,17 @@ class _CmaRun:
         d_idx = ctx.empty((mu,), dtype=t.int64)
         d_Y = ctx.empty((mu, n))  # artmp scratch of the covariance update
         h_Z = t.empty((P, n), dtype=t.float64).pin_memory() if self.rng == "numpy-legacy" else None
+        if self.penalize:
+            bweights = _BoundaryWeights(n)
+            d_v = ctx.empty((n,))
+            d_pen = ctx.empty((P,))
+            d_pen_loc = d_pen if self.world is None else ctx.empty((Pl,))
+            xold = np.zeros(n)  # the reference reads an uninitialised array here in generation 1 (np.empty)
+
+        def seen(rows):
+            """What the caller sees of standardised candidates: with Penalize the clipped points
+            (cmaes/_cmaes.py:238-256, 336-350), un-standardised."""
+            return unstd(np.clip(rows, -1.0, 1.0)) if self.penalize else unstd(rows)
 
         if self.return_all:
             nout = int(np.ceil(self.verbosity * P))
@@ -211,19 +263,34 @@ class _CmaRun:
             _lib.check(L.sx_cmaes_sample(ptr(d_xmean), sigma, ptr(d_B), ptr(d_D), ptr(d_Z), ptr(d_arx_loc), Pl, n, sp),
                        "sx_cmaes_sample")
             # ---- evaluate: fun(unstandardize(x)) fused (cmaes/_cmaes.py:173, 258) ----
-            _device.evaluate(ctx, self.fun_id, d_arx_loc, n, f=d_fit_loc, xm=d_xm, xstd=d_xstd)
+            if not self.penalize:
+                _device.evaluate(ctx, self.fun_id, d_arx_loc, n, f=d_fit_loc, xm=d_xm, xstd=d_xstd)
+            else:  # candidates clipped to the box before the objective (cmaes/_constraints.py:29-31)
+                _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd), None,
+                                                     ptr(d_fit_loc), None, sp), "sx_cmaes_eval_penalized")
             if self.world is not None:  # every rank gets all candidates and fitness values back
                 self.world.all_gather_rows(d_arx_loc, d_arx)
                 self.world.all_gather_rows(d_fit_loc, d_fit)
             arfit = d_fit.cpu().numpy()
+            if self.penalize:
+                # host: boundary weights from the raw fitness spread (:33-76); device: weighted squared excess (:79)
+                v = bweights.update(arfit, xmean, xold, sigma, diagC, mueff, it, P)
+                if v.any():
+                    d_v.copy_(t.from_numpy(np.ascontiguousarray(v)))
+                    _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd),
+                                                         ptr(d_v), ptr(d_fit_loc), ptr(d_pen_loc), sp),
+                               "sx_cmaes_eval_penalized")
+                    if self.world is not None:
+                        self.world.all_gather_rows(d_pen_loc, d_pen)
+                    arfit = arfit + d_pen.cpu().numpy()
             nfev += P
             if self.return_all:
                 if nout > 0:
-                    xall[it - 1] = unstd(d_arx[:nout].cpu().numpy())
+                    xall[it - 1] = seen(d_arx[:nout].cpu().numpy())
                     funall[it - 1] = arfit[:nout]
                 else:
                     k = int(arfit.argmin())
-                    xall[it - 1] = unstd(d_arx[k].cpu().numpy())
+                    xall[it - 1] = seen(d_arx[k].cpu().numpy())
                     funall[it - 1] = arfit[k]
             # ---- rank and recombine (cmaes/_cmaes.py:272-277) ----
             order = np.argsort(arfit)
@@ -266,11 +333,11 @@ class _CmaRun:
                     status = _stop_status(it, n, self.maxiter, xmean, xold, besthist, arfit, order, sigma, insigma,
                                           ilim, pc, self.xtol, self.ftol, diagC, B, D)
                     if self.callback is not None:
-                        res = OptimizeResult(x=unstd(d_arx[int(order[0])].cpu().numpy()), fun=arfit[order[0]],
+                        res = OptimizeResult(x=seen(d_arx[int(order[0])].cpu().numpy()), fun=arfit[order[0]],
                                              nfev=nfev, nit=it)
                         if self.return_all:
                             res.update({"xall": xall[:it], "funall": funall[:it]})
-                        self.callback(unstd(d_arx.cpu().numpy()), res)
+                        self.callback(seen(d_arx.cpu().numpy()), res)
                     if status is not None:
                         break
                     continue
@@ -289,15 +356,15 @@ class _CmaRun:
             status = _stop_status(it, n, self.maxiter, xmean, xold, besthist, arfit, order, sigma, insigma, ilim, pc,
                                   self.xtol, self.ftol, diagC, B, D)
             if self.callback is not None:
-                res = OptimizeResult(x=unstd(d_arx[int(order[0])].cpu().numpy()), fun=arfit[order[0]], nfev=nfev, nit=it)
+                res = OptimizeResult(x=seen(d_arx[int(order[0])].cpu().numpy()), fun=arfit[order[0]], nfev=nfev, nit=it)
                 if self.return_all:
                     res.update({"xall": xall[:it], "funall": funall[:it]})
-                self.callback(unstd(d_arx.cpu().numpy()), res)
+                self.callback(seen(d_arx.cpu().numpy()), res)
             if status is not None:
                 break
 
         res = OptimizeResult(
-            x=unstd(d_arx[int(order[0])].cpu().numpy()),
+            x=seen(d_arx[int(order[0])].cpu().numpy()),
             success=status >= 0,
             status=status,
             message=_common.messages[status],

@@ -110,7 +110,7 @@ def _minimize_and_save(rank, world, cfg, out_dir):
     n = cfg["n"]
     opts = dict(cfg["options"], backend="hip", workers=world)
     opts.setdefault("rng", "philox")
-    res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), [[-5.12, 5.12]] * n, method=cfg["method"],
+    res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), cfg.get("bounds", [[-5.12, 5.12]] * n), method=cfg["method"],
                                options=opts)
     np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
     np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))

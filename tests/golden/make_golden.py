@@ -308,8 +308,47 @@ def configs():
     print("wrote configs_pops.npz", os.path.getsize(os.path.join(HERE, "configs_pops.npz")))
 
 
+# --------------------------------------------------------------------------- #
+# 5. CMA-ES with constraints="Penalize" (stochopy/optimize/cmaes/_constraints.py:4-82): the reference's own
+#    test rows (tests/test_optimize.py:9-20) and boxes in which the penalty is actually at work
+# --------------------------------------------------------------------------- #
+def penalize():
+    out = dict(STAMP)
+    cases = []
+    arrays = {}
+
+    def add(tag, fun, n, opts, bounds=None, x0=None, xref=None):
+        o = dict(opts, constraints="Penalize", return_all=True)
+        entry, res, pops = run_ref(fun, n, "cmaes", o, x0=x0, bounds=bounds, full=True)
+        entry["tag"] = tag
+        if xref is not None:
+            entry["xref_from_reference_tests"] = xref
+            assert np.allclose(xref, res.x), (tag, xref, res.x)
+        arrays[tag + "__xall"] = res.xall
+        arrays[tag + "__funall"] = res.funall
+        cases.append(entry)
+        print(" ", tag, "fun", float(res.fun), "nit", res.nit, "status", res.status)
+
+    suite_opts = {"maxiter": 128, "popsize": 8, "seed": 42, "sigma": 0.1, "muperc": 0.5}
+    add("cmaes_penalize", "rosenbrock", 2, suite_opts, xref=[0.18765786, 0.05858025])
+    add("cmaes_penalize_x0", "rosenbrock", 2, suite_opts, x0=[-5.0, -5.0], xref=[0.99998135, 0.99995618])
+    # optimum outside / on the edge of the box: the mean leaves the box and the boundary weights grow
+    add("cmaes_penalize_rosen_n4_edge", "rosenbrock", 4, {"maxiter": 60, "popsize": 12, "seed": 3},
+        bounds=[[-5.12, 0.5]] * 4)
+    add("cmaes_penalize_sphere_n6_outside", "sphere", 6, {"maxiter": 80, "popsize": 10, "seed": 7, "sigma": 0.3},
+        bounds=[[1.0, 5.0]] * 6)
+    add("cmaes_penalize_rastrigin_n24_p48", "rastrigin", 24, {"maxiter": 40, "popsize": 48, "seed": 1, "sigma": 0.5},
+        bounds=[[-5.12, 2.0]] * 24)
+    out["cases"] = cases
+    dump("cmaes_penalize.json", out)
+    np.savez_compressed(os.path.join(HERE, "cmaes_penalize_xall.npz"), **arrays)
+    print("wrote cmaes_penalize_xall.npz", os.path.getsize(os.path.join(HERE, "cmaes_penalize_xall.npz")))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "factory", "suite", "configs"]
+    which = sys.argv[1:] or ["rng", "factory", "suite", "configs", "penalize"]
+    if "penalize" in which:
+        penalize()
     if "rng" in which:
         rng_stream()
     if "factory" in which:

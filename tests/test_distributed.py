@@ -178,6 +178,25 @@ def test_sharded_cmaes_matches_single_gpu(rng):
 
 
 @pytest.mark.gpu
+def test_sharded_cmaes_penalize_matches_single_gpu():
+    """The same with constraints="Penalize" and a box whose optimum lies outside: raw fitness, weights and the
+    penalty term are settled per generation across the shards (two extra all-gathers while weights are active)."""
+    import stochopy_amd as sa
+    from _dist_workers import gpu_minimize_worker
+
+    n = 6
+    bounds = [[1.0, 5.0]] * n
+    opts = {"maxiter": 60, "popsize": 12, "seed": 99, "sigma": 0.3, "constraints": "Penalize", "rng": "philox"}
+    cfg = {"n": n, "objective": "sphere", "method": "cmaes", "options": opts, "bounds": bounds}
+    one = sa.optimize.minimize(sa.factory.sphere, bounds, method="cmaes", options=dict(opts, backend="hip"))
+    out = _spawn(gpu_minimize_worker, 2, cfg)
+    for r in range(2):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (one.fun, one.nit, one.nfev, one.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), one.x)
+
+
+@pytest.mark.gpu
 def test_sharded_path_over_rccl_single_rank():
     """backend "nccl" (RCCL) with one rank: the device-side all_gather_into_tensor exchange used in production."""
     from _dist_workers import nccl_single_rank_worker

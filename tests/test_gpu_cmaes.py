@@ -143,6 +143,52 @@ def test_cmaes_reference_suite_xrefs(sa, tag):
     assert res.xall.shape[1:] == (8, 2)
 
 
+PENALIZE_CASES = load_golden("cmaes_penalize.json")["cases"]
+
+
+@pytest.mark.parametrize("case", PENALIZE_CASES, ids=lambda c: c["tag"])
+def test_cmaes_penalize_matches_reference_golden(sa, case):
+    """constraints="Penalize": clipping + objective + weighted squared excess on the device, boundary-weight
+    bookkeeping on the host.  The reference's per-generation best-f, its full history and its result within the
+    north-star tolerance (1e-6 rel); every visible point inside the box (reference tests/helpers.py:23-25)."""
+    import os
+
+    from conftest import GOLDEN
+
+    assert _eigenbasis_is_determined(case)
+    trace = []
+    opts = dict(case["options"], backend="hip", rng="numpy-legacy")
+    res = sa.optimize.minimize(getattr(sa.factory, case["objective"]), case_bounds(case), x0=case["x0"], method="cmaes",
+                               options=opts, callback=lambda X, r: trace.append(float(r.fun)))
+    ref = case["result"]
+    want = unhex(case["fun_trace"])
+    assert len(trace) == len(want) and np.allclose(trace, want, rtol=1e-6, atol=1e-300)
+    assert (res.nit, res.nfev, res.status, res.message) == (ref["nit"], ref["nfev"], ref["status"], ref["message"])
+    assert np.isclose(res.fun, unhex(ref["fun"]), rtol=1e-6, atol=0)
+    assert np.allclose(res.x, unhex(ref["x"]), rtol=1e-5, atol=1e-7)
+    arrays = np.load(os.path.join(GOLDEN, "cmaes_penalize_xall.npz"))
+    assert np.allclose(res.funall, arrays[case["tag"] + "__funall"], rtol=1e-6, atol=1e-300)
+    assert np.allclose(res.xall, arrays[case["tag"] + "__xall"], rtol=1e-5, atol=1e-6)
+    lo, hi = np.transpose(case_bounds(case))
+    assert np.all(res.xall + 1.0e-15 >= lo) and np.all(res.xall - 1.0e-15 <= hi)
+    if "xref_from_reference_tests" in case:
+        assert np.allclose(case["xref_from_reference_tests"], res.x)
+
+
+def test_cmaes_penalize_philox_and_sharded_eval_shapes(sa):
+    """Philox draws: hip == oracle within tolerance while the mean sits outside the box (weights active)."""
+    n, P = 6, 10
+    bounds = [[1.0, 5.0]] * n
+    opts = {"maxiter": 60, "popsize": P, "seed": 99, "sigma": 0.3, "constraints": "Penalize"}
+    t_ref, t_got = [], []
+    ref = oracle.minimize("sphere", bounds, method="cmaes", options=dict(opts), rng="philox",
+                          callback=lambda X, r: t_ref.append(r.fun))
+    got = sa.optimize.minimize(sa.factory.sphere, bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"),
+                               callback=lambda X, r: t_got.append(r.fun))
+    assert np.allclose(t_got, t_ref, rtol=1e-6) and got.nit == ref.nit and got.status == ref.status
+    assert np.all(got.x >= 1.0 - 1e-15) and np.allclose(got.x, ref.x, rtol=1e-5, atol=1e-7)
+
+
 def test_cmaes_philox_vs_oracle(sa):
     n, P = 20, 48  # mu + 1 >= n: the eigenbasis is determined (see _eigenbasis_is_determined)
     opts = {"maxiter": 12, "popsize": P, "seed": 4242, "sigma": 0.2}

@@ -85,6 +85,28 @@ def test_reference_suite_xrefs(case):
         assert np.all(res.xall + 1.0e-15 >= -5.12) and np.all(res.xall - 1.0e-15 <= 5.12)  # helpers.py:23-25
 
 
+PENALIZE = load_golden("cmaes_penalize.json")["cases"]
+
+
+@pytest.mark.parametrize("case", PENALIZE, ids=lambda c: c["tag"])
+def test_cmaes_penalize_bit_exact(case):
+    """constraints="Penalize" (cmaes/_constraints.py:4-82): the reference's own test rows
+    (tests/test_optimize.py:14-15) and boxes whose optimum lies on / outside the boundary."""
+    trace = []
+    res = _run(case, trace)
+    ref = case["result"]
+    assert np.array_equal(unhex(case["fun_trace"]), np.array([t[0] for t in trace]))
+    assert (res.nit, res.nfev, res.status, res.message) == (ref["nit"], ref["nfev"], ref["status"], ref["message"])
+    assert np.array_equal(unhex(ref["x"]), res.x) and float(res.fun).hex() == ref["fun"]
+    arrays = np.load(os.path.join(GOLDEN, "cmaes_penalize_xall.npz"))
+    assert np.array_equal(arrays[case["tag"] + "__xall"], res.xall)
+    assert np.array_equal(arrays[case["tag"] + "__funall"], res.funall)
+    lo, hi = np.transpose(case_bounds(case))
+    assert np.all(res.xall + 1.0e-15 >= lo) and np.all(res.xall - 1.0e-15 <= hi)  # tests/helpers.py:23-25
+    if "xref_from_reference_tests" in case:
+        assert np.allclose(case["xref_from_reference_tests"], res.x)
+
+
 def test_populations_bit_exact():
     arrays = np.load(os.path.join(GOLDEN, "configs_pops.npz"))
     by_tag = {c["tag"]: c for c in CONFIGS}
