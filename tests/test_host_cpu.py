@@ -202,6 +202,34 @@ def test_exchange_buffer_geometry(lib):
     assert lib.sx_xchg_probe(C.byref(x), 8, 1, None) != 0 and b"world / rank" in lib.sx_last_error()
 
 
+def test_penalize_host_bookkeeping_follows_the_oracle():
+    """The host half of constraints="Penalize" (stochopy_amd.optimize._cmaes._BoundaryWeights) against the
+    oracle's restatement (itself pinned to the reference) over a random walk of the mean in and out of the box:
+    identical boundary weights / history / flags, and the same penalised fitness."""
+    import oracle
+    from oracle import engine as oe
+    from stochopy_amd.optimize._cmaes import _BoundaryWeights
+
+    rs = np.random.RandomState(5)
+    n, P, mueff = 7, 12, 3.4
+    ref, got = oe.PenalizeState(n), _BoundaryWeights(n)
+    fun = oracle.OBJECTIVES["sphere"]
+    xold = np.zeros(n)
+    xmean = rs.uniform(-0.5, 0.5, n)
+    for it in range(1, 60):
+        sigma = 0.05 + 0.3 * rs.rand()
+        diagC = rs.uniform(0.2, 3.0, n)
+        arx = xmean + sigma * rs.randn(P, n) * np.sqrt(diagC)
+        fit_ref, valid = ref.apply(arx, xmean, xold, sigma, diagC, mueff, it, fun)
+        raw = fun(np.clip(arx, -1.0, 1.0))
+        v = got.update(raw, xmean, xold, sigma, diagC, mueff, it, P)
+        assert np.array_equal(got.weights, ref.weights) and np.array_equal(got.spreads, ref.dfithist)
+        assert (got.have_spread, got.initial_phase) == (ref.validfitval, ref.iniphase)
+        assert np.allclose(raw + ((np.clip(arx, -1.0, 1.0) - arx) ** 2) @ v, fit_ref, rtol=1e-13)
+        xold, xmean = xmean, xmean + rs.uniform(-0.4, 0.6, n) * (1.0 if it % 7 else -2.0)
+    assert ref.weights.max() > 0.0 and not ref.iniphase  # the walk did leave the box and weights did grow
+
+
 def test_api_surface_and_validation():
     """Signatures/defaults of the reference (de/_de.py:13-33 etc.) and its bare ValueError/TypeError validation."""
     import inspect
