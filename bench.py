@@ -113,7 +113,7 @@ def main():
     upper = np.full(n, 5.12)
     # weak scaling: every GPU owns P rows of a global population of world*P (same seed on every rank)
     run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, world * P, 0.5, 0.9, strategy, None, 0.0,
-                     -1.0, False, 1.0, None, "philox", 1234, world, autorun=False)
+                     -1.0, False, 1.0, None, "philox", 1234, world, autorun=False, donors=os.environ.get("SX_DONORS"))
     ctx = run.ctx
 
     def barrier():

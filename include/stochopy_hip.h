@@ -228,6 +228,12 @@ typedef struct sx_xchg_args {
                                      more than 128 elements are read from here after workgroup 0 has copied the
                                      winning record out of the uncached exchange buffer (once per generation,
                                      instead of once per wavefront) */
+    /* donors over the WHOLE population (exact reference semantics, de/_de.py:304-311, at the price of remote
+     * row reads over xGMI): global_rows = world * shard_rows > 0 and pop0/pop1[r] = rank r's two population
+     * buffers (sx_pop_alloc + sx_xchg_open).  global_rows = 0: donors are drawn inside the shard. */
+    const double *pop0[SX_MAX_PEERS];
+    const double *pop1[SX_MAX_PEERS];
+    int64_t global_rows, shard_rows;
 } sx_xchg_args;
 /* bytes of one exchange buffer for `world` ranks and rows of n doubles (includes the probe area) */
 int64_t sx_xchg_bytes(int world, int n);
@@ -235,6 +241,9 @@ int64_t sx_xchg_relay_bytes(int n);
 /* allocate + zero an exchange buffer on the current device and export it (handle: 64 bytes) */
 int sx_xchg_alloc(int64_t bytes, void **ptr, void *handle);
 int sx_xchg_free(void *ptr);
+/* ordinary device memory that peers can map (population buffers read remotely with global donors); release with
+ * sx_xchg_free, map / unmap with sx_xchg_open / sx_xchg_close */
+int sx_pop_alloc(int64_t bytes, void **ptr, void *handle);
 /* map a peer's buffer from the handle it exported / unmap it */
 int sx_xchg_open(const void *handle, void **ptr);
 int sx_xchg_close(void *ptr);

@@ -64,7 +64,8 @@ SX_IPC_HANDLE_BYTES = 64
 
 class SxXchgArgs(C.Structure):
     _fields_ = [("peer", vp * SX_MAX_PEERS), ("world", i32), ("rank", i32), ("timeout_ticks", i64), ("error", vp),
-                ("relay", vp)]
+                ("relay", vp), ("pop0", vp * SX_MAX_PEERS), ("pop1", vp * SX_MAX_PEERS), ("global_rows", i64),
+                ("shard_rows", i64)]
 
 
 # name -> (restype, argtypes); every symbol include/stochopy_hip.h declares
@@ -90,6 +91,7 @@ PROTOTYPES = {
     "sx_xchg_relay_bytes": (i64, [C.c_int]),
     "sx_xchg_alloc": (C.c_int, [i64, C.POINTER(vp), vp]),
     "sx_xchg_free": (C.c_int, [vp]),
+    "sx_pop_alloc": (C.c_int, [i64, C.POINTER(vp), vp]),
     "sx_xchg_open": (C.c_int, [vp, C.POINTER(vp)]),
     "sx_xchg_close": (C.c_int, [vp]),
     "sx_xchg_probe": (C.c_int, [C.POINTER(SxXchgArgs), C.c_int, C.c_int, vp]),

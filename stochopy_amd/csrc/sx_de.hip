@@ -310,8 +310,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
 
     int64_t d[kMaxDonors];
     int irand;
+    // P2P with global donors: drawn over the WHOLE population (global row ids), fetched from the owner's HBM
+    const bool gdon = P2P && x.global_rows > 0;
     if (RNG == SX_RNG_PHILOX) {
-        philox_donors(P, k, rowc, grow, gen, a.key0, a.key1, n, d, irand);
+        philox_donors(gdon ? x.global_rows : P, k, gdon ? a.row0 + rowc : rowc, grow, gen, a.key0, a.key1, n, d, irand);
     } else {
 #pragma unroll
         for (int t = 0; t < kMaxDonors; ++t) d[t] = t < k ? (int64_t)a.donors[(int64_t)t * P + rowc] : 0;
@@ -321,6 +323,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const double *pd[kMaxDonors];
 #pragma unroll
     for (int t = 0; t < kMaxDonors; ++t) pd[t] = cur + d[t] * ld;
+    if (gdon) {
+#pragma unroll
+        for (int t = 0; t < kMaxDonors; ++t) {
+            const int owner = (int)(d[t] / x.shard_rows);
+            const int64_t lrow = d[t] - (int64_t)owner * x.shard_rows;
+            const double *base = nullptr;
+#pragma unroll
+            for (int r = 0; r < SX_MAX_PEERS; ++r)  // select chain: the kernel-argument arrays stay in SGPRs
+                if (r == owner) base = (it & 1) ? x.pop1[r] : x.pop0[r];
+            pd[t] = base + lrow * ld;
+        }
+    }
     const double F = a.F, CR = a.CR;
     const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
     const double *rsrow = (RNG == SX_RNG_HOST && repair) ? a.resample + rowc * (int64_t)n : nullptr;
@@ -340,7 +354,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
             const bool in = FULL || e < n;
             bx[t] = in ? xi[e] : 0.0;
 #pragma unroll
-            for (int s = 0; s < kMaxDonors; ++s) bd[s][t] = (s < k && in) ? pd[s][e] : 0.0;
+            for (int s = 0; s < kMaxDonors; ++s) {
+                if (P2P && gdon)  // a peer's row of the previous generation: read past the caches (system scope)
+                    bd[s][t] = (s < k && in) ? __hip_atomic_load(pd[s] + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                             : 0.0;
+                else
+                    bd[s][t] = (s < k && in) ? pd[s][e] : 0.0;
+            }
             br[t] = 2.0;
             brs[t] = 0.0;
             if (RNG == SX_RNG_HOST && in) {
@@ -367,7 +387,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
             }
         }
     };
-    load_batch(0, B0);
+    // remote donor rows may only be read once their owners have finished the previous generation, which the
+    // arrival of every rank's record (stage C) proves: with global donors the first batch waits for that
+    if (!gdon) load_batch(0, B0);
 
     // ---- C. (CHAIN) best of the predecessor generation, status, publication
     int64_t gbidx = 0;
@@ -409,6 +431,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         }
         part_f_out = a.part_f + (int64_t)(1 - chain_p) * npart;
         part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
+        if (gdon) load_batch(0, B0);
     } else if (CHAIN) {
         double bf = pfv[0];
         rec_t br = piv[0];

@@ -92,6 +92,21 @@ extern "C" int sx_xchg_alloc(int64_t bytes, void **ptr, void *handle) {
     return 0;
 }
 
+extern "C" int sx_pop_alloc(int64_t bytes, void **ptr, void *handle) {
+    SX_REQUIRE(ptr != nullptr && handle != nullptr && bytes > 0, "sx_pop_alloc: bad arguments");
+    void *p = nullptr;
+    SX_HIP(hipMalloc(&p, (size_t)bytes));
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return hip_fail(e, "hipIpcGetMemHandle", __FILE__, __LINE__);
+    }
+    std::memcpy(handle, &h, sizeof h);
+    *ptr = p;
+    return 0;
+}
+
 extern "C" int sx_xchg_free(void *ptr) {
     if (ptr) SX_HIP(hipFree(ptr));
     return 0;

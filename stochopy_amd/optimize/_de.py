@@ -42,6 +42,7 @@ def minimize(
     callback=None,
     rng=None,
     exchange=None,
+    donors=None,
 ):
     """Minimize an objective function using Differential Evolution on MI355X.
 
@@ -54,6 +55,11 @@ def minimize(
     per-generation global best travels between GPUs: ``"p2p"`` (the generation kernel writes its shard's
     record straight into the peers' HBM over xGMI), ``"rccl"`` (one all-gather per generation) or ``None`` /
     ``"auto"`` (p2p if its self-test passes on every rank, else rccl); both give identical results.
+    ``donors`` (``workers > 1``): ``"shard"`` (default) draws the donor rows of an individual inside its own
+    GPU's shard -- an island model with a shared global best, no population traffic; ``"global"`` draws them over
+    the whole population like the reference does (de/_de.py:304-311) and reads them from their owners' HBM over
+    xGMI inside the generation kernel: the result of the unsharded run, at the price of remote row reads
+    (needs the peer exchange).
     """
     fun_id = _common.resolve_objective(fun, args)
     lower, upper = _common.as_bounds(bounds)
@@ -84,7 +90,7 @@ def minimize(
 
     run = _DeRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(mutation), float(recombination),
                  strategy, constraints, float(xtol), float(ftol), bool(return_all), float(verbosity), callback, rng,
-                 seed, workers, exchange=exchange)
+                 seed, workers, exchange=exchange, donors=donors)
     return run.result()
 
 
@@ -92,7 +98,7 @@ class _DeRun:
     GRAPH_CHUNK = 50
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, F, CR, strategy, constraints, xtol, ftol, return_all,
-                 verbosity, callback, rng, seed, workers, autorun=True, exchange=None):
+                 verbosity, callback, rng, seed, workers, autorun=True, exchange=None, donors=None):
         self.fun_id, self.lower, self.upper = fun_id, lower, upper
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.F, self.CR, self.strategy, self.constraints = F, CR, strategy, constraints
@@ -114,6 +120,9 @@ class _DeRun:
             self.row0, self.P = self.world.shard(P)  # this rank's rows; self.P is the LOCAL population from here on
             if self.P - 1 < self.k:
                 raise ValueError("shard too small for the strategy")
+        if donors not in (None, "shard", "global"):
+            raise ValueError('donors must be "shard" or "global"')
+        self.global_donors = donors == "global" and self.world is not None
         self.x0 = x0
         # single GPU + in-kernel draws + nothing to report per generation: one kernel per generation
         # ("chained finalize", include/stochopy_hip.h sx_de_chain_launch)
@@ -140,6 +149,9 @@ class _DeRun:
                     self.exchange, self.chain = "p2p", True
                 elif exchange == "p2p":
                     raise RuntimeError(f'exchange="p2p" is not available: {self.exchange_note}')
+            if self.global_donors and self.px is None:
+                raise RuntimeError('donors="global" needs the peer exchange (exchange="p2p"/"auto"): '
+                                   f'{self.exchange_note or "it was switched off"}')
         self._graph = None
         self._chain_graphs = {}
         self._shard_calls = None
@@ -165,6 +177,8 @@ class _DeRun:
         self._chain_graphs = {}
         if self.px is not None:
             self.ctx.sync()
+            if self.global_donors:
+                self.bufs = None  # views of the shared allocation that px.close() releases
             self.px.close()
             self.px = None
 
@@ -305,7 +319,11 @@ class _DeRun:
         if self.world is not None:  # every rank builds the same global population and keeps its rows
             X0 = np.ascontiguousarray(X0[self.row0 : self.row0 + P])
         # generation g lives in bufs[g & 1]; the initial population is generation 1
-        self.bufs = [ctx.empty((P, n)), ctx.upload(X0)]
+        if self.global_donors:  # buffers every peer maps: donor rows are read from their owners over xGMI
+            self.bufs = list(self.px.share_population(P, n))
+            self.bufs[1].copy_(ctx.upload(X0))
+        else:
+            self.bufs = [ctx.empty((P, n)), ctx.upload(X0)]
         self.fit = ctx.empty((P,))
         self.candfit = ctx.empty((P,))
         self.d_lower = ctx.upload(self.lower)

@@ -116,6 +116,8 @@ class PeerExchange:
         self.opened = []
         self.args = None
         self.error = None
+        self.pop_own = None
+        self.pop_opened = []
 
     @classmethod
     def negotiate(cls, ctx, world, n, timeout_s=20.0, probe_rounds=8, probe_timeout_s=3.0):
@@ -175,6 +177,55 @@ class PeerExchange:
         px.args = a
         return px, None
 
+    def share_population(self, rows, n):
+        """Global donors: this rank's two population buffers (rows, n) in memory every peer maps, so that the
+        generation kernels can read donor rows from their owners over xGMI.  Returns the two tensors (views of
+        one IPC-exported allocation).  Collective; raises on every rank if any rank fails."""
+        import ctypes as C
+
+        from . import _lib
+
+        L, world, ctx = self.ctx.L, self.world, self.ctx
+        t = __import__("torch")
+        nbytes = 2 * rows * n * 8
+        own = C.c_void_p()
+        hbuf = C.create_string_buffer(_lib.SX_IPC_HANDLE_BYTES)
+        ok = L.sx_pop_alloc(nbytes, C.byref(own), hbuf) == 0
+        why = None if ok else "alloc: " + L.sx_last_error().decode()
+        handles = world.all_gather_object(hbuf.raw if ok else None)
+        if any(h is None for h in handles):
+            if ok:
+                L.sx_xchg_free(own)
+            raise RuntimeError(f'donors="global" is not available: {why or "a peer could not export its population"}')
+        self.pop_own = own
+        bases = []
+        for r, h in enumerate(handles):
+            if r == world.rank:
+                bases.append(own.value)
+                continue
+            p = C.c_void_p()
+            if L.sx_xchg_open(h, C.byref(p)) != 0:
+                ok, why = False, "open: " + L.sx_last_error().decode()
+                break
+            self.pop_opened.append(p)
+            bases.append(p.value)
+        if not world.all_agree(ok):
+            raise RuntimeError(f'donors="global" is not available: {why or "a peer could not map this population"}')
+        a = self.args
+        for r, b in enumerate(bases):
+            a.pop0[r] = b
+            a.pop1[r] = b + rows * n * 8
+        a.shard_rows = rows
+        a.global_rows = rows * world.size
+
+        class _Mem:  # zero-copy view of the exported allocation for torch
+            __cuda_array_interface__ = {"shape": (2, rows, n), "typestr": "<f8", "data": (own.value, False),
+                                        "version": 2, "strides": None}
+
+        self._pop_holder = _Mem()
+        both = t.as_tensor(self._pop_holder, device=ctx.device)
+        return both[0], both[1]
+
     def failed(self):
         """True if a wait inside a kernel timed out (synchronises)."""
         self.ctx.sync()
@@ -200,6 +251,12 @@ class PeerExchange:
         if self.own is not None:
             L.sx_xchg_free(self.own)
             self.own = None
+        for p in self.pop_opened:
+            L.sx_xchg_close(p)
+        self.pop_opened = []
+        if self.pop_own is not None:  # the tensors handed out by share_population die with it
+            L.sx_xchg_free(self.pop_own)
+            self.pop_own = None
         self.args = None
 
 

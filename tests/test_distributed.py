@@ -116,6 +116,32 @@ def test_p2p_exchange_cases(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,case", [
+    (2, dict(n=24, P=128, gens=30, seed=77)),
+    (4, dict(n=24, P=128, gens=30, seed=77)),
+    (2, dict(n=13, P=40, gens=20, seed=3, strategy="rand2bin", constraints="Random")),   # 5 donors, two Philox calls
+    (2, dict(n=300, P=48, gens=12, seed=4, strategy="rand1bin")),                         # whole-wave rows
+    (4, dict(n=128, P=256, gens=60, seed=5)),                                             # bounds-test-free kernel
+])
+def test_global_donors_reproduce_the_unsharded_run(world, case):
+    """donors="global": donor rows are drawn over the whole population and read from their owners' HBM
+    (IPC-mapped population buffers) inside the generation kernel -- the sharded run IS the unsharded run."""
+    from _dist_workers import gpu_minimize_worker
+
+    case = dict(case)
+    n, P, gens, seed = case.pop("n"), case.pop("P"), case.pop("gens"), case.pop("seed")
+    cfg = _de_cfg(n, P, gens, seed, "p2p", donors="global", **case)
+    out = _spawn(gpu_minimize_worker, world, cfg)
+    opts = {k: v for k, v in cfg["options"].items() if k not in ("exchange", "donors")}
+    ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method="de", options=dict(opts, updating="deferred"),
+                          rng="philox")
+    for r in range(world):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+
+
+@pytest.mark.gpu
 def test_p2p_exchange_timeout_is_reported():
     """A rank that never shows up: the others give up after the timeout and raise (no hang)."""
     from _dist_workers import gpu_p2p_straggler_worker
