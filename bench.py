@@ -189,6 +189,8 @@ def main():
                              "(tagged (n+2)-double record per rank)" if run.exchange == "p2p" else
                              "global best per generation (RCCL all_gather of an (n+2)-double record)"),
                 "exchange_note": getattr(run, "exchange_note", None),
+                "donors": (None if run.world is None else "global (rows read from their owners over xGMI)"
+                           if run.global_donors else "shard-local (island model with a shared global best)"),
             },
             "roofline": {
                 "bound": "hbm",
