@@ -293,7 +293,7 @@ int sx_pso_generation(const sx_pso_args *a, int finalize, void *stream);
 /* Competitive restart, cpso/_cpso.py:405-426.
  * sx_pso_radius: part_r[b] = max over the rows of workgroup b of ||X_i - gbest||_2 (:410)
  *   part_r DEVICE (sx_num_partials(P,n)).
- * sx_pso_restart_select (one workgroup, P <= 32768): radius = max(part_r)/sqrt(4n); if
+ * sx_pso_restart_select (one workgroup; keys in registers up to 32768 particles, re-read from L2 above): radius = max(part_r)/sqrt(4n); if
  *   radius < delta: nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09))) and the nw-th largest
  *   pbestfit (radix descent).  out3 DEVICE uint64[3] = {nw, threshold key, radius bits}.
  * sx_pso_restart_apply: rows with pbestfit among the nw worst get V=0, X=uniform(lower,upper),
@@ -308,7 +308,7 @@ int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, const int64
 /* Sharded swarm (one process per GPU, a->P rows each): the same selection over the WHOLE swarm.
  * gathered DEVICE (world, a->P + sx_num_partials(a->P, n)): row r = rank r's [pbestfit | part_r] after one
  * all-gather per generation (the allreduce(max) of the radius and the fitness all-gather of SURVEY.md
- * section 8e in one message).  Every rank computes the same {nw, threshold, radius}; world * a->P <= 32768. */
+ * section 8e in one message).  Every rank computes the same {nw, threshold, radius}. */
 int sx_pso_restart_select_gathered(const sx_pso_args *a, const double *gathered, int world, double delta,
                                    double gamma, uint64_t *out3, void *stream);
 /* hipGraph of `ngen` generations of the cpso loop body (cpso/_cpso.py:257-307), single GPU + SX_RNG_PHILOX:

@@ -203,7 +203,7 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
 }
 
 constexpr int kSelThreads = 1024;
-constexpr int kSelPerThread = 32;  // P <= 32768 per GPU for the on-device worst-nw selection
+constexpr int kSelPerThread = 32;  // keys held in registers up to 32768 particles (larger swarms re-read them each pass)
 
 // One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
 // and the nw-th largest pbestfit is found by an 8-step (one byte per step) radix descent over keys held in registers.
@@ -244,11 +244,13 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         out[2] = (unsigned long long)__double_as_longlong(radius);
     }
     if (nw <= 0) return;  // uniform
+    // up to 32768 particles the keys stay in registers for the 8 passes; larger swarms re-read them (L2)
+    const bool in_regs = Ptot <= (int64_t)kSelThreads * kSelPerThread;
     unsigned long long key[kSelPerThread];
 #pragma unroll
     for (int k = 0; k < kSelPerThread; ++k) {
         const int64_t i = (int64_t)k * kSelThreads + tid;
-        key[k] = i < Ptot ? sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]) : 0ull;  // 0 < every real key
+        key[k] = (in_regs && i < Ptot) ? sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]) : 0ull;  // 0 < real keys
     }
     // radix descent, 8 bits per step: histogram (LDS atomics) of the next byte over the keys that match the
     // prefix found so far; the byte of the `remaining`-th largest of them is where the suffix count crosses it
@@ -260,10 +262,26 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         if (tid < 256) bins[tid] = 0u;
         __syncthreads();
         const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        if (in_regs) {
 #pragma unroll
-        for (int k = 0; k < kSelPerThread; ++k) {
-            const int64_t i = (int64_t)k * kSelThreads + tid;
-            if (i < Ptot && (key[k] & himask) == prefix) atomicAdd(&bins[(unsigned)(key[k] >> shift) & 255u], 1u);
+            for (int k = 0; k < kSelPerThread; ++k) {
+                const int64_t i = (int64_t)k * kSelThreads + tid;
+                if (i < Ptot && (key[k] & himask) == prefix) atomicAdd(&bins[(unsigned)(key[k] >> shift) & 255u], 1u);
+            }
+        } else {
+            for (int64_t i0 = tid; i0 < Ptot; i0 += (int64_t)kSelThreads * 8) {
+                unsigned long long kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kSelThreads;
+                    kk[u] = i < Ptot ? sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]) : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kSelThreads;
+                    if (i < Ptot && (kk[u] & himask) == prefix) atomicAdd(&bins[(unsigned)(kk[u] >> shift) & 255u], 1u);
+                }
+            }
         }
         __syncthreads();
         if (tid < kWave) {  // wave 0: lane l owns bins 4l..4l+3; suffix sums locate the crossing byte
@@ -367,7 +385,6 @@ extern "C" int sx_pso_restart_select(const sx_pso_args *a, const double *part_r,
                                      uint64_t *out3, void *stream) {
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(part_r && out3, "sx_pso_restart_select: null pointer");
-    SX_REQUIRE(a->P <= (int64_t)kSelThreads * kSelPerThread, "sx_pso_restart_select: P > 32768 per GPU (select on the host instead)");
     const Geometry g = geometry(a->P, a->n);
     hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a,
                        (const double *)a->pbestfit, part_r, 1, a->P, (int64_t)g.blocks, a->P, delta, gamma,
@@ -382,8 +399,6 @@ extern "C" int sx_pso_restart_select_gathered(const sx_pso_args *a, const double
                                               double gamma, uint64_t *out3, void *stream) {
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(gathered && out3 && world >= 1, "sx_pso_restart_select_gathered: bad arguments");
-    SX_REQUIRE(a->P * world <= (int64_t)kSelThreads * kSelPerThread,
-               "sx_pso_restart_select_gathered: more than 32768 particles in total");
     const int64_t npart = (int64_t)geometry(a->P, a->n).blocks;
     hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a, gathered,
                        gathered + a->P, world, a->P, npart, a->P + npart, delta, gamma, (unsigned long long *)out3);
@@ -445,8 +460,6 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     SX_REQUIRE(out != nullptr && ngen >= 1, "sx_pso_graph_create: bad arguments");
     SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_pso_graph_create: graphs need in-kernel (Philox) draws");
     SX_REQUIRE((part_r == nullptr) == (sel3 == nullptr), "sx_pso_graph_create: restart needs part_r AND sel3");
-    SX_REQUIRE(part_r == nullptr || a->P <= (int64_t)kSelThreads * kSelPerThread,
-               "sx_pso_graph_create: P > 32768 (restart selection)");
     SX_REQUIRE(part_r == nullptr || (a->lower && a->upper), "sx_pso_graph_create: bounds missing");
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;

@@ -106,9 +106,6 @@ class _PsoRun:
                 raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
             if callback is not None or return_all:
                 raise NotImplementedError("callback / return_all are not available with workers > 1")
-            if gamma and P > 32768:
-                raise NotImplementedError("competitive restart with workers > 1: at most 32768 particles in total "
-                                          "(the worst-nw selection runs in one workgroup over the gathered fitness)")
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
         self.x0 = x0
         self.ctx = _device.Context()
@@ -347,7 +344,7 @@ class _PsoRun:
         """Enqueue `ngen` generations (and their restarts) without host synchronisation (Philox mode).
         Single GPU: full chunks replay one instantiated hipGraph of the loop body."""
         ctx = self.ctx
-        if self.world is None and (not self.gamma or self.P <= 32768):
+        if self.world is None:
             while ngen >= self.GRAPH_CHUNK:
                 if self._graph is None:
                     g = C.c_void_p()

@@ -93,6 +93,18 @@ def test_pso_philox_matches_oracle(sa, method, constraints, shape):
     assert np.array_equal(r_ref.x, r_got.x) and r_ref.nit == r_got.nit and r_ref.status == r_got.status
 
 
+def test_cpso_restart_selection_above_32768_particles(sa):
+    """The one-workgroup radix selection keeps its keys in registers up to 32768 particles and re-reads them per
+    pass above that: a swarm of 40000 whose restarts fire every generation must still follow the oracle."""
+    n, P = 8, 40000
+    opts = {"maxiter": 6, "popsize": P, "seed": 13, "updating": "deferred"}
+    bounds = [[-5.12, 5.12]] * n
+    ref = oracle.minimize("sphere", bounds, method="cpso", options=dict(opts), rng="philox")
+    assert len(ref["_restarts"]) >= 3
+    got = sa.optimize.minimize(sa.factory.sphere, bounds, method="cpso", options=dict(opts, backend="hip", rng="philox"))
+    assert got.fun == ref.fun and np.array_equal(got.x, ref.x) and got.nit == ref.nit
+
+
 def test_cpso_philox_restarts_fire_and_match_oracle(sa):
     """Ackley n16 P256: restarts fire; device selection must reset the same rows."""
     n, P = 16, 256
