@@ -84,7 +84,7 @@ int64_t sx_fun_terms(int fun_id, int n);
  *           given (x -> x*xstd + xm before the objective).
  * X DEVICE (P,ldx); f DEVICE (P); xm/xstd DEVICE (n) or NULL.
  * part_f/part_i DEVICE (sx_num_partials(P,n)) or NULL: per-workgroup (min f, first row)
- * records for sx_select_finalize.  16, 32 or 64 lanes evaluate one individual; n <= 2560.
+ * records for sx_select_finalize.  16, 32 or 64 lanes evaluate one individual; n <= 4096.
  * ------------------------------------------------------------------------- */
 int64_t sx_num_partials(int64_t P, int n);
 int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd,

@@ -102,7 +102,7 @@ extern "C" int64_t sx_num_partials(int64_t P, int n) { return (int64_t)row_geome
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out) {
     if (n > kMaxDim) {
-        set_error("dimension above the LDS staging limit (n <= 2560)");
+        set_error("dimension above the kernel limit (n <= 4096)");
         return -1;
     }
     const int64_t m = sx_fun_terms(fun_id, n);

@@ -23,8 +23,8 @@ constexpr int kGroup = 8;     // numpy's 8 running accumulators
 constexpr int kWave = 64;     // gfx950 wavefront = one individual
 constexpr int kMaxRowsPerBlock = 16;
 constexpr int kMaxWavesPerBlock = 8;
-constexpr int kMaxLeaf = 48;  // leaves carried in kernel arguments (n <= kMaxDim has at most 40)
-constexpr int kMaxDim = 2560; // leaf table (kMaxLeaf) and LDS staging (<= 64 KiB per workgroup) are sized for this
+constexpr int kMaxLeaf = 64;  // leaves carried in kernel arguments; also one lane per leaf in the merge (<= 64)
+constexpr int kMaxDim = 4096; // leaves hold > 64 terms, so n <= 4096 has at most 64; LDS: n+8+2(n/64+2) doubles per row
 
 // Rows of more than 256 elements form their objective terms inside the reduction (row_reduce_leaves_fused:
 // one leaf of <= 128 terms per 8-lane group, so >= 3 of the 8 groups are busy); shorter rows have too few

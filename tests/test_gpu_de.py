@@ -20,7 +20,8 @@ def sa():
     return stochopy_amd
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 13, 16, 17, 64, 127, 128, 129, 130, 255, 256, 257, 1000, 1023, 1024, 1025, 2049])
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 13, 16, 17, 64, 127, 128, 129, 130, 255, 256, 257, 1000, 1023, 1024, 1025, 2049, 3071, 4095,
+                               4096])
 @pytest.mark.parametrize("name", sorted(OBJECTIVES))
 def test_objectives_vs_oracle(sa, name, n):
     rs = np.random.RandomState(n * 7 + 1)

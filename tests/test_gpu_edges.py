@@ -104,7 +104,8 @@ def test_early_termination_statuses_match_oracle_in_philox_mode(sa):
             assert got.status == want
 
 
-@pytest.mark.parametrize("n,P", [(1, 8), (2, 6), (65, 33), (129, 70), (257, 40), (1000, 24), (2560, 12)])
+@pytest.mark.parametrize("n,P", [(1, 8), (2, 6), (65, 33), (129, 70), (257, 40), (1000, 24), (2560, 12), (4095, 9),
+                                 (4096, 10)])
 def test_ragged_shapes_philox_de_and_pso(sa, n, P):
     b = [[-3.0, 3.0]] * n
     for method in ("de", "pso"):
@@ -157,7 +158,7 @@ def test_dimension_limit_is_loud(sa):
     from stochopy_amd._lib import HipLibraryError
 
     with pytest.raises(HipLibraryError):
-        sa.optimize.minimize(sa.factory.sphere, [[-1.0, 1.0]] * 2561, method="de", options={"maxiter": 2, "popsize": 8, "seed": 0})
+        sa.optimize.minimize(sa.factory.sphere, [[-1.0, 1.0]] * 4097, method="de", options={"maxiter": 2, "popsize": 8, "seed": 0})
 
 
 def test_result_surface(sa):
