@@ -350,6 +350,12 @@ int sx_symmetrize_upper(double *C, int n, void *stream);
  * f_raw DEVICE (P) = fun(unstandardise(clip(X))); pen DEVICE (P) = sum_j (clip(x_ij) - x_ij)^2 v_j (NULL with v). */
 int sx_cmaes_eval_penalized(int fun_id, const double *X, int64_t P, int n, const double *xm, const double *xstd,
                             const double *v, double *f_raw, double *pen, void *stream);
+/* VD-CMA sampling, vdcma/_vdcma.py:236-248: for candidates row0 .. row0+P-1 of the generation
+ *   ary[i] = dvec o (Z[i] + coef * (Z[i] . vn) * vn)   (coef = sqrt(1 + |v|^2) - 1),   arx[i] = xmean + sigma * ary[i];
+ * dy != NULL: global rows 0 and 1 become +dy / -dy (mean-shift injection, :241-247).
+ * Z, ary, arx DEVICE (P,n); dvec, vn, xmean, dy DEVICE (n).  One wavefront per candidate, O(n). */
+int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, const double *dvec, const double *vn, double coef,
+                    const double *xmean, double sigma, const double *dy, double *ary, double *arx, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * numpy-legacy random stream (host): bit-exact MT19937 replica of what the

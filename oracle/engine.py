@@ -293,11 +293,11 @@ def cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, ins
         return 0
     if fb <= ftol:
         return 1
-    if (np.abs(0.1 * sigma * B[:, i] * D[i]) < 1.0e-10).all():
+    if B is not None and (np.abs(0.1 * sigma * B[:, i] * D[i]) < 1.0e-10).all():
         return -2
     if (0.2 * sigma * sq < 1.0e-10).any():
         return -3
-    if D.max() > 1.0e7 * D.min():
+    if D is not None and D.max() > 1.0e7 * D.min():
         return -4
     if it >= ilim:
         win = bestfit_hist[it - ilim : it + 1]
@@ -440,6 +440,143 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
     return _final(unstd(arxvalid[order[0]]), arfit[order[0]], status, nfev, it, hist)
 
 
+def vd_moments(vn, norm_v2, y, w=None):
+    """vdcma/_vdcma.py:428-444: the (weighted) first-order statistics p, q of y under the model D(I + vv^T)D."""
+    t = np.dot(y, vn)
+    shrink = norm_v2 / (1.0 + norm_v2)
+    if w is None:
+        p = y**2 - shrink * (t * y * vn) - 1.0
+        q = t * y - (0.5 * (t**2 + 1.0 + norm_v2)) * vn
+        return p, q
+    p = np.dot(w, y**2 - shrink * (t * (y * vn).T).T - 1.0)
+    q = np.dot(w, (t * y.T).T - np.outer(0.5 * (t**2 + 1.0 + norm_v2), vn))
+    return p, q
+
+
+def vd_natural_gradient(dvec, vn, vnn, norm_v, norm_v2, alpha, avec, bsca, invavnn, p, q):
+    """vdcma/_vdcma.py:447-460: natural-gradient steps for v and d from the moments."""
+    r = p - alpha / (1.0 + norm_v2) * ((2.0 + norm_v2) * q * vn - norm_v2 * np.dot(vn, q) * vnn)
+    s = r / avec - bsca * np.dot(r, invavnn) / (1.0 + bsca * np.dot(vnn, invavnn)) * invavnn
+    ngv = q / norm_v - alpha / norm_v * ((2.0 + norm_v2) * (vn * s) - np.dot(s, vnn) * vn)
+    return ngv, dvec * s
+
+
+def run_vdcma(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, sigma=0.1, muperc=0.5,
+              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, **_ignored):
+    """VD-CMA (vdcma/_vdcma.py:144-425): covariance model D (I + v v^T) D, O(n) per sample."""
+    if constraints not in (None, "Penalize"):
+        raise KeyError(constraints)
+    n = len(lower)
+    P = popsize
+    pen = PenalizeState(n) if constraints == "Penalize" else None
+    xm = 0.5 * (upper + lower)
+    xstd = 0.5 * (upper - lower)
+    unstd = lambda x: x * xstd + xm  # noqa: E731
+    xmean = stream.cma_initial_mean(n) if x0 is None else (np.asarray(x0, dtype=np.float64) - xm) / xstd
+    xold = np.empty(n)
+    mu = int(muperc * P)
+    w = np.log(mu + 0.5) - np.log(np.arange(1, mu + 1))
+    w /= w.sum()
+    mueff = w.sum() ** 2 / np.square(w).sum()
+    cc = (4.0 + mueff / n) / (n + 4.0 + 2.0 * mueff / n)           # :193-199
+    cfactor = (n - 5.0) / 6.0
+    c1 = cfactor * 2.0 / ((n + 1.3) ** 2 + mueff)
+    cmu = min(1.0 - c1, cfactor * 2.0 * (mueff - 2.0 + 1.0 / mueff) / ((n + 2.0) ** 2 + mueff))
+    inject = False                                                 # :202-213
+    cs, ds = 0.3, np.sqrt(n)
+    dx = np.zeros(n)
+    ps = 0.0
+    dvec = np.ones(n)
+    vvec = stream.vd_initial_direction(n) / np.sqrt(n)
+    norm_v2 = np.dot(vvec, vvec)
+    norm_v = np.sqrt(norm_v2)
+    vn = vvec / norm_v
+    vnn = vn**2
+    pc = np.zeros(n)
+    hist = History(return_all, maxiter, P, n, verbosity)
+    nfev = 0
+    bestfit_hist = np.zeros(maxiter)
+    ilim = int(10 + 30 * n / P)
+    insigma = sigma
+    it = 0
+    while True:
+        it += 1
+        arz = stream.cma_normals(it, P, n)                          # :236-247
+        ary = dvec * (arz + (np.sqrt(1.0 + norm_v2) - 1.0) * np.outer(np.dot(arz, vn), vn))
+        if inject:
+            ddx = dx / dvec
+            mnorm = (ddx**2).sum() - np.dot(ddx, vvec) ** 2 / (1.0 + norm_v2)
+            dy = np.linalg.norm(stream.vd_injection_normals(it, P, n)) / np.sqrt(mnorm) * dx
+            ary[0] = dy
+            ary[1] = -dy
+        arx = xmean + sigma * ary
+        diagC = np.diag(np.dot(np.dot(np.diag(dvec), np.eye(n) + np.outer(vvec, vvec)), np.diag(dvec)))  # :249-254
+        arxvalid = arx
+        if pen is None:
+            arfit = fobj(unstd(arx))
+        else:
+            arfit, arxvalid = pen.apply(arx, xmean, xold, sigma, diagC, mueff, it, lambda x: fobj(unstd(x)))
+        nfev += P
+        hist.put(it - 1, unstd(arxvalid), arfit)
+        order = np.argsort(arfit)                                   # :289-295
+        dx = np.dot(w, arx[order[:mu]]) - w.sum() * xmean
+        xold = xmean.copy()
+        xmean = xmean + dx
+        bestfit_hist[it - 1] = arfit[order[0]]
+        if inject:                                                  # :298-306
+            rank_gap = np.where(order == 1)[0][0] - np.where(order == 0)[0][0]
+            rank_gap = rank_gap / (P - 1.0)
+            ps += cs * (rank_gap - ps)
+            sigma *= np.exp(ps / ds)
+            cond = ps < 0.5
+        else:
+            inject = True
+            cond = True
+        pc *= 1.0 - cc                                              # :309-314
+        pc += np.sqrt(cc * (2.0 - cc) * mueff) * np.dot(w, ary[order[:mu]]) if cond else 0.0
+        gamma = 1.0 / np.sqrt(1.0 + norm_v2)                        # :317-328
+        alpha = np.sqrt(norm_v2**2 + (1.0 + norm_v2) / vnn.max() * (2.0 - gamma)) / (2.0 + norm_v2)
+        if alpha < 1.0:
+            beta = (4.0 - (2.0 - gamma) / vnn.max()) / (1.0 + 2.0 / norm_v2) ** 2
+        else:
+            alpha, beta = 1.0, 0.0
+        bsca = 2.0 * alpha**2 - beta
+        avec = 2.0 - (bsca + 2.0 * alpha**2) * vnn
+        invavnn = vnn / avec
+        if cmu == 0.0:                                              # :331-345
+            p_mu, q_mu = np.zeros(n), np.zeros(n)
+        else:
+            p_mu, q_mu = vd_moments(vn, norm_v2, ary[order[:mu]] / dvec, w)
+        if c1 == 0.0:
+            p_one, q_one = np.zeros(n), np.zeros(n)
+        else:
+            p_one, q_one = vd_moments(vn, norm_v2, pc / dvec)
+        p = cmu * p_mu                                              # :348-352
+        q = cmu * q_mu
+        if cond:
+            p += c1 * p_one
+            q += c1 * q_one
+        if cmu + c1 > 0.0:                                          # :355-368
+            ngv, ngd = vd_natural_gradient(dvec, vn, vnn, norm_v, norm_v2, alpha, avec, bsca, invavnn, p, q)
+            up = min(1.0, 0.7 * norm_v / np.sqrt(np.dot(ngv, ngv)))
+            up = min(up, 0.7 * (dvec / np.abs(ngd)).min())
+        else:
+            ngv, ngd, up = np.zeros(n), np.zeros(n), 1.0
+        vvec = vvec + up * ngv                                      # :371-378
+        dvec = dvec + up * ngd
+        norm_v2 = np.dot(vvec, vvec)
+        norm_v = np.sqrt(norm_v2)
+        vn = vvec / norm_v
+        vnn = vn**2
+        status = cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, insigma, ilim, pc,
+                          xtol, ftol, diagC, None, None)
+        if callback is not None:
+            callback(unstd(arxvalid), Result(x=unstd(arxvalid[order[0]]), fun=arfit[order[0]], nfev=nfev, nit=it))
+        if status is not None:
+            break
+    return _final(unstd(arxvalid[order[0]]), arfit[order[0]], status, nfev, it, hist)
+
+
 def run_de_sharded(fobj, lower, upper, stream, world, maxiter=100, popsize=10, mutation=0.5, recombination=0.9,
                    strategy="best1bin", xtol=1e-8, ftol=1e-8, constraints=None, **_ignored):
     """The multi-GPU semantics of the build (NOT a reference algorithm):
@@ -472,7 +609,7 @@ def run_de_sharded(fobj, lower, upper, stream, world, maxiter=100, popsize=10, m
     return res
 
 
-RUNNERS = {"de": run_de, "pso": run_pso, "cpso": run_pso, "cmaes": run_cmaes}
+RUNNERS = {"de": run_de, "pso": run_pso, "cpso": run_pso, "cmaes": run_cmaes, "vdcma": run_vdcma}
 
 
 def minimize(objective, bounds, x0=None, method="de", options=None, callback=None, rng="numpy-legacy"):

@@ -111,6 +111,14 @@ class LegacyStream:
     def cma_normals(self, gen, P, n, row0=0):
         return np.array([self.rs.randn(n) for _ in range(P)])
 
+    def vd_initial_direction(self, n):
+        """vdcma/_vdcma.py:208: np.random.normal(0, 1, n) right after the initial mean."""
+        return self.rs.normal(0.0, 1.0, n)
+
+    def vd_injection_normals(self, gen, P, n):
+        """vdcma/_vdcma.py:245: one more randn(n) per generation once injection is on, after the P x n block."""
+        return self.rs.randn(n)
+
 
 class PhiloxStream:
     """Counter-based draws, identical to the HIP kernels' device generator.
@@ -140,6 +148,13 @@ class PhiloxStream:
 
     def cma_initial_mean(self, n):
         return self.init.cma_initial_mean(n)
+
+    def vd_initial_direction(self, n):
+        return self.init.vd_initial_direction(n)
+
+    def vd_injection_normals(self, gen, P, n):
+        """The injection draw is "row P" of the generation's normals (one row past the population)."""
+        return self.cma_normals(gen, 1, n, row0=P)[0]
 
     @staticmethod
     def lanes_per_row(n):

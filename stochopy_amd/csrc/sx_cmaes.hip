@@ -330,3 +330,46 @@ extern "C" int sx_symmetrize_upper(double *C, int n, void *stream) {
     SX_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// VD-CMA sampling (stochopy/optimize/vdcma/_vdcma.py:236-248): with the covariance model D (I + v v^T) D a
+// candidate costs O(n):  y = d o (z + (sqrt(1 + |v|^2) - 1) (z . vn) vn),  x = xmean + sigma * y.
+// One wavefront per candidate; rows 0 and 1 of the generation are replaced by +dy / -dy when the mean-shift
+// injection is on (:241-247).  Both y (needed by the host's moment sums) and x are written.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void vd_sample_kernel(const double *__restrict__ Z, int64_t P, int n, int64_t row0,
+                                                        const double *__restrict__ dvec, const double *__restrict__ vn,
+                                                        double coef, const double *__restrict__ xmean, double sigma,
+                                                        const double *__restrict__ dy, double *__restrict__ ary,
+                                                        double *__restrict__ arx) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= P) return;
+    const double *z = Z + row * (int64_t)n;
+    double t = 0.0;
+    for (int e = lane; e < n; e += kWave) t += z[e] * vn[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+    const int64_t grow = row0 + row;
+    const bool inj = dy != nullptr && grow < 2;
+    const double sgn = grow == 0 ? 1.0 : -1.0;
+    for (int e = lane; e < n; e += kWave) {
+        const double y = inj ? sgn * dy[e] : dvec[e] * (z[e] + coef * (t * vn[e]));
+        ary[row * (int64_t)n + e] = y;
+        arx[row * (int64_t)n + e] = xmean[e] + sigma * y;
+    }
+}
+}  // namespace
+
+extern "C" int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, const double *dvec, const double *vn,
+                               double coef, const double *xmean, double sigma, const double *dy, double *ary,
+                               double *arx, void *stream) {
+    SX_REQUIRE(Z && dvec && vn && xmean && ary && arx && P >= 1 && n >= 1 && row0 >= 0, "sx_vdcma_sample: bad arguments");
+    const int rows_per_block = 4;
+    hipLaunchKernelGGL(vd_sample_kernel, dim3((unsigned)((P + rows_per_block - 1) / rows_per_block)),
+                       dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, row0, dvec, vn, coef, xmean, sigma,
+                       dy, ary, arx);
+    SX_LAUNCH_CHECK();
+    return 0;
+}

@@ -5,5 +5,6 @@ from ._cmaes import minimize as cmaes
 from ._cpso import minimize as cpso
 from ._de import minimize as de
 from ._pso import minimize as pso
+from ._vdcma import minimize as vdcma
 
-__all__ = ["OptimizeResult", "minimize", "register", "cmaes", "cpso", "de", "pso"]
+__all__ = ["OptimizeResult", "minimize", "register", "cmaes", "cpso", "de", "pso", "vdcma"]

@@ -131,11 +131,11 @@ def _stop_status(it, n, maxiter, xmean, xold, besthist, arfit, order, sigma, ins
         return 0
     if fbest <= ftol:
         return 1
-    if (np.abs(0.1 * sigma * B[:, axis] * D[axis]) < 1.0e-10).all():
+    if B is not None and (np.abs(0.1 * sigma * B[:, axis] * D[axis]) < 1.0e-10).all():  # VD-CMA passes no B, D
         return -2
     if (0.2 * sigma * sd < 1.0e-10).any():
         return -3
-    if D.max() > 1.0e7 * D.min():
+    if D is not None and D.max() > 1.0e7 * D.min():
         return -4
     if it >= ilim:
         window = besthist[it - ilim : it + 1]

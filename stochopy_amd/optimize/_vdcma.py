@@ -1,0 +1,314 @@
+"""VD-CMA front end + generation loop for ``backend="hip"``.
+
+Reference: stochopy/optimize/vdcma/_vdcma.py:12-141 (``minimize``) and :144-425 (``vdcma`` loop), :428-460
+(the moment and natural-gradient helpers); stopping rules shared with CMA-ES (cmaes/_cmaes.py:360-434 without
+B and D).  SURVEY.md section 8f rank 3: the covariance model is D (I + v v^T) D, so a generation is O(P n):
+
+* on the device (csrc/sx_cmaes.hip ``vd_sample_kernel``, csrc/sx_core.hip): the P candidates
+  ``y = d o (z + (sqrt(1+|v|^2)-1)(z.vn) vn)``, ``x = xmean + sigma y`` (one wavefront each, normals from the
+  numpy-legacy stream or in-kernel Philox), the objective with fused un-standardisation and -- with
+  ``constraints="Penalize"`` -- the clipping and the weighted squared excess (shared with CMA-ES);
+* on the host, as in the reference: ranking, the weighted sums over the mu selected rows (moments p, q of
+  :428-444), the natural-gradient step for v and d (:447-460), step size, stopping rules -- O(mu n) numpy.
+
+``workers > 1``: candidates sharded by rows like CMA-ES (one all-gather of y, x and the fitness per generation).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _device, _lib, _rng
+from . import _common
+from ._cmaes import _BoundaryWeights, _stop_status
+from ._helpers import OptimizeResult, register
+
+__all__ = ["minimize"]
+
+
+def minimize(
+    fun,
+    bounds,
+    x0=None,
+    args=(),
+    maxiter=100,
+    popsize=10,
+    sigma=0.1,
+    muperc=0.5,
+    seed=None,
+    xtol=1.0e-8,
+    ftol=1.0e-8,
+    constraints=None,
+    workers=1,
+    backend=None,
+    return_all=False,
+    verbosity=1.0,
+    callback=None,
+    rng=None,
+):
+    """Minimize an objective function using VD-CMA on MI355X (reference vdcma/_vdcma.py:12-30)."""
+    fun_id = _common.resolve_objective(fun, args)
+    lower, upper = _common.as_bounds(bounds)
+    if x0 is not None:
+        if np.ndim(x0) != 1 or len(x0) != len(bounds):
+            raise ValueError()
+    if sigma <= 0.0:
+        raise ValueError()
+    if not 0.0 < muperc <= 1.0:
+        raise ValueError()
+    if constraints not in (None, "Penalize"):
+        raise KeyError(constraints)
+    if callback is not None and not hasattr(callback, "__call__"):
+        raise ValueError()
+    _common.resolve_backend(backend)
+    rng = _common.resolve_rng(rng)
+    workers = _common.resolve_workers(workers)
+    run = _VdRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
+                 float(ftol), bool(return_all), float(verbosity), callback, rng, seed, workers,
+                 constraints == "Penalize")
+    return run.result()
+
+
+def _moments(vn, norm_v2, y, w=None):
+    """Moments p, q of the selected steps under the current model (vdcma/_vdcma.py:428-444)."""
+    t = np.dot(y, vn)
+    shrink = norm_v2 / (1.0 + norm_v2)
+    if w is None:
+        return y**2 - shrink * (t * y * vn) - 1.0, t * y - (0.5 * (t**2 + 1.0 + norm_v2)) * vn
+    p = np.dot(w, y**2 - shrink * (t[:, None] * (y * vn)) - 1.0)
+    q = np.dot(w, t[:, None] * y - np.outer(0.5 * (t**2 + 1.0 + norm_v2), vn))
+    return p, q
+
+
+def _natural_gradient(dvec, vn, vnn, norm_v, norm_v2, alpha, avec, bsca, invavnn, p, q):
+    """Steps for v and d (vdcma/_vdcma.py:447-460)."""
+    r = p - alpha / (1.0 + norm_v2) * ((2.0 + norm_v2) * q * vn - norm_v2 * np.dot(vn, q) * vnn)
+    s = r / avec - bsca * np.dot(r, invavnn) / (1.0 + bsca * np.dot(vnn, invavnn)) * invavnn
+    ngv = q / norm_v - alpha / norm_v * ((2.0 + norm_v2) * (vn * s) - np.dot(s, vnn) * vn)
+    return ngv, dvec * s
+
+
+class _VdRun:
+    def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, return_all, verbosity,
+                 callback, rng, seed, workers, penalize):
+        self.penalize = penalize
+        self.world = None
+        if workers != 1:
+            from ..parallel import require_world
+
+            self.world = require_world(workers)
+            self.world.shard(P)  # popsize must divide evenly
+        self.fun_id, self.lower, self.upper, self.x0 = fun_id, lower, upper, x0
+        self.maxiter, self.P, self.n = maxiter, P, len(lower)
+        self.sigma0, self.muperc, self.xtol, self.ftol = sigma, muperc, xtol, ftol
+        self.return_all, self.verbosity, self.callback = return_all, verbosity, callback
+        self.rng, self.seed = rng, seed
+        self.ctx = _device.Context()
+        t = _device.torch()
+        with t.cuda.stream(self.ctx.stream):
+            self._run()
+
+    def _run(self):
+        ctx, L, n, P = self.ctx, self.ctx.L, self.n, self.P
+        t = _device.torch()
+        sp = ctx.stream_ptr
+        ptr = _device.ptr
+        stream = _rng.make_init_stream(self.rng, self.seed)
+        key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
+        xm = 0.5 * (self.upper + self.lower)
+        xstd = 0.5 * (self.upper - self.lower)
+
+        def seen(rows):  # what the caller sees: un-standardised, clipped to the box with Penalize
+            return (np.clip(rows, -1.0, 1.0) if self.penalize else rows) * xstd + xm
+
+        d_xm, d_xstd = ctx.upload(xm), ctx.upload(xstd)
+        xmean = stream.uniform(-1.0, 1.0, n) if self.x0 is None else (np.asarray(self.x0, dtype=np.float64) - xm) / xstd
+        xold = np.zeros(n)  # the reference leaves this uninitialised until the first update
+
+        # selection weights and learning rates (vdcma/_vdcma.py:185-199)
+        mu = int(self.muperc * P)
+        w = np.log(mu + 0.5) - np.log(np.arange(1, mu + 1))
+        w /= w.sum()
+        mueff = w.sum() ** 2 / np.square(w).sum()
+        cc = (4.0 + mueff / n) / (n + 4.0 + 2.0 * mueff / n)
+        cfactor = (n - 5.0) / 6.0
+        c1 = cfactor * 2.0 / ((n + 1.3) ** 2 + mueff)
+        cmu = min(1.0 - c1, cfactor * 2.0 * (mueff - 2.0 + 1.0 / mueff) / ((n + 2.0) ** 2 + mueff))
+
+        # dynamic state (:202-213); the first direction comes right after the initial mean in the stream
+        inject = False
+        cs, ds = 0.3, np.sqrt(n)
+        dx = np.zeros(n)
+        ps = 0.0
+        dvec = np.ones(n)
+        vvec = stream.randn(n) / np.sqrt(n)
+        norm_v2 = np.dot(vvec, vvec)
+        norm_v = np.sqrt(norm_v2)
+        vn = vvec / norm_v
+        vnn = vn**2
+        pc = np.zeros(n)
+        sigma = self.sigma0
+
+        row0, Pl = (0, P) if self.world is None else self.world.shard(P)
+        d_Z = ctx.empty((Pl, n))
+        d_ary = ctx.empty((P, n))
+        d_arx = ctx.empty((P, n))
+        d_fit = ctx.empty((P,))
+        d_ary_loc = d_ary if self.world is None else ctx.empty((Pl, n))
+        d_arx_loc = d_arx if self.world is None else ctx.empty((Pl, n))
+        d_fit_loc = d_fit if self.world is None else ctx.empty((Pl,))
+        d_dvec, d_vn, d_xmean, d_dy = ctx.empty((n,)), ctx.empty((n,)), ctx.empty((n,)), ctx.empty((n,))
+        d_zinj = ctx.empty((1, n))
+        h_Z = t.empty((P, n), dtype=t.float64).pin_memory() if self.rng == "numpy-legacy" else None
+        if self.penalize:
+            bweights = _BoundaryWeights(n)
+            d_v = ctx.empty((n,))
+            d_pen = ctx.empty((P,))
+            d_pen_loc = d_pen if self.world is None else ctx.empty((Pl,))
+        if self.return_all:
+            nout = int(np.ceil(self.verbosity * P))
+            xall = np.empty((self.maxiter, max(1, nout), n))
+            funall = np.empty((self.maxiter, max(1, nout)))
+
+        def up(dst, a):
+            dst.copy_(t.from_numpy(np.ascontiguousarray(a)))
+
+        nfev = 0
+        besthist = np.zeros(self.maxiter)
+        ilim = int(10 + 30 * n / P)
+        insigma = sigma
+        it = 0
+        while True:
+            it += 1
+            # ---- candidates (vdcma/_vdcma.py:236-248): normals, then the O(n) model on the device ----
+            if self.rng == "numpy-legacy":
+                stream.randn(None, out=h_Z.numpy())
+                d_Z.copy_(h_Z[row0 : row0 + Pl], non_blocking=True)
+            else:
+                _lib.check(L.sx_cmaes_normals(ptr(d_Z), Pl, n, row0, it, key0, key1, sp), "sx_cmaes_normals")
+            dy = None
+            if inject:  # mean-shift injection: rows 0 and 1 become +-dy (:241-247)
+                ddx = dx / dvec
+                mnorm = (ddx**2).sum() - np.dot(ddx, vvec) ** 2 / (1.0 + norm_v2)
+                if self.rng == "numpy-legacy":
+                    zinj = stream.randn(n)
+                else:  # "row P" of the generation's normals, one past the population
+                    _lib.check(L.sx_cmaes_normals(ptr(d_zinj), 1, n, P, it, key0, key1, sp), "sx_cmaes_normals")
+                    zinj = d_zinj.cpu().numpy()[0]
+                dy = np.linalg.norm(zinj) / np.sqrt(mnorm) * dx
+                up(d_dy, dy)
+            up(d_dvec, dvec)
+            up(d_vn, vn)
+            up(d_xmean, xmean)
+            _lib.check(L.sx_vdcma_sample(ptr(d_Z), Pl, n, row0, ptr(d_dvec), ptr(d_vn), float(np.sqrt(1.0 + norm_v2) - 1.0),
+                                         ptr(d_xmean), float(sigma), ptr(d_dy) if dy is not None else None,
+                                         ptr(d_ary_loc), ptr(d_arx_loc), sp), "sx_vdcma_sample")
+            diagC = (dvec * (1.0 + vvec * vvec)) * dvec  # diag of D (I + v v^T) D (:249-254)
+            # ---- objective (+ Penalize), as in CMA-ES ----
+            if not self.penalize:
+                _device.evaluate(ctx, self.fun_id, d_arx_loc, n, f=d_fit_loc, xm=d_xm, xstd=d_xstd)
+            else:
+                _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd), None,
+                                                     ptr(d_fit_loc), None, sp), "sx_cmaes_eval_penalized")
+            if self.world is not None:
+                self.world.all_gather_rows(d_ary_loc, d_ary)
+                self.world.all_gather_rows(d_arx_loc, d_arx)
+                self.world.all_gather_rows(d_fit_loc, d_fit)
+            arfit = d_fit.cpu().numpy()
+            if self.penalize:
+                v = bweights.update(arfit, xmean, xold, sigma, diagC, mueff, it, P)
+                if v.any():
+                    up(d_v, v)
+                    _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd),
+                                                         ptr(d_v), ptr(d_fit_loc), ptr(d_pen_loc), sp),
+                               "sx_cmaes_eval_penalized")
+                    if self.world is not None:
+                        self.world.all_gather_rows(d_pen_loc, d_pen)
+                    arfit = arfit + d_pen.cpu().numpy()
+            nfev += P
+            if self.return_all:
+                if nout > 0:
+                    xall[it - 1] = seen(d_arx[:nout].cpu().numpy())
+                    funall[it - 1] = arfit[:nout]
+                else:
+                    k = int(arfit.argmin())
+                    xall[it - 1] = seen(d_arx[k].cpu().numpy())
+                    funall[it - 1] = arfit[k]
+            # ---- rank, mean shift (:289-295): the mu selected rows of y and x come to the host ----
+            order = np.argsort(arfit)
+            sel = t.from_numpy(np.ascontiguousarray(order[:mu], dtype=np.int64)).to(ctx.device)
+            arx_sel = d_arx.index_select(0, sel).cpu().numpy()
+            ary_sel = d_ary.index_select(0, sel).cpu().numpy()
+            dx = np.dot(w, arx_sel) - w.sum() * xmean
+            xold = xmean.copy()
+            xmean = xmean + dx
+            besthist[it - 1] = arfit[order[0]]
+            # ---- step size from the rank gap of the injected pair (:298-306) ----
+            if inject:
+                gap = (np.where(order == 1)[0][0] - np.where(order == 0)[0][0]) / (P - 1.0)
+                ps += cs * (gap - ps)
+                sigma *= np.exp(ps / ds)
+                cond = ps < 0.5
+            else:
+                inject = True
+                cond = True
+            # ---- evolution path, model constants (:309-328) ----
+            pc *= 1.0 - cc
+            if cond:
+                pc += np.sqrt(cc * (2.0 - cc) * mueff) * np.dot(w, ary_sel)
+            gamma = 1.0 / np.sqrt(1.0 + norm_v2)
+            alpha = np.sqrt(norm_v2**2 + (1.0 + norm_v2) / vnn.max() * (2.0 - gamma)) / (2.0 + norm_v2)
+            if alpha < 1.0:
+                beta = (4.0 - (2.0 - gamma) / vnn.max()) / (1.0 + 2.0 / norm_v2) ** 2
+            else:
+                alpha, beta = 1.0, 0.0
+            bsca = 2.0 * alpha**2 - beta
+            avec = 2.0 - (bsca + 2.0 * alpha**2) * vnn
+            invavnn = vnn / avec
+            # ---- moments, natural gradient, update of v and d (:331-378) ----
+            p_mu, q_mu = (np.zeros(n), np.zeros(n)) if cmu == 0.0 else _moments(vn, norm_v2, ary_sel / dvec, w)
+            p_one, q_one = (np.zeros(n), np.zeros(n)) if c1 == 0.0 else _moments(vn, norm_v2, pc / dvec)
+            p = cmu * p_mu
+            q = cmu * q_mu
+            if cond:
+                p = p + c1 * p_one
+                q = q + c1 * q_one
+            if cmu + c1 > 0.0:
+                ngv, ngd = _natural_gradient(dvec, vn, vnn, norm_v, norm_v2, alpha, avec, bsca, invavnn, p, q)
+                step = min(1.0, 0.7 * norm_v / np.sqrt(np.dot(ngv, ngv)), 0.7 * (dvec / np.abs(ngd)).min())
+                vvec = vvec + step * ngv
+                dvec = dvec + step * ngd
+            norm_v2 = np.dot(vvec, vvec)
+            norm_v = np.sqrt(norm_v2)
+            vn = vvec / norm_v
+            vnn = vn**2
+            status = _stop_status(it, n, self.maxiter, xmean, xold, besthist, arfit, order, sigma, insigma, ilim, pc,
+                                  self.xtol, self.ftol, diagC, None, None)
+            if self.callback is not None:
+                res = OptimizeResult(x=seen(d_arx[int(order[0])].cpu().numpy()), fun=arfit[order[0]], nfev=nfev, nit=it)
+                if self.return_all:
+                    res.update({"xall": xall[:it], "funall": funall[:it]})
+                self.callback(seen(d_arx.cpu().numpy()), res)
+            if status is not None:
+                break
+
+        res = OptimizeResult(
+            x=seen(d_arx[int(order[0])].cpu().numpy()),
+            success=status >= 0,
+            status=status,
+            message=_common.messages[status],
+            fun=arfit[order[0]],
+            nfev=nfev,
+            nit=it,
+        )
+        if self.return_all:
+            res.update({"xall": xall[:it], "funall": funall[:it]})
+        if self.rng == "numpy-legacy":
+            stream.sync_back()
+        ctx.sync()
+        self._res = res
+
+    def result(self):
+        return self._res
+
+
+register("vdcma", minimize)

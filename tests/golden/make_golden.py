@@ -345,8 +345,49 @@ def penalize():
     print("wrote cmaes_penalize_xall.npz", os.path.getsize(os.path.join(HERE, "cmaes_penalize_xall.npz")))
 
 
+# --------------------------------------------------------------------------- #
+# 6. VD-CMA (stochopy/optimize/vdcma/_vdcma.py:12-460): the reference's own test rows
+#    (tests/test_optimize.py:119-132) and mid-size problems where v and d actually adapt (n > 5)
+# --------------------------------------------------------------------------- #
+def vdcma():
+    out = dict(STAMP)
+    cases = []
+    arrays = {}
+
+    def add(tag, fun, n, opts, bounds=None, x0=None, xref=None):
+        o = dict(opts, return_all=True)
+        entry, res, pops = run_ref(fun, n, "vdcma", o, x0=x0, bounds=bounds, full=True)
+        entry["tag"] = tag
+        if xref is not None:
+            entry["xref_from_reference_tests"] = xref
+            assert np.allclose(xref, res.x), (tag, xref, res.x)
+        arrays[tag + "__xall"] = res.xall
+        arrays[tag + "__funall"] = res.funall
+        cases.append(entry)
+        print(" ", tag, "fun", float(res.fun), "nit", res.nit, "status", res.status)
+
+    suite_opts = {"maxiter": 128, "popsize": 8, "seed": 42, "sigma": 0.1, "muperc": 0.5}
+    add("vdcma_none", "rosenbrock", 2, dict(suite_opts, constraints=None), xref=[0.90013445, 0.85037782])
+    add("vdcma_none_x0", "rosenbrock", 2, dict(suite_opts, constraints=None), x0=[-5.0, -5.0],
+        xref=[0.84059993, 0.69998341])
+    add("vdcma_penalize", "rosenbrock", 2, dict(suite_opts, constraints="Penalize"), xref=[0.90013445, 0.85037782])
+    add("vdcma_penalize_x0", "rosenbrock", 2, dict(suite_opts, constraints="Penalize"), x0=[-5.0, -5.0],
+        xref=[0.82405114, 0.61993136])
+    add("vdcma_rosen_n12_p16", "rosenbrock", 12, {"maxiter": 150, "popsize": 16, "seed": 3})
+    add("vdcma_sphere_n9_outside", "sphere", 9,
+        {"maxiter": 80, "popsize": 12, "seed": 7, "sigma": 0.3, "constraints": "Penalize"}, bounds=[[1.0, 5.0]] * 9)
+    add("vdcma_rastrigin_n40_p24", "rastrigin", 40, {"maxiter": 60, "popsize": 24, "seed": 1, "sigma": 0.4})
+    add("vdcma_sphere_n16_ftol", "sphere", 16, {"maxiter": 600, "popsize": 16, "seed": 5, "ftol": 1e-6})
+    out["cases"] = cases
+    dump("vdcma.json", out)
+    np.savez_compressed(os.path.join(HERE, "vdcma_xall.npz"), **arrays)
+    print("wrote vdcma_xall.npz", os.path.getsize(os.path.join(HERE, "vdcma_xall.npz")))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "factory", "suite", "configs", "penalize"]
+    which = sys.argv[1:] or ["rng", "factory", "suite", "configs", "penalize", "vdcma"]
+    if "vdcma" in which:
+        vdcma()
     if "penalize" in which:
         penalize()
     if "rng" in which:

@@ -204,6 +204,26 @@ def test_sharded_cmaes_matches_single_gpu(rng):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rng", ["philox", "numpy-legacy"])
+def test_sharded_vdcma_matches_single_gpu(rng):
+    """VD-CMA with workers=2 (candidates sampled / evaluated by shards, incl. the injected pair in rank 0's
+    shard) == workers=1."""
+    import stochopy_amd as sa
+    from _dist_workers import gpu_minimize_worker
+
+    n = 30
+    opts = {"maxiter": 40, "popsize": 20, "seed": 8, "sigma": 0.25, "rng": rng}
+    cfg = {"n": n, "objective": "rosenbrock", "method": "vdcma", "options": opts}
+    one = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="vdcma",
+                               options=dict(opts, backend="hip"))
+    out = _spawn(gpu_minimize_worker, 2, cfg)
+    for r in range(2):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (one.fun, one.nit, one.nfev, one.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), one.x)
+
+
+@pytest.mark.gpu
 def test_sharded_cmaes_penalize_matches_single_gpu():
     """The same with constraints="Penalize" and a box whose optimum lies outside: raw fitness, weights and the
     penalty term are settled per generation across the shards (two extra all-gathers while weights are active)."""

@@ -107,6 +107,26 @@ def test_cmaes_penalize_bit_exact(case):
         assert np.allclose(case["xref_from_reference_tests"], res.x)
 
 
+VDCMA = load_golden("vdcma.json")["cases"]
+
+
+@pytest.mark.parametrize("case", VDCMA, ids=lambda c: c["tag"])
+def test_vdcma_bit_exact(case):
+    """VD-CMA (vdcma/_vdcma.py:144-460): the reference's own test rows (tests/test_optimize.py:119-132), with
+    and without Penalize, and mid-size problems in which v and d adapt (n > 5) and the run stops on ftol."""
+    trace = []
+    res = _run(case, trace)
+    ref = case["result"]
+    assert np.array_equal(unhex(case["fun_trace"]), np.array([t[0] for t in trace]))
+    assert (res.nit, res.nfev, res.status, res.message) == (ref["nit"], ref["nfev"], ref["status"], ref["message"])
+    assert np.array_equal(unhex(ref["x"]), res.x) and float(res.fun).hex() == ref["fun"]
+    arrays = np.load(os.path.join(GOLDEN, "vdcma_xall.npz"))
+    assert np.array_equal(arrays[case["tag"] + "__xall"], res.xall)
+    assert np.array_equal(arrays[case["tag"] + "__funall"], res.funall)
+    if "xref_from_reference_tests" in case:
+        assert np.allclose(case["xref_from_reference_tests"], res.x)
+
+
 def test_populations_bit_exact():
     arrays = np.load(os.path.join(GOLDEN, "configs_pops.npz"))
     by_tag = {c["tag"]: c for c in CONFIGS}
