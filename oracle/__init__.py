@@ -3,7 +3,8 @@
 This package is a numpy restatement of the per-generation path of
 keurfonluu/stochopy v2.3.0 (batched objective evaluation, DE mutation /
 crossover / selection, PSO / CPSO velocity-position update with competitive
-restart, CMA-ES sampling and covariance update).  Every function cites the
+restart, CMA-ES sampling and covariance update; plus, from the "next" rows,
+the CMA-ES "Penalize" boundary handling and VD-CMA).  Every function cites the
 reference file:line it follows (paths relative to the reference checkout).
 
 Parity status: PINNED.  tests/test_oracle_golden.py checks this oracle against
@@ -11,7 +12,8 @@ golden vectors captured by running the reference itself
 (tests/golden/make_golden.py, numpy 2.2.6): the reference's own test-suite
 xrefs (tests/test_optimize.py), the objective known answers
 (tests/test_factory.py), the README example, the BASELINE.json configs and
-mid-size coverage cases -- bit-for-bit for DE/PSO/CPSO/CMA-ES state.
+mid-size coverage cases, CMA-ES with Penalize and VD-CMA -- bit-for-bit for
+DE/PSO/CPSO/CMA-ES/VD-CMA state.
 
 Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
 import this package, and only as the checker / the timed CPU baseline.  The
