@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="de_rosenbrock_n128_p4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU work spent on the baseline sample")
     ap.add_argument("--kernel-timing-launches", type=int, default=400)
     args = ap.parse_args()
 
@@ -206,7 +207,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(objective, n, min(P, 4096), strategy)
+            line["cpu_baseline"] = cpu_baseline(objective, n, min(P, 4096), strategy, args.cpu_baseline_seconds)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
