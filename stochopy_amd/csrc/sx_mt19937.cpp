@@ -26,6 +26,8 @@ struct sx_mt {
     int pos;
     int has_gauss;
     double gauss;
+    uint32_t out[624];  // the tempered words of the current block (filled by mt_twist; not part of the state)
+    int out_valid;      // out[] matches mt[] (cleared whenever mt[] is set from outside)
 };
 
 namespace {
@@ -36,6 +38,20 @@ inline void mt_seed(sx_mt *g, uint32_t s) {
     g->pos = 624;
     g->has_gauss = 0;
     g->gauss = 0.0;
+    g->out_valid = 0;
+}
+
+inline uint32_t temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+inline void mt_temper_block(sx_mt *g) {  // one vectorisable pass instead of 624 dependent call sites
+    for (int k = 0; k < 624; ++k) g->out[k] = temper(g->mt[k]);
+    g->out_valid = 1;
 }
 
 inline void mt_twist(sx_mt *g) {
@@ -44,25 +60,22 @@ inline void mt_twist(sx_mt *g) {
     int k = 0;
     for (; k < 624 - 397; ++k) {
         const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
-        mt[k] = mt[k + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        mt[k] = mt[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
     }
     for (; k < 623; ++k) {
         const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
-        mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
     }
     const uint32_t y = (mt[623] & UP) | (mt[0] & LO);
-    mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
     g->pos = 0;
+    mt_temper_block(g);
 }
 
 inline uint32_t next32(sx_mt *g) {
     if (g->pos == 624) mt_twist(g);
-    uint32_t y = g->mt[g->pos++];
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
+    else if (!g->out_valid) mt_temper_block(g);
+    return g->out[g->pos++];
 }
 
 inline double next_double(sx_mt *g) {
@@ -97,6 +110,33 @@ inline uint64_t bounded(sx_mt *g, uint64_t mx, uint64_t mask) {
         } while (v > mx);
     }
     return v;
+}
+
+// Fisher-Yates from the end for n <= 2^31 elements (the DE donor permutations, 16.8 million steps per
+// generation at P = 4096): same words, same rejections as shuffle(), with the mask held per power-of-two range
+// of i and 32-bit arithmetic throughout.
+inline void shuffle_small(sx_mt *g, int32_t *a, int32_t n) {
+    int32_t i = n - 1;
+    while (i >= 1) {
+        uint32_t mask = (uint32_t)i;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        const int32_t lo = (int32_t)(mask >> 1) + 1;  // smallest i with this mask
+        // one word per trip, no data-dependent branch: a rejected word (v > i) swaps a[i] with itself and
+        // leaves i where it is (the rejection branch of the textbook loop mispredicts ~30 % of the time)
+        while (i >= lo) {
+            const uint32_t v = next32(g) & mask;
+            const int32_t take = v <= (uint32_t)i;
+            const int32_t j = take ? (int32_t)v : i;
+            const int32_t t = a[i];
+            a[i] = a[j];
+            a[j] = t;
+            i -= take;
+        }
+    }
 }
 
 template <class T>
@@ -174,7 +214,7 @@ extern "C" void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors) {
     std::vector<int32_t> a((size_t)(P - 1));
     for (int64_t i = 0; i < P; ++i) {
         for (int64_t v = 0; v < P - 1; ++v) a[v] = (int32_t)v;
-        shuffle(g, a.data(), P - 1);
+        shuffle_small(g, a.data(), (int32_t)(P - 1));
         for (int t = 0; t < k; ++t) {
             const int32_t v = a[t];
             donors[(int64_t)t * P + i] = v + (v >= i ? 1 : 0);
@@ -191,6 +231,7 @@ extern "C" void sx_mt_get_state(sx_mt *g, uint32_t *key, int *pos, int *has_gaus
 }
 extern "C" void sx_mt_set_state(sx_mt *g, const uint32_t *key, int pos, int has_gauss, double gauss) {
     std::memcpy(g->mt, key, sizeof g->mt);
+    g->out_valid = 0;
     g->pos = pos;
     g->has_gauss = has_gauss;
     g->gauss = gauss;
