@@ -12,7 +12,7 @@
 //   gauss      Marsaglia polar method, second variate cached across calls
 //   bounded    mask = next_pow2(max) - 1; redraw (word & mask) until <= max
 //   shuffle    Fisher-Yates from the end, j = bounded(i)
-// Pinned bit-for-bit against numpy by tests/test_host_rng.py and
+// Pinned bit-for-bit against numpy by tests/test_host_cpu.py and
 // tests/golden/rng_stream.json.
 #include <cmath>
 #include <cstdint>
@@ -115,7 +115,8 @@ inline uint64_t bounded(sx_mt *g, uint64_t mx, uint64_t mask) {
 // Fisher-Yates from the end for n <= 2^31 elements (the DE donor permutations, 16.8 million steps per
 // generation at P = 4096): same words, same rejections as shuffle(), with the mask held per power-of-two range
 // of i and 32-bit arithmetic throughout.
-inline void shuffle_small(sx_mt *g, int32_t *a, int32_t n) {
+template <class T>
+inline void shuffle_small(sx_mt *g, T *a, int32_t n) {
     int32_t i = n - 1;
     while (i >= 1) {
         uint32_t mask = (uint32_t)i;
@@ -131,7 +132,7 @@ inline void shuffle_small(sx_mt *g, int32_t *a, int32_t n) {
             const uint32_t v = next32(g) & mask;
             const int32_t take = v <= (uint32_t)i;
             const int32_t j = take ? (int32_t)v : i;
-            const int32_t t = a[i];
+            const T t = a[i];
             a[i] = a[j];
             a[j] = t;
             i -= take;
@@ -141,6 +142,10 @@ inline void shuffle_small(sx_mt *g, int32_t *a, int32_t n) {
 
 template <class T>
 inline void shuffle(sx_mt *g, T *a, int64_t n) {
+    if (n <= 0x7fffffff) {
+        shuffle_small(g, a, (int32_t)n);
+        return;
+    }
     for (int64_t i = n - 1; i >= 1; --i) {
         const uint64_t j = bounded(g, (uint64_t)i, mask_for((uint64_t)i));
         const T t = a[i];
