@@ -105,8 +105,11 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
 // the generation tag into every peer's exchange buffer (one wavefront per peer) and publishes the state;
 // the row workgroups (blockIdx 1..) wait for the tagged headers of all ranks in their OWN rank's buffer,
 // pick the global best and read its row from there.  Still one kernel per generation; the only
-// cross-GPU dependency is "all ranks have reached this generation".
-// XM = 2, workgroup 0: shard best -> peers, global best -> state.  Returns nothing; sets *x.error on timeout.
+// cross-GPU dependency is "all ranks have reached this generation".  With x.global_rows > 0 the donor rows
+// are drawn over the whole population and read from their owners' (IPC-mapped) population buffers.
+
+// XM = 2, workgroup 0: shard best -> peers, global best -> state (and, for whole-wave rows, the winning record
+// into the cacheable relay).  Sets *x.error on timeout.
 __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_args &x, int chain_p, int mode,
                                             int64_t npart, const sx_state *sin, bool relay) {
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), nw = (int)(blockDim.x >> 6);
@@ -141,25 +144,25 @@ __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_a
         for (int u = 0; u < 8; ++u) argmin_combine(bf, bi, f[u], i[u]);
         wave_argmin_ordered(bf, bi);
     } else {
-    for (int64_t k0 = threadIdx.x; k0 < npart; k0 += (int64_t)blockDim.x * 8) {
-        double f[8];
-        int64_t i[8];
+        for (int64_t k0 = threadIdx.x; k0 < npart; k0 += (int64_t)blockDim.x * 8) {
+            double f[8];
+            int64_t i[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t k = k0 + (int64_t)u * blockDim.x;
-            f[u] = k < npart ? pf[k] : __builtin_huge_val();
-            i[u] = k < npart ? pi[k] : INT64_MAX;
+            for (int u = 0; u < 8; ++u) {
+                const int64_t k = k0 + (int64_t)u * blockDim.x;
+                f[u] = k < npart ? pf[k] : __builtin_huge_val();
+                i[u] = k < npart ? pi[k] : INT64_MAX;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) argmin_combine(bf, bi, f[u], i[u]);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) argmin_combine(bf, bi, f[u], i[u]);
-    }
-    wave_argmin_all(bf, bi);
-    if (lane == 0) {
-        svc_f[wave] = bf;
-        svc_i[wave] = bi;
-    }
-    __syncthreads();
-    for (int w = 0; w < nw; ++w) argmin_combine(bf, bi, svc_f[w], svc_i[w]);
+        wave_argmin_all(bf, bi);
+        if (lane == 0) {
+            svc_f[wave] = bf;
+            svc_i[wave] = bi;
+        }
+        __syncthreads();
+        for (int w = 0; w < nw; ++w) argmin_combine(bf, bi, svc_f[w], svc_i[w]);
     }
     if (done0) {
         if (mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
