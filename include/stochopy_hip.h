@@ -252,6 +252,13 @@ int sx_xchg_close(void *ptr);
 int sx_xchg_probe(const sx_xchg_args *x, int n, int rounds, void *stream);
 /* decode slot[parity][src] of the own buffer into record[n+2] (host memory); synchronises the stream */
 int sx_xchg_read_record(const sx_xchg_args *x, int n, int parity, int src, double *record, void *stream);
+/* The same exchange as ONE one-workgroup kernel for generation kernels that are not chained (PSO / CPSO):
+ * sx_shard_best + all-gather + sx_gather_finalize without a collective -- shard best from the workgroup
+ * records, record into every peer's slot, wait for all ranks, global best, dx, gbest, status, it++
+ * (_common.py:131-158).  rows0/rows1, ld, row0 as for sx_shard_best; gbest/state as for sx_gather_finalize. */
+int sx_xchg_finalize(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                     const double *rows1, int64_t ld, int n, int64_t row0, double *gbest, sx_state *state, int maxiter,
+                     double xtol, double ftol, const sx_xchg_args *x, void *stream);
 int sx_de_p2p_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, int finalize_only, void *stream);
 int sx_de_p2p_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ngen, int start_parity, sx_graph **out);
 

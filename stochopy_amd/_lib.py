@@ -96,6 +96,8 @@ PROTOTYPES = {
     "sx_xchg_close": (C.c_int, [vp]),
     "sx_xchg_probe": (C.c_int, [C.POINTER(SxXchgArgs), C.c_int, C.c_int, vp]),
     "sx_xchg_read_record": (C.c_int, [C.POINTER(SxXchgArgs), C.c_int, C.c_int, C.c_int, vp, vp]),
+    "sx_xchg_finalize": (C.c_int, [vp, vp, i64, vp, vp, i64, C.c_int, i64, vp, vp, C.c_int, f64, f64,
+                                   C.POINTER(SxXchgArgs), vp]),
     "sx_de_p2p_launch": (C.c_int, [C.POINTER(SxDeArgs), C.POINTER(SxXchgArgs), C.c_int, C.c_int, vp]),
     "sx_de_p2p_graph_create": (C.c_int, [C.POINTER(SxDeArgs), C.POINTER(SxXchgArgs), C.c_int, C.c_int,
                                          C.POINTER(vp)]),

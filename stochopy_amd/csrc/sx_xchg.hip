@@ -183,3 +183,134 @@ extern "C" int sx_xchg_read_record(const sx_xchg_args *x, int n, int parity, int
     set_error("sx_xchg_read_record: record is torn (mixed generation tags)");
     return -1;
 }
+
+// ---------------------------------------------------------------------------
+// Best-of-generation over all ranks as ONE one-workgroup kernel (for generation kernels that are not chained:
+// PSO / CPSO, the DE two-kernel path): what sx_shard_best + an all-gather + sx_gather_finalize do over RCCL.
+//   records of this shard -> shard best -> its record into every peer's slot (one wavefront per peer) ->
+//   wait for all ranks' records of this generation -> global best (lowest f, ties to the lowest global row)
+//   -> dx, gbest, status, it++ (_common.py:131-158), identically on every rank.
+// Slots are double-buffered by generation parity; a rank can be at most one generation ahead of a peer (it
+// needs every peer's record of generation g to produce generation g+1).
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kXfThreads = 512;
+
+__global__ __launch_bounds__(kXfThreads) void xchg_finalize_kernel(
+    const double *__restrict__ part_f, const int64_t *__restrict__ part_i, int64_t npart,
+    const double *__restrict__ rows0, const double *__restrict__ rows1, int64_t ld, int n, int64_t row0,
+    double *__restrict__ gbest, sx_state *__restrict__ state, int maxiter, double xtol, double ftol,
+    const sx_xchg_args x) {
+    __shared__ double sf[kXfThreads / kWave];
+    __shared__ int64_t si[kXfThreads / kWave];
+    __shared__ double sd[kXfThreads / kWave];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = kXfThreads / kWave;
+    // records first (they do not depend on the state word), then the state
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int64_t k0 = tid; k0 < npart; k0 += (int64_t)kXfThreads * 8) {
+        double f[8];
+        int64_t i[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t k = k0 + (int64_t)u * kXfThreads;
+            f[u] = k < npart ? part_f[k] : __builtin_huge_val();
+            i[u] = k < npart ? part_i[k] : INT64_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (f[u] < bf || (f[u] == bf && i[u] < bi)) {
+                bf = f[u];
+                bi = i[u];
+            }
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double f2 = __shfl_xor(bf, off, kWave);
+        const int64_t i2 = __shfl_xor((long long)bi, off, kWave);
+        if (f2 < bf || (f2 == bf && i2 < bi)) {
+            bf = f2;
+            bi = i2;
+        }
+    }
+    if (lane == 0) {
+        sf[wave] = bf;
+        si[wave] = bi;
+    }
+    __syncthreads();
+    for (int w = 0; w < nw; ++w)
+        if (sf[w] < bf || (sf[w] == bf && si[w] < bi)) {
+            bf = sf[w];
+            bi = si[w];
+        }
+    if (state->done || *x.error) return;  // uniform
+    const int64_t it = state->it + 1;     // the generation being finalised
+    const uint32_t tag = (uint32_t)(it + 1);
+    const int parity = (int)(it & 1);
+    const double *row = ((it & 1) ? rows1 : rows0) + bi * ld;
+    for (int r = wave; r < x.world; r += nw)
+        xchg_push_record(x.peer[r] + xchg_slot_offset(n, parity, x.rank), bf, row0 + bi, row, n, tag, lane);
+    double gf;
+    int64_t gi;
+    int winner;
+    if (!xchg_wait_best(x.peer[x.rank] + xchg_slot_offset(n, parity, 0), n, x.world, tag, x.timeout_ticks, lane, gf, gi,
+                        winner)) {
+        if (lane == 0) atomicExch(x.error, 1);
+        return;
+    }
+    // the winner's row out of its slot (tagged words; a word still in flight is re-read), dx, gbest
+    const uint64_t *src = x.peer[x.rank] + xchg_slot_offset(n, parity, winner) + 4;
+    const uint64_t t0 = wall_clock64();
+    double acc = 0.0;
+    for (int e = tid; e < n; e += kXfThreads) {
+        uint64_t lo, hi;
+        for (;;) {
+            lo = ll_load(src + 2 * e);
+            hi = ll_load(src + 2 * e + 1);
+            if (ll_ok(lo, tag) && ll_ok(hi, tag)) break;
+            if ((int64_t)(wall_clock64() - t0) > x.timeout_ticks) {
+                atomicExch(x.error, 1);
+                break;
+            }
+        }
+        const double v = ll_join_f64(lo, hi);
+        const double d = gbest[e] - v;
+        acc += d * d;
+        gbest[e] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if (lane == 0) sd[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double ss = 0.0;
+        for (int w = 0; w < nw; ++w) ss += sd[w];
+        const double dx = sqrt(ss);
+        int status = SX_STATUS_NONE;
+        if (dx <= xtol && gf <= ftol)
+            status = 0;
+        else if (gf <= ftol)
+            status = 1;
+        else if (it >= maxiter)
+            status = -1;
+        state->it = it;
+        state->gbidx = gi;
+        state->gfit = gf;
+        state->dx = dx;
+        state->status = status;
+        state->done = status != SX_STATUS_NONE;
+    }
+}
+}  // namespace
+
+extern "C" int sx_xchg_finalize(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                                const double *rows1, int64_t ld, int n, int64_t row0, double *gbest, sx_state *state,
+                                int maxiter, double xtol, double ftol, const sx_xchg_args *x, void *stream) {
+    if (int rc = check_xchg(x, "sx_xchg_finalize")) return rc;
+    SX_REQUIRE(part_f && part_i && rows0 && rows1 && gbest && state && npart >= 1 && n >= 1 && row0 >= 0,
+               "sx_xchg_finalize: bad arguments");
+    hipLaunchKernelGGL(xchg_finalize_kernel, dim3(1), dim3(kXfThreads), 0, (hipStream_t)stream, part_f, part_i, npart,
+                       rows0, rows1, ld, n, row0, gbest, state, maxiter, xtol, ftol, *x);
+    SX_LAUNCH_CHECK();
+    return 0;
+}

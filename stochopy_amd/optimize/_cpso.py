@@ -112,6 +112,20 @@ class _PsoRun:
         self._graph = None
         self._rccl_graph = None
         self._rccl_graph_note = None
+        # sharded swarm: the per-generation best travels by peer writes over xGMI (one one-workgroup kernel,
+        # parallel.PeerExchange) when that transport passes its self-test on every rank, else by one all-gather
+        self.px, self.exchange, self.exchange_note = None, None, None
+        if self.world is not None:
+            self.exchange = "rccl"
+            if os.environ.get("SX_EXCHANGE", "auto") != "rccl":
+                from ..parallel import PeerExchange
+
+                self.px, self.exchange_note = PeerExchange.negotiate(
+                    self.ctx, self.world, self.n, float(os.environ.get("SX_XCHG_TIMEOUT_S", "20")))
+                if self.px is not None:
+                    self.exchange = "p2p"
+                elif os.environ.get("SX_EXCHANGE") == "p2p":
+                    raise RuntimeError(f"SX_EXCHANGE=p2p is not available: {self.exchange_note}")
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
@@ -128,6 +142,10 @@ class _PsoRun:
             self.ctx.sync()
             self.ctx.L.sx_graph_destroy(self._graph)
             self._graph = None
+        if self.px is not None:
+            self.ctx.sync()
+            self.px.close()
+            self.px = None
 
     # ------------------------------------------------------------------ setup
     def _setup(self):
@@ -243,6 +261,11 @@ class _PsoRun:
         # sharded swarm: local generation, then the global-best exchange (parallel.py)
         p, n = _device.ptr, self.n
         _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 0, ctx.stream_ptr), "sx_pso_generation")
+        if self.px is not None:
+            _lib.check(ctx.L.sx_xchg_finalize(p(self.part_f), p(self.part_i), self.npart, p(self.pbest), p(self.pbest),
+                                              n, n, self.row0, p(self.gbest), p(self.state), self.maxiter, self.xtol,
+                                              self.ftol, C.byref(self.px.args), ctx.stream_ptr), "sx_xchg_finalize")
+            return
         _lib.check(ctx.L.sx_shard_best(p(self.part_f), p(self.part_i), self.npart, p(self.pbest), p(self.pbest), n, n,
                                        p(self.state), self.row0, p(self.record), ctx.stream_ptr), "sx_shard_best")
         self.world.all_gather_records(self.record, self.records)
@@ -322,6 +345,9 @@ class _PsoRun:
             else:
                 self.enqueue(min(max(self.maxiter - st.it, 1), self.CHECK_EVERY))
                 st = ctx.read_state(self.state)
+                if self.px is not None and self.px.failed():
+                    raise RuntimeError("peer exchange timed out: a rank did not reach the generation the others "
+                                       "were waiting for (SX_XCHG_TIMEOUT_S)")
         self.st = st
         status = int(st.status)
         res = OptimizeResult(
@@ -338,6 +364,8 @@ class _PsoRun:
         if self.rng == "numpy-legacy":
             self.stream.sync_back()
         ctx.sync()
+        if self.px is not None:
+            self.world.barrier()  # no rank frees its exchange buffer while a peer may still write into it
         self._res = res
 
     def enqueue(self, ngen):

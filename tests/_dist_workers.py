@@ -89,23 +89,25 @@ def cpu_rows_worker(rank, world, port, cfg, out_dir):
 
 
 def _spy_on_de_runs():
-    """Record the _DeRun objects minimize() creates (to see which exchange a run ended up with)."""
-    from stochopy_amd.optimize import _de
+    """Record the _DeRun / _PsoRun objects minimize() creates (to see which exchange a run ended up with)."""
+    from stochopy_amd.optimize import _cpso, _de
 
     runs = []
-    orig = _de._DeRun.__init__
+    for cls in (_de._DeRun, _cpso._PsoRun):
+        orig = cls.__init__
 
-    def spy(self, *a, **k):
-        runs.append(self)
-        orig(self, *a, **k)
+        def spy(self, *a, _orig=orig, **k):
+            runs.append(self)
+            _orig(self, *a, **k)
 
-    _de._DeRun.__init__ = spy
+        cls.__init__ = spy
     return runs
 
 
 def _minimize_and_save(rank, world, cfg, out_dir):
     import stochopy_amd as sa
 
+    os.environ.update(cfg.get("env", {}))
     runs = _spy_on_de_runs()
     n = cfg["n"]
     opts = dict(cfg["options"], backend="hip", workers=world)

@@ -151,30 +151,34 @@ def test_p2p_exchange_timeout_is_reported():
 
 
 @pytest.mark.gpu
-def test_sharded_pso_on_gpu_is_exact():
-    """PSO state is row-local and the Philox counters use global rows: 2 shards == the unsharded run."""
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+def test_sharded_pso_on_gpu_is_exact(exchange):
+    """PSO state is row-local and the Philox counters use global rows: 2 shards == the unsharded run, with the
+    best record travelling through the process group or by peer writes (one-workgroup exchange kernel)."""
     from _dist_workers import gpu_minimize_worker
 
-    opts = {"maxiter": 12, "popsize": 96, "seed": 77, "ftol": -1.0, "xtol": 0.0}
-    cfg = {"n": 20, "objective": "rosenbrock", "method": "pso", "options": opts}
+    opts = {"maxiter": 40, "popsize": 96, "seed": 77, "ftol": -1.0, "xtol": 0.0}
+    cfg = {"n": 20, "objective": "rosenbrock", "method": "pso", "options": opts, "env": {"SX_EXCHANGE": exchange}}
     out = _spawn(gpu_minimize_worker, 2, cfg)
     ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * 20, method="pso", options=dict(opts), rng="philox")
     for r in range(2):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
         assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+        assert open(os.path.join(out, f"exchange_{r}.txt")).read() == exchange
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_sharded_cpso_restart_is_exact(world):
+def test_sharded_cpso_restart_is_exact(world, exchange):
     """Competitive restart over a sharded swarm: the radius (a max) and the worst-nw rule (a rank) span ALL
     particles -- one all-gather of [pbestfit | partial radii] per generation -- and the new positions are keyed
     by the global row, so the shards reproduce the unsharded run.  Restarts must actually fire."""
     from _dist_workers import gpu_minimize_worker
 
     opts = {"maxiter": 30, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
-    cfg = {"n": 16, "objective": "sphere", "method": "cpso", "options": opts}
+    cfg = {"n": 16, "objective": "sphere", "method": "cpso", "options": opts, "env": {"SX_EXCHANGE": exchange}}
     out = _spawn(gpu_minimize_worker, world, cfg)
     ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method="cpso", options=dict(opts), rng="philox")
     assert len(ref["_restarts"]) > 0
@@ -266,7 +270,7 @@ def test_sharded_pso_rccl_graph_capture_single_rank(method):
     from _dist_workers import nccl_single_rank_worker
 
     opts = {"maxiter": 70, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
-    cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts}
+    cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts, "env": {"SX_EXCHANGE": "rccl"}}
     out = _spawn(nccl_single_rank_worker, 1, cfg)
     ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts), rng="philox")
     fun, nit, nfev, status = np.load(os.path.join(out, "meta_0.npy"))
