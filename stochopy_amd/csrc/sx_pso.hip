@@ -202,6 +202,24 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// histogram increment for one key per lane (dig < 0: this lane has none).  The top bytes of the keys (sign,
+// exponent, leading mantissa bits) are the same for most of the swarm, so plain LDS atomics would serialise on
+// one or two bins: there the wave first agrees on the distinct digits and adds one count per digit.
+__device__ __forceinline__ void hist_add(unsigned *bins, int dig, bool clustered, int lane) {
+    if (!clustered) {
+        if (dig >= 0) atomicAdd(&bins[dig], 1u);
+        return;
+    }
+    unsigned long long todo = __ballot(dig >= 0);
+    while (todo) {
+        const int leader = (int)__ffsll((long long)todo) - 1;
+        const int d = __shfl(dig, leader, kWave);
+        const unsigned long long same = __ballot(dig == d);
+        if (lane == leader) atomicAdd(&bins[d], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 constexpr int kSelThreads = 1024;
 constexpr int kSelPerThread = 32;  // keys held in registers up to 32768 particles (larger swarms re-read them each pass)
 
@@ -262,11 +280,13 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         if (tid < 256) bins[tid] = 0u;
         __syncthreads();
         const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        const bool clustered = shift >= 48;  // sign + exponent (+ 4 mantissa bits): a handful of distinct digits
         if (in_regs) {
 #pragma unroll
             for (int k = 0; k < kSelPerThread; ++k) {
                 const int64_t i = (int64_t)k * kSelThreads + tid;
-                if (i < Ptot && (key[k] & himask) == prefix) atomicAdd(&bins[(unsigned)(key[k] >> shift) & 255u], 1u);
+                const bool mine = i < Ptot && (key[k] & himask) == prefix;
+                hist_add(bins, mine ? (int)((key[k] >> shift) & 255u) : -1, clustered, lane);
             }
         } else {
             for (int64_t i0 = tid; i0 < Ptot; i0 += (int64_t)kSelThreads * 8) {
@@ -279,7 +299,8 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int64_t i = i0 + (int64_t)u * kSelThreads;
-                    if (i < Ptot && (kk[u] & himask) == prefix) atomicAdd(&bins[(unsigned)(kk[u] >> shift) & 255u], 1u);
+                    const bool mine = i < Ptot && (kk[u] & himask) == prefix;
+                    hist_add(bins, mine ? (int)((kk[u] >> shift) & 255u) : -1, clustered, lane);
                 }
             }
         }
