@@ -68,6 +68,7 @@ def _de_reference(cfg, world):
     n = cfg["n"]
     seed = o.pop("seed")
     o.pop("exchange", None)
+    o.pop("donors", None)
     return oe.run_de_sharded(oracle.OBJECTIVES[cfg["objective"]], np.full(n, -5.12), np.full(n, 5.12),
                              oracle.PhiloxStream(seed), world, **o)
 
@@ -136,6 +137,33 @@ def test_global_donors_reproduce_the_unsharded_run(world, case):
     ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method="de", options=dict(opts, updating="deferred"),
                           rng="philox")
     for r in range(world):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,extra", [("de", {"exchange": "p2p"}), ("de", {"exchange": "p2p", "donors": "global"}),
+                                          ("de", {"exchange": "rccl"}), ("pso", {})])
+def test_eight_ranks_share_one_gpu(method, extra):
+    """The full node's world size (8 ranks: one pushing wavefront per peer, 32 header words per wait) on the one
+    test GPU, DE through both transports and with global donors, PSO through the exchange kernel."""
+    from _dist_workers import gpu_minimize_worker
+
+    n, P, gens, seed = 128, 256, 25, 41
+    cfg = _de_cfg(n, P, gens, seed, extra.get("exchange", "p2p"), **{k: v for k, v in extra.items() if k != "exchange"})
+    cfg["method"] = method
+    if method == "pso":
+        cfg["options"].pop("exchange")
+        cfg["env"] = {"SX_EXCHANGE": "p2p"}
+    out = _spawn(gpu_minimize_worker, 8, cfg)
+    opts = {k: v for k, v in cfg["options"].items() if k not in ("exchange", "donors")}
+    if method == "de" and extra.get("donors") != "global":
+        ref = _de_reference(cfg, 8)
+    else:
+        ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method=method, options=dict(opts, updating="deferred"),
+                              rng="philox")
+    for r in range(8):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
         assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
