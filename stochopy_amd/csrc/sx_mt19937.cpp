@@ -183,9 +183,26 @@ extern "C" sx_mt *sx_mt_create(uint32_t seed) {
 extern "C" void sx_mt_destroy(sx_mt *g) { delete g; }
 extern "C" void sx_mt_seed(sx_mt *g, uint32_t seed) { mt_seed(g, seed); }
 
-extern "C" void sx_mt_random(sx_mt *g, double *out, int64_t count) {
-    for (int64_t i = 0; i < count; ++i) out[i] = next_double(g);
+// count doubles, two consecutive words each: whole pairs of the current tempered block are converted in one
+// vectorisable loop; a pair that straddles a block boundary goes through next_double()
+static void fill_doubles(sx_mt *g, double *out, int64_t count) {
+    int64_t i = 0;
+    while (i < count) {
+        if (g->pos >= 624 || !g->out_valid || 624 - g->pos < 2) {
+            out[i++] = next_double(g);
+            continue;
+        }
+        const int64_t pairs = (624 - g->pos) / 2;
+        const int64_t take = pairs < count - i ? pairs : count - i;
+        const uint32_t *w = g->out + g->pos;
+        for (int64_t k = 0; k < take; ++k)
+            out[i + k] = ((double)(w[2 * k] >> 5) * 67108864.0 + (double)(w[2 * k + 1] >> 6)) / 9007199254740992.0;
+        g->pos += (int)(2 * take);
+        i += take;
+    }
 }
+
+extern "C" void sx_mt_random(sx_mt *g, double *out, int64_t count) { fill_doubles(g, out, count); }
 
 extern "C" void sx_mt_uniform(sx_mt *g, double lo, double hi, double *out, int64_t count) {
     const double range = hi - lo;
