@@ -150,15 +150,27 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const double *xr = X + id.rowc * ldx;
     const bool affine = xm != nullptr;
     double pacc = 0.0;
-    for (int e = id.l; e < n; e += LPR) {
-        double v = xr[e];
-        if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
-            const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
-            if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
-            v = c;
+    constexpr int kBatch = 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
+    for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
+        double xv[kBatch];
+#pragma unroll
+        for (int t = 0; t < kBatch; ++t) {
+            const int e = e0 + t * LPR;
+            xv[t] = e < n ? xr[e] : 0.0;
         }
-        if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
-        U[e] = v;
+#pragma unroll
+        for (int t = 0; t < kBatch; ++t) {
+            const int e = e0 + t * LPR;
+            if (e >= n) continue;
+            double v = xv[t];
+            if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
+                const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+                if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
+                v = c;
+            }
+            if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
+            U[e] = v;
+        }
     }
     if (pen_out != nullptr) {
         pacc = row_sum<LPR>(pacc);
