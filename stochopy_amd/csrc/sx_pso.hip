@@ -181,9 +181,19 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(co
     const RowIds<LPR> id(a.P);
     const double *__restrict__ xr = a.X + id.rowc * a.ld;
     double acc = 0.0;
-    for (int e = id.l; e < a.n; e += LPR) {
-        const double d = xr[e] - a.gbest[e];
-        acc += d * d;
+    for (int e0 = id.l; e0 < a.n; e0 += 4 * LPR) {  // four row loads in flight per lane
+        double xv[4], gv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = e0 + t * LPR;
+            xv[t] = e < a.n ? xr[e] : 0.0;
+            gv[t] = e < a.n ? a.gbest[e] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double d = xv[t] - gv[t];
+            acc += d * d;
+        }
     }
     acc = sqrt(row_sum<LPR>(acc));
     if (id.l == 0) sr[id.slot] = id.active ? acc : 0.0;
