@@ -283,7 +283,8 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
     // radix descent, 8 bits per step: histogram (LDS atomics) of the next byte over the keys that match the
     // prefix found so far; the byte of the `remaining`-th largest of them is where the suffix count crosses it
     __shared__ unsigned bins[256];
-    __shared__ unsigned s_digit, s_above;
+    __shared__ unsigned s_digit, s_above, s_count, s_ncand;
+    __shared__ unsigned long long cand[kSelThreads];
     unsigned long long prefix = 0ull;
     unsigned remaining = (unsigned)nw;
     for (int shift = 56; shift >= 0; shift -= 8) {
@@ -339,11 +340,44 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
                 }
                 s_digit = digit;
                 s_above = acc;  // keys (matching the prefix) with a larger byte than `digit`
+                s_count = bins[digit];
             }
         }
         __syncthreads();
         prefix |= (unsigned long long)s_digit << shift;
         remaining -= s_above;
+        // few keys left with this prefix (after three bytes -- sign, exponent, 12 mantissa bits -- typically a
+        // handful): gather them and rank them against each other instead of five more passes over the swarm
+        const unsigned cnt = s_count;
+        if (shift > 0 && cnt <= (unsigned)kSelThreads) {
+            const unsigned long long lomask = ~0ull << shift;
+            if (tid == 0) s_ncand = 0u;
+            __syncthreads();
+            if (in_regs) {
+#pragma unroll
+                for (int k = 0; k < kSelPerThread; ++k) {
+                    const int64_t i = (int64_t)k * kSelThreads + tid;
+                    if (i < Ptot && (key[k] & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = key[k];
+                }
+            } else {
+                for (int64_t i = tid; i < Ptot; i += kSelThreads) {
+                    const unsigned long long kk = sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]);
+                    if ((kk & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = kk;
+                }
+            }
+            __syncthreads();
+            if ((unsigned)tid < cnt) {  // the remaining-th largest candidate: `greater` < remaining <= greater + equal
+                const unsigned long long mine = cand[tid];
+                unsigned greater = 0u, equal = 0u;
+                for (unsigned c = 0; c < cnt; ++c) {
+                    const unsigned long long o = cand[c];
+                    greater += o > mine;
+                    equal += o == mine;
+                }
+                if (greater < remaining && remaining <= greater + equal) out[1] = mine;  // same value from every tie
+            }
+            return;
+        }
     }
     if (tid == 0) out[1] = prefix;
 }
