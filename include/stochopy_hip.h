@@ -325,6 +325,19 @@ int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_r, double d
                         sx_graph **out);
 
 /* ------------------------------------------------------------------------- *
+ * updating="immediate": ONE asynchronous generation, i.e. the sequential sweep in which individual i sees
+ * what individuals 0..i-1 did in the same generation (csrc/sx_async.hip; one row group walks the population).
+ * replaces: de/_de.py:354-391 de_async, cpso/_cpso.py:364-402 pso_async, _common.py:163-194 selection_async
+ *           (`<=` acceptance, best row + status updated per individual, the last individual's status wins,
+ *           then `it >= maxiter -> -1`), cpso/_constraints.py:56-64 (Shrink, one-row form), objective fused.
+ * State: population in place (DE: a->buf0 only; PSO: X, V, pbest), a->gbest (n) in/out = the best row,
+ * a->state->it / gfit in/out, status / done out.  SX_RNG_HOST inputs as for the synchronous generation, but
+ * drawn in the asynchronous order (sx_mt_de_async_draws).  part_f / part_i / buf1 are not used.
+ * Single GPU (row0 = 0, P = whole population). */
+int sx_de_async_generation(const sx_de_args *a, void *stream);
+int sx_pso_async_generation(const sx_pso_args *a, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * CMA-ES device kernels (fp64 MFMA, v_mfma_f64_16x16x4_f64, LDS-tiled 64x64x32)
  * sx_cmaes_sample   replaces cmaes/_cmaes.py:232-237:
  *     arx[i,:] = xmean + sigma * dot(B, D * Z[i,:])          Z (P,n) standard normals
@@ -383,6 +396,11 @@ void sx_mt_randint(sx_mt *g, int64_t high, int64_t *out, int64_t count); /* rand
 void sx_mt_permutation(sx_mt *g, int64_t n, int64_t *out); /* permutation(n)                     */
 /* de/_de.py:304-311 delete_shuffle_sync: P permutations of P-1, first k rows kept: donors[k][P] */
 void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors);
+/* the per-individual draws of ONE de_async generation after r1 (de/_de.py:376-382): for i = 0..P-1
+ * permutation(delete(arange(P), i)) -> donors[t*P+i] (t < k), randint(n) -> irand[i], and with
+ * constraints="Random" uniform(lower, upper, n) -> resample[i*n ..] (resample NULL: not drawn) */
+void sx_mt_de_async_draws(sx_mt *g, int64_t P, int k, int n, int32_t *donors, int32_t *irand, const double *lower,
+                          const double *upper, double *resample);
 /* interchange with np.random.get_state()/set_state(): key[624], pos, has_gauss, cached_gaussian */
 void sx_mt_get_state(sx_mt *g, uint32_t *key, int *pos, int *has_gauss, double *gauss);
 void sx_mt_set_state(sx_mt *g, const uint32_t *key, int pos, int has_gauss, double gauss);

@@ -85,6 +85,21 @@ def greedy_select(it, cand, candfun, xbest, x, xfun, maxiter, xtol, ftol):
     return x[k].copy(), xfun[k], status
 
 
+def async_select(u, fu, i, x, xfun, xbest, xbestfun, xtol, ftol):
+    """_common.py:163-194 for individual i after its evaluation: `<=` acceptance, and the best row / status
+    are updated on the spot.  Returns (xbest, xbestfun, status of THIS individual)."""
+    status = None
+    if fu <= xfun[i]:
+        x[i] = u
+        xfun[i] = fu
+        if fu <= xbestfun:
+            if fu <= ftol:
+                status = 0 if np.linalg.norm(xbest - u) <= xtol else 1
+            xbest = u.copy()
+            xbestfun = fu
+    return xbest, xbestfun, status
+
+
 class History:
     """return_all bookkeeping of de/_de.py:221-234, 270-278 (same for cpso)."""
 
@@ -152,10 +167,11 @@ def de_candidates(X, gbest, draws, F, CR, strategy, lower, upper, constraints):
 
 def run_de(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, mutation=0.5,
            recombination=0.9, strategy="best1bin", xtol=1e-8, ftol=1e-8, constraints=None,
-           return_all=False, verbosity=1.0, **_ignored):
+           return_all=False, verbosity=1.0, updating="deferred", **_ignored):
     n = len(lower)
     P = popsize
     k = DONORS[strategy]
+    immediate = updating == "immediate"
     X = np.array(x0, dtype=np.float64) if x0 is not None else latin_hypercube(stream, P, n, lower, upper)
     pfit = fobj(X)
     fit = pfit.copy()
@@ -169,10 +185,27 @@ def run_de(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=1
     it = 1
     while True:
         it += 1
-        draws = stream.de_generation(it, P, n, k, (lower, upper) if constraints == "Random" else None)
-        U = de_candidates(X, gbest, draws, mutation, recombination, strategy, lower, upper, constraints)
-        pfit = fobj(U)  # NB de/_de.py:270-273: funall pairs post-selection X with CANDIDATE fitness
-        gbest, gfit, status = greedy_select(it, U, pfit, gbest, X, fit, maxiter, xtol, ftol)
+        rb = (lower, upper) if constraints == "Random" else None
+        if immediate:
+            # de/_de.py:354-391: one individual at a time, on the population as it stands
+            draws = stream.de_generation_async(it, P, n, k, rb)
+            pfit = np.empty(P)
+            for i in range(P):
+                V = de_mutants(strategy, draws["donors"][:, i], mutation, X, gbest)
+                take = draws["r1"][i] <= recombination
+                take[draws["irand"][i]] = True
+                u = np.where(take, V, X[i])
+                if constraints == "Random":
+                    u = np.where((u < lower) | (u > upper), draws["resample"][i], u)
+                pfit[i] = fobj(u[None, :])[0]
+                gbest, gfit, status = async_select(u, pfit[i], i, X, fit, gbest, gfit, xtol, ftol)
+            if status is None and it >= maxiter:
+                status = -1
+        else:
+            draws = stream.de_generation(it, P, n, k, rb)
+            U = de_candidates(X, gbest, draws, mutation, recombination, strategy, lower, upper, constraints)
+            pfit = fobj(U)  # NB de/_de.py:270-273: funall pairs post-selection X with CANDIDATE fitness
+            gbest, gfit, status = greedy_select(it, U, pfit, gbest, X, fit, maxiter, xtol, ftol)
         hist.put(it - 1, X, pfit)
         if callback is not None:
             callback(X, Result(x=gbest, fun=gfit, nfev=it * P, nit=it))
@@ -216,10 +249,11 @@ def restart_count(it, maxiter, P, gamma):
 
 def run_pso(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, inertia=0.7298,
             cognitivity=1.49618, sociability=1.49618, competitivity=None, xtol=1e-8, ftol=1e-8,
-            constraints=None, return_all=False, verbosity=1.0, **_ignored):
+            constraints=None, return_all=False, verbosity=1.0, updating="deferred", **_ignored):
     n = len(lower)
     P = popsize
     gamma = competitivity
+    immediate = updating == "immediate"
     if gamma:
         delta = np.log(1.0 + 0.003 * P) / np.max((0.2, np.log(0.01 * maxiter)))
     X = np.array(x0, dtype=np.float64) if x0 is not None else latin_hypercube(stream, P, n, lower, upper)
@@ -239,9 +273,21 @@ def run_pso(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=
     while True:
         it += 1
         r1, r2 = stream.pso_generation(it, P, n)
-        X, V = pso_move(X, V, pbest, gbest, inertia, cognitivity, sociability, r1, r2, lower, upper, constraints)
-        pfit = fobj(X)
-        gbest, gfit, status = greedy_select(it, X, pfit, gbest, pbest, pbestfit, maxiter, xtol, ftol)
+        if immediate:
+            # cpso/_cpso.py:364-402: particle by particle, each against the best row as it stands
+            pfit = np.empty(P)
+            for i in range(P):
+                xi, vi = pso_move(X[i : i + 1], V[i : i + 1], pbest[i : i + 1], gbest, inertia, cognitivity,
+                                  sociability, r1[i : i + 1], r2[i : i + 1], lower, upper, constraints)
+                X[i], V[i] = xi[0], vi[0]
+                pfit[i] = fobj(X[i : i + 1])[0]
+                gbest, gfit, status = async_select(X[i].copy(), pfit[i], i, pbest, pbestfit, gbest, gfit, xtol, ftol)
+            if status is None and it >= maxiter:
+                status = -1
+        else:
+            X, V = pso_move(X, V, pbest, gbest, inertia, cognitivity, sociability, r1, r2, lower, upper, constraints)
+            pfit = fobj(X)
+            gbest, gfit, status = greedy_select(it, X, pfit, gbest, pbest, pbestfit, maxiter, xtol, ftol)
         hist.put(it - 1, X, pfit)
         if callback is not None:
             callback(X, Result(x=gbest, fun=gfit, nfev=it * P, nit=it))
@@ -615,7 +661,9 @@ RUNNERS = {"de": run_de, "pso": run_pso, "cpso": run_pso, "cmaes": run_cmaes, "v
 def minimize(objective, bounds, x0=None, method="de", options=None, callback=None, rng="numpy-legacy"):
     """Oracle counterpart of stochopy.optimize.minimize (_helpers.py:44-94) for named objectives."""
     opts = dict(options or {})
-    opts.pop("updating", None)
+    updating = opts.pop("updating", "deferred")  # NB the oracle's default is the synchronous form
+    if method in ("de", "pso", "cpso"):
+        opts["updating"] = updating
     opts.pop("workers", None)
     opts.pop("backend", None)
     seed = opts.pop("seed", None)

@@ -94,6 +94,22 @@ class LegacyStream:
             resample = rs.uniform(lo, hi, (P, n))
         return {"r1": r1, "donors": donors, "irand": irand, "resample": resample}
 
+    # -- DE generation, updating="immediate": de/_de.py:250, then PER INDIVIDUAL :376 (donor permutation),
+    #    :380 (randint(ndim)) and the constraint's uniform(lower, upper, (n,)) (de/_constraints.py:24) --------
+    def de_generation_async(self, gen, P, n, k, resample_bounds=None):
+        rs = self.rs
+        r1 = rs.rand(P, n)
+        donors = np.empty((k, P), dtype=np.int64)
+        irand = np.empty(P, dtype=np.int64)
+        resample = np.empty((P, n)) if resample_bounds is not None else None
+        for i in range(P):
+            p = rs.permutation(P - 1)[:k]
+            donors[:, i] = p + (p >= i)
+            irand[i] = rs.randint(n)
+            if resample is not None:
+                resample[i] = rs.uniform(resample_bounds[0], resample_bounds[1], n)
+        return {"r1": r1, "donors": donors, "irand": irand, "resample": resample}
+
     # -- PSO generation: cpso/_cpso.py:262-263 ---------------------------------
     def pso_generation(self, gen, P, n, row0=0):
         r1 = self.rs.rand(P, n)
@@ -209,6 +225,10 @@ class PhiloxStream:
             d = self._uniform_block(rows, n, gen, PURPOSE_DE_RESAMPLE)
             resample = lo + (hi - lo) * d
         return {"r1": r1, "donors": donors, "irand": irand, "resample": resample}
+
+    def de_generation_async(self, gen, P, n, k, resample_bounds=None):
+        """Counter-based draws do not depend on the order they are consumed in: the synchronous block."""
+        return self.de_generation(gen, P, n, k, resample_bounds)
 
     def pso_generation(self, gen, P, n, row0=0):
         """32-bit uniforms, one call per two steps: slot = (q >> 1) * 64 + l;

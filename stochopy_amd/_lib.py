@@ -109,6 +109,8 @@ PROTOTYPES = {
     "sx_pso_restart_apply": (C.c_int, [C.POINTER(SxPsoArgs), vp, vp, vp, i64, vp]),
     "sx_pso_restart_select_gathered": (C.c_int, [C.POINTER(SxPsoArgs), vp, C.c_int, f64, f64, vp, vp]),
     "sx_pso_graph_create": (C.c_int, [C.POINTER(SxPsoArgs), C.c_int, vp, f64, f64, vp, C.POINTER(vp)]),
+    "sx_de_async_generation": (C.c_int, [C.POINTER(SxDeArgs), vp]),
+    "sx_pso_async_generation": (C.c_int, [C.POINTER(SxPsoArgs), vp]),
     "sx_cmaes_sample": (C.c_int, [vp, f64, vp, vp, vp, vp, i64, C.c_int, vp]),
     "sx_cmaes_recombine": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "sx_cmaes_rank_mu": (C.c_int, [vp, vp, vp, C.c_int, vp, f64, vp, f64, f64, f64, vp, vp, C.c_int, vp]),
@@ -126,6 +128,7 @@ PROTOTYPES = {
     "sx_mt_randint": (None, [vp, i64, vp, i64]),
     "sx_mt_permutation": (None, [vp, i64, vp]),
     "sx_mt_de_donors": (None, [vp, i64, C.c_int, vp]),
+    "sx_mt_de_async_draws": (None, [vp, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "sx_mt_get_state": (None, [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64)]),
     "sx_mt_set_state": (None, [vp, vp, C.c_int, C.c_int, f64]),
 }

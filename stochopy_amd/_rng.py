@@ -84,6 +84,15 @@ class LegacyHostStream:
         self._L.sx_mt_de_donors(self._h, P, k, out.ctypes.data)
         return out
 
+    def de_async_draws(self, P, k, n, donors, irand, lower=None, upper=None, resample=None):
+        """The per-individual draws of one de_async generation after r1 (de/_de.py:376-382), into the arrays."""
+        lo = hi = rs = None
+        if resample is not None:
+            lower = np.ascontiguousarray(lower, dtype=np.float64)
+            upper = np.ascontiguousarray(upper, dtype=np.float64)
+            lo, hi, rs = lower.ctypes.data, upper.ctypes.data, resample.ctypes.data
+        self._L.sx_mt_de_async_draws(self._h, P, k, n, donors.ctypes.data, irand.ctypes.data, lo, hi, rs)
+
     # -- composite: initial population (reference _common.py:109-120) ----------
     def latin_hypercube(self, P, n, lower, upper):
         x = self.random((P, n))

@@ -49,49 +49,6 @@ extern "C" int sx_trace_read(unsigned long long *out) {
 
 namespace {
 
-constexpr int kMaxDonors = 5;
-
-__host__ __device__ inline int donors_of(int strategy) {
-    return strategy == SX_DE_RAND1BIN ? 3 : strategy == SX_DE_RAND2BIN ? 5 : strategy == SX_DE_BEST1BIN ? 2 : 4;
-}
-
-// Philox donors: k distinct rows != i, uniform without replacement.  Word 1+t of the
-// donor calls gives r_t = mulhi(w, P-1-t); r_t is then shifted past the
-// sorted exclusion list {i, d_0..d_{t-1}} (oracle/streams.py PhiloxStream.de_generation).
-__device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint32_t grow, uint32_t gen, uint32_t k0,
-                                              uint32_t k1, int n, int64_t (&d)[kMaxDonors], int &irand) {
-    // word 0 -> forced crossover index, word 1+t -> donor t; the second call only for 4- and 5-donor strategies
-    const U4 a = philox4x32_10(0u, grow, gen, kPurposeDeDonor, k0, k1);
-    U4 b = {0u, 0u, 0u, 0u};
-    if (k > 3) b = philox4x32_10(1u, grow, gen, kPurposeDeDonor, k0, k1);
-    const uint32_t w[5] = {a.y, a.z, a.w, b.x, b.y};
-    uint32_t excl[kMaxDonors + 1];  // P < 2^31 (checked on the host): 32-bit index arithmetic
-    excl[0] = (uint32_t)i;
-    const uint32_t Pm1 = (uint32_t)(P - 1);
-#pragma unroll
-    for (int t = 0; t < kMaxDonors; ++t) {
-        if (t < k) {
-            uint32_t v = __umulhi(w[t], Pm1 - (uint32_t)t);
-#pragma unroll
-            for (int s = 0; s <= t; ++s) v += (v >= excl[s]) ? 1u : 0u;
-            d[t] = (int64_t)v;
-            uint32_t carry = v;  // insert v into the sorted list excl[0..t]
-#pragma unroll
-            for (int s = 0; s <= t; ++s) {
-                if (carry < excl[s]) {
-                    const uint32_t tmp = excl[s];
-                    excl[s] = carry;
-                    carry = tmp;
-                }
-            }
-            excl[t + 1] = carry;
-        } else {
-            d[t] = 0;
-        }
-    }
-    irand = (int)__umulhi(a.x, (uint32_t)n);
-}
-
 // XM = 0: a.state is ONE sx_state, the best/termination step is a separate kernel.
 // XM = 1 ("chained finalize", single GPU + Philox): a.state is sx_state[3], a.part_f/part_i are
 // [2][npart].  Launch L (parity p = L & 1) first finalises the generation its predecessor produced --

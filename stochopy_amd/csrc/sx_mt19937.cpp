@@ -244,6 +244,25 @@ extern "C" void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors) {
     }
 }
 
+extern "C" void sx_mt_de_async_draws(sx_mt *g, int64_t P, int k, int n, int32_t *donors, int32_t *irand,
+                                     const double *lower, const double *upper, double *resample) {
+    // de_async, per individual (de/_de.py:376-382): donor permutation, forced crossover index, Random's block
+    std::vector<int32_t> a((size_t)(P - 1));
+    const uint64_t mx = (uint64_t)(n - 1);
+    const uint64_t mask = mask_for(mx);
+    for (int64_t i = 0; i < P; ++i) {
+        for (int64_t v = 0; v < P - 1; ++v) a[v] = (int32_t)v;
+        shuffle_small(g, a.data(), (int32_t)(P - 1));
+        for (int t = 0; t < k; ++t) {
+            const int32_t v = a[t];
+            donors[(int64_t)t * P + i] = v + (v >= i ? 1 : 0);
+        }
+        irand[i] = (int32_t)bounded(g, mx, mask);
+        if (resample != nullptr)
+            for (int c = 0; c < n; ++c) resample[i * n + c] = lower[c] + (upper[c] - lower[c]) * next_double(g);
+    }
+}
+
 // np.random.get_state() / set_state() interchange: key[624], pos, has_gauss, cached_gaussian
 extern "C" void sx_mt_get_state(sx_mt *g, uint32_t *key, int *pos, int *has_gauss, double *gauss) {
     std::memcpy(key, g->mt, sizeof g->mt);

@@ -42,12 +42,15 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
+    strict_updating=False,
 ):
     """Minimize an objective function using Competitive PSO on MI355X.
 
     Parameters are those of the reference (cpso/_cpso.py:12-33) plus ``rng``
     ("numpy-legacy" default = the reference's stream, or "philox" = in-kernel draws);
-    ``backend`` must be ``"hip"`` and forces synchronous updating (cpso/_cpso.py:147-150).
+    ``backend`` must be ``"hip"`` and forces synchronous updating (cpso/_cpso.py:147-150) -- unless
+    ``strict_updating=True`` asks for the reference's serial semantics: ``updating="immediate"`` then runs
+    pso_async (cpso/_cpso.py:364-402), one sequential sweep per generation on one GPU (``workers=1``).
     """
     fun_id = _common.resolve_objective(fun, args)
     lower, upper = _common.as_bounds(bounds)
@@ -77,7 +80,8 @@ def minimize(
     workers = _common.resolve_workers(workers)
     run = _PsoRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(inertia), float(cognitivity),
                   float(sociability), competitivity, constraints, float(xtol), float(ftol), bool(return_all),
-                  float(verbosity), callback, rng, seed, workers)
+                  float(verbosity), callback, rng, seed, workers,
+                  immediate=bool(strict_updating) and updating == "immediate" and workers == 1)
     return run.result()
 
 
@@ -86,7 +90,7 @@ class _PsoRun:
     GRAPH_CHUNK = 16  # generations per hipGraph replay (2 or 5 kernel nodes each)
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, w, c1, c2, gamma, constraints, xtol, ftol, return_all,
-                 verbosity, callback, rng, seed, workers, autorun=True):
+                 verbosity, callback, rng, seed, workers, autorun=True, immediate=False):
         self.fun_id, self.lower, self.upper = fun_id, lower, upper
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.w, self.c1, self.c2, self.gamma, self.constraints = w, c1, c2, gamma, constraints
@@ -96,6 +100,7 @@ class _PsoRun:
         self.world = None
         self.Ptotal = P
         self.row0 = 0
+        self.immediate = immediate  # pso_async: one sequential sweep per generation (csrc/sx_async.hip)
         import os
 
         if workers != 1 or os.environ.get("SX_FORCE_SHARDED") == "1":  # env switch: a 1-rank group (tests)
@@ -107,6 +112,8 @@ class _PsoRun:
             if callback is not None or return_all:
                 raise NotImplementedError("callback / return_all are not available with workers > 1")
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
+            if immediate:
+                raise ValueError("immediate updating is a single-GPU sweep")
         self.x0 = x0
         self.ctx = _device.Context()
         self._graph = None
@@ -255,6 +262,9 @@ class _PsoRun:
             for h, d in zip(self.h_r, self.d_r):
                 self.stream.random(None, out=h.numpy())
                 d.copy_(h, non_blocking=True)
+        if self.immediate:
+            _lib.check(ctx.L.sx_pso_async_generation(C.byref(self.args), ctx.stream_ptr), "sx_pso_async_generation")
+            return
         if self.world is None:
             _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_pso_generation")
             return
@@ -342,6 +352,12 @@ class _PsoRun:
                         self._restart_host_order(st.it)
                     else:
                         self._restart_device()
+            elif self.immediate:  # sweeps are long (P sequential particles): look after every few of them
+                for _ in range(min(max(self.maxiter - st.it, 1), 8)):
+                    self._generation()
+                    if self.gamma:
+                        self._restart_device()
+                st = ctx.read_state(self.state)
             else:
                 self.enqueue(min(max(self.maxiter - st.it, 1), self.CHECK_EVERY))
                 st = ctx.read_state(self.state)
@@ -361,6 +377,9 @@ class _PsoRun:
         )
         if self.return_all:
             res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
+        # pso_async assigns X[i] row by row, i.e. works in place on the caller's x0 (cpso/_cpso.py:389)
+        if self.immediate and isinstance(self.x0, np.ndarray) and self.x0.dtype == np.float64:
+            self.x0[...] = self.X.cpu().numpy()
         if self.rng == "numpy-legacy":
             self.stream.sync_back()
         ctx.sync()

@@ -43,6 +43,7 @@ def minimize(
     rng=None,
     exchange=None,
     donors=None,
+    strict_updating=False,
 ):
     """Minimize an objective function using Differential Evolution on MI355X.
 
@@ -51,7 +52,10 @@ def minimize(
     random-draw source: ``"numpy-legacy"`` (default; the reference's stream, so the
     same seed gives the reference's result) or ``"philox"`` (in-kernel counter-based
     draws, the throughput mode).  As in the reference, choosing a parallel backend
-    forces ``updating="deferred"`` (de/_de.py:142-145).  ``exchange`` (``workers > 1`` only) picks how the
+    forces ``updating="deferred"`` (de/_de.py:142-145) -- unless ``strict_updating=True`` asks for the
+    reference's *serial* semantics: ``updating="immediate"`` then runs de_async (de/_de.py:354-391) as one
+    sequential sweep per generation on one GPU (``workers=1``; with more workers the reference's own rule
+    applies and the run is deferred).  ``exchange`` (``workers > 1`` only) picks how the
     per-generation global best travels between GPUs: ``"p2p"`` (the generation kernel writes its shard's
     record straight into the peers' HBM over xGMI), ``"rccl"`` (one all-gather per generation) or ``None`` /
     ``"auto"`` (p2p if its self-test passes on every rank, else rccl); both give identical results.
@@ -90,7 +94,8 @@ def minimize(
 
     run = _DeRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(mutation), float(recombination),
                  strategy, constraints, float(xtol), float(ftol), bool(return_all), float(verbosity), callback, rng,
-                 seed, workers, exchange=exchange, donors=donors)
+                 seed, workers, exchange=exchange, donors=donors,
+                 immediate=bool(strict_updating) and updating == "immediate" and workers == 1)
     return run.result()
 
 
@@ -98,7 +103,7 @@ class _DeRun:
     GRAPH_CHUNK = 50
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, F, CR, strategy, constraints, xtol, ftol, return_all,
-                 verbosity, callback, rng, seed, workers, autorun=True, exchange=None, donors=None):
+                 verbosity, callback, rng, seed, workers, autorun=True, exchange=None, donors=None, immediate=False):
         self.fun_id, self.lower, self.upper = fun_id, lower, upper
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.F, self.CR, self.strategy, self.constraints = F, CR, strategy, constraints
@@ -109,6 +114,7 @@ class _DeRun:
         self.world = None
         self.Ptotal = P
         self.row0 = 0
+        self.immediate = immediate  # de_async: one sequential sweep per generation (csrc/sx_async.hip)
         if workers != 1 or os.environ.get("SX_FORCE_SHARDED") == "1":  # the env switch lets a 1-rank group
             from ..parallel import require_world                         # exercise the exchange path (tests)
 
@@ -118,6 +124,8 @@ class _DeRun:
             if callback is not None or return_all:
                 raise NotImplementedError("callback / return_all are not available with workers > 1")
             self.row0, self.P = self.world.shard(P)  # this rank's rows; self.P is the LOCAL population from here on
+            if immediate:
+                raise ValueError("immediate updating is a single-GPU sweep")
             if self.P - 1 < self.k:
                 raise ValueError("shard too small for the strategy")
         if donors not in (None, "shard", "global"):
@@ -129,7 +137,7 @@ class _DeRun:
         # -- every wavefront re-reduces the per-workgroup records, so only while those are few (<= 512)
         npart = int(_lib.lib().sx_num_partials(self.P, self.n))
         self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
-                      and npart <= 512)
+                      and npart <= 512 and not immediate)
         self.launches = 0
         self.ctx = _device.Context()
         # multi-GPU: the chained kernel with the peer exchange in its prologue, if the transport checks out
@@ -368,6 +376,8 @@ class _DeRun:
         key0, key1 = _rng.philox_key(self.seed) if self.rng == "philox" else (0, 0)
         a = _lib.SxDeArgs()
         a.buf0, a.buf1 = self.bufs[0].data_ptr(), self.bufs[1].data_ptr()
+        if self.immediate:  # ONE population, updated in place (the initial one sits in bufs[1])
+            a.buf0 = a.buf1
         a.fit, a.candfit = self.fit.data_ptr(), self.candfit.data_ptr()
         a.lower, a.upper, a.state = self.d_lower.data_ptr(), self.d_upper.data_ptr(), self.state.data_ptr()
         a.part_f, a.part_i = self.part_f.data_ptr(), self.part_i.data_ptr()
@@ -411,7 +421,7 @@ class _DeRun:
     # --------------------------------------------------------------- helpers
     def _population(self, it):
         """Device view of generation `it`'s population (P, n)."""
-        return self.bufs[it & 1]
+        return self.bufs[1] if self.immediate else self.bufs[it & 1]
 
     def _record(self, it):
         """return_all bookkeeping for generation `it` (de/_de.py:270-278)."""
@@ -457,6 +467,15 @@ class _DeRun:
         """One generation of the numpy-legacy stream, in the reference's order."""
         s = self.stream
         s.random(None, out=self.h_r1.numpy())                      # de/_de.py:250
+        if self.immediate:  # :376-382, individual by individual: donors, forced index, Random's block
+            rs = self.h_rs.numpy() if self.args.constraints else None
+            s.de_async_draws(self.P, self.k, self.n, self.h_don.numpy(), self.h_irand.numpy(), self.lower, self.upper, rs)
+            self.d_r1.copy_(self.h_r1, non_blocking=True)
+            self.d_don.copy_(self.h_don, non_blocking=True)
+            self.d_irand.copy_(self.h_irand, non_blocking=True)
+            if rs is not None:
+                self.d_rs.copy_(self.h_rs, non_blocking=True)
+            return
         s.de_donors(self.P, self.k, out=self.h_don.numpy())        # :304-311
         self.h_irand.numpy()[:] = s.randint(self.n, self.P)        # :340
         self.d_r1.copy_(self.h_r1, non_blocking=True)
@@ -465,6 +484,14 @@ class _DeRun:
         if self.args.constraints:
             s.uniform_rows(self.lower, self.upper, self.P, out=self.h_rs.numpy())  # de/_constraints.py:24
             self.d_rs.copy_(self.h_rs, non_blocking=True)
+
+    def _generation(self):
+        """One generation on the engine stream: the fused kernel + best/termination, or the sequential sweep."""
+        ctx = self.ctx
+        if self.immediate:
+            _lib.check(ctx.L.sx_de_async_generation(C.byref(self.args), ctx.stream_ptr), "sx_de_async_generation")
+        else:
+            _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")
 
     # ------------------------------------------------------------------ loop
     def _run(self):
@@ -483,17 +510,21 @@ class _DeRun:
             remaining = max(self.maxiter - st.it, 1)
             if record_async:
                 for j in range(min(remaining, 32)):
-                    _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")
+                    self._generation()
                     self._record(st.it + 1 + j)  # generations after convergence are no-ops; their slots are cut off
                 st = ctx.read_state(self.state)
             elif stepwise:
                 if self.rng == "numpy-legacy":
                     self._host_draws()
-                _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")
+                self._generation()
                 self._record(st.it + 1)
                 st = ctx.read_state(self.state)
                 if self.callback is not None:
                     self.callback(self._population(st.it).cpu().numpy(), self._partial_result(st))
+            elif self.immediate:  # sweeps are long (P sequential individuals): look after every few of them
+                for _ in range(min(remaining, 8)):
+                    self._generation()
+                st = ctx.read_state(self.state)
             else:
                 # termination is tested on the device every generation; the host looks every <=4 chunks
                 self.enqueue(min(remaining, 4 * self.GRAPH_CHUNK))

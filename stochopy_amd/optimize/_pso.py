@@ -30,10 +30,12 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
+    strict_updating=False,
 ):
     """Minimize an objective function using PSO on MI355X (reference pso/_pso.py:9-29)."""
     return _cpso.minimize(fun, bounds, x0, args, maxiter, popsize, inertia, cognitivity, sociability, None, seed,
-                          xtol, ftol, constraints, updating, workers, backend, return_all, verbosity, callback, rng)
+                          xtol, ftol, constraints, updating, workers, backend, return_all, verbosity, callback, rng,
+                          strict_updating)
 
 
 register("pso", minimize)

@@ -384,8 +384,70 @@ def vdcma():
     print("wrote vdcma_xall.npz", os.path.getsize(os.path.join(HERE, "vdcma_xall.npz")))
 
 
+# --------------------------------------------------------------------------- #
+# 7. updating="immediate" (de/_de.py:354-391 de_async, cpso/_cpso.py:364-402 pso_async,
+#    _common.py:163-194 selection_async): the reference's own test rows (tests/test_optimize.py:27-117) and
+#    mid-size problems for every strategy / constraint, incl. runs that stop on ftol / xtol
+# --------------------------------------------------------------------------- #
+def immediate():
+    out = dict(STAMP)
+    cases = []
+    arrays = {}
+
+    def add(tag, fun, n, method, opts, xref=None):
+        o = dict(opts, updating="immediate", return_all=True)
+        entry, res, pops = run_ref(fun, n, method, o, full=True)
+        entry["tag"] = tag
+        if xref is not None:
+            entry["xref_from_reference_tests"] = xref
+            assert np.allclose(xref, res.x), (tag, xref, res.x)
+        arrays[tag + "__xall"] = res.xall
+        arrays[tag + "__funall"] = res.funall
+        cases.append(entry)
+        print(" ", tag, "fun", float(res.fun), "nit", res.nit, "status", res.status)
+
+    base = {"maxiter": 128, "popsize": 8, "seed": 42}
+    de_common = dict(base, recombination=0.1, mutation=0.5)
+    add("de_rand1bin_immediate", "rosenbrock", 2, "de", dict(de_common, strategy="rand1bin", constraints=None),
+        [0.85658185, 0.726094])
+    add("de_rand1bin_random_immediate", "rosenbrock", 2, "de", dict(de_common, strategy="rand1bin", constraints="Random"),
+        [0.99438151, 0.9944796])
+    pso_common = dict(base, cognitivity=1.49618, sociability=1.49618)
+    add("pso_none_immediate", "rosenbrock", 2, "pso", dict(pso_common, inertia=0.7298, constraints=None),
+        [0.95909508, 0.91977272])
+    add("pso_shrink_immediate", "rosenbrock", 2, "pso", dict(pso_common, inertia=0.91, constraints="Shrink"),
+        [0.76668308, 0.58381385])
+    cpso_common = dict(pso_common, competitivity=1.0)
+    add("cpso_none_immediate", "rosenbrock", 2, "cpso", dict(cpso_common, inertia=0.7298, constraints=None),
+        [0.93258856, 0.86919435])
+    add("cpso_shrink_immediate", "rosenbrock", 2, "cpso", dict(cpso_common, inertia=0.91, constraints="Shrink"),
+        [0.76668308, 0.58381385])
+    for strat in ("rand1bin", "rand2bin", "best1bin", "best2bin"):
+        for cons in (None, "Random"):
+            add("de_%s_%s_n10_p40_immediate" % (strat, cons or "none"), "rastrigin", 10, "de",
+                {"maxiter": 12, "popsize": 40, "seed": 7, "strategy": strat, "constraints": cons,
+                 "mutation": 0.9 if cons else 0.5})
+    add("de_best1bin_rosen_n150_p24_immediate", "rosenbrock", 150, "de", {"maxiter": 8, "popsize": 24, "seed": 2})
+    for cons in (None, "Shrink"):
+        add("pso_%s_ackley_n16_p64_immediate" % (cons or "none"), "ackley", 16, "pso",
+            {"maxiter": 30, "popsize": 64, "seed": 5, "constraints": cons, "inertia": 0.91 if cons else 0.7298})
+        add("cpso_%s_ackley_n16_p96_immediate" % (cons or "none"), "ackley", 16, "cpso",
+            {"maxiter": 30, "popsize": 96, "seed": 5, "constraints": cons, "inertia": 0.91 if cons else 0.7298})
+    add("pso_styblinski_n130_p20_immediate", "styblinski_tang", 130, "pso", {"maxiter": 10, "popsize": 20, "seed": 4})
+    add("de_status_sphere_n4_p32_immediate", "sphere", 4, "de",
+        {"maxiter": 400, "popsize": 32, "seed": 9, "ftol": 1e-6, "xtol": 1e-3})
+    add("pso_status_sphere_n4_p32_immediate", "sphere", 4, "pso",
+        {"maxiter": 400, "popsize": 32, "seed": 9, "ftol": 1e-6, "xtol": 1e-3})
+    out["cases"] = cases
+    dump("immediate.json", out)
+    np.savez_compressed(os.path.join(HERE, "immediate_xall.npz"), **arrays)
+    print("wrote immediate_xall.npz", os.path.getsize(os.path.join(HERE, "immediate_xall.npz")))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "factory", "suite", "configs", "penalize", "vdcma"]
+    which = sys.argv[1:] or ["rng", "factory", "suite", "configs", "penalize", "vdcma", "immediate"]
+    if "immediate" in which:
+        immediate()
     if "vdcma" in which:
         vdcma()
     if "penalize" in which:

@@ -127,6 +127,27 @@ def test_vdcma_bit_exact(case):
         assert np.allclose(case["xref_from_reference_tests"], res.x)
 
 
+IMMEDIATE = load_golden("immediate.json")["cases"]
+
+
+@pytest.mark.parametrize("case", IMMEDIATE, ids=lambda c: c["tag"])
+def test_immediate_updating_bit_exact(case):
+    """updating="immediate" (de_async / pso_async / selection_async): the reference's own test rows
+    (tests/test_optimize.py:27-117) and mid-size problems for every strategy and constraint; the sphere rows
+    pin the status rule (only the LAST individual of a sweep can end the run)."""
+    trace = []
+    res = _run(case, trace)
+    ref = case["result"]
+    assert np.array_equal(unhex(case["fun_trace"]), np.array([t[0] for t in trace]))
+    assert (res.nit, res.nfev, res.status, res.message) == (ref["nit"], ref["nfev"], ref["status"], ref["message"])
+    assert np.array_equal(unhex(ref["x"]), res.x) and float(res.fun).hex() == ref["fun"]
+    arrays = np.load(os.path.join(GOLDEN, "immediate_xall.npz"))
+    assert np.array_equal(arrays[case["tag"] + "__xall"], res.xall)
+    assert np.array_equal(arrays[case["tag"] + "__funall"], res.funall)
+    if "xref_from_reference_tests" in case:
+        assert np.allclose(case["xref_from_reference_tests"], res.x)
+
+
 def test_populations_bit_exact():
     arrays = np.load(os.path.join(GOLDEN, "configs_pops.npz"))
     by_tag = {c["tag"]: c for c in CONFIGS}
