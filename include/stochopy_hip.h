@@ -325,8 +325,10 @@ int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_r, double d
                         sx_graph **out);
 
 /* ------------------------------------------------------------------------- *
- * updating="immediate": ONE asynchronous generation, i.e. the sequential sweep in which individual i sees
- * what individuals 0..i-1 did in the same generation (csrc/sx_async.hip; one row group walks the population).
+ * updating="immediate": ONE asynchronous generation, i.e. the ordered sweep in which individual i sees
+ * what individuals 0..i-1 did in the same generation (csrc/sx_async.hip: one workgroup; rounds of up to 64
+ * individuals are proposed together, judged in order, and the few that depended on an earlier one of their
+ * round are proposed again -- the sequential result, bit for bit).
  * replaces: de/_de.py:354-391 de_async, cpso/_cpso.py:364-402 pso_async, _common.py:163-194 selection_async
  *           (`<=` acceptance, best row + status updated per individual, the last individual's status wins,
  *           then `it >= maxiter -> -1`), cpso/_constraints.py:56-64 (Shrink, one-row form), objective fused.

@@ -75,6 +75,12 @@ PHILOX = [
     ("pso", "sphere", 4, {"popsize": 32, "maxiter": 300, "ftol": 1e-6, "xtol": 1e-3}),
     ("cpso", "sphere", 16, {"popsize": 96, "maxiter": 30, "constraints": "Shrink", "inertia": 0.91}),
     ("cpso", "rosenbrock", 8, {"popsize": 128, "maxiter": 40}),
+    # many rounds of 64 / 32 / 16 individuals per sweep, ragged last round
+    ("de", "rosenbrock", 16, {"popsize": 701, "maxiter": 6, "strategy": "best1bin"}),
+    ("de", "sphere", 100, {"popsize": 333, "maxiter": 5, "strategy": "rand1bin", "constraints": "Random", "mutation": 1.3}),
+    ("de", "rosenbrock", 300, {"popsize": 150, "maxiter": 4, "strategy": "rand2bin"}),
+    ("pso", "sphere", 20, {"popsize": 517, "maxiter": 8, "constraints": "Shrink", "inertia": 0.91}),
+    ("cpso", "rosenbrock", 200, {"popsize": 130, "maxiter": 8}),
 ]
 
 
