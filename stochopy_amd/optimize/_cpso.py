@@ -109,8 +109,6 @@ class _PsoRun:
             self.world = require_world(workers)
             if rng != "philox":
                 raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
-            if callback is not None or return_all:
-                raise NotImplementedError("callback / return_all are not available with workers > 1")
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
             if immediate:
                 raise ValueError("immediate updating is a single-GPU sweep")
@@ -224,14 +222,18 @@ class _PsoRun:
             self.h_r = [t.empty((P, n), dtype=t.float64).pin_memory() for _ in range(2)]
             self.d_r = [ctx.empty((P, n)) for _ in range(2)]
             a.r1, a.r2 = self.d_r[0].data_ptr(), self.d_r[1].data_ptr()
+        if self.world is not None and (self.return_all or self.callback is not None):
+            self.Xfull = ctx.empty((self.Ptotal, n))
+            self.candfull = ctx.empty((self.Ptotal,))
         if self.return_all:
-            self.nout = int(np.ceil(self.verbosity * P))
+            self.nout = int(np.ceil(self.verbosity * self.Ptotal))
             rows = max(self.nout, 1)
             self.xall = ctx.empty((self.maxiter, rows, n))
             self.funall = ctx.empty((self.maxiter, rows))
             if self.nout > 0:
-                self.xall[0].copy_(self.X[: self.nout])
-                self.funall[0].copy_(self.pbestfit[: self.nout])
+                X1, f1 = self._whole_swarm()  # candfit == pbestfit for the initial swarm
+                self.xall[0].copy_(X1[: self.nout])
+                self.funall[0].copy_(f1[: self.nout])
             else:
                 self.xall[0, 0].copy_(self.gbest)
                 self.funall[0, 0] = st.gfit
@@ -239,19 +241,29 @@ class _PsoRun:
         self.restarts = []
 
     # --------------------------------------------------------------- helpers
+    def _whole_swarm(self):
+        """(positions, their fitness) as the caller sees them: with workers > 1 every rank gathers all shards
+        (callbacks / return_all only)."""
+        if self.world is None:
+            return self.X, self.candfit
+        self.world.all_gather_rows(self.X, self.Xfull)
+        self.world.all_gather_rows(self.candfit, self.candfull)
+        return self.Xfull, self.candfull
+
     def _record(self, it):
         if not self.return_all:
             return
+        X, cand = self._whole_swarm()
         if self.nout > 0:
-            self.xall[it - 1].copy_(self.X[: self.nout])
-            self.funall[it - 1].copy_(self.candfit[: self.nout])
+            self.xall[it - 1].copy_(X[: self.nout])
+            self.funall[it - 1].copy_(cand[: self.nout])
         else:
-            k = int(self.candfit.argmin())
-            self.xall[it - 1, 0].copy_(self.X[k])
-            self.funall[it - 1, 0] = self.candfit[k]
+            k = int(cand.argmin())
+            self.xall[it - 1, 0].copy_(X[k])
+            self.funall[it - 1, 0] = cand[k]
 
     def _partial_result(self, st):
-        res = OptimizeResult(x=self.gbest.cpu().numpy(), fun=st.gfit, nfev=st.it * self.P, nit=st.it)
+        res = OptimizeResult(x=self.gbest.cpu().numpy(), fun=st.gfit, nfev=st.it * self.Ptotal, nit=st.it)
         if self.return_all:
             res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
         return res
@@ -327,7 +339,7 @@ class _PsoRun:
         self._setup()
         st = self.st
         if self.callback is not None:
-            self.callback(self.X.cpu().numpy(), self._partial_result(st))
+            self.callback(self._whole_swarm()[0].cpu().numpy(), self._partial_result(st))
         # return_all with in-kernel draws: history copies (cpso/_cpso.py:283-295) are device-side and ordered on
         # the engine stream, so the host need not look at every generation
         record_async = (self.return_all and self.rng == "philox" and self.callback is None and self.nout > 0
@@ -346,7 +358,7 @@ class _PsoRun:
                 self._record(st.it + 1)
                 st = ctx.read_state(self.state)
                 if self.callback is not None:
-                    self.callback(self.X.cpu().numpy(), self._partial_result(st))
+                    self.callback(self._whole_swarm()[0].cpu().numpy(), self._partial_result(st))
                 if not st.done and self.gamma:
                     if self.rng == "numpy-legacy":
                         self._restart_host_order(st.it)

@@ -121,8 +121,6 @@ class _DeRun:
             self.world = require_world(workers)
             if rng != "philox":
                 raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
-            if callback is not None or return_all:
-                raise NotImplementedError("callback / return_all are not available with workers > 1")
             self.row0, self.P = self.world.shard(P)  # this rank's rows; self.P is the LOCAL population from here on
             if immediate:
                 raise ValueError("immediate updating is a single-GPU sweep")
@@ -405,16 +403,24 @@ class _DeRun:
                 self.d_rs = ctx.empty((P, n))
                 a.resample = self.d_rs.data_ptr()
         # return_all history (de/_de.py:221-234) kept in HBM, copied out once at the end
+        self.st = st
+        if self.world is not None and (self.return_all or self.callback is not None):
+            self.Xfull = ctx.empty((self.Ptotal, n))
+            self.candfull = ctx.empty((self.Ptotal,))
+            if self.px is not None:  # generation 1 finalised over all ranks (a finalise-only launch on every rank)
+                st = self.read_state()
+                self.gbest.copy_(ctx.upload(self._best_row(st)))
         if self.return_all:
-            self.nout = int(np.ceil(self.verbosity * P))
+            self.nout = int(np.ceil(self.verbosity * self.Ptotal))
             rows = max(self.nout, 1)
             self.xall = ctx.empty((self.maxiter, rows, n))
             self.funall = ctx.empty((self.maxiter, rows))
             if self.nout > 0:
-                self.xall[0].copy_(self.bufs[1][: self.nout])
-                self.funall[0].copy_(self.fit[: self.nout])
+                X1, f1 = self._whole_population(1)
+                self.xall[0].copy_(X1[: self.nout])
+                self.funall[0].copy_(f1[: self.nout])
             else:
-                self.xall[0, 0].copy_(self.bufs[1][g])
+                self.xall[0, 0].copy_(self.gbest if self.world is not None else self.bufs[1][g])
                 self.funall[0, 0] = st.gfit
         self.st = st
 
@@ -423,18 +429,29 @@ class _DeRun:
         """Device view of generation `it`'s population (P, n)."""
         return self.bufs[1] if self.immediate else self.bufs[it & 1]
 
+    def _whole_population(self, it):
+        """(population, candidate fitness) of generation `it` as the caller sees them: with workers > 1 every
+        rank gathers all shards (callbacks / return_all only -- the reference's parallel backends also hand the
+        whole population to the callback on every rank)."""
+        X = self._population(it)
+        if self.world is None:
+            return X, self.candfit
+        self.world.all_gather_rows(X, self.Xfull)
+        self.world.all_gather_rows(self.candfit, self.candfull)
+        return self.Xfull, self.candfull
+
     def _record(self, it):
         """return_all bookkeeping for generation `it` (de/_de.py:270-278)."""
         if not self.return_all:
             return
-        X = self._population(it)
+        X, cand = self._whole_population(it)
         if self.nout > 0:
             self.xall[it - 1].copy_(X[: self.nout])
-            self.funall[it - 1].copy_(self.candfit[: self.nout])  # candidate fitness, de/_de.py:270-273
+            self.funall[it - 1].copy_(cand[: self.nout])  # candidate fitness, de/_de.py:270-273
         else:
-            k = int(self.candfit.argmin())
+            k = int(cand.argmin())
             self.xall[it - 1, 0].copy_(X[k])
-            self.funall[it - 1, 0] = self.candfit[k]
+            self.funall[it - 1, 0] = cand[k]
 
     def _best_row(self, st):
         """The best individual of generation st.it (host copy)."""
@@ -458,7 +475,7 @@ class _DeRun:
         return status
 
     def _partial_result(self, st):
-        res = OptimizeResult(x=self._best_row(st), fun=st.gfit, nfev=st.it * self.P, nit=st.it)
+        res = OptimizeResult(x=self._best_row(st), fun=st.gfit, nfev=st.it * self.Ptotal, nit=st.it)
         if self.return_all:
             res.update({"xall": self.xall[: st.it].cpu().numpy(), "funall": self.funall[: st.it].cpu().numpy()})
         return res
@@ -486,9 +503,15 @@ class _DeRun:
             self.d_rs.copy_(self.h_rs, non_blocking=True)
 
     def _generation(self):
-        """One generation on the engine stream: the fused kernel + best/termination, or the sequential sweep."""
+        """One generation on the engine stream: the fused kernel + best/termination, or the sequential sweep;
+        with workers > 1 the shard's generation + the exchange of the global best."""
         ctx = self.ctx
-        if self.immediate:
+        if self.px is not None:
+            self._chain_launch(self.launches & 1, 0)
+            self.launches += 1
+        elif self.world is not None:
+            self._sharded_generation()
+        elif self.immediate:
             _lib.check(ctx.L.sx_de_async_generation(C.byref(self.args), ctx.stream_ptr), "sx_de_async_generation")
         else:
             _lib.check(ctx.L.sx_de_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_de_generation")
@@ -499,7 +522,7 @@ class _DeRun:
         self._setup()
         st = self.st
         if self.callback is not None:
-            self.callback(self._population(1).cpu().numpy(), self._partial_result(st))
+            self.callback(self._whole_population(1)[0].cpu().numpy(), self._partial_result(st))
         # return_all with in-kernel draws: the per-generation history copies (de/_de.py:270-278) are device-side
         # and ordered on the engine stream, so the host need not look at every generation
         record_async = (self.return_all and self.rng == "philox" and self.callback is None and self.nout > 0
@@ -512,15 +535,15 @@ class _DeRun:
                 for j in range(min(remaining, 32)):
                     self._generation()
                     self._record(st.it + 1 + j)  # generations after convergence are no-ops; their slots are cut off
-                st = ctx.read_state(self.state)
+                st = self.read_state()
             elif stepwise:
                 if self.rng == "numpy-legacy":
                     self._host_draws()
                 self._generation()
                 self._record(st.it + 1)
-                st = ctx.read_state(self.state)
+                st = self.read_state()
                 if self.callback is not None:
-                    self.callback(self._population(st.it).cpu().numpy(), self._partial_result(st))
+                    self.callback(self._whole_population(st.it)[0].cpu().numpy(), self._partial_result(st))
             elif self.immediate:  # sweeps are long (P sequential individuals): look after every few of them
                 for _ in range(min(remaining, 8)):
                     self._generation()

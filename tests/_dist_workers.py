@@ -112,8 +112,16 @@ def _minimize_and_save(rank, world, cfg, out_dir):
     n = cfg["n"]
     opts = dict(cfg["options"], backend="hip", workers=world)
     opts.setdefault("rng", "philox")
+    seen = []
+    cb = (lambda X, r: seen.append((np.array(X, copy=True), float(r.fun), int(r.nit), int(r.nfev)))) if cfg.get("callback") else None
     res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), cfg.get("bounds", [[-5.12, 5.12]] * n), method=cfg["method"],
-                               options=opts)
+                               options=opts, callback=cb)
+    if "xall" in res:
+        np.save(os.path.join(out_dir, f"xall_{rank}.npy"), res.xall)
+        np.save(os.path.join(out_dir, f"funall_{rank}.npy"), res.funall)
+    if cb is not None:
+        np.save(os.path.join(out_dir, f"cbX_{rank}.npy"), np.array([c[0] for c in seen]))
+        np.save(os.path.join(out_dir, f"cbmeta_{rank}.npy"), np.array([c[1:] for c in seen]))
     np.save(os.path.join(out_dir, f"x_{rank}.npy"), res.x)
     np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([res.fun, res.nit, res.nfev, res.status]))
     if runs:

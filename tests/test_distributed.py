@@ -217,6 +217,59 @@ def test_sharded_cpso_restart_is_exact(world, exchange):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method,extra,env", [
+    ("pso", {}, {"SX_EXCHANGE": "rccl"}),
+    ("cpso", {"constraints": "Shrink", "inertia": 0.91}, {"SX_EXCHANGE": "p2p"}),
+    ("de", {"exchange": "p2p", "donors": "global", "strategy": "rand1bin"}, {}),
+    ("de", {"exchange": "p2p", "donors": "global", "verbosity": 0.0}, {}),
+])
+@pytest.mark.parametrize("with_callback", [False, True])
+def test_sharded_callbacks_and_return_all(method, extra, env, with_callback):
+    """workers > 1 with return_all / callback: every rank sees the WHOLE population each generation (as the
+    reference's parallel backends do).  PSO / CPSO shards and DE with global donors are the unsharded run, so
+    xall, funall and everything the callback receives must equal the oracle's, on every rank."""
+    from _dist_workers import gpu_minimize_worker
+
+    n, world = 12, 2
+    opts = dict({"maxiter": 25, "popsize": 64, "seed": 21, "ftol": -1.0, "xtol": 0.0, "return_all": True}, **extra)
+    cfg = {"n": n, "objective": "sphere" if method == "cpso" else "rosenbrock", "method": method, "options": opts,
+           "env": env, "callback": with_callback}
+    out = _spawn(gpu_minimize_worker, world, cfg)
+    seen = []
+    oopts = {k: v for k, v in opts.items() if k not in ("exchange", "donors")}
+    ref = oracle.minimize(cfg["objective"], [[-5.12, 5.12]] * n, method=method, options=oopts, rng="philox",
+                          callback=lambda X, r: seen.append((X.copy(), float(r.fun), int(r.nit), int(r.nfev))))
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+        assert np.array_equal(np.load(os.path.join(out, f"xall_{r}.npy")), ref.xall)
+        assert np.array_equal(np.load(os.path.join(out, f"funall_{r}.npy")), ref.funall)
+        if with_callback:
+            assert np.array_equal(np.load(os.path.join(out, f"cbX_{r}.npy")), np.array([c[0] for c in seen]))
+            assert np.array_equal(np.load(os.path.join(out, f"cbmeta_{r}.npy")), np.array([c[1:] for c in seen]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+def test_sharded_de_island_model_with_return_all(exchange):
+    """Shard-local donors (the default island model) with return_all + callback: same best as the run without
+    them, and the recorded rows are the gathered shards (first rows = rank 0's)."""
+    from _dist_workers import gpu_minimize_worker
+
+    cfg = _de_cfg(24, 128, 9, 2024, exchange)
+    plain = _spawn(gpu_minimize_worker, 2, cfg)
+    cfg2 = _de_cfg(24, 128, 9, 2024, exchange, return_all=True)
+    cfg2["callback"] = True
+    out = _spawn(gpu_minimize_worker, 2, cfg2)
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), np.load(os.path.join(plain, f"x_{r}.npy")))
+        xall, funall = np.load(os.path.join(out, f"xall_{r}.npy")), np.load(os.path.join(out, f"funall_{r}.npy"))
+        assert xall.shape == (9, 128, 24) and funall.shape == (9, 128)
+        cbX = np.load(os.path.join(out, f"cbX_{r}.npy"))
+        assert cbX.shape == (9, 128, 24) and np.array_equal(cbX, xall)  # full verbosity: the callback's X is xall[it-1]
+    assert np.array_equal(np.load(os.path.join(out, "xall_0.npy")), np.load(os.path.join(out, "xall_1.npy")))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rng", ["philox", "numpy-legacy"])
 def test_sharded_cmaes_matches_single_gpu(rng):
     """CMA-ES with workers=2: candidates sampled / evaluated by shards, model update replicated == workers=1."""
