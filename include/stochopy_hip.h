@@ -325,6 +325,24 @@ int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_r, double d
                         sx_graph **out);
 
 /* ------------------------------------------------------------------------- *
+ * Generations around a CALLER-SUPPLIED objective (the backend hook contract of _common.py:27-106: `fun(X)` maps
+ * the (P,n) population to (P,) values -- here a callable working on the device array).  The objective cannot
+ * be fused, so a generation is: sx_de_propose / sx_pso_move -> caller's objective -> sx_rows_select ->
+ * sx_select_finalize (or the shard-best exchange).  Same draws / arithmetic / records as the fused kernels.
+ *   sx_de_propose : cand (P,n) row-major <- the trial vectors of generation state->it + 1 (de/_de.py:333-344,
+ *                   de/_strategy.py, de/_constraints.py:13-28); nothing else is written.
+ *   sx_pso_move   : V, X updated in place (cpso/_cpso.py:324-329, cpso/_constraints.py:4-53).
+ *   sx_rows_select: selection_sync after the evaluation (_common.py:127-129): rows with f[i] < xfun[i] take
+ *                   cand[i] (xout row <- cand row, xfun[i] <- f[i]); the others keep xin's row (copied when
+ *                   xout != xin: DE's other population buffer); candfit[i] <- f[i] (or NULL); part_f/part_i <-
+ *                   the workgroup records sx_select_finalize / sx_shard_best expect. */
+int sx_de_propose(const sx_de_args *a, double *cand, void *stream);
+int sx_pso_move(const sx_pso_args *a, void *stream);
+int sx_rows_select(const double *cand, int64_t ldc, const double *f, const double *xin, double *xout, int64_t ldx,
+                   double *xfun, double *candfit, int64_t P, int n, const sx_state *state, double *part_f,
+                   int64_t *part_i, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * updating="immediate": ONE asynchronous generation, i.e. the ordered sweep in which individual i sees
  * what individuals 0..i-1 did in the same generation (csrc/sx_async.hip: one workgroup; rounds of up to 64
  * individuals are proposed together, judged in order, and the few that depended on an earlier one of their

@@ -110,6 +110,9 @@ PROTOTYPES = {
     "sx_pso_restart_select_gathered": (C.c_int, [C.POINTER(SxPsoArgs), vp, C.c_int, f64, f64, vp, vp]),
     "sx_pso_graph_create": (C.c_int, [C.POINTER(SxPsoArgs), C.c_int, vp, f64, f64, vp, C.POINTER(vp)]),
     "sx_de_async_generation": (C.c_int, [C.POINTER(SxDeArgs), vp]),
+    "sx_de_propose": (C.c_int, [C.POINTER(SxDeArgs), vp, vp]),
+    "sx_pso_move": (C.c_int, [C.POINTER(SxPsoArgs), vp]),
+    "sx_rows_select": (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp, i64, C.c_int, vp, vp, vp, vp]),
     "sx_pso_async_generation": (C.c_int, [C.POINTER(SxPsoArgs), vp]),
     "sx_cmaes_sample": (C.c_int, [vp, f64, vp, vp, vp, vp, i64, C.c_int, vp]),
     "sx_cmaes_recombine": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),

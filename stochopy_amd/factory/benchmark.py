@@ -19,6 +19,8 @@ __all__ = [
     "rosenbrock",
     "sphere",
     "styblinski_tang",
+    "batched",
+    "host_callable",
 ]
 
 
@@ -66,3 +68,34 @@ rastrigin = Objective("rastrigin")
 rosenbrock = Objective("rosenbrock")
 sphere = Objective("sphere")
 styblinski_tang = Objective("styblinski_tang")
+
+
+class batched:
+    """Tag a user objective that works on the device population: ``fun(X, *args)`` receives the (P, n) float64
+    ROCm tensor of candidates (on the engine's current stream) and returns the (P,) float64 fitness tensor on the
+    same device.  This is the backend's hook contract (reference _common.py:27-106: after decoration ``fun(X)``
+    maps the (P, n) population to (P,) values).  The objective cannot be fused into the generation kernels, so a
+    generation becomes propose -> fun -> select (csrc/sx_unfused.hip); everything else stays as it is."""
+
+    host = False
+
+    def __init__(self, fun):
+        if not hasattr(fun, "__call__"):
+            raise TypeError()
+        self.fun = fun
+        self.__name__ = getattr(fun, "__name__", "objective")
+
+    def __repr__(self):
+        return f"<stochopy_amd {'host' if self.host else 'device-batched'} objective {self.__name__}>"
+
+    def __call__(self, *a, **k):
+        return self.fun(*a, **k)
+
+
+class host_callable(batched):
+    """Tag a plain Python objective ``fun(x, *args)`` (1-D numpy row -> float), the reference's own calling
+    convention.  EXPLICITLY slow: every generation the candidates are copied to the host and evaluated row by row
+    by the caller's code (exactly what the reference's serial backend does, _common.py:79-80); proposal,
+    selection and best/termination stay on the GPU.  Never chosen silently -- untagged callables are refused."""
+
+    host = True

@@ -264,10 +264,9 @@ class _CmaRun:
                        "sx_cmaes_sample")
             # ---- evaluate: fun(unstandardize(x)) fused (cmaes/_cmaes.py:173, 258) ----
             if not self.penalize:
-                _device.evaluate(ctx, self.fun_id, d_arx_loc, n, f=d_fit_loc, xm=d_xm, xstd=d_xstd)
+                _common.evaluate_rows(ctx, self.fun_id, d_arx_loc, n, d_fit_loc, xm=d_xm, xstd=d_xstd)
             else:  # candidates clipped to the box before the objective (cmaes/_constraints.py:29-31)
-                _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd), None,
-                                                     ptr(d_fit_loc), None, sp), "sx_cmaes_eval_penalized")
+                _common.evaluate_rows(ctx, self.fun_id, d_arx_loc, n, d_fit_loc, xm=d_xm, xstd=d_xstd, clip=True)
             if self.world is not None:  # every rank gets all candidates and fitness values back
                 self.world.all_gather_rows(d_arx_loc, d_arx)
                 self.world.all_gather_rows(d_fit_loc, d_fit)
@@ -277,9 +276,7 @@ class _CmaRun:
                 v = bweights.update(arfit, xmean, xold, sigma, diagC, mueff, it, P)
                 if v.any():
                     d_v.copy_(t.from_numpy(np.ascontiguousarray(v)))
-                    _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd),
-                                                         ptr(d_v), ptr(d_fit_loc), ptr(d_pen_loc), sp),
-                               "sx_cmaes_eval_penalized")
+                    _common.penalty_rows(ctx, self.fun_id, d_arx_loc, n, d_xm, d_xstd, d_v, d_fit_loc, d_pen_loc)
                     if self.world is not None:
                         self.world.all_gather_rows(d_pen_loc, d_pen)
                     arfit = arfit + d_pen.cpu().numpy()

@@ -37,24 +37,80 @@ def resolve_backend(backend):
     raise ValueError(f"unknown backend '{backend}'")  # reference _common.py:74-75
 
 
-def resolve_objective(fun, args):
-    """Map the user's callable to a device kernel id.
+class External:
+    """A caller-supplied objective as the generation loops use it: ``ext(ctx, X)`` -> (P,) device tensor."""
 
-    Only the factory objectives (stochopy_amd.factory, tagged with ``sx_id``) run
-    fused on the device.  Arbitrary Python callables would have to be evaluated
-    on the host every generation -- that is the reference's own CPU path, not
-    this backend's, so it is refused instead of silently falling back.
+    def __init__(self, tagged, args):
+        self.fun, self.host = tagged.fun, tagged.host
+        self.args = tuple(args) if args not in ((), None) else ()
+        self.name = tagged.__name__
+
+    def __call__(self, ctx, X):
+        t = __import__("torch")
+        P = X.shape[0]
+        if self.host:  # the caller's own code, on the host, row by row (reference _common.py:79-80)
+            Xh = X.cpu().numpy()
+            return ctx.upload(np.array([self.fun(x, *self.args) for x in Xh], dtype=np.float64))
+        f = self.fun(X, *self.args)
+        if not isinstance(f, t.Tensor) or f.device != X.device:
+            raise TypeError(f"batched objective {self.name}: expected a tensor on {X.device}, got {type(f).__name__}")
+        if f.shape != (P,):
+            raise ValueError(f"batched objective {self.name}: expected shape ({P},), got {tuple(f.shape)}")
+        return f.to(t.float64).contiguous()
+
+
+def resolve_objective(fun, args):
+    """Map the user's callable to a device kernel id, or to an External for tagged caller-supplied objectives.
+
+    The factory objectives (stochopy_amd.factory, tagged with ``sx_id``) run fused in the generation kernels.
+    ``factory.batched(fun)`` (device tensors in, device tensor out) and ``factory.host_callable(fun)`` (the
+    reference's per-row convention, explicitly slow) run between a propose and a select kernel.  Untagged
+    callables are refused: nothing falls back to the host silently.
     """
+    from ..factory.benchmark import batched
+
     if not hasattr(fun, "__call__"):
         raise TypeError()
     if isinstance(fun, Objective):
         if args not in ((), None):
             raise TypeError("factory objectives take no extra args")
         return fun.sx_id
+    if isinstance(fun, batched):
+        return External(fun, args)
     raise TypeError(
         "backend='hip' needs a device objective from stochopy_amd.factory "
-        "(ackley, griewank, quartic, rastrigin, rosenbrock, sphere, styblinski_tang); "
-        f"got {fun!r}.  There is no host fallback.")
+        "(ackley, griewank, quartic, rastrigin, rosenbrock, sphere, styblinski_tang), "
+        "a device-batched callable tagged with stochopy_amd.factory.batched, or -- explicitly slow -- a Python "
+        f"callable tagged with stochopy_amd.factory.host_callable; got {fun!r}.  There is no silent host fallback.")
+
+
+def evaluate_rows(ctx, fun, X, n, f, xm=None, xstd=None, clip=False):
+    """f[i] = fun(row i of X) -- optionally of clip(X, -1, 1) (Penalize) and of X * xstd + xm (CMA-ES
+    standardisation, cmaes/_cmaes.py:167-173) -- by the fused device kernel or the caller's objective."""
+    from .. import _device, _lib
+
+    if isinstance(fun, int):
+        if not clip:
+            return _device.evaluate(ctx, fun, X, n, f=f, xm=xm, xstd=xstd)
+        p = _device.ptr
+        _lib.check(ctx.L.sx_cmaes_eval_penalized(fun, p(X), X.shape[0], n, p(xm), p(xstd), None, p(f), None,
+                                                 ctx.stream_ptr), "sx_cmaes_eval_penalized")
+        return f
+    Xs = X.clamp(-1.0, 1.0) if clip else X
+    f.copy_(fun(ctx, Xs if xm is None else Xs * xstd + xm))
+    return f
+
+
+def penalty_rows(ctx, fun, X, n, xm, xstd, v, f_raw, pen):
+    """Penalize's second pass (cmaes/_constraints.py:79): pen[i] = sum_j (clip(x_ij) - x_ij)^2 * v[j]."""
+    from .. import _device, _lib
+
+    if isinstance(fun, int):
+        p = _device.ptr
+        _lib.check(ctx.L.sx_cmaes_eval_penalized(fun, p(X), X.shape[0], n, p(xm), p(xstd), p(v), p(f_raw), p(pen),
+                                                 ctx.stream_ptr), "sx_cmaes_eval_penalized")
+    else:
+        pen.copy_((((X.clamp(-1.0, 1.0) - X) ** 2) * v).sum(dim=1))
 
 
 def resolve_workers(workers):

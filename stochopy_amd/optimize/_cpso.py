@@ -92,6 +92,7 @@ class _PsoRun:
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, w, c1, c2, gamma, constraints, xtol, ftol, return_all,
                  verbosity, callback, rng, seed, workers, autorun=True, immediate=False):
         self.fun_id, self.lower, self.upper = fun_id, lower, upper
+        self.external = None if isinstance(fun_id, int) else fun_id  # caller-supplied objective: move -> fun -> select
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.w, self.c1, self.c2, self.gamma, self.constraints = w, c1, c2, gamma, constraints
         self.xtol, self.ftol = xtol, ftol
@@ -112,6 +113,9 @@ class _PsoRun:
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
             if immediate:
                 raise ValueError("immediate updating is a single-GPU sweep")
+        if immediate and self.external is not None:
+            raise ValueError("immediate updating evaluates particles one by one inside the sweep kernel: "
+                             "only the factory objectives can do that")
         self.x0 = x0
         self.ctx = _device.Context()
         self._graph = None
@@ -182,7 +186,7 @@ class _PsoRun:
         self.part_f = ctx.empty((npart,))
         self.part_i = ctx.empty((npart,), dtype=t.int64)
         self.sel3 = ctx.zeros((3,), dtype=t.int64)
-        _device.evaluate(ctx, self.fun_id, self.X, n, f=self.pbestfit)
+        _common.evaluate_rows(ctx, self.fun_id, self.X, n, self.pbestfit)
         self.candfit.copy_(self.pbestfit)
         out_i = ctx.empty((1,), dtype=t.int64)
         out_f = ctx.empty((1,))
@@ -211,7 +215,9 @@ class _PsoRun:
         a.lower, a.upper, a.state = self.d_lower.data_ptr(), self.d_upper.data_ptr(), self.state.data_ptr()
         a.part_f, a.part_i = self.part_f.data_ptr(), self.part_i.data_ptr()
         a.P, a.ld, a.row0, a.n = P, n, self.row0, n
-        a.fun_id = self.fun_id
+        a.fun_id = self.fun_id if self.external is None else 0
+        if self.external is not None:
+            self.cand_f = ctx.empty((P,))
         a.constraints = 1 if self.constraints == "Shrink" else 0
         a.rng = _lib.SX_RNG_PHILOX if self.rng == "philox" else _lib.SX_RNG_HOST
         a.maxiter = self.maxiter
@@ -277,12 +283,24 @@ class _PsoRun:
         if self.immediate:
             _lib.check(ctx.L.sx_pso_async_generation(C.byref(self.args), ctx.stream_ptr), "sx_pso_async_generation")
             return
-        if self.world is None:
+        p, n = _device.ptr, self.n
+        if self.external is not None:
+            # around the caller's objective (csrc/sx_unfused.hip): move, evaluate the new positions, pbest selection
+            _lib.check(ctx.L.sx_pso_move(C.byref(self.args), ctx.stream_ptr), "sx_pso_move")
+            self.cand_f.copy_(self.external(ctx, self.X))
+            _lib.check(ctx.L.sx_rows_select(p(self.X), n, p(self.cand_f), p(self.pbest), p(self.pbest), n,
+                                            p(self.pbestfit), p(self.candfit), self.P, n, p(self.state),
+                                            p(self.part_f), p(self.part_i), ctx.stream_ptr), "sx_rows_select")
+            if self.world is None:
+                _lib.check(ctx.L.sx_select_finalize(p(self.part_f), p(self.part_i), self.npart, p(self.pbest),
+                                                    p(self.pbest), n, n, p(self.gbest), p(self.state), self.maxiter,
+                                                    self.xtol, self.ftol, ctx.stream_ptr), "sx_select_finalize")
+                return
+        elif self.world is None:
             _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 1, ctx.stream_ptr), "sx_pso_generation")
             return
-        # sharded swarm: local generation, then the global-best exchange (parallel.py)
-        p, n = _device.ptr, self.n
-        _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 0, ctx.stream_ptr), "sx_pso_generation")
+        else:  # sharded swarm: local generation, then the global-best exchange (parallel.py)
+            _lib.check(ctx.L.sx_pso_generation(C.byref(self.args), 0, ctx.stream_ptr), "sx_pso_generation")
         if self.px is not None:
             _lib.check(ctx.L.sx_xchg_finalize(p(self.part_f), p(self.part_i), self.npart, p(self.pbest), p(self.pbest),
                                               n, n, self.row0, p(self.gbest), p(self.state), self.maxiter, self.xtol,
@@ -364,8 +382,10 @@ class _PsoRun:
                         self._restart_host_order(st.it)
                     else:
                         self._restart_device()
-            elif self.immediate:  # sweeps are long (P sequential particles): look after every few of them
-                for _ in range(min(max(self.maxiter - st.it, 1), 8)):
+            elif self.immediate or self.external is not None:
+                # long sweeps / the caller's objective between kernels: no graph, look after every few generations
+                look = 8 if self.immediate else (1 if self.external.host else self.CHECK_EVERY)
+                for _ in range(min(max(self.maxiter - st.it, 1), look)):
                     self._generation()
                     if self.gamma:
                         self._restart_device()

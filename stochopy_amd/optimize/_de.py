@@ -105,6 +105,8 @@ class _DeRun:
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, F, CR, strategy, constraints, xtol, ftol, return_all,
                  verbosity, callback, rng, seed, workers, autorun=True, exchange=None, donors=None, immediate=False):
         self.fun_id, self.lower, self.upper = fun_id, lower, upper
+        # a caller-supplied objective (factory.batched / host_callable) cannot be fused: propose -> fun -> select
+        self.external = None if isinstance(fun_id, int) else fun_id
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.F, self.CR, self.strategy, self.constraints = F, CR, strategy, constraints
         self.xtol, self.ftol = xtol, ftol
@@ -124,6 +126,9 @@ class _DeRun:
             self.row0, self.P = self.world.shard(P)  # this rank's rows; self.P is the LOCAL population from here on
             if immediate:
                 raise ValueError("immediate updating is a single-GPU sweep")
+        if immediate and self.external is not None:
+            raise ValueError("immediate updating evaluates individuals one by one inside the sweep kernel: "
+                             "only the factory objectives can do that")
             if self.P - 1 < self.k:
                 raise ValueError("shard too small for the strategy")
         if donors not in (None, "shard", "global"):
@@ -135,7 +140,7 @@ class _DeRun:
         # -- every wavefront re-reduces the per-workgroup records, so only while those are few (<= 512)
         npart = int(_lib.lib().sx_num_partials(self.P, self.n))
         self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
-                      and npart <= 512 and not immediate)
+                      and npart <= 512 and not immediate and self.external is None)
         self.launches = 0
         self.ctx = _device.Context()
         # multi-GPU: the chained kernel with the peer exchange in its prologue, if the transport checks out
@@ -146,6 +151,11 @@ class _DeRun:
             if exchange not in ("auto", "p2p", "rccl"):
                 raise ValueError('exchange must be "auto", "p2p" or "rccl"')
             self.exchange, self.exchange_note = "rccl", None
+            if self.external is not None:
+                if exchange == "p2p" or self.global_donors:
+                    raise ValueError("a caller-supplied objective runs between kernels: the peer exchange lives "
+                                     'inside the fused generation kernel (use exchange="rccl", donors="shard")')
+                exchange = "rccl"
             if exchange != "rccl":
                 from ..parallel import PeerExchange
 
@@ -338,7 +348,7 @@ class _DeRun:
         self.part_f = ctx.empty((npart,))
         self.part_i = ctx.empty((npart,), dtype=t.int64)
         # initial evaluation and best (de/_de.py:212-218)
-        _device.evaluate(ctx, self.fun_id, self.bufs[1], n, f=self.fit)
+        _common.evaluate_rows(ctx, self.fun_id, self.bufs[1], n, self.fit)
         self.candfit.copy_(self.fit)
         out_i = ctx.empty((1,), dtype=t.int64)
         out_f = ctx.empty((1,))
@@ -382,7 +392,11 @@ class _DeRun:
         # chained mode reads the best row straight from the population (row state.gbidx): no copy to maintain
         a.gbest = None if self.chain else self.gbest.data_ptr()
         a.P, a.ld, a.row0, a.n = P, n, self.row0, n
-        a.fun_id, a.strategy = self.fun_id, _lib.DE_STRATEGIES[self.strategy]
+        a.fun_id, a.strategy = (self.fun_id if self.external is None else 0), _lib.DE_STRATEGIES[self.strategy]
+        if self.external is not None:
+            self.cand = ctx.empty((P, n))
+            self.cand_f = ctx.empty((P,))
+        self.it_enq = 1  # generation the device holds once everything enqueued so far has run
         a.constraints = 1 if self.constraints == "Random" else 0
         a.rng = _lib.SX_RNG_PHILOX if self.rng == "philox" else _lib.SX_RNG_HOST
         a.maxiter = self.maxiter
@@ -502,11 +516,37 @@ class _DeRun:
             s.uniform_rows(self.lower, self.upper, self.P, out=self.h_rs.numpy())  # de/_constraints.py:24
             self.d_rs.copy_(self.h_rs, non_blocking=True)
 
+    def _external_generation(self):
+        """One generation around the caller's objective: candidates -> fun -> selection -> best/termination
+        (csrc/sx_unfused.hip).  Generation g lives in bufs[g & 1]; after convergence every kernel is a no-op."""
+        ctx, L, p, n = self.ctx, self.ctx.L, _device.ptr, self.n
+        it = self.it_enq
+        _lib.check(L.sx_de_propose(C.byref(self.args), p(self.cand), ctx.stream_ptr), "sx_de_propose")
+        self.cand_f.copy_(self.external(ctx, self.cand))
+        cur, nxt = self.bufs[it & 1], self.bufs[(it + 1) & 1]
+        _lib.check(L.sx_rows_select(p(self.cand), n, p(self.cand_f), p(cur), p(nxt), n, p(self.fit), p(self.candfit),
+                                    self.P, n, p(self.state), p(self.part_f), p(self.part_i), ctx.stream_ptr),
+                   "sx_rows_select")
+        npart = int(L.sx_num_partials(self.P, n))
+        if self.world is None:
+            _lib.check(L.sx_select_finalize(p(self.part_f), p(self.part_i), npart, p(self.bufs[0]), p(self.bufs[1]), n, n,
+                                            p(self.gbest), p(self.state), self.maxiter, self.xtol, self.ftol,
+                                            ctx.stream_ptr), "sx_select_finalize")
+        else:
+            _lib.check(L.sx_shard_best(p(self.part_f), p(self.part_i), npart, p(self.bufs[0]), p(self.bufs[1]), n, n,
+                                       p(self.state), self.row0, p(self.record), ctx.stream_ptr), "sx_shard_best")
+            self.world.all_gather_records(self.record, self.records)
+            _lib.check(L.sx_gather_finalize(p(self.records), self.world.size, n, p(self.gbest), p(self.state),
+                                            self.maxiter, self.xtol, self.ftol, ctx.stream_ptr), "sx_gather_finalize")
+        self.it_enq = it + 1
+
     def _generation(self):
         """One generation on the engine stream: the fused kernel + best/termination, or the sequential sweep;
         with workers > 1 the shard's generation + the exchange of the global best."""
         ctx = self.ctx
-        if self.px is not None:
+        if self.external is not None:
+            self._external_generation()
+        elif self.px is not None:
             self._chain_launch(self.launches & 1, 0)
             self.launches += 1
         elif self.world is not None:
@@ -536,18 +576,25 @@ class _DeRun:
                     self._generation()
                     self._record(st.it + 1 + j)  # generations after convergence are no-ops; their slots are cut off
                 st = self.read_state()
+                self.it_enq = int(st.it)
             elif stepwise:
                 if self.rng == "numpy-legacy":
                     self._host_draws()
                 self._generation()
                 self._record(st.it + 1)
                 st = self.read_state()
+                self.it_enq = int(st.it)
                 if self.callback is not None:
                     self.callback(self._whole_population(st.it)[0].cpu().numpy(), self._partial_result(st))
             elif self.immediate:  # sweeps are long (P sequential individuals): look after every few of them
                 for _ in range(min(remaining, 8)):
                     self._generation()
                 st = ctx.read_state(self.state)
+            elif self.external is not None:  # kernels and the caller's objective, queued on the engine stream
+                for _ in range(min(remaining, 1 if self.external.host else 32)):
+                    self._generation()
+                st = self.read_state()
+                self.it_enq = int(st.it)
             else:
                 # termination is tested on the device every generation; the host looks every <=4 chunks
                 self.enqueue(min(remaining, 4 * self.GRAPH_CHUNK))

@@ -205,10 +205,9 @@ class _VdRun:
             diagC = (dvec * (1.0 + vvec * vvec)) * dvec  # diag of D (I + v v^T) D (:249-254)
             # ---- objective (+ Penalize), as in CMA-ES ----
             if not self.penalize:
-                _device.evaluate(ctx, self.fun_id, d_arx_loc, n, f=d_fit_loc, xm=d_xm, xstd=d_xstd)
+                _common.evaluate_rows(ctx, self.fun_id, d_arx_loc, n, d_fit_loc, xm=d_xm, xstd=d_xstd)
             else:
-                _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd), None,
-                                                     ptr(d_fit_loc), None, sp), "sx_cmaes_eval_penalized")
+                _common.evaluate_rows(ctx, self.fun_id, d_arx_loc, n, d_fit_loc, xm=d_xm, xstd=d_xstd, clip=True)
             if self.world is not None:
                 self.world.all_gather_rows(d_ary_loc, d_ary)
                 self.world.all_gather_rows(d_arx_loc, d_arx)
@@ -218,9 +217,7 @@ class _VdRun:
                 v = bweights.update(arfit, xmean, xold, sigma, diagC, mueff, it, P)
                 if v.any():
                     up(d_v, v)
-                    _lib.check(L.sx_cmaes_eval_penalized(self.fun_id, ptr(d_arx_loc), Pl, n, ptr(d_xm), ptr(d_xstd),
-                                                         ptr(d_v), ptr(d_fit_loc), ptr(d_pen_loc), sp),
-                               "sx_cmaes_eval_penalized")
+                    _common.penalty_rows(ctx, self.fun_id, d_arx_loc, n, d_xm, d_xstd, d_v, d_fit_loc, d_pen_loc)
                     if self.world is not None:
                         self.world.all_gather_rows(d_pen_loc, d_pen)
                     arfit = arfit + d_pen.cpu().numpy()

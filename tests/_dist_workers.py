@@ -112,10 +112,14 @@ def _minimize_and_save(rank, world, cfg, out_dir):
     n = cfg["n"]
     opts = dict(cfg["options"], backend="hip", workers=world)
     opts.setdefault("rng", "philox")
+    fun = getattr(sa.factory, cfg["objective"])
+    if cfg.get("external") == "batched":  # a caller-supplied device objective (torch ops on the shard's rows)
+        fun = sa.factory.batched(lambda X: (X * X).sum(dim=1))
+    elif cfg.get("external") == "host":
+        fun = sa.factory.host_callable(lambda x: np.sum(x**2))
     seen = []
     cb = (lambda X, r: seen.append((np.array(X, copy=True), float(r.fun), int(r.nit), int(r.nfev)))) if cfg.get("callback") else None
-    res = sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), cfg.get("bounds", [[-5.12, 5.12]] * n), method=cfg["method"],
-                               options=opts, callback=cb)
+    res = sa.optimize.minimize(fun, cfg.get("bounds", [[-5.12, 5.12]] * n), method=cfg["method"], options=opts, callback=cb)
     if "xall" in res:
         np.save(os.path.join(out_dir, f"xall_{rank}.npy"), res.xall)
         np.save(os.path.join(out_dir, f"funall_{rank}.npy"), res.funall)

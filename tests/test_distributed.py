@@ -249,6 +249,32 @@ def test_sharded_callbacks_and_return_all(method, extra, env, with_callback):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["pso", "cpso", "de"])
+def test_sharded_run_with_a_caller_supplied_objective(method):
+    """workers=2 around factory.host_callable(numpy sphere) -- numpy's bits = the fused kernel's, so sharded PSO /
+    CPSO must again be the unsharded oracle run, and sharded DE the sharded oracle -- and around a torch objective
+    (factory.batched) both ranks must agree."""
+    from _dist_workers import gpu_minimize_worker
+
+    n = 10
+    opts = {"maxiter": 20, "popsize": 64, "seed": 8, "ftol": -1.0, "xtol": 0.0}
+    cfg = {"n": n, "objective": "sphere", "method": method, "options": opts, "external": "host",
+           "env": {"SX_EXCHANGE": "rccl"}}
+    out = _spawn(gpu_minimize_worker, 2, cfg)
+    if method == "de":
+        ref = oe.run_de_sharded(oracle.OBJECTIVES["sphere"], np.full(n, -5.12), np.full(n, 5.12), oracle.PhiloxStream(8),
+                                2, maxiter=20, popsize=64, ftol=-1.0, xtol=0.0)
+    else:
+        ref = oracle.minimize("sphere", [[-5.12, 5.12]] * n, method=method, options=dict(opts), rng="philox")
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+        assert np.load(os.path.join(out, f"meta_{r}.npy"))[0] == ref.fun
+    out = _spawn(gpu_minimize_worker, 2, dict(cfg, external="batched"))
+    assert np.array_equal(np.load(os.path.join(out, "x_0.npy")), np.load(os.path.join(out, "x_1.npy")))
+    assert np.load(os.path.join(out, "meta_0.npy"))[0] < 10.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange", ["rccl", "p2p"])
 def test_sharded_de_island_model_with_return_all(exchange):
     """Shard-local donors (the default island model) with return_all + callback: same best as the run without

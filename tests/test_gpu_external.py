@@ -1,0 +1,116 @@
+"""Caller-supplied objectives (backend hook contract): factory.batched (device tensor in, device
+tensor out) and factory.host_callable (the reference's per-row Python convention, explicitly slow).  The
+generation becomes propose -> objective -> select (csrc/sx_unfused.hip); with bit-identical fitness values the
+run must be the fused run, bit for bit -- in both rng modes, for every method."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bounds(n):
+    return [[-5.12, 5.12]] * n
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import stochopy_amd
+
+    return stochopy_amd
+
+
+def device_objective(sa, name):
+    """A "user" objective that happens to return the fused kernels' values: sx_eval on the stream it is called on."""
+    import torch
+
+    from stochopy_amd import _lib
+
+    L, fid = _lib.lib(), _lib.FUN_IDS[name]
+
+    def fun(X):
+        P, n = X.shape
+        f = torch.empty((P,), dtype=torch.float64, device=X.device)
+        X = X.contiguous()
+        assert L.sx_eval(fid, X.data_ptr(), P, n, n, None, None, f.data_ptr(), None, None,
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        return f
+
+    fun.__name__ = "device_" + name
+    return sa.factory.batched(fun)
+
+
+CASES = [
+    ("de", "rosenbrock", 10, {"popsize": 40, "maxiter": 25, "strategy": "best1bin"}),
+    ("de", "sphere", 70, {"popsize": 33, "maxiter": 12, "strategy": "rand2bin", "constraints": "Random", "mutation": 1.5}),
+    ("de", "rosenbrock", 300, {"popsize": 20, "maxiter": 6, "strategy": "rand1bin"}),
+    ("de", "rastrigin", 24, {"popsize": 50, "maxiter": 15, "strategy": "best2bin"}),
+    ("de", "sphere", 4, {"popsize": 32, "maxiter": 400, "ftol": 1e-6, "xtol": 1e-3}),
+    ("pso", "ackley", 16, {"popsize": 64, "maxiter": 30}),
+    ("pso", "sphere", 130, {"popsize": 30, "maxiter": 10, "constraints": "Shrink", "inertia": 0.91}),
+    ("cpso", "sphere", 16, {"popsize": 256, "maxiter": 30}),
+    ("cpso", "rosenbrock", 8, {"popsize": 128, "maxiter": 40, "constraints": "Shrink", "inertia": 0.91}),
+    ("cmaes", "rosenbrock", 6, {"popsize": 12, "maxiter": 60}),
+    ("cmaes", "sphere", 6, {"popsize": 10, "maxiter": 60, "constraints": "Penalize", "sigma": 0.3}),
+    ("vdcma", "rosenbrock", 12, {"popsize": 16, "maxiter": 80}),
+]
+
+
+@pytest.mark.parametrize("rng", ["philox", "numpy-legacy"])
+@pytest.mark.parametrize("method,objective,n,opts", CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "")
+def test_batched_objective_reproduces_the_fused_run(sa, method, objective, n, opts, rng):
+    bounds = [[1.0, 5.0]] * n if opts.get("constraints") == "Penalize" else _bounds(n)
+    o = dict(opts, seed=13, rng=rng, backend="hip", return_all=True)
+    fused = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method=method, options=dict(o))
+    ext = sa.optimize.minimize(device_objective(sa, objective), bounds, method=method, options=dict(o))
+    assert (ext.nit, ext.nfev, ext.status) == (fused.nit, fused.nfev, fused.status)
+    if opts.get("constraints") == "Penalize":  # the penalty sum is a torch reduction here: same run up to rounding
+        assert np.allclose(ext.x, fused.x, rtol=1e-9, atol=1e-12) and np.isclose(ext.fun, fused.fun, rtol=1e-9)
+        return
+    assert np.array_equal(ext.x, fused.x) and ext.fun == fused.fun
+    assert np.array_equal(ext.xall, fused.xall) and np.array_equal(ext.funall, fused.funall)
+
+
+def test_host_callable_is_the_reference_convention(sa):
+    """fun(x) on 1-D numpy rows, evaluated by the caller's code on the host: numpy's sphere has the fused kernel's
+    bits, so the run is the fused run; extra args travel as in the reference (fun(x, *args))."""
+    calls = []
+
+    def sphere(x, scale):
+        calls.append(x.shape)
+        return scale * np.sum(x**2)
+
+    o = {"popsize": 24, "maxiter": 12, "seed": 5, "backend": "hip"}
+    fused = sa.optimize.minimize(sa.factory.sphere, _bounds(9), method="de", options=dict(o))
+    host = sa.optimize.minimize(sa.factory.host_callable(sphere), _bounds(9), args=(1.0,), method="de", options=dict(o))
+    assert np.array_equal(host.x, fused.x) and host.fun == fused.fun and host.nit == fused.nit
+    assert len(calls) == 24 * 12 and set(calls) == {(9,)}
+    for method in ("pso", "cpso", "cmaes", "vdcma"):
+        a = sa.optimize.minimize(sa.factory.sphere, _bounds(9), method=method, options=dict(o))
+        b = sa.optimize.minimize(sa.factory.host_callable(lambda x: np.sum(x**2)), _bounds(9), method=method,
+                                 options=dict(o))
+        assert np.array_equal(a.x, b.x) and a.fun == b.fun and a.nit == b.nit, method
+
+
+def test_user_written_torch_objective(sa):
+    """A genuinely user-written device objective (torch ops on the population tensor)."""
+    import torch
+
+    target = torch.linspace(-2.0, 2.0, 20, dtype=torch.float64, device="cuda")
+    f = sa.factory.batched(lambda X, w: ((X - target) ** 2 * w).sum(dim=1))
+    res = sa.optimize.minimize(f, _bounds(20), args=(2.0,), method="de",
+                               options={"popsize": 200, "maxiter": 300, "seed": 1, "rng": "philox", "backend": "hip"})
+    assert res.fun < 0.1 and np.allclose(res.x, target.cpu().numpy(), atol=0.1)
+    assert np.isclose(res.fun, 2.0 * np.sum((res.x - target.cpu().numpy()) ** 2), rtol=1e-9, atol=1e-15)
+
+
+def test_untagged_callables_are_refused(sa):
+    with pytest.raises(TypeError, match="no silent host fallback"):
+        sa.optimize.minimize(lambda x: float(np.sum(x**2)), _bounds(3), method="de", options={"backend": "hip"})
+    bad = sa.factory.batched(lambda X: X.sum(dim=1).cpu())
+    with pytest.raises(TypeError, match="expected a tensor on"):
+        sa.optimize.minimize(bad, _bounds(3), method="pso", options={"backend": "hip", "popsize": 8, "maxiter": 3})
+    with pytest.raises(ValueError):
+        sa.optimize.minimize(sa.factory.batched(lambda X: X.sum(dim=1)), _bounds(3), method="de",
+                             options={"backend": "hip", "strict_updating": True, "updating": "immediate"})
