@@ -383,9 +383,14 @@ class _PsoRun:
                     else:
                         self._restart_device()
             elif self.immediate or self.external is not None:
-                # long sweeps / the caller's objective between kernels: no graph, look after every few generations
+                # long sweeps: look after every few of them.  A caller's device objective between our kernels:
+                # chunks of generations captured into one graph (kernels + objective) and replayed, else eagerly
                 look = 8 if self.immediate else (1 if self.external.host else self.CHECK_EVERY)
-                for _ in range(min(max(self.maxiter - st.it, 1), look)):
+                todo = min(max(self.maxiter - st.it, 1), look)
+                while self.external is not None and todo >= self.GRAPH_CHUNK and self._capture_sharded_chunk():
+                    self._rccl_graph.replay()
+                    todo -= self.GRAPH_CHUNK
+                for _ in range(todo):
                     self._generation()
                     if self.gamma:
                         self._restart_device()
@@ -452,7 +457,9 @@ class _PsoRun:
 
         if self._rccl_graph is not None:
             return True
-        if self._rccl_graph_note is not None or self.world.backend != "nccl" or os.environ.get("SX_RCCL_GRAPH") == "0":
+        if (self._rccl_graph_note is not None or (self.world is not None and self.world.backend != "nccl")
+                or os.environ.get("SX_RCCL_GRAPH") == "0"
+                or (self.external is not None and (self.external.host or os.environ.get("SX_EXT_GRAPH") == "0"))):
             return False
         t = _device.torch()
         try:

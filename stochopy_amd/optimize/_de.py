@@ -170,6 +170,7 @@ class _DeRun:
                                    f'{self.exchange_note or "it was switched off"}')
         self._graph = None
         self._chain_graphs = {}
+        self._ext_graphs, self._ext_graph_note = {}, None
         self._shard_calls = None
         self._rccl_graph = None
         self._rccl_graph_note = None
@@ -182,9 +183,10 @@ class _DeRun:
                     self.close()
 
     def close(self):
-        if self._rccl_graph is not None:
+        if self._rccl_graph is not None or self._ext_graphs:
             self.ctx.sync()
             self._rccl_graph = None
+            self._ext_graphs = {}
         if self._graph is not None:
             self.ctx.L.sx_graph_destroy(self._graph)
             self._graph = None
@@ -540,6 +542,39 @@ class _DeRun:
                                             self.maxiter, self.xtol, self.ftol, ctx.stream_ptr), "sx_gather_finalize")
         self.it_enq = it + 1
 
+    EXT_CHUNK = 16  # generations per captured graph around a caller-supplied objective (even: buffer parity)
+
+    def _external_graph(self, parity):
+        """EXT_CHUNK generations -- our kernels AND the caller's device objective -- captured once into a graph
+        (in-kernel draws, device objective).  False when that is not possible (host objective, host draws, gloo,
+        SX_EXT_GRAPH=0, or an objective that cannot be captured): the caller then launches eagerly."""
+        if parity in self._ext_graphs:
+            return True
+        if (self._ext_graph_note is not None or self.external.host or self.rng != "philox"
+                or (self.world is not None and self.world.backend != "nccl") or os.environ.get("SX_EXT_GRAPH") == "0"):
+            return False
+        t = _device.torch()
+        it0 = self.it_enq
+        try:
+            self.ctx.sync()
+            g = t.cuda.CUDAGraph()
+            with t.cuda.graph(g, stream=self.ctx.stream):
+                for _ in range(self.EXT_CHUNK):
+                    self._external_generation()
+            self._ext_graphs[parity] = g
+        except Exception as e:  # capture is an optimisation, never a requirement
+            self._ext_graph_note = f"graph capture around the objective failed: {e}"
+        self.it_enq = it0  # capturing ran nothing
+        return parity in self._ext_graphs
+
+    def _enqueue_external(self, ngen):
+        while ngen >= self.EXT_CHUNK and self._external_graph(self.it_enq & 1):
+            self._ext_graphs[self.it_enq & 1].replay()
+            self.it_enq += self.EXT_CHUNK
+            ngen -= self.EXT_CHUNK
+        for _ in range(ngen):
+            self._external_generation()
+
     def _generation(self):
         """One generation on the engine stream: the fused kernel + best/termination, or the sequential sweep;
         with workers > 1 the shard's generation + the exchange of the global best."""
@@ -591,8 +626,7 @@ class _DeRun:
                     self._generation()
                 st = ctx.read_state(self.state)
             elif self.external is not None:  # kernels and the caller's objective, queued on the engine stream
-                for _ in range(min(remaining, 1 if self.external.host else 32)):
-                    self._generation()
+                self._enqueue_external(min(remaining, 1 if self.external.host else 4 * self.EXT_CHUNK))
                 st = self.read_state()
                 self.it_enq = int(st.it)
             else:
