@@ -125,7 +125,9 @@ __device__ __forceinline__ void p2p_service(const sx_de_args &a, const sx_xchg_a
         if (mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
         return;
     }
-    if (err0) return;  // an earlier wait timed out: the run is dead, the host raises
+    // an earlier wait timed out: the run is dead, the host raises.  With the relay a barrier follows: the whole
+    // workgroup has to agree (the flag may have been raised between two wavefronts' loads)
+    if (relay ? __syncthreads_or(err0) : err0) return;
     const int64_t it = it0 + 1;  // the generation the population holds
     const uint32_t tag = (uint32_t)(it + 1);
     const double *row = ((it & 1) ? a.buf1 : a.buf0) + bi * a.ld;
@@ -214,6 +216,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
+    __shared__ double s_gf;  // P2P: what wavefront 0 found in the record headers
+    __shared__ int64_t s_gi;
+    __shared__ int s_winner;
     SX_TP(0);
     const int n = a.n;
     const int64_t P = a.P, ld = a.ld;
@@ -252,7 +257,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         if (CHAIN && mode == 1 && threadIdx.x == 0) a.state[2] = *sin;
         return;
     }
-    if (P2P && *x.error) return;  // an earlier wait timed out: the run is dead, the host raises
+    // (P2P: an earlier timed-out wait -- *x.error -- is looked at by wavefront 0 in stage C, so that the whole
+    //  workgroup takes the same way out and nobody is left alone at a barrier)
     const int64_t it = CHAIN ? sin->it + 1 : sin->it;  // the generation the population holds; we produce it+1
     SX_TP(6);
 
@@ -358,37 +364,48 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const uint32_t xtag = (uint32_t)(it + 1);
     const uint64_t *gbw = nullptr;  // P2P: the winner's row as tagged words
     if (P2P) {
-        double bf;
-        int64_t bi;
-        int winner;
-        if (!xchg_wait_best(x.peer[x.rank] + xchg_slot_offset(n, chain_p, 0), n, x.world, xtag, x.timeout_ticks,
-                            id.lane, bf, bi, winner)) {
-            if (id.lane == 0) atomicExch(x.error, 1);
-            return;
-        }
-        if (it >= 2 && (bf <= a.ftol || it >= a.maxiter)) return;  // same rule as the service workgroup
-        gbidx = bi;
-        // short rows read the winner's row straight from the exchange buffer; whole-wave rows from the relay
-        if (LPR == kWave) {
-            const uint64_t *rel = x.relay + (int64_t)chain_p * xchg_relay_stride(n);
-            if (use_best) {
-                // wait (past the caches) until workgroup 0 has published this generation's copy.  Relaxed: the
-                // ready word only keeps early readers from caching lines of the previous copy; every word read
-                // afterwards is verified by its own tag, so no acquire (= L2 invalidate) is needed
+        // ONE wavefront per workgroup polls the uncached exchange buffer (all waves doing so would queue 8x the
+        // requests on the few channels that hold the headers); the others meet it at the barrier, their donor /
+        // row loads already in flight
+        const uint64_t *rel = x.relay + (int64_t)chain_p * xchg_relay_stride(n);
+        if (id.wave == 0) {
+            double bf;
+            int64_t bi;
+            int winner;
+            bool ok = __atomic_load_n(x.error, __ATOMIC_RELAXED) == 0 &&  // an earlier wait timed out: the run is dead
+                      xchg_wait_best(x.peer[x.rank] + xchg_slot_offset(n, chain_p, 0), n, x.world, xtag,
+                                     x.timeout_ticks, id.lane, bf, bi, winner);
+            if (ok && LPR == kWave && use_best && !(it >= 2 && (bf <= a.ftol || it >= a.maxiter))) {
+                // whole-wave rows read the winner's row from the cacheable relay: wait (past the caches) until
+                // workgroup 0 has published this generation's copy.  Relaxed: the ready word only keeps early
+                // readers from caching lines of the previous copy; every word read afterwards is verified by its
+                // own tag, so no acquire (= L2 invalidate) is needed
                 const uint64_t t0 = wall_clock64();
                 while (__hip_atomic_load(rel + xchg_slot_words(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
                        (uint64_t)xtag) {
                     if ((int64_t)(wall_clock64() - t0) > x.timeout_ticks) {
-                        if (id.lane == 0) atomicExch(x.error, 1);
-                        return;
+                        ok = false;
+                        break;
                     }
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
-            gbw = rel + 4;
-        } else {
-            gbw = x.peer[x.rank] + xchg_slot_offset(n, chain_p, winner) + 4;
+            if (id.lane == 0) {
+                s_gf = bf;
+                s_gi = bi;
+                s_winner = ok ? winner : -1;
+                if (!ok) atomicExch(x.error, 1);
+            }
         }
+        __syncthreads();
+        const int winner = s_winner;
+        if (winner < 0) return;
+        const double bf = s_gf;
+        const int64_t bi = s_gi;
+        if (it >= 2 && (bf <= a.ftol || it >= a.maxiter)) return;  // same rule as the service workgroup
+        gbidx = bi;
+        // short rows read the winner's row straight from the exchange buffer; whole-wave rows from the relay
+        gbw = LPR == kWave ? rel + 4 : x.peer[x.rank] + xchg_slot_offset(n, chain_p, winner) + 4;
         part_f_out = a.part_f + (int64_t)(1 - chain_p) * npart;
         part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
         if (gdon) load_batch(0, B0);
