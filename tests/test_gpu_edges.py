@@ -154,6 +154,28 @@ def test_c5_shard_shape_three_generations(sa):
     assert fast.fun == ref.fun and np.array_equal(fast.x, ref.x)
 
 
+def test_c5_full_population_properties(sa):
+    """BASELINE config 5 at FULL size on one GPU (DE, n=1024, P=131072: two 1 GiB population buffers), where the
+    oracle is out of reach: size-independent properties instead -- the run is deterministic (two runs, same bits),
+    the best value never increases and is the objective of the returned row, counters add up, and the history
+    (verbosity 0: the best candidate of each generation) never beats the running best."""
+    n, P, gens = 1024, 131072, 6
+    b = [[-5.12, 5.12]] * n
+    opts = {"maxiter": gens, "popsize": P, "seed": 17, "ftol": -1.0, "xtol": 0.0, "backend": "hip", "rng": "philox"}
+    a1 = sa.optimize.minimize(sa.factory.rosenbrock, b, method="de", options=dict(opts))
+    trace = []
+    a2 = sa.optimize.minimize(sa.factory.rosenbrock, b, method="de", options=dict(opts, return_all=True, verbosity=0.0),
+                              callback=lambda X, r: trace.append((float(r.fun), X.shape, int(r.nfev))))
+    assert a1.fun == a2.fun and np.array_equal(a1.x, a2.x)                      # graph replay == stepwise, same bits
+    assert (a1.nit, a1.nfev, a1.status) == (gens, gens * P, -1)
+    assert a1.fun == sa.factory.rosenbrock(a1.x)                                # the value of the returned row
+    f = np.array([t[0] for t in trace])
+    assert len(trace) == gens and np.all(np.diff(f) <= 0.0) and f[-1] == a1.fun
+    assert all(t[1] == (P, n) and t[2] == (k + 1) * P for k, t in enumerate(trace))
+    assert a2.xall.shape == (gens, 1, n) and np.all(a2.funall[1:, 0] >= f[1:])  # a candidate cannot beat the best kept
+    assert np.all(np.abs(a2.xall) < 5.12 * 3)                                   # best1bin without repair stays near the box
+
+
 def test_dimension_limit_is_loud(sa):
     from stochopy_amd._lib import HipLibraryError
 
