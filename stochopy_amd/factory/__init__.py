@@ -1,2 +1,7 @@
-from .benchmark import *  # noqa: F401,F403
-from .benchmark import Objective, __all__  # noqa: F401
+"""Objective handles for the MI355X backend: the seven benchmark functions as device kernels, plus the two tags
+(`batched`, `host_callable`) under which a caller's own objective is accepted (see factory/benchmark.py)."""
+from . import benchmark as _benchmark
+from .benchmark import Objective  # noqa: F401
+
+__all__ = list(_benchmark.__all__)
+globals().update({_name: getattr(_benchmark, _name) for _name in __all__})

@@ -1,10 +1,20 @@
-"""Same public names as stochopy.optimize (reference optimize/__init__.py:1-18),
-restricted to the methods on the MI355X hot path."""
-from ._helpers import OptimizeResult, minimize, register
-from ._cmaes import minimize as cmaes
-from ._cpso import minimize as cpso
-from ._de import minimize as de
-from ._pso import minimize as pso
-from ._vdcma import minimize as vdcma
+"""Public surface of the MI355X backend's optimizers.
 
-__all__ = ["OptimizeResult", "minimize", "register", "cmaes", "cpso", "de", "pso", "vdcma"]
+The names a stochopy user expects under ``stochopy.optimize`` (reference optimize/__init__.py:1-18) resolve
+here to the HIP-backed front ends; the neighbourhood algorithm is not offered (DESIGN.md section 8 explains why).
+Importing a front end also registers it with ``minimize(method=...)``.
+"""
+import importlib
+
+from . import _helpers
+
+OptimizeResult = _helpers.OptimizeResult
+minimize = _helpers.minimize
+register = _helpers.register
+
+# method name -> module holding its `minimize` front end (each module registers itself on import)
+_FRONT_ENDS = {"de": "_de", "pso": "_pso", "cpso": "_cpso", "cmaes": "_cmaes", "vdcma": "_vdcma"}
+for _method, _module in _FRONT_ENDS.items():
+    globals()[_method] = importlib.import_module("." + _module, __name__).minimize
+
+__all__ = ["OptimizeResult", "minimize", "register", *_FRONT_ENDS]
