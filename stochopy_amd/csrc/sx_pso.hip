@@ -212,29 +212,28 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// histogram increment for one key per lane (dig < 0: this lane has none).  The top bytes of the keys (sign,
-// exponent, leading mantissa bits) are the same for most of the swarm, so plain LDS atomics would serialise on
-// one or two bins: there the wave first agrees on the distinct digits and adds one count per digit.
-__device__ __forceinline__ void hist_add(unsigned *bins, int dig, bool clustered, int lane) {
-    if (!clustered) {
-        if (dig >= 0) atomicAdd(&bins[dig], 1u);
-        return;
-    }
+// histogram increment for one key per lane (dig < 0: this lane has none).  Fitness values of a converged swarm
+// pile up in very few bins, where plain LDS atomics would serialise: the wave first looks for large groups of
+// equal digits (up to four) and adds one count per group; whatever is left is spread out and goes as plain atomics.
+__device__ __forceinline__ void hist_add(unsigned *bins, int dig, int lane) {
     unsigned long long todo = __ballot(dig >= 0);
-    while (todo) {
+    for (int r = 0; r < 4 && todo; ++r) {
         const int leader = (int)__ffsll((long long)todo) - 1;
         const int d = __shfl(dig, leader, kWave);
         const unsigned long long same = __ballot(dig == d);
+        if (__popcll(same) < 4) break;
         if (lane == leader) atomicAdd(&bins[d], (unsigned)__popcll(same));
         todo &= ~same;
     }
+    if ((todo >> lane) & 1ull) atomicAdd(&bins[dig], 1u);
 }
 
 constexpr int kSelThreads = 1024;
-constexpr int kSelPerThread = 32;  // keys held in registers up to 32768 particles (larger swarms re-read them each pass)
+constexpr int kSelPerThread = 16;  // keys held in registers up to 16384 particles (larger swarms re-read them each step)
 
 // One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
-// and the nw-th largest pbestfit is found by an 8-step (one byte per step) radix descent over keys held in registers.
+// and the nw-th largest pbestfit is found by a radix descent over keys held in registers, starting at the first bit in
+// which the keys differ at all (see below).
 // out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
 // The swarm is `nseg` segments (one per rank; 1 on a single GPU) of `seg_len` fitness values followed by
 // `seg_npart` partial radii, `seg_stride` doubles apart: fit = base, part_r = base + seg_len.
@@ -245,15 +244,32 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
                                                                          int64_t seg_stride, double delta, double gamma,
                                                                          unsigned long long *__restrict__ out) {
     const int64_t Ptot = (int64_t)nseg * seg_len, npart = (int64_t)nseg * seg_npart;
+    // element i of the (segmented) fitness / radius arrays; 32-bit arithmetic (Ptot < 2^31), nothing for one segment
+    const unsigned useg = (unsigned)seg_len, unp = (unsigned)seg_npart;
+    auto fit_at = [&](int64_t i) -> double {
+        if (nseg == 1) return fit[i];
+        const unsigned sg = (unsigned)i / useg;
+        return fit[(int64_t)sg * seg_stride + ((unsigned)i - sg * useg)];
+    };
     __shared__ double smax[kSelThreads / kWave];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (a.state->done) {
+#ifdef SX_SELTRACE
+#define SEL_TP(k) do { if (tid == 0) ((unsigned long long *)a.candfit)[k] = wall_clock64(); } while (0)
+#else
+#define SEL_TP(k) do {} while (0)
+#endif
+    SEL_TP(0);
+    const int done = a.state->done;
+    const int64_t it = a.state->it;  // (fetched together: every dependent load is a trip to L2)
+    if (done) {
         if (tid == 0) out[0] = 0;
         return;
     }
     double m = 0.0;
-    for (int64_t k = tid; k < npart; k += kSelThreads)
-        m = fmax(m, part_r[(k / seg_npart) * seg_stride + k % seg_npart]);
+    for (int64_t k = tid; k < npart; k += kSelThreads) {
+        const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
+        m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
     if (lane == 0) smax[wv] = m;
@@ -261,7 +277,6 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
     m = smax[0];
     for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
     const double radius = m / sqrt(4.0 * (double)a.n);
-    const int64_t it = a.state->it;
     int64_t nw = 0;
     if (radius < delta) {
         const double inorm = (double)it / (double)a.maxiter;
@@ -271,33 +286,93 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         out[0] = (unsigned long long)(nw > 0 ? nw : 0);
         out[2] = (unsigned long long)__double_as_longlong(radius);
     }
+    SEL_TP(1);
     if (nw <= 0) return;  // uniform
     // up to 32768 particles the keys stay in registers for the 8 passes; larger swarms re-read them (L2)
     const bool in_regs = Ptot <= (int64_t)kSelThreads * kSelPerThread;
     unsigned long long key[kSelPerThread];
+    // (the loops over the register array are fully unrolled; `k * kSelThreads < Ptot` is uniform, so the
+    //  iterations past the swarm cost one scalar branch each)
+    // loads in batches of 8, unconditionally (indices past the swarm are clamped): one latency per batch, not per load
 #pragma unroll
-    for (int k = 0; k < kSelPerThread; ++k) {
-        const int64_t i = (int64_t)k * kSelThreads + tid;
-        key[k] = (in_regs && i < Ptot) ? sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]) : 0ull;  // 0 < real keys
+    for (int k0 = 0; k0 < kSelPerThread; k0 += 8) {
+        double fv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = (int64_t)(k0 + u) * kSelThreads + tid;
+            fv[u] = (in_regs && (int64_t)k0 * kSelThreads < Ptot) ? fit_at(i < Ptot ? i : Ptot - 1) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = (int64_t)(k0 + u) * kSelThreads + tid;
+            key[k0 + u] = (in_regs && i < Ptot) ? sort_key(fv[u]) : 0ull;  // 0 < real keys
+        }
     }
-    // radix descent, 8 bits per step: histogram (LDS atomics) of the next byte over the keys that match the
-    // prefix found so far; the byte of the `remaining`-th largest of them is where the suffix count crosses it
-    __shared__ unsigned bins[256];
+    SEL_TP(2);
+    // 1. the keys' common leading bits carry no information (sign, exponent and the first mantissa bits are the
+    //    same all over a converged swarm): find the highest bit in which any two keys differ
+    __shared__ unsigned long long s_min[kSelThreads / kWave], s_max[kSelThreads / kWave];
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kSelPerThread; ++k) {
+            const int64_t i = (int64_t)k * kSelThreads + tid;
+            if ((int64_t)k * kSelThreads < Ptot && i < Ptot) {
+                kmin = key[k] < kmin ? key[k] : kmin;
+                kmax = key[k] > kmax ? key[k] : kmax;
+            }
+        }
+    } else {
+        for (int64_t i = tid; i < Ptot; i += kSelThreads) {
+            const unsigned long long kk = sort_key(fit_at(i));
+            kmin = kk < kmin ? kk : kmin;
+            kmax = kk > kmax ? kk : kmax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long omin = __shfl_xor(kmin, off, kWave), omax = __shfl_xor(kmax, off, kWave);
+        kmin = omin < kmin ? omin : kmin;
+        kmax = omax > kmax ? omax : kmax;
+    }
+    if (lane == 0) {
+        s_min[wv] = kmin;
+        s_max[wv] = kmax;
+    }
+    __syncthreads();
+    for (int k = 0; k < kSelThreads / kWave; ++k) {
+        kmin = s_min[k] < kmin ? s_min[k] : kmin;
+        kmax = s_max[k] > kmax ? s_max[k] : kmax;
+    }
+    SEL_TP(3);
+    if (kmin == kmax) {  // one value all over the swarm: it is the threshold
+        if (tid == 0) out[1] = kmin;
+        return;
+    }
+    // 2. radix descent from that bit, up to 10 bits per step (one histogram bin per thread): histogram (LDS
+    //    atomics) of the digit over the keys that match the prefix found so far; the digit of the `remaining`-th
+    //    largest of them is where the suffix count crosses it.  As soon as at most 512 keys share the prefix --
+    //    after the first step, as a rule -- they are gathered and ranked against each other directly.
+    __shared__ unsigned bins[kSelThreads];
+    __shared__ unsigned wsum[kSelThreads / kWave];
     __shared__ unsigned s_digit, s_above, s_count, s_ncand;
     __shared__ unsigned long long cand[kSelThreads];
-    unsigned long long prefix = 0ull;
+    int top = 63 - __clzll((long long)(kmin ^ kmax));  // keys agree above this bit
+    unsigned long long prefix = top == 63 ? 0ull : (kmax >> (top + 1)) << (top + 1);
     unsigned remaining = (unsigned)nw;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        if (tid < 256) bins[tid] = 0u;
+    for (;;) {
+        const int shift = top >= 9 ? top - 9 : 0, width = top - shift + 1;
+        const unsigned dmask = (1u << width) - 1u;
+        const unsigned long long himask = top == 63 ? 0ull : (~0ull << (top + 1));
+        bins[tid] = 0u;
         __syncthreads();
-        const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-        const bool clustered = shift >= 48;  // sign + exponent (+ 4 mantissa bits): a handful of distinct digits
         if (in_regs) {
 #pragma unroll
             for (int k = 0; k < kSelPerThread; ++k) {
                 const int64_t i = (int64_t)k * kSelThreads + tid;
-                const bool mine = i < Ptot && (key[k] & himask) == prefix;
-                hist_add(bins, mine ? (int)((key[k] >> shift) & 255u) : -1, clustered, lane);
+                if ((int64_t)k * kSelThreads < Ptot)
+                    hist_add(bins, (i < Ptot && (key[k] & himask) == prefix) ? (int)((unsigned)(key[k] >> shift) & dmask) : -1,
+                             lane);
             }
         } else {
             for (int64_t i0 = tid; i0 < Ptot; i0 += (int64_t)kSelThreads * 8) {
@@ -305,51 +380,44 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int64_t i = i0 + (int64_t)u * kSelThreads;
-                    kk[u] = i < Ptot ? sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]) : 0ull;
+                    kk[u] = i < Ptot ? sort_key(fit_at(i)) : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int64_t i = i0 + (int64_t)u * kSelThreads;
-                    const bool mine = i < Ptot && (kk[u] & himask) == prefix;
-                    hist_add(bins, mine ? (int)((kk[u] >> shift) & 255u) : -1, clustered, lane);
+                    hist_add(bins, (i < Ptot && (kk[u] & himask) == prefix) ? (int)((unsigned)(kk[u] >> shift) & dmask) : -1, lane);
                 }
             }
         }
         __syncthreads();
-        if (tid < kWave) {  // wave 0: lane l owns bins 4l..4l+3; suffix sums locate the crossing byte
-            const unsigned c0 = bins[4 * lane], c1 = bins[4 * lane + 1], c2 = bins[4 * lane + 2], c3 = bins[4 * lane + 3];
-            const unsigned mine = c0 + c1 + c2 + c3;
-            unsigned suf = mine;  // inclusive suffix sum over lanes >= lane
+        SEL_TP(4);
+        // thread t owns bin t: inclusive suffix sums over the bins >= t (wave scan, then the waves above)
+        const unsigned c = bins[tid];
+        unsigned suf = c;
 #pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-                const unsigned o = __shfl_down(suf, off, kWave);
-                if (lane + off < kWave) suf += o;
-            }
-            const unsigned above = suf - mine;  // keys in bins of higher lanes
-            if (above < remaining && suf >= remaining) {  // exactly one lane
-                unsigned acc = above, digit = 4u * lane + 3u;
-                if (acc + c3 >= remaining) {
-                    digit = 4u * lane + 3u;
-                } else if ((acc += c3) + c2 >= remaining) {
-                    digit = 4u * lane + 2u;
-                } else if ((acc += c2) + c1 >= remaining) {
-                    digit = 4u * lane + 1u;
-                } else {
-                    acc += c1;
-                    digit = 4u * lane;
-                }
-                s_digit = digit;
-                s_above = acc;  // keys (matching the prefix) with a larger byte than `digit`
-                s_count = bins[digit];
-            }
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned o = __shfl_down(suf, off, kWave);
+            if (lane + off < kWave) suf += o;
+        }
+        if (lane == 0) wsum[wv] = suf;  // the wave's total
+        __syncthreads();
+        for (int k = wv + 1; k < kSelThreads / kWave; ++k) suf += wsum[k];
+        const unsigned above = suf - c;  // keys (matching the prefix) with a larger digit than t
+        if (above < remaining && suf >= remaining) {  // exactly one thread
+            s_digit = (unsigned)tid;
+            s_above = above;
+            s_count = c;
         }
         __syncthreads();
         prefix |= (unsigned long long)s_digit << shift;
         remaining -= s_above;
-        // few keys left with this prefix (after three bytes -- sign, exponent, 12 mantissa bits -- typically a
-        // handful): gather them and rank them against each other instead of five more passes over the swarm
         const unsigned cnt = s_count;
-        if (shift > 0 && cnt <= (unsigned)kSelThreads) {
+        SEL_TP(5);
+        if (shift == 0) {  // every bit fixed: the candidates are all equal to the prefix
+            if (tid == 0) out[1] = prefix;
+            return;
+        }
+        if (cnt <= 512u) {  // ranking costs ~11 ns per candidate, a further histogram step ~6.5 us
             const unsigned long long lomask = ~0ull << shift;
             if (tid == 0) s_ncand = 0u;
             __syncthreads();
@@ -357,29 +425,33 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 #pragma unroll
                 for (int k = 0; k < kSelPerThread; ++k) {
                     const int64_t i = (int64_t)k * kSelThreads + tid;
-                    if (i < Ptot && (key[k] & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = key[k];
+                    if ((int64_t)k * kSelThreads < Ptot && i < Ptot && (key[k] & lomask) == prefix)
+                        cand[atomicAdd(&s_ncand, 1u)] = key[k];
                 }
             } else {
                 for (int64_t i = tid; i < Ptot; i += kSelThreads) {
-                    const unsigned long long kk = sort_key(fit[(i / seg_len) * seg_stride + i % seg_len]);
+                    const unsigned long long kk = sort_key(fit_at(i));
                     if ((kk & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = kk;
                 }
             }
             __syncthreads();
+            SEL_TP(6);
             if ((unsigned)tid < cnt) {  // the remaining-th largest candidate: `greater` < remaining <= greater + equal
                 const unsigned long long mine = cand[tid];
                 unsigned greater = 0u, equal = 0u;
-                for (unsigned c = 0; c < cnt; ++c) {
-                    const unsigned long long o = cand[c];
+#pragma unroll 8
+                for (unsigned cc = 0; cc < cnt; ++cc) {
+                    const unsigned long long o = cand[cc];
                     greater += o > mine;
                     equal += o == mine;
                 }
                 if (greater < remaining && remaining <= greater + equal) out[1] = mine;  // same value from every tie
             }
+            SEL_TP(7);
             return;
         }
+        top = shift - 1;
     }
-    if (tid == 0) out[1] = prefix;
 }
 
 // rows whose pbestfit is among the nw worst: V = 0, X = uniform(lower, upper), pbest = X, pbestfit = 1e30 (:420-424)
