@@ -27,11 +27,12 @@ namespace {
 // Exact sweeps, B individuals at a time.  ONE workgroup; every row group (LPR lanes) owns a slot.  A round
 //   1. computes the trial rows and fitness values of individuals i0..i0+B-1 in parallel, as if none of them
 //      influenced another (on the population / best row as they stand after the previous round);
-//   2. walks them in order (every thread runs the same walk on values in LDS): individual j is "dirty" if one
-//      of its donors was replaced by an earlier individual of this round, or (strategies / PSO that read the
-//      best row) the best row changed earlier in this round -- then j and all individuals after it are
-//      proposed again, together, on the current state before the walk goes on; then selection_async's rules
-//      apply to j.
+//   2. judges them in order, lane-parallel (lane j of every wave holds individual j; every wave derives the same
+//      decisions): the accept mask is one ballot; individual j is "dirty" if one of its donors is accepted
+//      earlier in this round (dep & accepted & below(j)), or (strategies / PSO that read the best row) the best
+//      row improves earlier in this round.  The longest run that is valid on the values at hand is committed by
+//      selection_async's rules; if it ends before the round does, the rest of the round is proposed again,
+//      together, on the state as it stands then.
 // The result is the sequential sweep's, bit for bit; conflicts are rare (k*B/(2P) donors per individual, a
 // handful of best-row improvements per generation), and each costs one more parallel proposal.
 // ---------------------------------------------------------------------------
