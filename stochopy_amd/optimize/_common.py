@@ -117,6 +117,15 @@ def resolve_workers(workers):
     """`workers` = number of GPUs (processes are launched by torchrun; see parallel.py)."""
     if workers in (None, 0, 1):
         return 1
+    if int(workers) == -1:  # "all": every rank of the initialised process group (one GPU without one)
+        try:
+            import torch.distributed as dist
+
+            return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        except ImportError:
+            return 1
+    if int(workers) < 1:
+        raise ValueError(f"workers={workers}: expected the number of GPUs (or -1 for all)")
     return int(workers)
 
 

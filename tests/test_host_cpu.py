@@ -333,3 +333,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp")):
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_workers_option_resolution():
+    """`workers` = number of GPUs; None / 0 / 1 = one; -1 = all ranks of the process group (none here -> 1)."""
+    from stochopy_amd.optimize import _common
+
+    assert [_common.resolve_workers(w) for w in (None, 0, 1, -1, 4)] == [1, 1, 1, 1, 4]
+    with pytest.raises(ValueError):
+        _common.resolve_workers(-3)
