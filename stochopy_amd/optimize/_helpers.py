@@ -42,10 +42,13 @@ def minimize(fun, bounds, x0=None, args=(), method="de", options=None, callback=
     """Minimize ``fun`` with a stochastic optimizer on the GPU.
 
     Same signature and dispatch as the reference (``_helpers.py:44-94``):
-    ``options`` is splatted into the per-method function.  Methods on the
-    MI355X hot path: ``"de"``, ``"pso"``, ``"cpso"``, ``"cmaes"``.  Options added
-    by this backend: ``backend="hip"`` (the default here), ``workers`` = number
-    of GPUs, ``rng`` in {"numpy-legacy", "philox"}.
+    ``options`` is splatted into the per-method function.  Methods offered:
+    ``"de"``, ``"pso"``, ``"cpso"``, ``"cmaes"``, ``"vdcma"``.  Options added by this backend:
+    ``backend="hip"`` (the default here), ``workers`` = number of GPUs (-1 = every rank of the process group),
+    ``rng`` in {"numpy-legacy", "philox"}, ``strict_updating`` (honour ``updating="immediate"`` with the
+    reference's serial semantics), and for DE with several GPUs ``exchange`` / ``donors``.  ``fun`` is a
+    ``stochopy_amd.factory`` objective, or a caller's own objective tagged with ``factory.batched`` /
+    ``factory.host_callable``.
     """
     options = options if options else {}
     try:
