@@ -150,15 +150,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void de_async_kernel(const sx_d
 #pragma unroll
             for (int t = 0; t < kMaxDonors; ++t) dv[t] = t < k ? X[d[t] * ld + e] : 0.0;
             const double x = xi[e], g = G[e];
-            double v;  // de/_strategy.py, same association
-            if (strategy == SX_DE_BEST1BIN)
-                v = g + F * (dv[0] - dv[1]);
-            else if (strategy == SX_DE_RAND1BIN)
-                v = dv[0] + F * (dv[1] - dv[2]);
-            else if (strategy == SX_DE_BEST2BIN)
-                v = g + F * (((dv[0] + dv[1]) - dv[2]) - dv[3]);
-            else
-                v = dv[0] + F * (((dv[1] + dv[2]) - dv[3]) - dv[4]);
+            const double v = de_mutant(strategy, g, dv[0], dv[1], dv[2], dv[3], dv[4], F);
             const double r = RNG == SX_RNG_HOST ? a.r1[i * (int64_t)n + e] : rr[t];
             double cand = (e == irand || r <= CR) ? v : x;  // de/_de.py:381-384
             if (repair && (cand < a.lower[e] || cand > a.upper[e]))
@@ -292,7 +284,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void pso_async_kernel(const sx_
                 r1 = a.r1[i * (int64_t)n + e];
                 r2 = a.r2[i * (int64_t)n + e];
             }
-            const double vn = (w * v + (c1 * r1) * (p - x)) + (c2 * r2) * (g - x);  // cpso/_cpso.py:326
+            const double vn = pso_velocity(w, v, c1, r1, p, x, c2, r2, g);
             Vn[e] = vn;
             const double xc = x + vn;
             U[e] = xc;

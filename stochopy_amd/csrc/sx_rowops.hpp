@@ -177,6 +177,22 @@ __device__ __forceinline__ void philox_donors(int64_t P, int k, int64_t i, uint3
     irand = (int)__umulhi(a.x, (uint32_t)n);
 }
 
+// mutant of one element (de/_strategy.py:1-38, the reference's association order; no FMA): g = best row,
+// d0..d4 = donor rows
+__device__ __forceinline__ double de_mutant(int strategy, double g, double d0, double d1, double d2, double d3,
+                                            double d4, double F) {
+    if (strategy == SX_DE_BEST1BIN) return g + F * (d0 - d1);
+    if (strategy == SX_DE_RAND1BIN) return d0 + F * (d1 - d2);
+    if (strategy == SX_DE_BEST2BIN) return g + F * (((d0 + d1) - d2) - d3);
+    return d0 + F * (((d1 + d2) - d3) - d4);
+}
+
+// new velocity of one element (cpso/_cpso.py:326, left to right): w*v + c1*r1*(p - x) + c2*r2*(g - x)
+__device__ __forceinline__ double pso_velocity(double w, double v, double c1, double r1, double p, double x, double c2,
+                                               double r2, double g) {
+    return (w * v + (c1 * r1) * (p - x)) + (c2 * r2) * (g - x);
+}
+
 // run `body(std::integral_constant<int, LPR>)` for the LPR that lanes_per_row(n) prescribes
 #define SX_DISPATCH_LPR(n, CALL)            \
     switch (lanes_per_row(n)) {             \

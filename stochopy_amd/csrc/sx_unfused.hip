@@ -74,15 +74,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_propose_kernel(co
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
             if (e >= n) continue;
-            double v;  // de/_strategy.py, same association
-            if (strategy == SX_DE_BEST1BIN)
-                v = g[t] + F * (dv[0][t] - dv[1][t]);
-            else if (strategy == SX_DE_RAND1BIN)
-                v = dv[0][t] + F * (dv[1][t] - dv[2][t]);
-            else if (strategy == SX_DE_BEST2BIN)
-                v = g[t] + F * (((dv[0][t] + dv[1][t]) - dv[2][t]) - dv[3][t]);
-            else
-                v = dv[0][t] + F * (((dv[1][t] + dv[2][t]) - dv[3][t]) - dv[4][t]);
+            const double v = de_mutant(strategy, g[t], dv[0][t], dv[1][t], dv[2][t], dv[3][t], dv[4][t], F);
             double c = (e == irand || r[t] <= CR) ? v : x[t];  // de/_de.py:341-344
             if (repair && (c < a.lower[e] || c > a.upper[e]))  // de/_constraints.py:21-26
                 c = RNG == SX_RNG_HOST ? rs[t]
@@ -126,7 +118,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(cons
                 r1 = a.r1[rowc * (int64_t)n + e];
                 r2 = a.r2[rowc * (int64_t)n + e];
             }
-            const double vn = (w * v + (c1 * r1) * (p - x)) + (c2 * r2) * (g - x);  // cpso/_cpso.py:326
+            const double vn = pso_velocity(w, v, c1, r1, p, x, c2, r2, g);
             if (shrink) {  // cpso/_constraints.py:22-50
                 Vn[e] = vn;
                 const double xc = x + vn, lo = a.lower[e], hi = a.upper[e];
