@@ -509,15 +509,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
             if (FULL || e < n) {
-                double v;
-                if (strategy == SX_DE_BEST1BIN)
-                    v = g[t] + F * (bd[0][t] - bd[1][t]);
-                else if (strategy == SX_DE_RAND1BIN)
-                    v = bd[0][t] + F * (bd[1][t] - bd[2][t]);
-                else if (strategy == SX_DE_BEST2BIN)
-                    v = g[t] + F * (((bd[0][t] + bd[1][t]) - bd[2][t]) - bd[3][t]);
-                else
-                    v = bd[0][t] + F * (((bd[1][t] + bd[2][t]) - bd[3][t]) - bd[4][t]);
+                const double v = de_mutant(strategy, g[t], bd[0][t], bd[1][t], bd[2][t], bd[3][t], bd[4][t], F);
                 double cand = (e == irand || br[t] <= CR) ? v : bx[t];
                 if (repair && (cand < a.lower[e] || cand > a.upper[e])) cand = brs[t];
                 U[e] = cand;

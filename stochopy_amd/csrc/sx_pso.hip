@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
             if (e < n) {
-                const double vn = (w * v[t] + (c1 * r1[t]) * (p[t] - x[t])) + (c2 * r2[t]) * (g[t] - x[t]);
+                const double vn = pso_velocity(w, v[t], c1, r1[t], p[t], x[t], c2, r2[t], g[t]);
                 if (shrink) {  // cpso/_constraints.py:22-50: beta = min over violated dims of (bound - x)/v
                     Vn[e] = vn;
                     const double xc = x[t] + vn;
