@@ -1,5 +1,5 @@
 """Objective handles for the MI355X backend: the seven benchmark functions as device kernels, plus the two tags
-(`batched`, `host_callable`) under which a caller's own objective is accepted (see factory/benchmark.py)."""
+(`batched`) under which a caller's own device objective is accepted (see factory/benchmark.py)."""
 from . import benchmark as _benchmark
 from .benchmark import Objective  # noqa: F401
 

@@ -20,7 +20,6 @@ __all__ = [
     "sphere",
     "styblinski_tang",
     "batched",
-    "host_callable",
 ]
 
 
@@ -75,9 +74,11 @@ class batched:
     ROCm tensor of candidates (on the engine's current stream) and returns the (P,) float64 fitness tensor on the
     same device.  This is the backend's hook contract (reference _common.py:27-106: after decoration ``fun(X)``
     maps the (P, n) population to (P,) values).  The objective cannot be fused into the generation kernels, so a
-    generation becomes propose -> fun -> select (csrc/sx_unfused.hip); everything else stays as it is."""
+    generation becomes propose -> fun -> select (csrc/sx_unfused.hip); everything else stays as it is.
 
-    host = False
+    This package itself never evaluates an objective on the host.  A caller whose objective only exists as
+    numpy code can do the round trip inside ``fun`` (``X.cpu().numpy()`` in, a tensor on ``X.device`` out) -- it is
+    then their code that is slow, visibly, and the generations are launched one by one instead of as a graph."""
 
     def __init__(self, fun):
         if not hasattr(fun, "__call__"):
@@ -86,16 +87,7 @@ class batched:
         self.__name__ = getattr(fun, "__name__", "objective")
 
     def __repr__(self):
-        return f"<stochopy_amd {'host' if self.host else 'device-batched'} objective {self.__name__}>"
+        return f"<stochopy_amd device-batched objective {self.__name__}>"
 
     def __call__(self, *a, **k):
         return self.fun(*a, **k)
-
-
-class host_callable(batched):
-    """Tag a plain Python objective ``fun(x, *args)`` (1-D numpy row -> float), the reference's own calling
-    convention.  EXPLICITLY slow: every generation the candidates are copied to the host and evaluated row by row
-    by the caller's code (exactly what the reference's serial backend does, _common.py:79-80); proposal,
-    selection and best/termination stay on the GPU.  Never chosen silently -- untagged callables are refused."""
-
-    host = True

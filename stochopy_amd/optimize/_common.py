@@ -41,16 +41,13 @@ class External:
     """A caller-supplied objective as the generation loops use it: ``ext(ctx, X)`` -> (P,) device tensor."""
 
     def __init__(self, tagged, args):
-        self.fun, self.host = tagged.fun, tagged.host
+        self.fun = tagged.fun
         self.args = tuple(args) if args not in ((), None) else ()
         self.name = tagged.__name__
 
     def __call__(self, ctx, X):
         t = __import__("torch")
         P = X.shape[0]
-        if self.host:  # the caller's own code, on the host, row by row (reference _common.py:79-80)
-            Xh = X.cpu().numpy()
-            return ctx.upload(np.array([self.fun(x, *self.args) for x in Xh], dtype=np.float64))
         f = self.fun(X, *self.args)
         if not isinstance(f, t.Tensor) or f.device != X.device:
             raise TypeError(f"batched objective {self.name}: expected a tensor on {X.device}, got {type(f).__name__}")
@@ -63,9 +60,8 @@ def resolve_objective(fun, args):
     """Map the user's callable to a device kernel id, or to an External for tagged caller-supplied objectives.
 
     The factory objectives (stochopy_amd.factory, tagged with ``sx_id``) run fused in the generation kernels.
-    ``factory.batched(fun)`` (device tensors in, device tensor out) and ``factory.host_callable(fun)`` (the
-    reference's per-row convention, explicitly slow) run between a propose and a select kernel.  Untagged
-    callables are refused: nothing falls back to the host silently.
+    ``factory.batched(fun)`` (device tensor in, device tensor out) runs between a propose and a select kernel.
+    Untagged callables are refused: this package never evaluates an objective on the host.
     """
     from ..factory.benchmark import batched
 
@@ -79,9 +75,8 @@ def resolve_objective(fun, args):
         return External(fun, args)
     raise TypeError(
         "backend='hip' needs a device objective from stochopy_amd.factory "
-        "(ackley, griewank, quartic, rastrigin, rosenbrock, sphere, styblinski_tang), "
-        "a device-batched callable tagged with stochopy_amd.factory.batched, or -- explicitly slow -- a Python "
-        f"callable tagged with stochopy_amd.factory.host_callable; got {fun!r}.  There is no silent host fallback.")
+        "(ackley, griewank, quartic, rastrigin, rosenbrock, sphere, styblinski_tang) or a callable that works on "
+        f"the device population, tagged with stochopy_amd.factory.batched; got {fun!r}.  There is no host fallback.")
 
 
 def evaluate_rows(ctx, fun, X, n, f, xm=None, xstd=None, clip=False):

@@ -385,7 +385,7 @@ class _PsoRun:
             elif self.immediate or self.external is not None:
                 # long sweeps: look after every few of them.  A caller's device objective between our kernels:
                 # chunks of generations captured into one graph (kernels + objective) and replayed, else eagerly
-                look = 8 if self.immediate else (1 if self.external.host else self.CHECK_EVERY)
+                look = 8 if self.immediate else self.CHECK_EVERY
                 todo = min(max(self.maxiter - st.it, 1), look)
                 while self.external is not None and todo >= self.GRAPH_CHUNK and self._capture_sharded_chunk():
                     self._rccl_graph.replay()
@@ -459,7 +459,7 @@ class _PsoRun:
             return True
         if (self._rccl_graph_note is not None or (self.world is not None and self.world.backend != "nccl")
                 or os.environ.get("SX_RCCL_GRAPH") == "0"
-                or (self.external is not None and (self.external.host or os.environ.get("SX_EXT_GRAPH") == "0"))):
+                or (self.external is not None and os.environ.get("SX_EXT_GRAPH") == "0")):
             return False
         t = _device.torch()
         try:

@@ -105,7 +105,7 @@ class _DeRun:
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, F, CR, strategy, constraints, xtol, ftol, return_all,
                  verbosity, callback, rng, seed, workers, autorun=True, exchange=None, donors=None, immediate=False):
         self.fun_id, self.lower, self.upper = fun_id, lower, upper
-        # a caller-supplied objective (factory.batched / host_callable) cannot be fused: propose -> fun -> select
+        # a caller-supplied objective (factory.batched) cannot be fused: propose -> fun -> select
         self.external = None if isinstance(fun_id, int) else fun_id
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.F, self.CR, self.strategy, self.constraints = F, CR, strategy, constraints
@@ -546,11 +546,11 @@ class _DeRun:
 
     def _external_graph(self, parity):
         """EXT_CHUNK generations -- our kernels AND the caller's device objective -- captured once into a graph
-        (in-kernel draws, device objective).  False when that is not possible (host objective, host draws, gloo,
-        SX_EXT_GRAPH=0, or an objective that cannot be captured): the caller then launches eagerly."""
+        (in-kernel draws).  False when that is not possible (host draws, gloo, SX_EXT_GRAPH=0, or an objective
+        that cannot be captured, e.g. one that synchronises): the caller then launches eagerly."""
         if parity in self._ext_graphs:
             return True
-        if (self._ext_graph_note is not None or self.external.host or self.rng != "philox"
+        if (self._ext_graph_note is not None or self.rng != "philox"
                 or (self.world is not None and self.world.backend != "nccl") or os.environ.get("SX_EXT_GRAPH") == "0"):
             return False
         t = _device.torch()
@@ -626,7 +626,7 @@ class _DeRun:
                     self._generation()
                 st = ctx.read_state(self.state)
             elif self.external is not None:  # kernels and the caller's objective, queued on the engine stream
-                self._enqueue_external(min(remaining, 1 if self.external.host else 4 * self.EXT_CHUNK))
+                self._enqueue_external(min(remaining, 4 * self.EXT_CHUNK))
                 st = self.read_state()
                 self.it_enq = int(st.it)
             else:

@@ -47,8 +47,7 @@ def minimize(fun, bounds, x0=None, args=(), method="de", options=None, callback=
     ``backend="hip"`` (the default here), ``workers`` = number of GPUs (-1 = every rank of the process group),
     ``rng`` in {"numpy-legacy", "philox"}, ``strict_updating`` (honour ``updating="immediate"`` with the
     reference's serial semantics), and for DE with several GPUs ``exchange`` / ``donors``.  ``fun`` is a
-    ``stochopy_amd.factory`` objective, or a caller's own objective tagged with ``factory.batched`` /
-    ``factory.host_callable``.
+    ``stochopy_amd.factory`` objective, or a caller's own device objective tagged with ``factory.batched``.
     """
     options = options if options else {}
     try:

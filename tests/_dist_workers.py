@@ -115,8 +115,21 @@ def _minimize_and_save(rank, world, cfg, out_dir):
     fun = getattr(sa.factory, cfg["objective"])
     if cfg.get("external") == "batched":  # a caller-supplied device objective (torch ops on the shard's rows)
         fun = sa.factory.batched(lambda X: (X * X).sum(dim=1))
-    elif cfg.get("external") == "host":
-        fun = sa.factory.host_callable(lambda x: np.sum(x**2))
+    elif cfg.get("external") == "device-sphere":  # the fused kernel's own values, handed in as a caller's objective
+        import ctypes as C
+
+        import torch
+
+        from stochopy_amd import _lib
+
+        def _sphere(X):
+            f = torch.empty((X.shape[0],), dtype=torch.float64, device=X.device)
+            Xc = X.contiguous()
+            assert _lib.lib().sx_eval(_lib.FUN_IDS["sphere"], Xc.data_ptr(), X.shape[0], X.shape[1], X.shape[1], None, None,
+                                      f.data_ptr(), None, None, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+            return f
+
+        fun = sa.factory.batched(_sphere)
     seen = []
     cb = (lambda X, r: seen.append((np.array(X, copy=True), float(r.fun), int(r.nit), int(r.nfev)))) if cfg.get("callback") else None
     res = sa.optimize.minimize(fun, cfg.get("bounds", [[-5.12, 5.12]] * n), method=cfg["method"], options=opts, callback=cb)

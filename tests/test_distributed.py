@@ -251,14 +251,14 @@ def test_sharded_callbacks_and_return_all(method, extra, env, with_callback):
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["pso", "cpso", "de"])
 def test_sharded_run_with_a_caller_supplied_objective(method):
-    """workers=2 around factory.host_callable(numpy sphere) -- numpy's bits = the fused kernel's, so sharded PSO /
-    CPSO must again be the unsharded oracle run, and sharded DE the sharded oracle -- and around a torch objective
-    (factory.batched) both ranks must agree."""
+    """workers=2 around a caller-supplied device objective that returns the fused kernel's values (sx_eval handed
+    in through factory.batched): sharded PSO / CPSO must again be the unsharded oracle run, and sharded DE the
+    sharded oracle -- and around a torch-written objective both ranks must agree."""
     from _dist_workers import gpu_minimize_worker
 
     n = 10
     opts = {"maxiter": 20, "popsize": 64, "seed": 8, "ftol": -1.0, "xtol": 0.0}
-    cfg = {"n": n, "objective": "sphere", "method": method, "options": opts, "external": "host",
+    cfg = {"n": n, "objective": "sphere", "method": method, "options": opts, "external": "device-sphere",
            "env": {"SX_EXCHANGE": "rccl"}}
     out = _spawn(gpu_minimize_worker, 2, cfg)
     if method == "de":
