@@ -90,7 +90,7 @@ def main():
 
     import torch
 
-    import stochopy_amd as sa
+    import stochopy_amd as sa  # noqa: F401  (fails loudly here if the HIP library is missing)
     from stochopy_amd import _lib
     from stochopy_amd.optimize import _de
 

@@ -12,7 +12,6 @@ which also fixes the eigenvector signs the same-seed parity depends on.
 candidates, the objective and the weighted squared excess run in one device kernel
 (``sx_cmaes_eval_penalized``); the scalar bookkeeping of the boundary weights stays on the host.
 """
-import ctypes as C
 
 import numpy as np
 

@@ -13,7 +13,6 @@ B and D).  SURVEY.md section 8f rank 3: the covariance model is D (I + v v^T) D,
 
 ``workers > 1``: candidates sharded by rows like CMA-ES (one all-gather of y, x and the fitness per generation).
 """
-import ctypes as C
 
 import numpy as np
 
