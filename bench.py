@@ -77,6 +77,43 @@ def cpu_baseline(objective, n, P, strategy, budget_s=12.0):
     }
 
 
+def _one_row(objective, x):
+    import oracle
+
+    return float(oracle.OBJECTIVES[objective](x[None, :])[0])
+
+
+def cpu_baseline_loky(objective, n, P, strategy, budget_s=6.0):
+    """The same oracle loop with the objective farmed out the way the reference's joblib backend does it
+    (_common.py:39-43: one task per individual, `Parallel(n_jobs=workers)(delayed(fun)(x) for x in X)`), on all
+    host cores through joblib's loky pool (kept warm across generations).  Reported next to the serial figure:
+    for objectives this cheap the per-task overhead makes it SLOWER than serial, as with the reference itself."""
+    import oracle
+    from joblib import Parallel, delayed
+
+    cores = min(os.cpu_count() or 1, 32)  # (pool start-up grows with the worker count; 32 is past the point of any gain)
+    stamps = []
+    with Parallel(n_jobs=cores, backend="loky") as pool:
+        def fobj(X):
+            return np.array(pool(delayed(_one_row)(objective, x) for x in X))
+
+        def cb(X, r):
+            stamps.append(time.perf_counter())
+            if len(stamps) >= 3 and stamps[-1] - stamps[0] > budget_s:
+                raise StopIteration
+
+        try:
+            oracle.minimize(fobj, [[-5.12, 5.12]] * n, method="de", callback=cb,
+                            options={"maxiter": 10**6, "popsize": P, "seed": 0, "strategy": strategy, "ftol": -1.0,
+                                     "xtol": 0.0})
+        except StopIteration:
+            pass
+    done, dt = len(stamps) - 1, stamps[-1] - stamps[0]
+    return {"value": P * done / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"oracle DE {strategy} {objective} n={n} P={P}, {done} generations in {dt:.1f}s, one joblib-loky task "
+                      f"per individual on {cores} workers (the reference's parallel backend scheme), host cpu_count={os.cpu_count()}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +260,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(objective, n, min(P, 4096), strategy, args.cpu_baseline_seconds)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            try:  # the reference's own parallel-backend scheme, as a second reported baseline
+                line["cpu_baseline_loky"] = cpu_baseline_loky(objective, n, min(P, 4096), strategy,
+                                                             min(6.0, args.cpu_baseline_seconds))
+            except Exception as e:  # noqa: BLE001  (joblib missing / pool failure: say so, keep the line)
+                line["cpu_baseline_loky"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
