@@ -386,6 +386,30 @@ def test_sharded_pso_rccl_graph_capture_single_rank(method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["de", "pso", "cpso"])
+def test_callbacks_and_return_all_over_rccl_single_rank(method):
+    """The shard gathers behind callback / return_all through the production collective (all_gather_into_tensor on
+    the device, backend nccl = RCCL) with one rank: history and callback populations == the oracle's."""
+    from _dist_workers import nccl_single_rank_worker
+
+    n = 10
+    opts = {"maxiter": 20, "popsize": 48, "seed": 4, "ftol": -1.0, "xtol": 0.0, "return_all": True}
+    if method == "de":
+        opts["exchange"] = "rccl"
+    cfg = {"n": n, "objective": "rosenbrock", "method": method, "options": opts, "callback": True,
+           "env": {"SX_EXCHANGE": "rccl"}}
+    out = _spawn(nccl_single_rank_worker, 1, cfg)
+    seen = []
+    oopts = {k: v for k, v in opts.items() if k != "exchange"}
+    ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method=method, options=oopts, rng="philox",
+                          callback=lambda X, r: seen.append(X.copy()))
+    assert np.array_equal(np.load(os.path.join(out, "x_0.npy")), ref.x)
+    assert np.array_equal(np.load(os.path.join(out, "xall_0.npy")), ref.xall)
+    assert np.array_equal(np.load(os.path.join(out, "funall_0.npy")), ref.funall)
+    assert np.array_equal(np.load(os.path.join(out, "cbX_0.npy")), np.array(seen))
+
+
+@pytest.mark.gpu
 def test_p2p_path_single_rank_nccl_setup():
     """Same with the peer exchange (handles and agreement travel over the RCCL group, the kernels write locally)."""
     from _dist_workers import nccl_single_rank_worker
