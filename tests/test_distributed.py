@@ -10,18 +10,33 @@ import oracle
 from oracle import engine as oe
 
 
+_used_ports = set()
+
+
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    """A rendezvous port nobody listens on and that this session has not handed out before (the kernel likes to
+    give the same ephemeral port again right after a process group went away, while its store may still be closing)."""
+    for _ in range(64):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        if port not in _used_ports:
+            _used_ports.add(port)
+            return port
+    raise RuntimeError("no free rendezvous port")
 
 
 def _spawn(fn, world, cfg):
     import torch.multiprocessing as mp
 
-    out = tempfile.mkdtemp(prefix="sx_dist_")
-    mp.spawn(fn, args=(world, _free_port(), cfg, out), nprocs=world, join=True)
-    return out
+    for attempt in range(3):
+        out = tempfile.mkdtemp(prefix="sx_dist_")
+        try:
+            mp.spawn(fn, args=(world, _free_port(), cfg, out), nprocs=world, join=True)
+            return out
+        except Exception as e:  # noqa: BLE001  a rendezvous port taken by someone else in the meantime: try another
+            if "EADDRINUSE" not in str(e) or attempt == 2:
+                raise
 
 
 def _sharded_oracle(cfg, world):
