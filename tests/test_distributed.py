@@ -34,8 +34,10 @@ def _spawn(fn, world, cfg):
         try:
             mp.spawn(fn, args=(world, _free_port(), cfg, out), nprocs=world, join=True)
             return out
-        except Exception as e:  # noqa: BLE001  a rendezvous port taken by someone else in the meantime: try another
-            if "EADDRINUSE" not in str(e) or attempt == 2:
+        except Exception as e:  # noqa: BLE001  rendezvous trouble (port taken meanwhile, store socket reset): again
+            rendezvous = any(w in str(e) for w in ("EADDRINUSE", "DistNetworkError", "TCPStore", "Connection reset",
+                                                   "Broken pipe", "failed to listen", "failed to connect"))
+            if not rendezvous or attempt == 2:
                 raise
 
 
