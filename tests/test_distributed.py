@@ -36,7 +36,8 @@ def _spawn(fn, world, cfg):
             return out
         except Exception as e:  # noqa: BLE001  rendezvous trouble (port taken meanwhile, store socket reset): again
             rendezvous = any(w in str(e) for w in ("EADDRINUSE", "DistNetworkError", "TCPStore", "Connection reset",
-                                                   "Broken pipe", "failed to listen", "failed to connect"))
+                                                   "Broken pipe", "failed to listen", "failed to connect",
+                                                   "terminated with signal"))  # (a persistent fault still fails 3x)
             if not rendezvous or attempt == 2:
                 raise
 
