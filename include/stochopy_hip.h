@@ -398,6 +398,27 @@ int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, const doubl
                     const double *xmean, double sigma, const double *dy, double *ary, double *arx, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Symmetric eigendecomposition on the device (csrc/sx_eigh.hip): parallel two-sided block Jacobi, the
+ * similarity updates as fp64 MFMA tile products, convergence decided on the device.
+ * replaces cmaes/_cmaes.py:303-305:
+ *     C = triu(C) + triu(C,1).T;  D, B = np.linalg.eigh(C);  idx = argsort(D);  D = D[idx];  B = B[:, idx]
+ * (numpy.linalg.eigh = LAPACK dsyevd, the reference's third-party call).
+ * C DEVICE (n,n) row-major, only its upper triangle is read (mirrored, as :303 does); w DEVICE (n) eigenvalues
+ * ascending; B DEVICE (n,n) row-major, eigenvector k in column k, unit norm, CANONICAL SIGN: the component of
+ * largest magnitude (lowest row on ties) is positive.  V0: NULL (reserved: starting basis).  ws: DEVICE scratch of
+ * sx_eigh_workspace_bytes(n) bytes; it starts with the run record read by sx_eigh_info.  max_sweeps <= 0: 24;
+ * tol <= 0: 1e-14 (a sweep is the last one when the off-diagonal mass it leaves behind, extrapolated from the mass
+ * met during the last two sweeps, is <= tol*|C|_F).
+ * Asynchronous on `stream`; the host never waits: launches after convergence are no-ops.
+ * sx_eigh_info (synchronises): sweeps carried out, whether the rule was met, off-diagonal mass / |C|_F met
+ * during the last sweep.
+ * ------------------------------------------------------------------------- */
+int64_t sx_eigh_workspace_bytes(int n);
+int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
+            double tol, void *stream);
+int sx_eigh_info(const void *ws, int *sweeps, int *converged, double *off_rel, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * numpy-legacy random stream (host): bit-exact MT19937 replica of what the
  * reference draws through np.random.* after np.random.seed(seed)
  * (de/_de.py:148-149, cpso/_cpso.py:153-154, cmaes/_cmaes.py:116-117;

@@ -420,8 +420,28 @@ class PenalizeState:
         return fit, valid
 
 
+def eigh_canonical(C):
+    """cmaes/_cmaes.py:303-305 (upper triangle mirrored, numpy.linalg.eigh, ascending order) followed by the sign
+    rule of the device eigensolver (csrc/sx_eigh.hip): the component of largest magnitude of every eigenvector
+    (lowest row on ties) is positive.  LAPACK leaves the signs to its internals; a basis that both sides of a
+    parity test can reproduce needs a rule, and this is the one the HIP path states.  Eigenvalues are untouched."""
+    C = np.triu(C) + np.triu(C, 1).T
+    D, B = np.linalg.eigh(C)
+    o = np.argsort(D, kind="stable")
+    D = D[o]
+    B = B[:, o]
+    top = np.argmax(np.abs(B), axis=0)  # first occurrence of the maximum = lowest row on ties
+    sgn = np.where(B[top, np.arange(B.shape[1])] < 0.0, -1.0, 1.0)
+    return D, B * sgn
+
+
 def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, sigma=0.1, muperc=0.5,
-              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, **_ignored):
+              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, eigh="lapack", **_ignored):
+    """eigh="lapack": the reference's call as is (pinned to the goldens); eigh="canonical": the same
+    decomposition with the device eigensolver's sign rule (what eigh="device" runs of the HIP path are compared
+    with)."""
+    if eigh not in ("lapack", "canonical"):
+        raise ValueError(eigh)
     if constraints not in (None, "Penalize"):
         raise KeyError(constraints)
     pen = PenalizeState(len(lower)) if constraints == "Penalize" else None
@@ -471,10 +491,13 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
         if nfev - eigeneval > P / (c1 + cmu) / n / 10.0:
             eigeneval = nfev
             C = np.triu(C) + np.triu(C, 1).T
-            D, B = np.linalg.eigh(C)
-            o = np.argsort(D)
-            D = D[o]
-            B = B[:, o]
+            if eigh == "canonical":
+                D, B = eigh_canonical(C)
+            else:
+                D, B = np.linalg.eigh(C)
+                o = np.argsort(D)
+                D = D[o]
+                B = B[:, o]
             D = np.sqrt(D)
             invsqrtC = np.dot(np.dot(B, np.diag(1.0 / D)), B.T)
         status = cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, insigma, ilim, pc,

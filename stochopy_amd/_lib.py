@@ -121,6 +121,9 @@ PROTOTYPES = {
     "sx_symmetrize_upper": (C.c_int, [vp, C.c_int, vp]),
     "sx_cmaes_eval_penalized": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "sx_vdcma_sample": (C.c_int, [vp, i64, C.c_int, i64, vp, vp, f64, vp, f64, vp, vp, vp, vp]),
+    "sx_eigh_workspace_bytes": (i64, [C.c_int]),
+    "sx_eigh": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, vp]),
+    "sx_eigh_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64), vp]),
     "sx_mt_create": (vp, [C.c_uint32]),
     "sx_mt_destroy": (None, [vp]),
     "sx_mt_seed": (None, [vp, C.c_uint32]),
