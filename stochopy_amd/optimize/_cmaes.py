@@ -16,6 +16,7 @@ candidates, the objective and the weighted squared excess run in one device kern
 import numpy as np
 
 from .. import _device, _lib, _rng
+from ..linalg import Eigh
 from . import _common
 from ._helpers import OptimizeResult, register
 
@@ -46,10 +47,13 @@ def minimize(
     """Minimize an objective function using CMA-ES on MI355X (reference cmaes/_cmaes.py:12-30).
 
     ``eigh="host"`` decomposes C with numpy/LAPACK exactly like the reference (cmaes/_cmaes.py:304 -- the
-    reference's own third-party call), which also pins the eigenbasis that same-seed parity depends on: the
-    default in the parity mode ``rng="numpy-legacy"``.  ``eigh="device"`` keeps C on the GPU and uses rocSOLVER
-    through ``torch.linalg.eigh``: a different, equally valid eigenbasis, no
-    2 x n^2 PCIe trip, 10x faster at n = 512 -- the default in the throughput mode ``rng="philox"``.
+    reference's own third-party call), whose eigenvector SIGNS (an accident of LAPACK's internals) same-seed
+    parity with the reference depends on: the default in the parity mode ``rng="numpy-legacy"``.
+    ``eigh="device"`` keeps C on the GPU and decomposes it with this package's own eigensolver
+    (csrc/sx_eigh.hip: parallel block Jacobi on the fp64 matrix cores): same
+    eigenvalues and eigenvectors to rounding, signs by a stated rule (largest component positive), no
+    2 x n^2 PCIe trip -- the default in the throughput mode ``rng="philox"``; the oracle reproduces such runs
+    with ``eigh="canonical"`` (LAPACK + the same sign rule).
 
     ``workers > 1`` (one process per GPU) shards what the reference's parallel backends shard -- the
     candidates: every rank samples and evaluates ``popsize / workers`` rows (same draws: the legacy stream is
@@ -250,6 +254,7 @@ class _CmaRun:
 
         nfev = 0
         eigeneval = 0
+        eig, eig_sweeps = None, 24  # device eigensolver: launches beyond convergence are no-ops, but not free
         besthist = np.zeros(self.maxiter)
         ilim = int(10.0 + 30.0 * n / P)
         insigma = sigma
@@ -323,10 +328,13 @@ class _CmaRun:
                 eigeneval = nfev
                 _lib.check(L.sx_symmetrize_upper(ptr(d_C), n, sp), "sx_symmetrize_upper")
                 if self.eigh == "device":
-                    Dt, Bt = t.linalg.eigh(d_C)  # rocSOLVER, ascending eigenvalues, eigenvectors in columns
-                    d_D.copy_(t.sqrt(Dt))
-                    d_B.copy_(Bt)
+                    if eig is None:
+                        eig = Eigh(ctx, n)
+                    Dt, _ = eig(d_C, B=d_B, max_sweeps=eig_sweeps)  # ascending eigenvalues, eigenvectors in columns
+                    t.sqrt(Dt, out=d_D)
                     D = d_D.cpu().numpy()
+                    used, ok, _off = eig.info()
+                    eig_sweeps = min(60, used + 3) if ok else 60
                     B = d_B.cpu().numpy()
                     diagC = d_C.diagonal().cpu().numpy()
                     status = _stop_status(it, n, self.maxiter, xmean, xold, besthist, arfit, order, sigma, insigma,

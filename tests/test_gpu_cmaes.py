@@ -203,9 +203,46 @@ def test_cmaes_philox_vs_oracle(sa):
     assert np.allclose(t_got, t_ref, rtol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 10), (5, 12), (20, 48), (33, 80), (70, 160), (130, 264)])
+def test_cmaes_device_eigensolver_vs_oracle_canonical(sa, shape):
+    """eigh="device" (csrc/sx_eigh.hip) against the oracle running the reference's LAPACK call with the same sign
+    rule (oracle eigh="canonical"): same seed, per-generation best-f within 1e-6 rel.  mu + 1 >= n, so the
+    eigenbasis is determined (see _eigenbasis_is_determined)."""
+    n, P = shape
+    opts = {"maxiter": 14, "popsize": P, "seed": 77 + n, "sigma": 0.2}
+    bounds = [[-3.0, 3.0]] * n
+    t_ref, t_got = [], []
+    ref = oracle.minimize("rosenbrock", bounds, method="cmaes", options=dict(opts, eigh="canonical"), rng="philox",
+                          callback=lambda X, r: t_ref.append(r.fun))
+    got = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="cmaes",
+                               options=dict(opts, backend="hip", rng="philox", eigh="device"),
+                               callback=lambda X, r: t_got.append(r.fun))
+    assert len(t_got) == len(t_ref) and np.allclose(t_got, t_ref, rtol=1e-6)
+    assert (got.nit, got.status) == (ref.nit, ref.status) and np.isclose(got.fun, ref.fun, rtol=1e-6)
+
+
+def test_cmaes_c4_device_eigensolver_vs_oracle_canonical(sa):
+    """BASELINE config 4 (CMA-ES Rosenbrock n=512 P=1024 seed 0, numpy-legacy draws) with the device eigensolver:
+    the oracle with LAPACK + the same sign rule gives the same per-generation best-f within 1e-6 rel; generation 1
+    (B = I) also equals the reference's golden value."""
+    case = {c["tag"]: c for c in CMA_CASES}
+    c4 = [c for c in CMA_CASES if c["ndim"] == 512][0]
+    opts = dict(c4["options"])
+    t_ref, t_got = [], []
+    oracle.minimize(c4["objective"], case_bounds(c4), x0=c4["x0"], method="cmaes", options=dict(opts, eigh="canonical"),
+                    callback=lambda X, r: t_ref.append(r.fun))
+    sa.optimize.minimize(getattr(sa.factory, c4["objective"]), case_bounds(c4), x0=c4["x0"], method="cmaes",
+                         options=dict(opts, backend="hip", rng="numpy-legacy", eigh="device"),
+                         callback=lambda X, r: t_got.append(float(r.fun)))
+    assert len(t_got) == len(t_ref) and np.allclose(t_got, t_ref, rtol=1e-6)
+    assert np.isclose(t_got[0], unhex(c4["fun_trace"])[0], rtol=1e-12)
+    assert len(case) == len(CMA_CASES)
+
+
 def test_cmaes_device_eigensolver_converges(sa):
-    """eigh="device" (rocSOLVER): a different eigenbasis, so no same-seed parity -- the run must still
-    behave like CMA-ES: converge on the sphere with status 1, and on the reference-suite problem."""
+    """eigh="device" in the cases where the eigenbasis is NOT determined (mu + 1 < n: a repeated eigenvalue, any
+    basis of its eigenspace is valid) -- the run must still behave like CMA-ES: converge on the sphere with
+    status 1, and on the reference-suite problem."""
     res = sa.optimize.minimize(sa.factory.sphere, [[-5.12, 5.12]] * 12, method="cmaes",
                                options={"maxiter": 600, "popsize": 32, "seed": 3, "eigh": "device"})
     assert res.status == 1 and res.fun <= 1e-8 and np.abs(res.x).max() < 1e-3
