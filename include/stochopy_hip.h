@@ -58,7 +58,7 @@ const char *sx_last_error(void);
 /* number of visible HIP devices (<0 on error); used by the loader to fail loudly */
 int sx_device_count(void);
 /* sizeof(sx_state / sx_de_args / sx_pso_args / sx_xchg_args) as compiled: lets a binding check its struct
- * mirror (which: 0 state, 1 DE args, 2 PSO args, 3 exchange args; -1 otherwise) */
+ * mirror (which: 0 state, 1 DE args, 2 PSO args, 3 exchange args, 4 CMA state, 5 CMA args; -1 otherwise) */
 int sx_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
@@ -396,6 +396,59 @@ int sx_cmaes_eval_penalized(int fun_id, const double *X, int64_t P, int n, const
  * Z, ary, arx DEVICE (P,n); dvec, vn, xmean, dy DEVICE (n).  One wavefront per candidate, O(n). */
 int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, const double *dvec, const double *vn, double coef,
                     const double *xmean, double sigma, const double *dy, double *ary, double *arx, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * CMA-ES, device-resident generation (csrc/sx_cma_loop.hip): one call enqueues a whole generation --
+ * normals, sampling (MFMA), objective, ranking, recombination, evolution paths, step size, covariance
+ * update (MFMA), [symmetrise + sx_eigh], the ten stopping rules -- and the host looks at the 128-byte
+ * state only every few generations.
+ * replaces cmaes/_cmaes.py:226-343 (one pass of the `while` loop) and :360-434 (`converge`), for draws made on the
+ * device (Philox), constraints=None, one GPU.  Everything in sx_cma_args is DEVICE memory unless stated.
+ *   gen       1-based generation number (the caller counts; it also keys the Philox normals)
+ *   do_eigh   the caller's evaluation of :301 (`nfev - eigeneval > popsize / (c1 + cmu) / ndim / 10`, a function of
+ *             gen only)
+ * After a stopping rule has fired (state->done) the bookkeeping kernels of later calls do nothing and
+ * xbest / state keep the result; besthist must be zero-initialised (the reference's np.zeros(maxiter), :220).
+ * ------------------------------------------------------------------------- */
+typedef struct sx_cma_state {
+    int64_t it;         /* generations completed                                                       */
+    int64_t nfev;       /* it * popsize                                                                */
+    int64_t best_row;   /* arindex[0] of the last generation                                           */
+    double fbest;       /* arfitness[arindex[0]]                                                       */
+    double sigma;       /* step size entering the next generation                                      */
+    double sigma_next;  /* scratch: step size after :298, published by the stop step                   */
+    double tmp_coef;    /* 0 when `cond` held (:283-291), else c1*cc*(2-cc)                            */
+    double psnorm;      /* |ps|                                                                        */
+    int32_t status;     /* SX_STATUS_NONE while running, else the reference's status (-8 .. 1)         */
+    int32_t done;       /* 1 once a stopping rule fired                                                */
+    int64_t stop_it;    /* generation at which it fired                                                */
+    double reserved[6];
+} sx_cma_state;
+
+typedef struct sx_cma_args {
+    double *Z, *arx;            /* (P,n) normals / candidates (standardised coordinates)              */
+    double *fit;                /* (P)                                                                */
+    double *xmean, *xold, *ps, *pc; /* (n)                                                            */
+    double *C, *B;              /* (n,n) covariance, eigenvectors in columns                          */
+    double *D;                  /* (n) sqrt of the eigenvalues                                        */
+    double *eigw;               /* (n) eigenvalues as sx_eigh returns them                            */
+    const double *w;            /* (mu) recombination weights                                         */
+    double *Y;                  /* (mu,n) scratch of the covariance update                            */
+    double *part;               /* (64,n) scratch of the recombination                                */
+    double *besthist;           /* (maxiter) zero-initialised                                         */
+    const double *xm, *xstd;    /* (n) un-standardisation x * xstd + xm (:167-173)                    */
+    double *xbest;              /* (n) result: best candidate of the stopping generation              */
+    int64_t *order;             /* (P) argsort of fit                                                 */
+    void *state;                /* sx_cma_state                                                       */
+    void *eigh_ws;              /* sx_eigh workspace                                                  */
+    int64_t eigh_ws_bytes;
+    int64_t P;
+    int32_t n, mu, fun_id, maxiter, ilim, eig_sweeps;
+    double cs, cc, c1, cmu, damps, chind, mueff, xtol, ftol, insigma;
+    uint32_t key0, key1;
+} sx_cma_args;
+
+int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Symmetric eigendecomposition on the device (csrc/sx_eigh.hip): parallel two-sided block Jacobi, the

@@ -68,6 +68,25 @@ class SxXchgArgs(C.Structure):
                 ("shard_rows", i64)]
 
 
+class SxCmaState(C.Structure):
+    _fields_ = [("it", i64), ("nfev", i64), ("best_row", i64), ("fbest", f64), ("sigma", f64), ("sigma_next", f64),
+                ("tmp_coef", f64), ("psnorm", f64), ("status", i32), ("done", i32), ("stop_it", i64),
+                ("reserved", f64 * 6)]
+
+
+class SxCmaArgs(C.Structure):
+    _fields_ = [
+        ("Z", vp), ("arx", vp), ("fit", vp), ("xmean", vp), ("xold", vp), ("ps", vp), ("pc", vp), ("C", vp), ("B", vp),
+        ("D", vp), ("eigw", vp), ("w", vp), ("Y", vp), ("part", vp), ("besthist", vp), ("xm", vp), ("xstd", vp),
+        ("xbest", vp), ("order", vp), ("state", vp), ("eigh_ws", vp),
+        ("eigh_ws_bytes", i64), ("P", i64),
+        ("n", i32), ("mu", i32), ("fun_id", i32), ("maxiter", i32), ("ilim", i32), ("eig_sweeps", i32),
+        ("cs", f64), ("cc", f64), ("c1", f64), ("cmu", f64), ("damps", f64), ("chind", f64), ("mueff", f64),
+        ("xtol", f64), ("ftol", f64), ("insigma", f64),
+        ("key0", C.c_uint32), ("key1", C.c_uint32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/stochopy_hip.h declares
 PROTOTYPES = {
     "sx_abi_version": (C.c_int, []),
@@ -121,6 +140,7 @@ PROTOTYPES = {
     "sx_symmetrize_upper": (C.c_int, [vp, C.c_int, vp]),
     "sx_cmaes_eval_penalized": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "sx_vdcma_sample": (C.c_int, [vp, i64, C.c_int, i64, vp, vp, f64, vp, f64, vp, vp, vp, vp]),
+    "sx_cmaes_generation": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, vp]),
     "sx_eigh_workspace_bytes": (i64, [C.c_int]),
     "sx_eigh": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, vp]),
     "sx_eigh_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64), vp]),

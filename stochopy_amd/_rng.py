@@ -123,6 +123,7 @@ def make_init_stream(rng, seed):
     """
     if rng == "numpy-legacy":
         return LegacyHostStream(seed)
+    philox_key(seed)  # rng="philox" without a seed: the explanatory ValueError, not an int(None) TypeError
     state = np.random.get_state()
     try:
         return LegacyHostStream(int(seed) & 0xFFFFFFFF)

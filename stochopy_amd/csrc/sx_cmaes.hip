@@ -33,6 +33,7 @@ struct SampleOp {  // arx = xmean + sigma * (Z o D) * B^T
     const double *xmean;  // (n)
     double *arx;          // (P,n)
     double sigma;
+    const double *sigma_p;  // when set: the step size lives on the device (device-resident loop)
     int64_t P;
     int n;
 };
@@ -43,15 +44,18 @@ struct RankMuOp {  // C = (1-c1-cmu)*C + cmu * Y^T diag(w) Y + c1 * pc pc^T + tm
     const double *pc;     // (n)
     double *C;            // (n,n) in place
     double decay, cmu, c1, tmpc;
+    const double *tmpc_p;  // when set: tmp coefficient on the device (0 when `cond` held, else c1*cc*(2-cc))
     int mu, n;
 };
 
 // Y[k][:] = (arx[idx[k]][:] - xold) / sigma   (cmaes/_cmaes.py:290), once per generation
 __global__ __launch_bounds__(256) void cma_y_kernel(const double *__restrict__ arx, const int64_t *__restrict__ idx,
-                                                    const double *__restrict__ xold, double sigma, int mu, int n,
+                                                    const double *__restrict__ xold, double sigma,
+                                                    const double *__restrict__ sigma_p, int mu, int n,
                                                     double *__restrict__ Y) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)mu * n) return;
+    if (sigma_p) sigma = *sigma_p;
     const int k = (int)(t / n), e = (int)(t % n);
     Y[t] = (arx[idx[k] * (int64_t)n + e] - xold[e]) / sigma;
 }
@@ -182,15 +186,17 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
                 const double g = acc[ti][tj][r];
                 if (MODE == 0) {
                     const SampleOp &o = (const SampleOp &)op;
-                    o.arx[gi * (int64_t)o.n + gj] = o.xmean[gj] + o.sigma * g;  // xmean + sigma * dot(B, D*z)
+                    const double sg = o.sigma_p ? *o.sigma_p : o.sigma;
+                    o.arx[gi * (int64_t)o.n + gj] = o.xmean[gj] + sg * g;  // xmean + sigma * dot(B, D*z)
                 } else {
                     const RankMuOp &o = (const RankMuOp &)op;
+                    const double tmpc = o.tmpc_p ? *o.tmpc_p : o.tmpc;
                     double *cp = o.C + gi * (int64_t)o.n + gj;
                     const double cold = *cp;
                     double c = cold * o.decay;             // C *= 1 - c1 - cmu
                     c = c + o.cmu * g;                     // C += cmu * A^T diag(w) A
                     c = c + o.c1 * (o.pc[gi] * o.pc[gj]);  // C += c1 * outer(pc, pc)
-                    c = c + o.tmpc * cold;                 // C += tmp  (tmp = c1*cc*(2-cc)*C_old, or 0)
+                    c = c + tmpc * cold;                   // C += tmp  (tmp = c1*cc*(2-cc)*C_old, or 0)
                     *cp = c;
                 }
             }
@@ -264,10 +270,23 @@ __global__ __launch_bounds__(256) void symmetrize_upper_kernel(double *__restric
 }  // namespace
 
 // tile choice: enough workgroups to cover the 256 CUs on the (small) CMA-ES shapes
+namespace sx {
+int cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, const double *B, const double *D,
+                      const double *Z, double *arx, int64_t P, int n, void *stream);
+int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
+                       const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
+                       const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream);
+}  // namespace sx
+
 extern "C" int sx_cmaes_sample(const double *xmean, double sigma, const double *B, const double *D, const double *Z,
                                double *arx, int64_t P, int n, void *stream) {
+    return sx::cma_sample_launch(xmean, sigma, nullptr, B, D, Z, arx, P, n, stream);
+}
+
+int sx::cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, const double *B, const double *D,
+                          const double *Z, double *arx, int64_t P, int n, void *stream) {
     SX_REQUIRE(xmean && B && D && Z && arx && P >= 1 && n >= 1, "sx_cmaes_sample: bad arguments");
-    SampleOp op{Z, B, D, xmean, arx, sigma, P, n};
+    SampleOp op{Z, B, D, xmean, arx, sigma, sigma_p, P, n};
     const int64_t big = ((P + 63) / 64) * ((n + 63) / 64);
     if (big >= 512) {
         dim3 grid((unsigned)((n + 63) / 64), (unsigned)((P + 63) / 64));
@@ -286,12 +305,18 @@ extern "C" int sx_cmaes_sample(const double *xmean, double sigma, const double *
 extern "C" int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold,
                                 double sigma, const double *pc, double c1, double cmu, double tmp_coef, double *C,
                                 double *ws_y, int n, void *stream) {
+    return sx::cma_rank_mu_launch(arx, idx, w, mu, xold, sigma, nullptr, pc, c1, cmu, tmp_coef, nullptr, C, ws_y, n, stream);
+}
+
+int sx::cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
+                           const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
+                           const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream) {
     SX_REQUIRE(arx && idx && w && xold && pc && C && ws_y && mu >= 1 && n >= 1, "sx_cmaes_rank_mu: bad arguments");
     const int64_t total = (int64_t)mu * n;
     hipLaunchKernelGGL(cma_y_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, arx, idx,
-                       xold, sigma, mu, n, ws_y);
+                       xold, sigma, sigma_p, mu, n, ws_y);
     SX_LAUNCH_CHECK();
-    RankMuOp op{ws_y, w, pc, C, 1.0 - c1 - cmu, cmu, c1, tmp_coef, mu, n};
+    RankMuOp op{ws_y, w, pc, C, 1.0 - c1 - cmu, cmu, c1, tmp_coef, tmp_coef_p, mu, n};
     const int64_t big = ((int64_t)(n + 63) / 64) * ((n + 63) / 64);
     if (big >= 512) {
         dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));

@@ -27,6 +27,8 @@ extern "C" int sx_struct_size(int which) {
         case 1: return (int)sizeof(sx_de_args);
         case 2: return (int)sizeof(sx_pso_args);
         case 3: return (int)sizeof(sx_xchg_args);
+        case 4: return (int)sizeof(sx_cma_state);
+        case 5: return (int)sizeof(sx_cma_args);
     }
     return -1;
 }

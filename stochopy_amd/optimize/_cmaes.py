@@ -81,10 +81,98 @@ def minimize(
         eigh = "host" if rng == "numpy-legacy" else "device"
     if eigh not in ("host", "device"):
         raise ValueError("eigh must be 'host' or 'device'")
+    if (rng == "philox" and eigh == "device" and isinstance(fun_id, int) and workers == 1 and constraints is None
+            and callback is None and not return_all):
+        # nothing the host has to see between generations: the whole loop stays on the device
+        return _CmaDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
+                             float(xtol), float(ftol), seed).result()
     run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                   float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh, workers,
                   penalize=constraints == "Penalize")
     return run.result()
+
+
+def _strategy_constants(n, P, muperc):
+    """cmaes/_cmaes.py:184-205."""
+    mu = int(muperc * P)
+    w = np.log(mu + 0.5) - np.log(np.arange(1, mu + 1))
+    w /= w.sum()
+    mueff = w.sum() ** 2 / np.square(w).sum()
+    cc = (4.0 + mueff / n) / (n + 4.0 + 2.0 * mueff / n)
+    cs = (mueff + 2.0) / (n + mueff + 5.0)
+    c1 = 2.0 / ((n + 1.3) ** 2 + mueff)
+    cmu = min(1.0 - c1, 2.0 * (mueff - 2.0 + 1.0 / mueff) / ((n + 2.0) ** 2 + mueff))
+    damps = 1.0 + 2.0 * max(0.0, np.sqrt((mueff - 1.0) / (n + 1.0)) - 1.0) + cs
+    chind = np.sqrt(n) * (1.0 - 1.0 / (4.0 * n) + 1.0 / (21.0 * n**2))
+    return mu, w, mueff, cc, cs, c1, cmu, damps, chind
+
+
+class _CmaDeviceRun:
+    """The reference's loop (cmaes/_cmaes.py:226-343) with every per-generation step on the device
+    (csrc/sx_cma_loop.hip): the host enqueues generations -- it only works out, from the generation number, when the
+    eigendecomposition is due (:301) -- and looks at the 128-byte state every LOOK generations (every generation
+    while one takes milliseconds).  Draws: Philox normals keyed by (seed, generation, row); eigenvectors with the
+    canonical sign of csrc/sx_eigh.hip."""
+
+    LOOK = 16
+
+    def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed):
+        import ctypes as C
+        import time
+
+        ctx = self.ctx = _device.Context()
+        t = _device.torch()
+        L, ptr, n = ctx.L, _device.ptr, len(lower)
+        with t.cuda.stream(ctx.stream):
+            init = _rng.make_init_stream("philox", seed)
+            key0, key1 = _rng.philox_key(seed)
+            xm, xstd = 0.5 * (upper + lower), 0.5 * (upper - lower)
+            xmean = init.uniform(-1.0, 1.0, n) if x0 is None else (np.asarray(x0, dtype=np.float64) - xm) / xstd
+            mu, w, mueff, cc, cs, c1, cmu, damps, chind = _strategy_constants(n, P, muperc)
+            eig = Eigh(ctx, n)
+            keep = self._keep = dict(
+                Z=ctx.empty((P, n)), arx=ctx.empty((P, n)), fit=ctx.empty((P,)), xmean=ctx.upload(xmean),
+                xold=ctx.zeros((n,)), ps=ctx.zeros((n,)), pc=ctx.zeros((n,)), C=ctx.upload(np.eye(n)),
+                B=ctx.upload(np.eye(n)), D=ctx.upload(np.ones(n)), eigw=eig.w, w=ctx.upload(w), Y=ctx.empty((mu, n)),
+                part=ctx.empty((64, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
+                xbest=ctx.zeros((n,)), order=ctx.empty((P,), dtype=t.int64), eigh_ws=eig.ws)
+            st = _lib.SxCmaState(it=0, nfev=0, best_row=0, fbest=0.0, sigma=sigma, sigma_next=sigma, tmp_coef=0.0,
+                                 psnorm=0.0, status=_lib.SX_STATUS_NONE, done=0, stop_it=0)
+            d_state = keep["state"] = ctx.upload(np.frombuffer(bytes(st), dtype=np.float64))
+            a = _lib.SxCmaArgs(**{k: ptr(v) for k, v in keep.items()})
+            a.eigh_ws_bytes, a.P, a.n, a.mu, a.fun_id, a.maxiter = eig.bytes, P, n, mu, fun_id, maxiter
+            a.ilim, a.eig_sweeps = int(10.0 + 30.0 * n / P), 24
+            a.cs, a.cc, a.c1, a.cmu, a.damps, a.chind, a.mueff = cs, cc, c1, cmu, damps, chind, mueff
+            a.xtol, a.ftol, a.insigma, a.key0, a.key1 = xtol, ftol, sigma, key0, key1
+            eig_every = P / (c1 + cmu) / n / 10.0  # :301
+            eigeneval, look, since, t0 = 0, 1, 0, time.perf_counter()
+            state = st
+            for gen in range(1, maxiter + 1):
+                due = gen * P - eigeneval > eig_every
+                if due:
+                    eigeneval = gen * P
+                _lib.check(L.sx_cmaes_generation(C.byref(a), gen, int(due), ctx.stream_ptr), "sx_cmaes_generation")
+                since += 1
+                if since >= look or gen == maxiter:
+                    state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
+                    if state.done:
+                        break
+                    used, ok, _off = eig.info()
+                    a.eig_sweeps = min(60, used + 3) if ok else 60
+                    now = time.perf_counter()
+                    if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
+                        look *= 2
+                    since, t0 = 0, now
+            if not state.done:  # cannot happen: generation maxiter sets status -1
+                raise RuntimeError("CMA-ES device loop ended without a status")
+            nit = int(state.stop_it)
+            self._res = OptimizeResult(x=keep["xbest"].cpu().numpy(), success=state.status >= 0, status=int(state.status),
+                                       message=_common.messages[int(state.status)], fun=float(state.fbest),
+                                       nfev=nit * P, nit=nit)
+            ctx.sync()
+
+    def result(self):
+        return self._res
 
 
 class _BoundaryWeights:

@@ -239,6 +239,41 @@ def test_cmaes_c4_device_eigensolver_vs_oracle_canonical(sa):
     assert len(case) == len(CMA_CASES)
 
 
+@pytest.mark.parametrize("cfg", [("rosenbrock", 2, 10, 100, 0.1), ("rosenbrock", 20, 48, 60, 0.2), ("sphere", 6, 12, 400, 0.3),
+                                 ("rastrigin", 33, 80, 40, 0.3), ("ackley", 70, 160, 30, 0.2), ("rosenbrock", 130, 264, 12, 0.2)],
+                         ids=lambda c: "%s_n%d_p%d" % c[:3])
+def test_cmaes_device_resident_loop_vs_oracle(sa, cfg):
+    """No callback, no history, Philox draws: the whole loop runs on the device (csrc/sx_cma_loop.hip: ranking,
+    recombination, paths, step size, stop rules; the host looks at the state every few generations).  Same seed as the
+    oracle with LAPACK + the canonical sign rule: same stopping generation and status, best-f / best-x within the
+    north-star tolerance."""
+    obj, n, P, maxiter, sigma = cfg
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 1234 + n, "sigma": sigma}
+    bounds = [[-3.0, 3.0]] * n
+    ref = oracle.minimize(obj, bounds, method="cmaes", options=dict(opts, eigh="canonical"), rng="philox")
+    got = sa.optimize.minimize(getattr(sa.factory, obj), bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"))
+    assert (got.nit, got.nfev, got.status, got.success, got.message) == (ref.nit, ref.nfev, ref.status, ref.success, ref.message)
+    assert np.isclose(got.fun, ref.fun, rtol=1e-6, atol=1e-300)
+    assert np.allclose(got.x, ref.x, rtol=1e-5, atol=1e-7)
+    # and the host-driven loop (taken when a callback is given) agrees with it
+    trace = []
+    via_host = sa.optimize.minimize(getattr(sa.factory, obj), bounds, method="cmaes",
+                                    options=dict(opts, backend="hip", rng="philox"), callback=lambda X, r: trace.append(r.fun))
+    assert (via_host.nit, via_host.status) == (got.nit, got.status) and np.isclose(via_host.fun, got.fun, rtol=1e-6)
+
+
+def test_cmaes_device_resident_loop_stop_rules(sa):
+    """Stopping rules other than maxiter / ftol on the device: TolX-type stops on a flat objective region."""
+    for obj, n, P, opts in (("sphere", 4, 8, {"maxiter": 3000, "ftol": -1.0, "xtol": 0.0, "sigma": 0.3}),
+                            ("quartic", 5, 10, {"maxiter": 3000, "ftol": -1.0, "xtol": 0.0, "sigma": 0.3})):
+        o = dict(opts, popsize=P, seed=5)
+        ref = oracle.minimize(obj, [[-2.0, 2.0]] * n, method="cmaes", options=dict(o, eigh="canonical"), rng="philox")
+        got = sa.optimize.minimize(getattr(sa.factory, obj), [[-2.0, 2.0]] * n, method="cmaes",
+                                   options=dict(o, backend="hip", rng="philox"))
+        assert ref.status < -1, ref.status  # one of the CMA-specific rules fired
+        assert got.status == ref.status and abs(got.nit - ref.nit) <= max(3, ref.nit // 50)
+
+
 def test_cmaes_device_eigensolver_converges(sa):
     """eigh="device" in the cases where the eigenbasis is NOT determined (mu + 1 < n: a repeated eigenvalue, any
     basis of its eigenspace is valid) -- the run must still behave like CMA-ES: converge on the sphere with
