@@ -8,6 +8,8 @@ is kept is the user-visible one: same ``minimize`` options, synchronous updating
 whenever a parallel backend is chosen (de/_de.py:142-145), identical results for
 a given seed (rng="numpy-legacy").
 """
+import warnings
+
 import numpy as np
 
 from ..factory.benchmark import Objective
@@ -56,12 +58,46 @@ class External:
         return f.to(t.float64).contiguous()
 
 
-def resolve_objective(fun, args):
-    """Map the user's callable to a device kernel id, or to an External for tagged caller-supplied objectives.
+class HostExternal(External):
+    """Any other Python callable (SURVEY.md section 8b case iii): the CALLER'S scalar function, evaluated the way
+    the reference's serial wrapper does it -- ``np.array([fun(xx, *args) for xx in x])`` (_common.py:79-80) -- on
+    a host copy of the candidates, between the propose and the select kernel.  Draws, mutation / velocity update,
+    selection and bookkeeping stay on the device; what is slow is the caller's Python, one call per individual, plus
+    a D2H / H2D round trip per generation (such a generation cannot be captured into a graph).  It is the caller's
+    function that runs on the host here, never this package's restatement of anything."""
 
-    The factory objectives (stochopy_amd.factory, tagged with ``sx_id``) run fused in the generation kernels.
-    ``factory.batched(fun)`` (device tensor in, device tensor out) runs between a propose and a select kernel.
-    Untagged callables are refused: this package never evaluates an objective on the host.
+    capturable = False
+    _warned = False
+
+    def __init__(self, fun, args):
+        self.fun = fun
+        self.args = tuple(args) if args not in ((), None) else ()
+        self.name = getattr(fun, "__name__", "objective")
+
+    def __call__(self, ctx, X):
+        t = __import__("torch")
+        if not HostExternal._warned:
+            HostExternal._warned = True
+            warnings.warn(
+                f"stochopy_amd: {self.name} is a plain Python callable -- it is evaluated on the host, one call per "
+                "individual, with a device-host round trip per generation.  Use stochopy_amd.factory objectives "
+                "(fused kernels) or factory.batched (device tensor in/out) for speed.", RuntimeWarning, stacklevel=3)
+        ctx.sync()
+        x = X.cpu().numpy()
+        f = np.array([self.fun(xx, *self.args) for xx in x], dtype=np.float64)  # reference _common.py:79-80
+        if f.shape != (x.shape[0],):
+            raise ValueError(f"objective {self.name}: expected one scalar per individual, got shape {f.shape}")
+        return t.from_numpy(np.ascontiguousarray(f)).to(X.device)
+
+
+def resolve_objective(fun, args):
+    """Map the user's callable to a device kernel id, or to an External for caller-supplied objectives -- the
+    three cases of the backend hook contract (reference _common.py:27-106):
+
+    (i)   the factory objectives (stochopy_amd.factory, tagged with ``sx_id``) run fused in the generation kernels;
+    (ii)  ``factory.batched(fun)`` (device tensor in, device tensor out) runs between a propose and a select kernel;
+    (iii) any other callable is the reference's ``fun(x, *args)`` on ONE individual: it runs on the host, per row
+          (HostExternal), with a one-time warning naming the cost.
     """
     from ..factory.benchmark import batched
 
@@ -73,10 +109,30 @@ def resolve_objective(fun, args):
         return fun.sx_id
     if isinstance(fun, batched):
         return External(fun, args)
-    raise TypeError(
-        "backend='hip' needs a device objective from stochopy_amd.factory "
-        "(ackley, griewank, quartic, rastrigin, rosenbrock, sphere, styblinski_tang) or a callable that works on "
-        f"the device population, tagged with stochopy_amd.factory.batched; got {fun!r}.  There is no host fallback.")
+    return HostExternal(fun, args)
+
+
+def resolve_updating(updating, strict_updating, workers, fun):
+    """Is the run an ordered sweep (the reference's default ``updating="immediate"``: de_async / pso_async)?
+
+    The reference runs it whenever no parallel backend is chosen (de/_de.py:142-145).  Here the sweep is one
+    kernel per generation on ONE GPU with the objective inside it, so it needs ``workers == 1`` and a factory
+    objective.  ``strict_updating``: None (default) honours "immediate" when that is possible and otherwise
+    switches to "deferred" WITH a warning; True insists (an impossible combination raises); False always defers,
+    silently -- the throughput choice, like picking a parallel backend in the reference."""
+    if updating != "immediate":
+        return False
+    import os
+
+    # (SX_FORCE_SHARDED=1: the test switch that runs a 1-rank process group through the sharded path)
+    possible = workers == 1 and isinstance(fun, int) and os.environ.get("SX_FORCE_SHARDED") != "1"
+    if strict_updating is None:
+        if not possible:
+            warnings.warn('stochopy_amd: updating="immediate" is an ordered sweep on one GPU with a fused factory '
+                          'objective; this run (workers > 1 or a caller-supplied objective) uses "deferred" updating, '
+                          "as a parallel backend of the reference does (de/_de.py:142-145).", RuntimeWarning, stacklevel=3)
+        return possible
+    return bool(strict_updating) and workers == 1
 
 
 def evaluate_rows(ctx, fun, X, n, f, xm=None, xstd=None, clip=False):

@@ -42,15 +42,17 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
-    strict_updating=False,
+    strict_updating=None,
 ):
     """Minimize an objective function using Competitive PSO on MI355X.
 
     Parameters are those of the reference (cpso/_cpso.py:12-33) plus ``rng``
     ("numpy-legacy" default = the reference's stream, or "philox" = in-kernel draws);
-    ``backend`` must be ``"hip"`` and forces synchronous updating (cpso/_cpso.py:147-150) -- unless
-    ``strict_updating=True`` asks for the reference's serial semantics: ``updating="immediate"`` then runs
-    pso_async (cpso/_cpso.py:364-402), one sequential sweep per generation on one GPU (``workers=1``).
+    ``backend`` must be ``"hip"``.  ``updating="immediate"`` (the reference's default) runs pso_async
+    (cpso/_cpso.py:364-402) as one ordered sweep per generation on one GPU whenever that is possible
+    (``workers=1``, a factory objective; same seed, same result as the reference's default call); otherwise the
+    run is deferred like with a parallel backend of the reference (cpso/_cpso.py:147-150), with a warning.
+    ``updating="deferred"`` is the throughput mode; ``strict_updating=False`` forces it silently.
     """
     fun_id = _common.resolve_objective(fun, args)
     lower, upper = _common.as_bounds(bounds)
@@ -81,7 +83,7 @@ def minimize(
     run = _PsoRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(inertia), float(cognitivity),
                   float(sociability), competitivity, constraints, float(xtol), float(ftol), bool(return_all),
                   float(verbosity), callback, rng, seed, workers,
-                  immediate=bool(strict_updating) and updating == "immediate" and workers == 1)
+                  immediate=_common.resolve_updating(updating, strict_updating, workers, fun_id))
     return run.result()
 
 
@@ -140,6 +142,12 @@ class _PsoRun:
             with t.cuda.stream(self.ctx.stream):
                 try:
                     self._run()
+                    if self.px is not None:
+                        # Peers may still be reading this rank's exchange / population memory (their last kernels,
+                        # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
+                        # stream.  On the success path only -- a rank that raised must not wait for the others.
+                        self.ctx.sync()
+                        self.world.barrier()
                 finally:
                     self.close()
 
@@ -459,7 +467,8 @@ class _PsoRun:
             return True
         if (self._rccl_graph_note is not None or (self.world is not None and self.world.backend != "nccl")
                 or os.environ.get("SX_RCCL_GRAPH") == "0"
-                or (self.external is not None and os.environ.get("SX_EXT_GRAPH") == "0")):
+                or (self.external is not None and (os.environ.get("SX_EXT_GRAPH") == "0"
+                                                   or not getattr(self.external, "capturable", True)))):
             return False
         t = _device.torch()
         try:

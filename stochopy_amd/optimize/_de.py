@@ -43,7 +43,7 @@ def minimize(
     rng=None,
     exchange=None,
     donors=None,
-    strict_updating=False,
+    strict_updating=None,
 ):
     """Minimize an objective function using Differential Evolution on MI355X.
 
@@ -51,11 +51,12 @@ def minimize(
     ``"hip"`` (default), ``workers`` is the number of GPUs, and ``rng`` selects the
     random-draw source: ``"numpy-legacy"`` (default; the reference's stream, so the
     same seed gives the reference's result) or ``"philox"`` (in-kernel counter-based
-    draws, the throughput mode).  As in the reference, choosing a parallel backend
-    forces ``updating="deferred"`` (de/_de.py:142-145) -- unless ``strict_updating=True`` asks for the
-    reference's *serial* semantics: ``updating="immediate"`` then runs de_async (de/_de.py:354-391) as one
-    sequential sweep per generation on one GPU (``workers=1``; with more workers the reference's own rule
-    applies and the run is deferred).  ``exchange`` (``workers > 1`` only) picks how the
+    draws, the throughput mode).  ``updating="immediate"`` (the reference's default) runs de_async
+    (de/_de.py:354-391) as one ordered sweep per generation on one GPU -- same seed, same result as the
+    reference's default call -- whenever that is possible (``workers=1``, a factory objective); otherwise the run
+    is deferred, as with a parallel backend of the reference (de/_de.py:142-145), and says so in a warning.
+    ``updating="deferred"`` is the throughput mode (whole generations in parallel); ``strict_updating=False``
+    forces it silently, ``True`` insists on the sweep.  ``exchange`` (``workers > 1`` only) picks how the
     per-generation global best travels between GPUs: ``"p2p"`` (the generation kernel writes its shard's
     record straight into the peers' HBM over xGMI), ``"rccl"`` (one all-gather per generation) or ``None`` /
     ``"auto"`` (p2p if its self-test passes on every rank, else rccl); both give identical results.
@@ -95,7 +96,7 @@ def minimize(
     run = _DeRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(mutation), float(recombination),
                  strategy, constraints, float(xtol), float(ftol), bool(return_all), float(verbosity), callback, rng,
                  seed, workers, exchange=exchange, donors=donors,
-                 immediate=bool(strict_updating) and updating == "immediate" and workers == 1)
+                 immediate=_common.resolve_updating(updating, strict_updating, workers, fun_id))
     return run.result()
 
 
@@ -129,11 +130,17 @@ class _DeRun:
         if immediate and self.external is not None:
             raise ValueError("immediate updating evaluates individuals one by one inside the sweep kernel: "
                              "only the factory objectives can do that")
-            if self.P - 1 < self.k:
-                raise ValueError("shard too small for the strategy")
         if donors not in (None, "shard", "global"):
             raise ValueError('donors must be "shard" or "global"')
         self.global_donors = donors == "global" and self.world is not None
+        if self.world is not None:
+            if self.P < 2:
+                raise ValueError(f"popsize {self.Ptotal} over {self.world.size} ranks leaves {self.P} row(s) per GPU: "
+                                 "a shard needs at least 2")
+            if (self.Ptotal if self.global_donors else self.P) - 1 < self.k:
+                raise ValueError(f"strategy {strategy} draws {self.k} donors: too few rows "
+                                 f"({'population' if self.global_donors else 'shard'} of "
+                                 f"{self.Ptotal if self.global_donors else self.P})")
         self.x0 = x0
         # single GPU + in-kernel draws + nothing to report per generation: one kernel per generation
         # ("chained finalize", include/stochopy_hip.h sx_de_chain_launch)
@@ -179,6 +186,12 @@ class _DeRun:
             with t.cuda.stream(self.ctx.stream):
                 try:
                     self._run()
+                    if self.px is not None:
+                        # Peers may still be reading this rank's exchange / population memory (their last kernels,
+                        # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
+                        # stream.  On the success path only -- a rank that raised must not wait for the others.
+                        self.ctx.sync()
+                        self.world.barrier()
                 finally:
                     self.close()
 
@@ -550,7 +563,7 @@ class _DeRun:
         that cannot be captured, e.g. one that synchronises): the caller then launches eagerly."""
         if parity in self._ext_graphs:
             return True
-        if (self._ext_graph_note is not None or self.rng != "philox"
+        if (self._ext_graph_note is not None or self.rng != "philox" or not getattr(self.external, "capturable", True)
                 or (self.world is not None and self.world.backend != "nccl") or os.environ.get("SX_EXT_GRAPH") == "0"):
             return False
         t = _device.torch()

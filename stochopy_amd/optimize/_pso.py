@@ -30,7 +30,7 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
-    strict_updating=False,
+    strict_updating=None,
 ):
     """Minimize an objective function using PSO on MI355X (reference pso/_pso.py:9-29)."""
     return _cpso.minimize(fun, bounds, x0, args, maxiter, popsize, inertia, cognitivity, sociability, None, seed,

@@ -163,6 +163,9 @@ class PeerExchange:
         a.error = t.data_ptr()
         px.relay = ctx.zeros((int(L.sx_xchg_relay_bytes(n)) // 8,))  # ordinary HBM (zero = no tag yet)
         a.relay = px.relay.data_ptr()
+        # the two memsets above ran on torch's CURRENT stream; the probe and the generation kernels use the engine
+        # stream, which is not ordered against it: a late memset must not clear a relay tag or the error word
+        _device_torch().cuda.current_stream(ctx.device).synchronize()
         if not world.all_agree(ok):
             px.close()
             return None, why or "a peer could not map this rank's exchange buffer"
@@ -258,6 +261,12 @@ class PeerExchange:
             L.sx_xchg_free(self.pop_own)
             self.pop_own = None
         self.args = None
+
+
+def _device_torch():
+    import torch
+
+    return torch
 
 
 def _torch_int32():

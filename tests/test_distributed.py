@@ -35,10 +35,12 @@ def _spawn(fn, world, cfg):
             mp.spawn(fn, args=(world, _free_port(), cfg, out), nprocs=world, join=True)
             return out
         except Exception as e:  # noqa: BLE001  rendezvous trouble (port taken meanwhile, store socket reset): again
+            # Only genuine rendezvous errors are retried.  A worker that dies on a signal (SIGSEGV / SIGABRT / SIGBUS)
+            # FAILS the test: that is what a memory fault in the peer exchange, a graph teardown or an RCCL capture
+            # would look like.
             rendezvous = any(w in str(e) for w in ("EADDRINUSE", "DistNetworkError", "TCPStore", "Connection reset",
-                                                   "Broken pipe", "failed to listen", "failed to connect",
-                                                   "terminated with signal"))  # (a persistent fault still fails 3x)
-            if not rendezvous or attempt == 2:
+                                                   "Broken pipe", "failed to listen", "failed to connect"))
+            if "terminated with signal" in str(e) or not rendezvous or attempt == 2:
                 raise
 
 
@@ -323,8 +325,13 @@ def test_sharded_cmaes_matches_single_gpu(rng):
     n = 20
     opts = {"maxiter": 40, "popsize": 48, "seed": 11, "rng": rng}
     cfg = {"n": n, "objective": "rosenbrock", "method": "cmaes", "options": opts, "rng": rng}
+    # the sharded run is driven by the host loop; with a callback so is the single-GPU run (bit-identical), without
+    # one the Philox run stays on the device (csrc/sx_cma_loop.hip: other summation orders, same run to rounding)
     one = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="cmaes",
-                               options=dict(opts, backend="hip"))
+                               options=dict(opts, backend="hip"), callback=lambda X, r: None)
+    resident = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="cmaes",
+                                    options=dict(opts, backend="hip"))
+    assert (resident.nit, resident.status) == (one.nit, one.status) and np.isclose(resident.fun, one.fun, rtol=1e-6)
     out = _spawn(gpu_minimize_worker, 2, cfg)
     for r in range(2):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))

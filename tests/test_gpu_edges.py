@@ -161,7 +161,8 @@ def test_c5_full_population_properties(sa):
     (verbosity 0: the best candidate of each generation) never beats the running best."""
     n, P, gens = 1024, 131072, 6
     b = [[-5.12, 5.12]] * n
-    opts = {"maxiter": gens, "popsize": P, "seed": 17, "ftol": -1.0, "xtol": 0.0, "backend": "hip", "rng": "philox"}
+    opts = {"maxiter": gens, "popsize": P, "seed": 17, "ftol": -1.0, "xtol": 0.0, "backend": "hip", "rng": "philox",
+            "updating": "deferred"}
     a1 = sa.optimize.minimize(sa.factory.rosenbrock, b, method="de", options=dict(opts))
     trace = []
     a2 = sa.optimize.minimize(sa.factory.rosenbrock, b, method="de", options=dict(opts, return_all=True, verbosity=0.0),

@@ -98,16 +98,30 @@ def test_immediate_philox_vs_oracle(sa, method, objective, n, opts):
     assert np.array_equal(res.xall, ref["xall"]) and np.array_equal(res.funall, ref["funall"])
 
 
-def test_immediate_needs_the_opt_in(sa):
-    """backend="hip" is a parallel backend: like the reference's (de/_de.py:142-145) it forces deferred updating
-    unless strict_updating asks for the serial semantics."""
+def test_immediate_is_honoured_by_default(sa):
+    """The reference runs de_async for a default call (updating="immediate", no parallel backend; de/_de.py:142-145).
+    So does this backend when it can (one GPU, factory objective): same seed, the reference's result.
+    strict_updating=False is the explicit throughput choice (deferred, silently); a run that cannot be an ordered
+    sweep (caller-supplied objective) is deferred WITH a warning."""
+    import warnings
+
     bounds = [[-5.12, 5.12]] * 2
     o = {"popsize": 8, "maxiter": 30, "seed": 42, "backend": "hip"}
-    a = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o, updating="immediate"))
+    a = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o))  # default: immediate
     b = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o, updating="deferred"))
     c = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de",
                              options=dict(o, updating="immediate", strict_updating=True))
-    assert np.array_equal(a.x, b.x) and not np.array_equal(a.x, c.x)
+    d = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o, strict_updating=False))
+    assert np.array_equal(a.x, c.x) and np.array_equal(d.x, b.x) and not np.array_equal(a.x, b.x)
+    ref = oracle.minimize("rosenbrock", bounds, method="de",
+                          options={"popsize": 8, "maxiter": 30, "seed": 42, "updating": "immediate"})  # the reference's default
+    assert np.array_equal(a.x, ref.x) and a.fun == ref.fun and a.nit == ref.nit
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        e = sa.optimize.minimize(sa.factory.batched(lambda X: (X * X).sum(dim=1)), bounds, method="de", options=dict(o))
+    assert any("deferred" in str(w.message) for w in seen)
+    f = sa.optimize.minimize(sa.factory.sphere, bounds, method="de", options=dict(o, updating="deferred"))
+    assert np.allclose(e.x, f.x) and np.isclose(e.fun, f.fun)
 
 
 def test_immediate_pso_updates_x0_in_place(sa):

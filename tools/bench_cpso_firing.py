@@ -5,7 +5,7 @@ import torch
 import stochopy_amd as sa
 
 b = [[-5.12, 5.12]] * 256
-o = {"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0}
+o = {"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "updating": "deferred"}
 
 
 def wall(m):

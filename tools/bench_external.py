@@ -27,7 +27,7 @@ def wall(fn):
 
 
 for method, name, n, P in (("de", "rosenbrock", 128, 4096), ("pso", "ackley", 256, 16384), ("de", "rosenbrock", 1024, 16384)):
-    o = {"popsize": P, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "backend": "hip"}
+    o = {"popsize": P, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "backend": "hip", "updating": "deferred"}
     objs = {"fused": getattr(sa.factory, name), "sx_eval as a batched objective": device_fun(name),
             "torch rosenbrock/sum": sa.factory.batched(
                 lambda X: (100.0 * (X[:, 1:] - X[:, :-1] ** 2) ** 2).sum(1) + ((1.0 - X[:, :-1]) ** 2).sum(1))}

@@ -17,10 +17,10 @@ def timed(label, make, short, long):
 
 b256 = [[-5.12, 5.12]] * 256
 for method in ("pso", "cpso"):
-    o = {"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0}
+    o = {"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "updating": "deferred"}
     timed(f"C3 {method} ackley n256 P16384", lambda m, method=method: sa.optimize.minimize(sa.factory.ackley, b256, method=method, options=dict(o, maxiter=m)), 100, 1100)
 b512 = [[-5.12, 5.12]] * 512
-o = {"popsize": 1024, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0}
+o = {"popsize": 1024, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "updating": "deferred"}
 timed("C4 cmaes rosenbrock n512 P1024", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m)), 4, 14)
 o = {"popsize": 1024, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "eigh": "device"}
 timed("C4 cmaes rosenbrock n512 P1024 eigh=device", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m)), 4, 14)

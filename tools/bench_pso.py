@@ -21,7 +21,7 @@ cases = sys.argv[1:] or ["ackley:256:16384", "sphere:256:16384", "rosenbrock:256
 for c in cases:
     name, n, P = c.split(":")
     n, P = int(n), int(P)
-    o = {"popsize": P, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0}
+    o = {"popsize": P, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "updating": "deferred"}
     per = per_gen(lambda m: sa.optimize.minimize(getattr(sa.factory, name), [[-5.12, 5.12]] * n, method="pso",
                                                  options=dict(o, maxiter=m)))
     byts = (48 * n + 24) * P

@@ -38,7 +38,7 @@ for c in range(cases):
     if RNG != "philox":
         P, gens = min(P, 420), min(gens, 15)
     objective = str(rs.choice(["sphere", "rosenbrock"])) if n > 1 else "sphere"
-    o = {"popsize": P, "maxiter": gens, "seed": int(rs.randint(1 << 30))}
+    o = {"popsize": P, "maxiter": gens, "seed": int(rs.randint(1 << 30)), "updating": "deferred"}
     if rs.rand() < 0.3:
         o.update(ftol=float(10 ** rs.uniform(-2, 3)), xtol=float(10 ** rs.uniform(-3, 1)))
     else:

@@ -23,7 +23,7 @@ def main():
         gens = int(rs.randint(3, 60))
         exchange = str(rs.choice(["p2p", "rccl"]))
         objective = str(rs.choice(["sphere", "rosenbrock"]))
-        o = {"maxiter": gens, "popsize": P, "seed": int(rs.randint(1 << 30))}
+        o = {"maxiter": gens, "popsize": P, "seed": int(rs.randint(1 << 30)), "updating": "deferred"}
         if rs.rand() < 0.3:
             o.update(ftol=float(10 ** rs.uniform(-2, 3)), xtol=float(10 ** rs.uniform(-3, 1)))
         else:

@@ -25,7 +25,7 @@ def restart(self):
 _cpso._PsoRun._restart_device = restart
 os.environ["SX_NO_GRAPH"] = "1"
 r = sa.optimize.minimize(sa.factory.ackley, [[-5.12, 5.12]] * 256, method="cpso",
-                         options={"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "maxiter": 30, "return_all": True, "verbosity": 0.0})
+                         options={"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "maxiter": 30, "return_all": True, "verbosity": 0.0, "updating": "deferred"})
 for s in stamps[5:12]:
     d = np.diff(s)
     print("ticks(10ns) between stamps 0..7:", d.tolist())

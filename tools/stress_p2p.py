@@ -25,7 +25,7 @@ def main():
         ("pso_p2p", "pso", {}, {"SX_EXCHANGE": "p2p"}),
         ("pso_rccl", "pso", {}, {"SX_EXCHANGE": "rccl"}),
     ):
-        o = {"maxiter": gens, "popsize": P, "seed": 123, "ftol": -1.0, "xtol": 0.0}
+        o = {"maxiter": gens, "popsize": P, "seed": 123, "ftol": -1.0, "xtol": 0.0, "updating": "deferred"}
         o.update(opts)
         cfg = {"n": n, "objective": "rastrigin", "method": method, "options": o, "env": env}
         out = tempfile.mkdtemp(prefix="sx_stress_")
@@ -41,7 +41,7 @@ def main():
 
     one = sa.optimize.minimize(sa.factory.rastrigin, [[-5.12, 5.12]] * n, method="de",
                                options={"maxiter": gens, "popsize": P, "seed": 123, "ftol": -1.0, "xtol": 0.0,
-                                        "rng": "philox"})
+                                        "rng": "philox", "updating": "deferred"})
     assert one.fun == results["de_global"][0][0] and np.array_equal(one.x, results["de_global"][1])
     print("stress ok: transports agree over %d generations; global donors == single GPU" % gens)
 
