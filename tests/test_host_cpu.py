@@ -279,8 +279,14 @@ def test_api_surface_and_validation():
     f, b = sa.factory.rosenbrock, [[-5.12, 5.12]] * 2
     with pytest.raises(TypeError):
         sa.optimize.minimize(42, b)
-    with pytest.raises(TypeError):  # arbitrary Python callables are refused, never evaluated on the host
-        sa.optimize.minimize(lambda x: float(np.sum(x)), b, options={"backend": "hip"})
+    # any other Python callable is the reference's fun(x, *args) (SURVEY.md 8b iii): accepted, evaluated per row on
+    # the host between the device kernels -- which still needs the GPU (here: the loud no-device error, not a refusal)
+    from stochopy_amd._device import NoDeviceError
+    from stochopy_amd.optimize import _common
+
+    assert isinstance(_common.resolve_objective(lambda x: float(np.sum(x)), ()), _common.HostExternal)
+    with pytest.raises(NoDeviceError):
+        sa.optimize.minimize(lambda x: float(np.sum(x)), b, options={"backend": "hip", "updating": "deferred"})
     with pytest.raises(ValueError):
         sa.optimize.minimize(f, [-1, 1])
     with pytest.raises(ValueError):
