@@ -10,8 +10,13 @@ popsize=4096, F=0.5, CR=0.9, bounds +-5.12, in-kernel Philox draws, ftol=-1 /
 xtol=0 so every step does the full work.  N>1: the same shard per GPU (weak
 scaling), one process per GPU, global best exchanged every generation.
 
-`value` = objective evaluations per second = N * popsize * K / t(K steps),
-population resident in HBM before the timed region.
+`value` = objective evaluations per second = N * popsize * (steps timed) / t, population resident in HBM
+before the timed region.  The K-step block is repeated back to back until the timed region lasts >= 50 ms
+(`blocks`; K steps alone take 0.2 ms at the default shape), bracketed by barrier + synchronize; the median block
+duration (HIP events between blocks) is reported next to it.  Also in the line:
+`minimize_wall` -- evals/s of a whole `minimize()` call after one warm-up call (host-side initial population
+included); `cpu_baseline` / `cpu_baseline_loky` with core count and CPU model; for N > 1 `c5` -- BASELINE config 5
+(DE n=1024, P=131072 in total = strong scaling) through both donor modes, with the number of ranks seen.
 """
 import argparse
 import json
@@ -38,6 +43,16 @@ WORKLOADS = {
     "de_rosenbrock_n2048_p16384": ("rosenbrock", 2048, 16384, "best1bin"),
     "de_rand1bin_n1024_p16384": ("rosenbrock", 1024, 16384, "rand1bin"),
 }
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def algorithmic_bytes_per_eval(n, k):
@@ -72,9 +87,32 @@ def cpu_baseline(objective, n, P, strategy, budget_s=12.0):
         "kind": "port",
         "sample": f"oracle DE {strategy} {objective} n={n} P={P}, {done} generations in {dt:.1f}s, serial numpy "
                   f"(numpy-legacy stream incl. the reference's O(P^2) donor permutations), "
-                  f"host cpu_count={os.cpu_count()}",
+                  f"host cpu_count={os.cpu_count()}, cpu model {cpu_model()}",
+        "cpu_model": cpu_model(),
         "t_first_eval_s": gens[0] - t0,
     }
+
+
+def minimize_wall(objective, n, P, strategy, maxiter=1000):
+    """evals/s = nit * popsize / wall around the WHOLE minimize() call (host-side Latin
+    hypercube, uploads, result download included) after one warm-up call; ftol=-1, xtol=0 so the run lasts maxiter."""
+    import torch
+
+    import stochopy_amd as sa
+
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 0, "strategy": strategy, "ftol": -1.0, "xtol": 0.0,
+            "updating": "deferred", "rng": "philox", "backend": "hip"}
+    fun = getattr(sa.factory, objective)
+    bounds = [[-5.12, 5.12]] * n
+    sa.optimize.minimize(fun, bounds, method="de", options=dict(opts, maxiter=50))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = sa.optimize.minimize(fun, bounds, method="de", options=opts)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"value": res.nit * P / wall, "unit": "evals/s", "wall_s": wall, "nit": int(res.nit), "nfev": int(res.nfev),
+            "note": "wall clock around stochopy_amd.optimize.minimize(method='de', updating='deferred', rng='philox') "
+                    "after one warm-up call; includes the host-side initial population (numpy-legacy LHS) and result copy"}
 
 
 def _one_row(objective, x):
@@ -91,11 +129,15 @@ def cpu_baseline_loky(objective, n, P, strategy, budget_s=6.0):
     import oracle
     from joblib import Parallel, delayed
 
-    cores = min(os.cpu_count() or 1, 32)  # (pool start-up grows with the worker count; 32 is past the point of any gain)
+    cores = os.cpu_count() or 1  # workers = os.cpu_count(), as SURVEY.md section 8d asks (pool warm before timing)
     stamps = []
     with Parallel(n_jobs=cores, backend="loky") as pool:
         def fobj(X):
             return np.array(pool(delayed(_one_row)(objective, x) for x in X))
+
+        t_pool = time.perf_counter()
+        pool(delayed(_one_row)(objective, np.zeros(n)) for _ in range(4 * cores))  # start every worker
+        t_pool = time.perf_counter() - t_pool
 
         def cb(X, r):
             stamps.append(time.perf_counter())
@@ -109,9 +151,10 @@ def cpu_baseline_loky(objective, n, P, strategy, budget_s=6.0):
         except StopIteration:
             pass
     done, dt = len(stamps) - 1, stamps[-1] - stamps[0]
-    return {"value": P * done / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+    return {"value": P * done / dt, "unit": "evals/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"oracle DE {strategy} {objective} n={n} P={P}, {done} generations in {dt:.1f}s, one joblib-loky task "
-                      f"per individual on {cores} workers (the reference's parallel backend scheme), host cpu_count={os.cpu_count()}"}
+                      f"per individual on {cores} workers = os.cpu_count() (the reference's parallel backend scheme; "
+                      f"pool started and warmed in {t_pool:.1f}s before timing), cpu model {cpu_model()}"}
 
 
 def main():
@@ -121,6 +164,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="de_rosenbrock_n128_p4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-minimize-wall", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU work spent on the baseline sample")
     ap.add_argument("--kernel-timing-launches", type=int, default=400)
     args = ap.parse_args()
@@ -137,28 +181,45 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
+    # (test switches, one-GPU boxes only: SX_BENCH_DEVICE pins every rank to one device, SX_BENCH_BACKEND=gloo sets the
+    #  process group up without RCCL, which refuses two ranks on one GPU; the driver uses neither)
+    device_index = int(os.environ.get("SX_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1 or ("RANK" in os.environ and os.environ.get("SX_FORCE_SHARDED") == "1"):
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     objective, n, P, strategy = WORKLOADS[args.workload]
     k = _lib.DE_DONORS[strategy]
     K, W = args.steps, args.warmup
-    lower = np.full(n, -5.12)
-    upper = np.full(n, 5.12)
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(exchange):
-        # weak scaling: every GPU owns P rows of a global population of world*P (same seed on every rank)
-        run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, world * P, 0.5, 0.9, strategy, None,
-                         0.0, -1.0, False, 1.0, None, "philox", 1234, world, autorun=False, exchange=exchange,
-                         donors=os.environ.get("SX_DONORS"))
+    def reduce_max(x, dtype):
+        """MAX over ranks of one host number (on the device for nccl, on the host for gloo)."""
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        tt = torch.tensor([x], dtype=dtype, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tt.item()
+
+    MIN_TIMED_S = 0.05
+
+    def measure(exchange, objective=objective, n=n, Ptotal=None, strategy=strategy, donors=os.environ.get("SX_DONORS"),
+                K=K, W=W, kernel_launches=args.kernel_timing_launches):
+        """One resident run: W warm-up steps, then blocks of K steps until >= 50 ms are timed.  Ptotal None: weak
+        scaling (every GPU owns P rows of a global population of world*P; same seed on every rank)."""
+        lower, upper = np.full(n, -5.12), np.full(n, 5.12)
+        run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, Ptotal or world * P, 0.5, 0.9, strategy,
+                         None, 0.0, -1.0, False, 1.0, None, "philox", 1234, world, autorun=False, exchange=exchange,
+                         donors=donors)
         ctx = run.ctx
         try:
             with torch.cuda.stream(ctx.stream):
@@ -166,18 +227,37 @@ def main():
                 run.prepare_graphs()
                 run.enqueue(W)
                 ctx.sync()
-                barrier()
-                t0 = time.perf_counter()
-                run.enqueue(K)
-                ctx.sync()
-                barrier()
-                t1 = time.perf_counter()
+                # K-step blocks, back to back, until the timed region lasts >= 50 ms (every rank times the same number)
+                blocks, steps_done = 1, 0
+                while True:
+                    evs = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+                    barrier()
+                    t0 = time.perf_counter()
+                    evs[0].record(ctx.stream)
+                    for b in range(blocks):
+                        run.enqueue(K)
+                        evs[b + 1].record(ctx.stream)
+                    ctx.sync()
+                    barrier()
+                    t1 = time.perf_counter()
+                    steps_done += blocks * K
+                    enough = t1 - t0 >= MIN_TIMED_S or blocks >= 8192
+                    if dist is not None:
+                        enough = reduce_max(0 if enough else 1, torch.int64) == 0  # all ranks or none
+                    if enough:
+                        break
+                    grow = int(np.ceil(1.3 * blocks * MIN_TIMED_S / max(t1 - t0, 1e-6)))
+                    blocks = max(2 * blocks, grow)
+                    if dist is not None:
+                        blocks = int(reduce_max(blocks, torch.int64))
+                    blocks = min(blocks, 8192)
                 st = run.read_state()  # raises if a wait inside the peer exchange timed out
-                assert st.it == 1 + W + K, (st.it, W, K)
+                assert st.it == 1 + W + steps_done, (st.it, W, K, blocks, steps_done)
+                block_ms = sorted(evs[b].elapsed_time(evs[b + 1]) for b in range(blocks))
 
                 # dominant kernel: HIP events on the engine stream around a replayed hipGraph of generation
                 # kernels (real generations, nothing else on the stream), average per launch
-                nl = (args.kernel_timing_launches // run.GRAPH_CHUNK) * run.GRAPH_CHUNK
+                nl = max(1, kernel_launches // run.GRAPH_CHUNK) * run.GRAPH_CHUNK
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 run.enqueue(run.GRAPH_CHUNK)
@@ -190,33 +270,59 @@ def main():
             barrier()  # no rank frees its exchange buffer while a peer may still write into it
         finally:
             run.close()
-        return run, t1 - t0, kern_ms, nl, kernels_per_gen
+        dt = t1 - t0
+        if dist is not None:
+            dt = float(reduce_max(dt, torch.float64))
+        return {"run": run, "dt": dt, "steps_timed": blocks * K, "blocks": blocks,
+                "block_ms_median": block_ms[len(block_ms) // 2], "kern_ms": kern_ms, "nl": nl,
+                "kernels_per_gen": kernels_per_gen, "rows_total": Ptotal or world * P}
 
-    try:
-        run, dt, kern_ms, nl, kernels_per_gen = measure(None)
-    except RuntimeError as e:
-        # a peer-exchange wait that timed out mid-run (every rank sees it within one timeout): the transport
-        # passed its self-test but is not usable here -- measure through the RCCL transport instead and say so
-        if dist is None or "peer exchange" not in str(e):
-            raise
-        print(f"[bench] rank {rank}: {e}; falling back to exchange='rccl'", file=sys.stderr, flush=True)
-        run, dt, kern_ms, nl, kernels_per_gen = measure("rccl")
-        run.exchange_note = f"p2p failed mid-run ({e})"
+    def measure_with_fallback(**kw):
+        try:
+            return measure(None, **kw)
+        except RuntimeError as e:
+            # a peer-exchange wait that timed out mid-run (every rank sees it within one timeout): the transport
+            # passed its self-test but is not usable here -- measure through the RCCL transport instead and say so
+            if dist is None or "peer exchange timed out" not in str(e) or kw.get("donors") == "global":
+                raise
+            print(f"[bench] rank {rank}: {e}; falling back to exchange='rccl'", file=sys.stderr, flush=True)
+            m = measure("rccl", **kw)
+            m["run"].exchange_note = f"p2p failed mid-run ({e})"
+            return m
 
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    value = world * P * K / dt
+    m = measure_with_fallback()
+    run, dt, kern_ms, nl, kernels_per_gen = m["run"], m["dt"], m["kern_ms"], m["nl"], m["kernels_per_gen"]
+    value = m["rows_total"] * m["steps_timed"] / dt
+
+    # BASELINE config 5 with N > 1: DE n=1024, P=131072 IN TOTAL (strong scaling), both donor modes
+    c5 = None
+    if world > 1:
+        c5 = {"workload": "de_rosenbrock_n1024_p131072 (total), best1bin", "n_ranks_seen": dist.get_world_size(),
+              "rows_per_gpu": 131072 // world, "scaling": "strong"}
+        for mode in ("shard", "global"):
+            try:
+                r = measure_with_fallback(objective="rosenbrock", n=1024, Ptotal=131072, strategy="best1bin", donors=mode,
+                                          K=20, W=10, kernel_launches=50)
+                c5["donors_" + mode] = {
+                    "value": 131072 * r["steps_timed"] / r["dt"], "unit": "evals/s",
+                    "ms_per_step": r["dt"] / r["steps_timed"] * 1e3, "steps_timed": r["steps_timed"],
+                    "exchange": r["run"].exchange, "exchange_note": getattr(r["run"], "exchange_note", None),
+                    "semantics": ("island model with a shared global best (documented deviation)" if mode == "shard" else
+                                  "the unsharded run: donor rows read from their owners' HBM over xGMI")}
+            except Exception as e:  # noqa: BLE001  (e.g. no peer mapping for global donors): say so, keep the line
+                c5["donors_" + mode] = {"error": str(e)[:300]}
 
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_eval(n, k) * P
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            try:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc.sh), with the
+                rec = json.load(open(pmc))  # commit they were measured at: not measured inside this run
+                traffic = rec.get(args.workload, {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc passes (tools/pmc.sh) at commit %s" % rec.get(
+                    "_commit", "unrecorded")
             except Exception:
                 traffic = None
         line = {
@@ -226,7 +332,11 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": dt / K * 1e3,
+            "ms_per_step": dt / m["steps_timed"] * 1e3,
+            "timed": {"blocks": m["blocks"], "steps_timed": m["steps_timed"], "seconds": dt,
+                      "block_ms_median": m["block_ms_median"],
+                      "note": "the K-step block repeated back to back until >= 50 ms are timed (one barrier + "
+                              "synchronize pair around the region); block_ms_median from HIP events between blocks"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -252,11 +362,16 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_us": kern_ms * 1e3,
                 "timing": "HIP events on the engine stream around %d generations (%d kernel(s) each)" % (nl, kernels_per_gen),
             },
         }
+        if c5 is not None:
+            line["c5"] = c5
+        if world == 1 and not args.no_minimize_wall:
+            line["minimize_wall"] = minimize_wall(objective, n, P, strategy)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(objective, n, min(P, 4096), strategy, args.cpu_baseline_seconds)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

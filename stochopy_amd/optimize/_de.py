@@ -234,25 +234,29 @@ class _DeRun:
             _lib.check(ctx.L.sx_de_chain_launch(C.byref(self.args), parity, finalize_only, ctx.stream_ptr),
                        "sx_de_chain_launch")
 
-    def _chain_graph(self, par):
-        if par not in self._chain_graphs:
+    TAIL_CHUNK = 10  # a second, short graph: runs of fewer than GRAPH_CHUNK generations are replayed too (even: parity)
+
+    def _chain_graph(self, par, size=None):
+        size = size or self.GRAPH_CHUNK
+        key = (par, size)
+        if key not in self._chain_graphs:
             g = C.c_void_p()
             if self.px is not None:
                 _lib.check(self.ctx.L.sx_de_p2p_graph_create(C.byref(self.args), C.byref(self.px.args),
-                                                             self.GRAPH_CHUNK, par, C.byref(g)),
-                           "sx_de_p2p_graph_create")
+                                                             size, par, C.byref(g)), "sx_de_p2p_graph_create")
             else:
-                _lib.check(self.ctx.L.sx_de_chain_graph_create(C.byref(self.args), self.GRAPH_CHUNK, par,
-                                                               C.byref(g)), "sx_de_chain_graph_create")
-            self._chain_graphs[par] = g
-        return self._chain_graphs[par]
+                _lib.check(self.ctx.L.sx_de_chain_graph_create(C.byref(self.args), size, par, C.byref(g)),
+                           "sx_de_chain_graph_create")
+            self._chain_graphs[key] = g
+        return self._chain_graphs[key]
 
     def prepare_graphs(self):
         """Instantiate the hipGraph(s) up front (otherwise the first full chunk pays for it)."""
         if self.world is not None and not self.chain:
             return
         if self.chain:
-            self._chain_graph(0)  # GRAPH_CHUNK is even: replays always start at parity 0 unless eager launches intervene
+            self._chain_graph(0)  # chunk sizes are even: replays always start at parity 0 unless eager launches intervene
+            self._chain_graph(0, self.TAIL_CHUNK)
         elif self.rng == "philox" and self._graph is None:
             g = C.c_void_p()
             _lib.check(self.ctx.L.sx_de_graph_create(C.byref(self.args), self.GRAPH_CHUNK, C.byref(g)),
@@ -261,11 +265,12 @@ class _DeRun:
 
     def _enqueue_chain(self, ngen):
         ctx = self.ctx
-        while ngen >= self.GRAPH_CHUNK:
-            par = self.launches & 1
-            _lib.check(ctx.L.sx_graph_launch(self._chain_graph(par), ctx.stream_ptr), "sx_graph_launch")
-            self.launches += self.GRAPH_CHUNK
-            ngen -= self.GRAPH_CHUNK
+        for size in (self.GRAPH_CHUNK, self.TAIL_CHUNK):
+            while ngen >= size:
+                par = self.launches & 1
+                _lib.check(ctx.L.sx_graph_launch(self._chain_graph(par, size), ctx.stream_ptr), "sx_graph_launch")
+                self.launches += size
+                ngen -= size
         for _ in range(ngen):
             self._chain_launch(self.launches & 1, 0)
             self.launches += 1

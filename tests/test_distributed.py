@@ -122,6 +122,14 @@ def test_sharded_de_on_gpu_matches_oracle(world, exchange):
 
 
 @pytest.mark.gpu
+def test_c5_full_size_sharded_over_eight_ranks_matches_oracle():
+    """BASELINE config 5 in its sharded form AT SIZE: DE n=1024, P=131072 over 8 ranks (16384 rows each; here the
+    ranks share the one test GPU, so the records travel between kernels: exchange="rccl"), shard-local donors, the
+    initial evaluation + 2 generations == oracle.run_de_sharded bit for bit on every rank (x, f, nit, status)."""
+    _check_sharded_de(8, _de_cfg(1024, 131072, 3, 2026, "rccl"))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [
     dict(n=128, P=64, gens=130, seed=5),                                   # bounds-test-free kernel, graph replays
     dict(n=300, P=36, gens=60, seed=6),                                    # whole wave per row, several leaves
@@ -143,6 +151,10 @@ def test_p2p_exchange_cases(case):
     (2, dict(n=13, P=40, gens=20, seed=3, strategy="rand2bin", constraints="Random")),   # 5 donors, two Philox calls
     (2, dict(n=300, P=48, gens=12, seed=4, strategy="rand1bin")),                         # whole-wave rows
     (4, dict(n=128, P=256, gens=60, seed=5)),                                             # bounds-test-free kernel
+    # BASELINE config 5's row length and rank count; the population is cut to what 8 ranks can keep co-resident on the
+    # ONE test GPU (ranks that share a device must all fit at once: a rank's waiting workgroups may otherwise fill it
+    # before a peer's record-pushing workgroup is resident -- with one GPU per rank that cannot happen)
+    (8, dict(n=1024, P=2048, gens=4, seed=6)),
 ])
 def test_global_donors_reproduce_the_unsharded_run(world, case):
     """donors="global": donor rows are drawn over the whole population and read from their owners' HBM

@@ -29,6 +29,11 @@ def test_bench_line_has_the_contract_fields():
                                                                                           "synthetic")
     assert d["vs_baseline"] is None and d["config"]["workload"] == "de_rosenbrock_n128_p4096"
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    t = d["timed"]
+    assert t["seconds"] >= 0.05 and t["steps_timed"] == t["blocks"] * 150 and t["block_ms_median"] > 0
+    w = d["minimize_wall"]
+    assert w["nit"] == 1000 and w["nfev"] == 1000 * 4096 and 0 < w["value"] <= d["value"] * 1.05
+    assert d["cpu_baseline"]["cpu_model"] and d["cpu_baseline_loky"].get("cores") == os.cpu_count()
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
@@ -44,3 +49,31 @@ def test_bench_other_workload_and_smoke():
     import __graft_entry__
 
     __graft_entry__.smoke()
+
+
+def test_bench_two_ranks_emits_the_c5_strong_scaling_figures():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank) -- here with both
+    ranks on the one test GPU and gloo for the process group: the weak-scaled metric line plus BASELINE config 5
+    (P = 131072 in total) through both donor modes, with the number of ranks the process group saw."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    # SX_EXCHANGE=rccl: two ranks SHARING one GPU must not wait for each other inside kernels at these sizes (a
+    # rank's waiting workgroups can fill the device before the peer's are resident); on a node every rank has its
+    # own GPU and the default exchange applies.  Global donors need the peer mapping: reported as unavailable here.
+    env = dict(os.environ, SX_BENCH_DEVICE="0", SX_BENCH_BACKEND="gloo", SX_EXCHANGE="rccl")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--kernel-timing-launches", "50"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["popsize_total"] == 8192
+    c5 = d["c5"]
+    assert c5["n_ranks_seen"] == 2 and c5["rows_per_gpu"] == 65536 and c5["scaling"] == "strong"
+    assert c5["donors_shard"].get("value", 0) > 0, c5["donors_shard"]
+    assert "donors_global" in c5 and ("value" in c5["donors_global"] or "peer exchange" in c5["donors_global"]["error"])
