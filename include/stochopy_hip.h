@@ -406,7 +406,7 @@ int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, const doubl
  * device (Philox), constraints=None, one GPU.  Everything in sx_cma_args is DEVICE memory unless stated.
  *   gen       1-based generation number (the caller counts; it also keys the Philox normals)
  *   do_eigh   the caller's evaluation of :301 (`nfev - eigeneval > popsize / (c1 + cmu) / ndim / 10`, a function of
- *             gen only)
+ *             gen only): 0 not due, 1 decompose, 2 decompose starting from the previous eigenvectors in B
  * After a stopping rule has fired (state->done) the bookkeeping kernels of later calls do nothing and
  * xbest / state keep the result; besthist must be zero-initialised (the reference's np.zeros(maxiter), :220).
  * ------------------------------------------------------------------------- */
@@ -458,7 +458,10 @@ int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *st
  * (numpy.linalg.eigh = LAPACK dsyevd, the reference's third-party call).
  * C DEVICE (n,n) row-major, only its upper triangle is read (mirrored, as :303 does); w DEVICE (n) eigenvalues
  * ascending; B DEVICE (n,n) row-major, eigenvector k in column k, unit norm, CANONICAL SIGN: the component of
- * largest magnitude (lowest row on ties) is positive.  V0: NULL (reserved: starting basis).  ws: DEVICE scratch of
+ * largest magnitude (lowest row on ties) is positive.  V0: NULL, or DEVICE (n,n) nearly orthonormal starting basis
+ * (e.g. the eigenvectors of the previous, slightly different matrix; may alias B): it is re-orthonormalised (one
+ * Newton-Schulz step) and the iteration starts from V0^T C V0 -- same result to rounding, fewer sweeps; ignored for
+ * n <= 64 (one-workgroup path).  ws: DEVICE scratch of
  * sx_eigh_workspace_bytes(n) bytes; it starts with the run record read by sx_eigh_info.  max_sweeps <= 0: 24;
  * tol <= 0: 1e-14 (a sweep is the last one when the off-diagonal mass it leaves behind, extrapolated from the mass
  * met during the last two sweeps, is <= tol*|C|_F).

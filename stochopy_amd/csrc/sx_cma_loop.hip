@@ -318,7 +318,9 @@ extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eig
         return rc;
     if (do_eigh) {
         if ((rc = sx_symmetrize_upper(a->C, n, stream))) return rc;
-        if ((rc = sx_eigh(a->C, n, nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes, a->eig_sweeps, 0.0, stream)))
+        // do_eigh == 2: start from the previous eigenvectors (B is both the starting basis and the output)
+        if ((rc = sx_eigh(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes,
+                          a->eig_sweeps, 0.0, stream)))
             return rc;
     }
     hipLaunchKernelGGL(cma_stop_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, do_eigh ? 1 : 0);

@@ -330,19 +330,21 @@ __global__ __launch_bounds__(jacobi_threads<M2>()) void eigh_small_kernel(const 
 // ---------------------------------------------------------------------------------------------------
 // n > 64
 // ---------------------------------------------------------------------------------------------------
-// M0 = C (upper triangle mirrored) padded with zeros to npad; V0 = I; both rotation buffers = I;
-// ||C||_F^2 into info->norm2 (info zeroed by the host beforehand)
+// M0 = C (upper triangle mirrored) padded with zeros to npad; V0 = I, or the caller's starting basis padded with
+// the identity; both rotation buffers = I; ||C||_F^2 into info->norm2 (info zeroed by the host beforehand)
 __global__ __launch_bounds__(256) void eigh_prepare_kernel(const double *__restrict__ C, int n, int npad,
-                                                           double *__restrict__ M0, double *__restrict__ V0,
-                                                           double *__restrict__ U, int64_t ucount, EighInfo *info) {
+                                                           const double *__restrict__ Vstart, double *__restrict__ M0,
+                                                           double *__restrict__ V0, double *__restrict__ U,
+                                                           int64_t ucount, EighInfo *info) {
     __shared__ double red[4];
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double v = 0.0;
     if (e < (int64_t)npad * npad) {
         const int i = (int)(e / npad), j = (int)(e % npad);
-        if (i < n && j < n) v = i <= j ? C[(int64_t)i * n + j] : C[(int64_t)j * n + i];
+        const bool in = i < n && j < n;
+        if (in) v = i <= j ? C[(int64_t)i * n + j] : C[(int64_t)j * n + i];
         M0[e] = v;
-        V0[e] = i == j ? 1.0 : 0.0;
+        V0[e] = (in && Vstart) ? Vstart[(int64_t)i * n + j] : (i == j ? 1.0 : 0.0);
     }
     if (e < ucount) {
         const int w = (int)(e % kUU);
@@ -376,6 +378,53 @@ __device__ __forceinline__ v4d mma_atb(const double *A, int lda, int i0, const d
     for (int k0 = 0; k0 < kM2; k0 += 4)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(k0 + lk) * lda + i0 + lr], B[(k0 + lk) * ldb + j0 + lr], acc, 0, 0, 0);
     return acc;
+}
+
+// Out = alpha * op(A) B + diag * I on npad x npad matrices (npad a multiple of 32): the four products of a warm
+// start.  One workgroup per 32x32 tile, four waves = its four 16x16 quadrants, K in chunks of 32 through LDS with
+// the next chunk's global loads in flight during the MFMAs.
+template <bool TA>
+__global__ __launch_bounds__(256) void eigh_gemm_kernel(const double *__restrict__ A, const double *__restrict__ B,
+                                                        double *__restrict__ Out, int npad, double alpha, double diag) {
+    __shared__ double As[kM2 * LDX], Bs[kM2 * LDU];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * kM2, j0 = blockIdx.x * kM2;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int lr = lane & 15, lk = lane >> 4;
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, r = e / kM2, c = e % kM2;
+            // As[i][k]: TA reads A[k0 + r][i0 + c] (r = k, c = i: coalesced along i), else A[i0 + r][k0 + c]
+            ra[u] = TA ? A[(int64_t)(k0 + r) * npad + i0 + c] : A[(int64_t)(i0 + r) * npad + k0 + c];
+            rb[u] = B[(int64_t)(k0 + r) * npad + j0 + c];
+        }
+    };
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    fetch(0);
+    for (int k0 = 0; k0 < npad; k0 += kM2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, r = e / kM2, c = e % kM2;
+            if (TA)
+                As[c * LDX + r] = ra[u];
+            else
+                As[r * LDX + c] = ra[u];
+            Bs[r * LDU + c] = rb[u];
+        }
+        __syncthreads();
+        if (k0 + kM2 < npad) fetch(k0 + kM2);
+#pragma unroll
+        for (int kk = 0; kk < kM2; kk += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(wi + lr) * LDX + kk + lk], Bs[(kk + lk) * LDU + wj + lr], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + lk + 4 * r, gj = j0 + wj + lr;
+        Out[(int64_t)gi * npad + gj] = alpha * acc[r] + (gi == gj ? diag : 0.0);
+    }
 }
 
 struct RoundLds {
@@ -696,7 +745,6 @@ extern "C" int64_t sx_eigh_workspace_bytes(int n) {
 extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
                        int max_sweeps, double tol, void *stream) {
     SX_REQUIRE(C && w && B && ws && n >= 1, "sx_eigh: bad arguments");
-    SX_REQUIRE(V0 == nullptr, "sx_eigh: a starting basis is not supported (pass NULL)");
     const EighWs L = eigh_layout(ws, n);
     SX_REQUIRE(ws_bytes >= L.bytes, "sx_eigh: workspace too small (sx_eigh_workspace_bytes)");
     if (max_sweeps <= 0) max_sweeps = 24;
@@ -715,8 +763,24 @@ extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, doub
         SX_LAUNCH_CHECK();
     } else {
         const int64_t tot = std::max<int64_t>((int64_t)npad * npad, L.ucount);
-        hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, n, npad, L.M[0],
-                           L.V[0], L.U[0], L.ucount, L.info);
+        if (V0 == nullptr) {
+            hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, n, npad,
+                               (const double *)nullptr, L.M[0], L.V[0], L.U[0], L.ucount, L.info);
+        } else {
+            // Warm start from a nearly orthonormal basis (the previous generation's eigenvectors):
+            //   V <- V0 (3 I - V0^T V0) / 2   one Newton-Schulz step: orthonormal to rounding, so that a basis handed
+            //                                 from decomposition to decomposition cannot drift
+            //   M <- V^T (C V)
+            // Four n^3 products on the matrix cores (~1 % of a cold decomposition); the sweeps then start from a
+            // nearly diagonal M and the stopping rule ends them after the few that are needed.
+            const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
+            hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, n, npad, V0,
+                               L.M[1], L.V[1], L.U[0], L.ucount, L.info);                       // M1 = C, V1 = V0
+            hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[1], L.V[1], L.M[0], npad, -0.5, 1.5);
+            hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.V[1], L.M[0], L.V[0], npad, 1.0, 0.0);
+            hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.M[1], L.V[0], L.V[1], npad, 1.0, 0.0);
+            hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[0], L.V[1], L.M[0], npad, 1.0, 0.0);
+        }
         SX_LAUNCH_CHECK();
         const int nb = npad / kBS, np = nb / 2;
         const unsigned grid = (unsigned)(np + np * np + (npad / kM2) * np);

@@ -30,14 +30,18 @@ class Eigh:
         self.w = ctx.empty((self.n,))
         self.B = ctx.empty((self.n, self.n))
 
-    def __call__(self, Cmat, w=None, B=None, max_sweeps=0, tol=0.0):
+    def __call__(self, Cmat, w=None, B=None, max_sweeps=0, tol=0.0, start=None):
+        """``start``: optional (n, n) nearly orthonormal basis to start from (the previous decomposition's B; may be
+        the output buffer itself)."""
         n = self.n
         if tuple(Cmat.shape) != (n, n) or not Cmat.is_contiguous():
             raise ValueError(f"expected a contiguous ({n},{n}) device matrix")
         w = self.w if w is None else w
         B = self.B if B is None else B
         p = _device.ptr
-        _lib.check(self.ctx.L.sx_eigh(p(Cmat), n, None, p(w), p(B), p(self.ws), self.bytes, int(max_sweeps),
+        if start is not None and (tuple(start.shape) != (n, n) or not start.is_contiguous()):
+            raise ValueError(f"start: expected a contiguous ({n},{n}) device matrix")
+        _lib.check(self.ctx.L.sx_eigh(p(Cmat), n, p(start), p(w), p(B), p(self.ws), self.bytes, int(max_sweeps),
                                       float(tol), self.ctx.stream_ptr), "sx_eigh")
         return w, B
 

@@ -149,7 +149,8 @@ class _CmaDeviceRun:
             state = st
             for gen in range(1, maxiter + 1):
                 due = gen * P - eigeneval > eig_every
-                if due:
+                if due:  # 1: first decomposition; 2: start from the previous eigenvectors (C changes by O(c1 + cmu))
+                    due = 2 if eigeneval else 1
                     eigeneval = gen * P
                 _lib.check(L.sx_cmaes_generation(C.byref(a), gen, int(due), ctx.stream_ptr), "sx_cmaes_generation")
                 since += 1
@@ -158,7 +159,7 @@ class _CmaDeviceRun:
                     if state.done:
                         break
                     used, ok, _off = eig.info()
-                    a.eig_sweeps = min(60, used + 3) if ok else 60
+                    a.eig_sweeps = min(60, used + 2) if ok else 60
                     now = time.perf_counter()
                     if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
                         look *= 2
@@ -342,7 +343,7 @@ class _CmaRun:
 
         nfev = 0
         eigeneval = 0
-        eig, eig_sweeps = None, 24  # device eigensolver: launches beyond convergence are no-ops, but not free
+        eig, eig_sweeps, eig_warm = None, 24, False  # device eigensolver: launches beyond convergence are no-ops, but not free
         besthist = np.zeros(self.maxiter)
         ilim = int(10.0 + 30.0 * n / P)
         insigma = sigma
@@ -418,7 +419,9 @@ class _CmaRun:
                 if self.eigh == "device":
                     if eig is None:
                         eig = Eigh(ctx, n)
-                    Dt, _ = eig(d_C, B=d_B, max_sweeps=eig_sweeps)  # ascending eigenvalues, eigenvectors in columns
+                    # ascending eigenvalues, eigenvectors in columns; from the second time on, started from the last ones
+                    Dt, _ = eig(d_C, B=d_B, max_sweeps=eig_sweeps, start=d_B if eig_warm else None)
+                    eig_warm = True
                     t.sqrt(Dt, out=d_D)
                     D = d_D.cpu().numpy()
                     used, ok, _off = eig.info()

@@ -115,6 +115,45 @@ def test_eigh_hard_spectra(ctx, kind, n):
     check(Cm, w, B, sweeps, conv)
 
 
+@pytest.mark.parametrize("n", [65, 128, 200, 512])
+@pytest.mark.parametrize("kind", ["cma", "graded", "repeated"])
+def test_eigh_warm_start(ctx, kind, n):
+    """A starting basis (the previous generation's eigenvectors in the CMA-ES loop) changes the number of sweeps, not
+    the result: the decomposition of a slightly different matrix started from B equals the cold one to rounding;
+    a basis that is only nearly orthonormal is repaired (Newton-Schulz) rather than trusted."""
+    import torch
+
+    from stochopy_amd.linalg import Eigh
+
+    rs = np.random.RandomState(400 + n)
+    C0 = make(kind, n, rs)
+    E = rs.randn(n, n) * 2e-3 * np.abs(C0).max() / np.sqrt(n)
+    C1 = C0 + 0.5 * (E + E.T) if kind != "repeated" else C0 * 1.01
+    eig = Eigh(ctx, n)
+    with torch.cuda.stream(ctx.stream):  # torch ops and the solver's kernels on ONE stream
+        _, B0 = eig(ctx.upload(C0), max_sweeps=40)
+        start = B0.clone()
+        start += 1e-9 * ctx.upload(rs.randn(n, n))  # not quite orthonormal any more
+        d1 = ctx.upload(C1)
+        wc, Bc = eig(d1, max_sweeps=40)
+        wc, Bc = wc.cpu().numpy(), Bc.cpu().numpy()
+        cold = eig.info()
+        ww, Bw = eig(d1, max_sweeps=40, start=start)
+        ww, Bw = ww.cpu().numpy(), Bw.cpu().numpy()
+        warm = eig.info()
+        # the output may alias the starting basis
+        Bio = start.clone()
+        eig(d1, B=Bio, max_sweeps=40, start=Bio)
+        Bio = Bio.cpu().numpy()
+    check(C1, ww, Bw, warm[0], warm[1])
+    assert np.abs(ww - wc).max() <= EIG_RTOL * np.abs(wc).max()
+    assert warm[0] <= cold[0]
+    if kind == "graded":  # a graded spectrum in a random basis costs ~20 sweeps from scratch; the perturbation here is
+        assert warm[0] <= cold[0] - 4  # unstructured (2e-3 |C|, far above the small eigenvalues), so not just 2 or 3
+    assert np.array_equal(Bio, Bw)
+    print(kind, n, "sweeps cold", cold[0], "warm", warm[0])
+
+
 def test_eigh_reads_the_upper_triangle_only(ctx):
     """cmaes/_cmaes.py:303 mirrors the upper triangle before the decomposition; so does the kernel."""
     rs = np.random.RandomState(5)
