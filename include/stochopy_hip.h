@@ -435,6 +435,8 @@ typedef struct sx_cma_args {
     const double *w;            /* (mu) recombination weights                                         */
     double *Y;                  /* (mu,n) scratch of the covariance update                            */
     double *part;               /* (64,n) scratch of the recombination                                */
+    double *step, *isc, *xnew;  /* (n) scratch: xmean - xold, C^(-1/2) step, the new mean             */
+    double *ypart;              /* (8,n) scratch of B^T step                                          */
     double *besthist;           /* (maxiter) zero-initialised                                         */
     const double *xm, *xstd;    /* (n) un-standardisation x * xstd + xm (:167-173)                    */
     double *xbest;              /* (n) result: best candidate of the stopping generation              */
@@ -473,6 +475,39 @@ int64_t sx_eigh_workspace_bytes(int n);
 int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
             double tol, void *stream);
 int sx_eigh_info(const void *ws, int *sweeps, int *converged, double *off_rel, void *stream);
+
+/* VD-CMA: everything of the model update that is O(mu n), on the device.
+ * replaces vdcma/_vdcma.py:289-295 (w . arx[arindex[:mu]]), :317 (w . ary[arindex[:mu]]) and :331-339 with :428-444 (the
+ * weighted moments p, q of the selected steps under D (I + v v^T) D):
+ *   out[0*n ..] = sum_k w_k arx[idx_k]        out[1*n ..] = sum_k w_k ary[idx_k]
+ *   out[2*n ..] = p_mu                        out[3*n ..] = q_mu                 (y_k = ary[idx_k] / dvec, t_k = y_k . vn)
+ * arx, ary DEVICE (P,n); idx DEVICE int64 (mu) best first; w, dvec, vn DEVICE; ws DEVICE scratch of
+ * (mu rounded up to 8) + 4*64*n doubles; out DEVICE (4,n).  The host keeps the O(n) natural-gradient step. */
+int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
+                     const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Neighbourhood Algorithm: the resampling walk (csrc/sx_na.hip)
+ * replaces na/_na.py:265-305 mutation(), everything that is O(popsize * models * ndim):
+ *   sx_na_begin    X[i] = model kidx[i];  d2[i][m] = ((U[:, 1:] - X[i, 1:]) ** 2).sum(axis=1)  (:277-280, numpy's
+ *                  pairwise order) for every stored model m
+ *   sx_na_axis     axis step j of all walks: the pending `d2 += (U[:, jp] - X[i, jp]) ** 2 - (U[:, jp+1] - X[i, jp+1]) ** 2`
+ *                  of the previous free axis jp (-1: none), lim (:288), low / high (:290-294),
+ *                  X[i, j] = low + (high - low) * u[i, j] (:296: np.random.uniform(low, high)); xnew[i] = X[i, j]
+ *   sx_na_commit   fixed axes of the finished samples -> 0 (:283-286) and the samples appended to the model store
+ *   sx_na_uniforms the generation's uniforms from the device generator (Philox, rng="philox")
+ * The scalar recurrence d1 (:298-300: numpy SCALAR `** 2` = libm pow) is evaluated by the caller between two
+ * axis steps and handed in as d1[i].  Models are stored column-major: XT[l * cap + m]; kidx DEVICE int64 (P) store
+ * positions; X DEVICE (P,n) the samples being built; d2 DEVICE (P,cap); u DEVICE (P,n) doubles in [0,1);
+ * ws DEVICE scratch of 2 * P * sx_na_blocks(M) doubles; fixed DEVICE int32 (n), 1 where upper == lower.
+ * ------------------------------------------------------------------------- */
+int sx_na_blocks(int64_t M);
+int sx_na_begin(const double *XT, int64_t cap, int64_t M, int n, const int64_t *kidx, int64_t P, double *X, double *d2,
+                void *stream);
+int sx_na_axis(const double *XT, int64_t cap, int64_t M, int n, int j, int jp, const int64_t *kidx, int64_t P,
+               const double *u, const double *d1, double *X, double *d2, double *ws, double *xnew, void *stream);
+int sx_na_commit(double *X, int64_t P, int n, const int32_t *fixed, double *XT, int64_t cap, int64_t M, void *stream);
+int sx_na_uniforms(double *U, int64_t P, int n, uint32_t gen, uint32_t key0, uint32_t key1, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * numpy-legacy random stream (host): bit-exact MT19937 replica of what the

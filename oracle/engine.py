@@ -420,6 +420,82 @@ class PenalizeState:
         return fit, valid
 
 
+# --------------------------------------------------------------------------- #
+# NA  (na/_na.py:131-262 loop, :265-305 mutation)
+# --------------------------------------------------------------------------- #
+def na_walk(models, k, u_row, free):
+    """One new sample (na/_na.py:275-303): start at model k, then axis by axis draw uniformly inside the Voronoi
+    cell of k restricted to the current axis line.  `u_row[j]` is the [0,1) double behind np.random.uniform(low,
+    high) (:298).  The cell-distance bookkeeping `d1` is SCALAR arithmetic in the reference: numpy scalars `** 2`,
+    i.e. libm pow (not always the correctly rounded square) -- kept as numpy scalars here; `d2` is array arithmetic
+    (`** 2` on arrays is an exact square)."""
+    n = models.shape[1]
+    centre = models[k]
+    x = centre.copy()
+    others = np.delete(models, k, axis=0)
+    d1 = 0.0
+    d2 = ((others[:, 1:] - x[1:]) ** 2).sum(axis=1)                                  # :280
+    for j in range(n):
+        if not free[j]:
+            x[j] = 0.0  # fixed axis: un-normalisation puts the bound back (:283-286)
+            continue
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lim = 0.5 * (centre[j] + others[:, j] + (d1 - d2) / (centre[j] - others[:, j]))   # :288
+        below = lim <= x[j]
+        low = max(lim[below].max(), 0.0) if below.sum() else 0.0                   # :290-291
+        above = lim >= x[j]
+        high = min(lim[above].min(), 1.0) if above.sum() else 1.0                  # :293-294
+        x[j] = low + (high - low) * u_row[j]                                        # :296 uniform(low, high)
+        if j < n - 1:                                                               # :298-303
+            d1 += (centre[j] - x[j]) ** 2 - (centre[j + 1] - x[j + 1]) ** 2
+            d2 += (others[:, j] - x[j]) ** 2 - (others[:, j + 1] - x[j + 1]) ** 2
+    return x
+
+
+def run_na(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, nrperc=0.5, xtol=1e-8, ftol=1e-8,
+           return_all=False, verbosity=1.0, **_ignored):
+    """Neighbourhood Algorithm, na/_na.py:131-262: all models ever sampled are kept (newest first); every generation
+    resamples popsize points inside the Voronoi cells of the nr best of them."""
+    n = len(lower)
+    P = popsize
+    span = upper - lower
+    free = span > 0.0
+    span = np.where(free, span, 1.0)                                                # :151-153
+    normalize = lambda x: np.where(free, (x - lower) / span, upper)  # noqa: E731   :154
+    unnormalize = lambda x: np.where(free, x * span + lower, upper)  # noqa: E731   :155
+    fun = lambda x: fobj(unnormalize(x))  # noqa: E731
+    nr = max(1, int(nrperc * P))                                                    # :160
+    X = np.asarray(x0, dtype=np.float64) if x0 is not None else latin_hypercube(stream, P, n, lower, upper)
+    X = normalize(X)
+    pbest = X.copy()
+    pfit = fun(X)
+    pbestfit = pfit.copy()
+    g = int(np.argmin(pbestfit))
+    gfit = pbestfit[g]
+    gbest = X[g].copy()
+    models, models_fit = X.copy(), pfit.copy()                                      # :177-178
+    hist = History(return_all, maxiter, P, n, verbosity)
+    hist.put(0, X, pfit, gbest, gfit)  # :185-193 -- NB the reference stores the NORMALISED rows at iteration 1
+    if callback is not None:
+        callback(unnormalize(X), Result(x=unnormalize(gbest), fun=gfit, nfev=P, nit=1))
+    it = 1
+    while True:
+        it += 1
+        u = stream.na_uniforms(it, P, n, free)
+        order = models_fit.argsort()[:nr]                                           # :274
+        X = np.array([na_walk(models, order[i % nr], u[i], free) for i in range(P)])
+        pfit = fun(X)
+        gbest, gfit, status = greedy_select(it, X, pfit, gbest, pbest, pbestfit, maxiter, xtol, ftol)
+        models = np.vstack((X, models))                                             # :223-224
+        models_fit = np.concatenate((pfit, models_fit))
+        hist.put(it - 1, unnormalize(X), pfit)
+        if callback is not None:
+            callback(unnormalize(X), Result(x=unnormalize(gbest), fun=gfit, nfev=it * P, nit=it))
+        if status is not None:
+            break
+    return _final(unnormalize(gbest), gfit, status, it * P, it, hist)
+
+
 def eigh_canonical(C):
     """cmaes/_cmaes.py:303-305 (upper triangle mirrored, numpy.linalg.eigh, ascending order) followed by the sign
     rule of the device eigensolver (csrc/sx_eigh.hip): the component of largest magnitude of every eigenvector
@@ -678,7 +754,7 @@ def run_de_sharded(fobj, lower, upper, stream, world, maxiter=100, popsize=10, m
     return res
 
 
-RUNNERS = {"de": run_de, "pso": run_pso, "cpso": run_pso, "cmaes": run_cmaes, "vdcma": run_vdcma}
+RUNNERS = {"de": run_de, "pso": run_pso, "cpso": run_pso, "cmaes": run_cmaes, "vdcma": run_vdcma, "na": run_na}
 
 
 def minimize(objective, bounds, x0=None, method="de", options=None, callback=None, rng="numpy-legacy"):

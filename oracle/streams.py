@@ -26,6 +26,7 @@ PURPOSE_PSO_R1 = 3
 PURPOSE_PSO_R2 = 4
 PURPOSE_PSO_RESTART = 5
 PURPOSE_CMA_NORMAL = 6
+PURPOSE_NA_UNIFORM = 7
 
 _M0 = np.uint64(0xD2511F53)
 _M1 = np.uint64(0xCD9E8D57)
@@ -130,6 +131,14 @@ class LegacyStream:
     def vd_initial_direction(self, n):
         """vdcma/_vdcma.py:208: np.random.normal(0, 1, n) right after the initial mean."""
         return self.rs.normal(0.0, 1.0, n)
+
+    # -- NA: na/_na.py:298 np.random.uniform(low, high), one per (individual, free axis), individual-major --------
+    def na_uniforms(self, gen, P, n, free):
+        """The [0, 1) doubles behind the generation's uniform(low, high) = low + (high - low) * u calls, as a (P, n)
+        array (columns of fixed axes are never drawn and stay 0)."""
+        u = np.zeros((P, n))
+        u[:, free] = self.rs.random_sample((P, int(np.count_nonzero(free))))
+        return u
 
     def vd_injection_normals(self, gen, P, n):
         """vdcma/_vdcma.py:245: one more randn(n) per generation once injection is on, after the P x n block."""
@@ -245,6 +254,10 @@ class PhiloxStream:
     def restart_rows(self, gen, lower, upper, rows, n, row0=0):
         d = self._uniform_block(np.asarray(rows, dtype=np.uint64) + np.uint64(row0), n, gen, PURPOSE_PSO_RESTART)
         return lower + (upper - lower) * d
+
+    def na_uniforms(self, gen, P, n, free):
+        """53-bit uniforms keyed by (row, generation): element (i, j) of the block layout of _uniform_block."""
+        return self._uniform_block(np.arange(P, dtype=np.uint64), n, gen, PURPOSE_NA_UNIFORM)
 
     def cma_normals(self, gen, P, n, row0=0):
         """Box-Muller on the two doubles of a call: half 0 -> cos branch, half 1 -> sin branch."""

@@ -77,7 +77,8 @@ class SxCmaState(C.Structure):
 class SxCmaArgs(C.Structure):
     _fields_ = [
         ("Z", vp), ("arx", vp), ("fit", vp), ("xmean", vp), ("xold", vp), ("ps", vp), ("pc", vp), ("C", vp), ("B", vp),
-        ("D", vp), ("eigw", vp), ("w", vp), ("Y", vp), ("part", vp), ("besthist", vp), ("xm", vp), ("xstd", vp),
+        ("D", vp), ("eigw", vp), ("w", vp), ("Y", vp), ("part", vp), ("step", vp), ("isc", vp), ("xnew", vp),
+        ("ypart", vp), ("besthist", vp), ("xm", vp), ("xstd", vp),
         ("xbest", vp), ("order", vp), ("state", vp), ("eigh_ws", vp),
         ("eigh_ws_bytes", i64), ("P", i64),
         ("n", i32), ("mu", i32), ("fun_id", i32), ("maxiter", i32), ("ilim", i32), ("eig_sweeps", i32),
@@ -140,6 +141,12 @@ PROTOTYPES = {
     "sx_symmetrize_upper": (C.c_int, [vp, C.c_int, vp]),
     "sx_cmaes_eval_penalized": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "sx_vdcma_sample": (C.c_int, [vp, i64, C.c_int, i64, vp, vp, f64, vp, f64, vp, vp, vp, vp]),
+    "sx_na_blocks": (C.c_int, [i64]),
+    "sx_na_begin": (C.c_int, [vp, i64, i64, C.c_int, vp, i64, vp, vp, vp]),
+    "sx_na_axis": (C.c_int, [vp, i64, i64, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+    "sx_na_commit": (C.c_int, [vp, i64, C.c_int, vp, vp, i64, i64, vp]),
+    "sx_na_uniforms": (C.c_int, [vp, i64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+    "sx_vdcma_moments": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, f64, vp, vp, vp]),
     "sx_cmaes_generation": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, vp]),
     "sx_eigh_workspace_bytes": (i64, [C.c_int]),
     "sx_eigh": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, vp]),

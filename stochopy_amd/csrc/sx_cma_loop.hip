@@ -38,21 +38,32 @@ static_assert(sizeof(sx_cma_state) == 128, "sx_cma_state is 128 bytes");
 // numpy sorts NaN last: a < b in that order
 __device__ __forceinline__ bool key_less(double a, double b) { return a < b || (b != b && a == a); }
 
-// order = argsort(fit) (ties: lower index first); best row / value and the history entry of the generation
+// order = argsort(fit) (ties: lower index first); best row / value and the history entry of the generation.
+// 64 elements per workgroup, 4 slices of the key range per element; the keys pass through LDS 4096 at a time.
 __global__ __launch_bounds__(256) void cma_rank_kernel(const double *__restrict__ fit, int64_t P,
                                                        int64_t *__restrict__ order, sx_cma_state *state,
                                                        double *__restrict__ besthist, int64_t gen) {
+    constexpr int CH = 4096;
+    __shared__ double keys[CH];
     __shared__ int part[4][64];
     if (state->done) return;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + tx;
     const double fi = i < P ? fit[i] : 0.0;
     int cnt = 0;
-    if (i < P) {
-        const int64_t span = (P + 3) / 4, k0 = ty * span, k1 = k0 + span < P ? k0 + span : P;
-        for (int64_t k = k0; k < k1; ++k) {
-            const double fk = fit[k];
-            cnt += (key_less(fk, fi) || (!key_less(fi, fk) && k < i)) ? 1 : 0;
+    for (int64_t c0 = 0; c0 < P; c0 += CH) {
+        const int len = (int)(P - c0 < CH ? P - c0 : CH);
+        __syncthreads();
+        for (int e = threadIdx.x; e < len; e += 256) keys[e] = fit[c0 + e];
+        __syncthreads();
+        if (i < P) {
+            const int span = (len + 3) / 4, k0 = ty * span, k1 = k0 + span < len ? k0 + span : len;
+            const int64_t ii = i - c0;
+#pragma unroll 16
+            for (int k = k0; k < k1; ++k) {
+                const double fk = keys[k];
+                cnt += (key_less(fk, fi) || (!key_less(fi, fk) && k < ii)) ? 1 : 0;
+            }
         }
     }
     part[ty][tx] = cnt;
@@ -106,56 +117,71 @@ __device__ double block_reduce(double v, double *red, F op) {  // all threads ge
     return s;
 }
 
-// mean, step, C^(-1/2) step = B ((B^T step) / D), evolution paths, cond, step size.  One workgroup.
-__global__ __launch_bounds__(kPathThreads) void cma_paths_kernel(const sx_cma_args a, int64_t gen) {
-    extern __shared__ double lds[];  // step[n] | y[n] | isc[n] | slices[16][64]
-    __shared__ double red[16];
+// The evolution-path step in three launches (the two products with B are spread over the chip):
+//   cma_step_bt_kernel   xold = xmean; xmean = sum of the 64 partial rows (:273-274); step = xmean - xold;
+//                        ypart[s][j] = sum over rows i of slice s of B[i][j] * step[i]          (grid n/64 x 8)
+//   cma_b_y_kernel       y = (sum_s ypart[s]) / D;  isc = B y  = C^(-1/2) step                  (4 rows per workgroup)
+//   cma_paths_kernel     ps, |ps|, cond, pc, sigma, tmp coefficient (:280-298), one workgroup
+constexpr int kYSlices = 8;
+
+__global__ __launch_bounds__(256) void cma_step_bt_kernel(const sx_cma_args a) {
+    __shared__ double st[512];       // step of this workgroup's row slice (slices are <= 512 rows: n <= 4096)
+    __shared__ double red[4][64];
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int span = (n + kYSlices - 1) / kYSlices, r0 = blockIdx.y * span, r1 = r0 + span < n ? r0 + span : n;
+    for (int i = r0 + tid; i < r1; i += 256) {
+        const double xo = a.xmean[i];  // (every column block reads the same old mean: only block x = 0 replaces it, below)
+        double xn = 0.0;
+#pragma unroll 8
+        for (int q = 0; q < kPartRows; ++q) xn += a.part[(int64_t)q * n + i];
+        st[i - r0] = xn - xo;
+        if (blockIdx.x == 0) a.step[i] = xn - xo, a.xold[i] = xo, a.xnew[i] = xn;
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 64 + tx;
+    double acc = 0.0;
+    if (col < n)
+        for (int i = r0 + ty; i < r1; i += 4) acc += a.B[(int64_t)i * n + col] * st[i - r0];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && col < n) a.ypart[(int64_t)blockIdx.y * n + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ __launch_bounds__(256) void cma_b_y_kernel(const sx_cma_args a) {
+    extern __shared__ double y[];  // n
     sx_cma_state *state = (sx_cma_state *)a.state;
     if (state->done) return;
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *step = lds, *y = lds + n, *isc = lds + 2 * n, *sl = lds + 3 * n;
+    for (int j = tid; j < n; j += 256) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < kYSlices; ++q) s += a.ypart[(int64_t)q * n + j];
+        y[j] = s / a.D[j];
+        if (blockIdx.x == 0) a.xmean[j] = a.xnew[j];  // the old mean has been consumed by every workgroup of the launch before
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) acc += a.B[(int64_t)i * n + j] * y[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if (lane == 0) a.isc[i] = acc;
+}
+
+__global__ __launch_bounds__(kPathThreads) void cma_paths_kernel(const sx_cma_args a, int64_t gen) {
+    __shared__ double red[16];
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x;
     const double sigma = state->sigma;
-    // xold = xmean; xmean = w @ arx[order[:mu]] (sum of the 64 partial rows, fixed order)   :273-274
-    for (int e = tid; e < n; e += kPathThreads) {
-        const double xo = a.xmean[e];
-        double xn = 0.0;
-#pragma unroll 8
-        for (int q = 0; q < kPartRows; ++q) xn += a.part[(int64_t)q * n + e];
-        a.xold[e] = xo;
-        a.xmean[e] = xn;
-        step[e] = xn - xo;
-    }
-    __syncthreads();
-    // y = (B^T step) / D: 64 columns at a time, 16 row slices
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int col = c0 + lane;
-        double acc = 0.0;
-        if (col < n)
-            for (int i = wave; i < n; i += 16) acc += a.B[(int64_t)i * n + col] * step[i];
-        sl[wave * 64 + lane] = acc;
-        __syncthreads();
-        if (wave == 0 && col < n) {
-            double s = sl[lane];
-#pragma unroll
-            for (int k = 1; k < 16; ++k) s += sl[k * 64 + lane];
-            y[col] = s / a.D[col];
-        }
-        __syncthreads();
-    }
-    // isc = B y: one wavefront per row
-    for (int i = wave; i < n; i += 16) {
-        double acc = 0.0;
-        for (int j = lane; j < n; j += 64) acc += a.B[(int64_t)i * n + j] * y[j];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
-        if (lane == 0) isc[i] = acc;
-    }
-    __syncthreads();
     // ps = (1-cs) ps + sqrt(cs (2-cs) mueff) * isc / sigma                                     :280-282
     const double kps = sqrt(a.cs * (2.0 - a.cs) * a.mueff);
     double q2 = 0.0;
     for (int e = tid; e < n; e += kPathThreads) {
-        const double p = (1.0 - a.cs) * a.ps[e] + kps * isc[e] / sigma;
+        const double p = (1.0 - a.cs) * a.ps[e] + kps * a.isc[e] / sigma;
         a.ps[e] = p;
         q2 += p * p;
     }
@@ -166,7 +192,7 @@ __global__ __launch_bounds__(kPathThreads) void cma_paths_kernel(const sx_cma_ar
     const double kpc = sqrt(a.cc * (2.0 - a.cc) * a.mueff);
     for (int e = tid; e < n; e += kPathThreads) {
         double p = a.pc[e] * (1.0 - a.cc);                                                     // :286
-        if (cond) p += kpc * step[e] / sigma;                                                  // :287
+        if (cond) p += kpc * a.step[e] / sigma;                                                // :287
         a.pc[e] = p;
     }
     if (tid == 0) {
@@ -179,7 +205,7 @@ __global__ __launch_bounds__(kPathThreads) void cma_paths_kernel(const sx_cma_ar
 // D = sqrt(eigenvalues) when a decomposition was made, then the ten ordered stopping rules (:360-434), the
 // result copy when one fires, and the publication of the new step size / generation counter.  One workgroup.
 __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_args a, int64_t gen, int did_eigh) {
-    __shared__ double red[16];
+    __shared__ double red14[kPathThreads / 64][14];
     sx_cma_state *state = (sx_cma_state *)a.state;
     if (state->done) return;
     const int n = a.n, tid = threadIdx.x;
@@ -190,9 +216,6 @@ __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_arg
     const double sigma = state->sigma_next, fbest = state->fbest;
     const int axis = (int)(gen % n);
     const double dax = a.D[axis];
-    auto fsum = [](double u, double v) { return u + v; };
-    auto fmx = [](double u, double v) { return fmax(u, v); };
-    auto fmn = [](double u, double v) { return fmin(u, v); };
     // per-dimension quantities.  "all(x < t)" is carried as the count of elements that FAIL (NaN fails, as in numpy)
     double dx2 = 0.0, fail4 = 0.0, any5 = 0.0, dmax = -__builtin_inf(), dmin = __builtin_inf(), any8 = 0.0;
     double sdmax = -__builtin_inf(), fail10 = 0.0, nan_sd = 0.0, nan_d = 0.0;
@@ -210,16 +233,6 @@ __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_arg
         sdmax = fmax(sdmax, sd);
         if (!(sigma * fabs(a.pc[e]) < 1.0e-11 * a.insigma)) fail10 += 1.0;
     }
-    dx2 = block_reduce(dx2, red, fsum);
-    fail4 = block_reduce(fail4, red, fsum);
-    any5 = block_reduce(any5, red, fsum);
-    dmax = block_reduce(dmax, red, fmx);
-    dmin = block_reduce(dmin, red, fmn);
-    any8 = block_reduce(any8, red, fsum);
-    sdmax = block_reduce(sdmax, red, fmx);
-    fail10 = block_reduce(fail10, red, fsum);
-    nan_sd = block_reduce(nan_sd, red, fsum);
-    nan_d = block_reduce(nan_d, red, fsum);
     // histories: window [gen-ilim, gen] of the zero-initialised best-fitness array (entry `gen` is not written yet),
     // and the whole array joined with this generation's fitness values
     double wmax = -__builtin_inf(), wmin = __builtin_inf(), jmax = -__builtin_inf(), jmin = __builtin_inf();
@@ -238,10 +251,32 @@ __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_arg
         const double v = a.fit[k];
         jmax = fmax(jmax, v), jmin = fmin(jmin, v);
     }
-    wmax = block_reduce(wmax, red, fmx);
-    wmin = block_reduce(wmin, red, fmn);
-    jmax = block_reduce(jmax, red, fmx);
-    jmin = block_reduce(jmin, red, fmn);
+    // one combined reduction: 7 sums, 4 maxima, 3 minima
+    double vs[14] = {dx2, fail4, any5, any8, fail10, nan_sd, nan_d, dmax, sdmax, wmax, jmax, dmin, wmin, jmin};
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(vs[q], off, kWave);
+            vs[q] = q < 7 ? vs[q] + o : (q < 11 ? fmax(vs[q], o) : fmin(vs[q], o));
+        }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 14; ++q) red14[tid >> 6][q] = vs[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        double r = red14[0][q];
+        for (int wv = 1; wv < kPathThreads / 64; ++wv) {
+            const double o = red14[wv][q];
+            r = q < 7 ? r + o : (q < 11 ? fmax(r, o) : fmin(r, o));
+        }
+        vs[q] = r;
+    }
+    dx2 = vs[0], fail4 = vs[1], any5 = vs[2], any8 = vs[3], fail10 = vs[4], nan_sd = vs[5], nan_d = vs[6];
+    dmax = vs[7], sdmax = vs[8], wmax = vs[9], jmax = vs[10], dmin = vs[11], wmin = vs[12], jmin = vs[13];
     int status = SX_STATUS_NONE;
     if (gen >= a.maxiter)
         status = -1;
@@ -285,7 +320,7 @@ __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_arg
 
 extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
     SX_REQUIRE(a && a->Z && a->arx && a->fit && a->xmean && a->xold && a->ps && a->pc && a->C && a->B && a->D && a->w &&
-                   a->Y && a->part && a->besthist && a->xm && a->xstd && a->xbest && a->eigw && a->order && a->state &&
+                   a->Y && a->part && a->step && a->isc && a->ypart && a->xnew && a->besthist && a->xm && a->xstd && a->xbest && a->eigw && a->order && a->state &&
                    a->eigh_ws,
                "sx_cmaes_generation: null pointer");
     SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->mu >= 1 && a->mu <= a->P && gen >= 1 && gen <= a->maxiter,
@@ -303,15 +338,9 @@ extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eig
                        a->besthist, gen);
     hipLaunchKernelGGL(cma_mean_partial_kernel, dim3((unsigned)((n + 63) / 64), kPartRows / 4), dim3(256), 0, st, a->arx,
                        a->order, a->w, a->mu, n, a->part);
-    const size_t lds = (size_t)(3 * n + 16 * 64) * sizeof(double);
-    if (lds > 48 * 1024) {
-        static bool raised = false;  // rows beyond ~1700 elements need more than the default dynamic-LDS limit
-        if (!raised) {
-            SX_HIP(hipFuncSetAttribute((const void *)cma_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL(cma_paths_kernel, dim3(1), dim3(kPathThreads), lds, st, *a, gen);
+    hipLaunchKernelGGL(cma_step_bt_kernel, dim3((unsigned)((n + 63) / 64), kYSlices), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(cma_b_y_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)n * sizeof(double), st, *a);
+    hipLaunchKernelGGL(cma_paths_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen);
     SX_LAUNCH_CHECK();
     if ((rc = sx::cma_rank_mu_launch(a->arx, a->order, a->w, a->mu, a->xold, 0.0, &state->sigma, a->pc, a->c1, a->cmu, 0.0,
                                      &state->tmp_coef, a->C, a->Y, n, stream)))

@@ -373,16 +373,42 @@ __global__ __launch_bounds__(256) void vd_sample_kernel(const double *__restrict
     if (row >= P) return;
     const double *z = Z + row * (int64_t)n;
     double t = 0.0;
-    for (int e = lane; e < n; e += kWave) t += z[e] * vn[e];
+    // 8 row loads per lane in flight (the row is streamed twice: the second pass hits L2)
+    int e = lane;
+    for (; e + 7 * kWave < n; e += 8 * kWave) {
+        double zz[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) zz[u] = z[e + u * kWave], vv[u] = vn[e + u * kWave];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += zz[u] * vv[u];
+    }
+    for (; e < n; e += kWave) t += z[e] * vn[e];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
     const int64_t grow = row0 + row;
     const bool inj = dy != nullptr && grow < 2;
     const double sgn = grow == 0 ? 1.0 : -1.0;
-    for (int e = lane; e < n; e += kWave) {
+    double *yo = ary + row * (int64_t)n, *xo = arx + row * (int64_t)n;
+    e = lane;
+    for (; e + 3 * kWave < n; e += 4 * kWave) {
+        double zz[4], vv[4], dd[4], xm[4], dj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = e + u * kWave;
+            zz[u] = z[c], vv[u] = vn[c], dd[u] = dvec[c], xm[u] = xmean[c], dj[u] = inj ? dy[c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = e + u * kWave;
+            const double y = inj ? sgn * dj[u] : dd[u] * (zz[u] + coef * (t * vv[u]));
+            yo[c] = y;
+            xo[c] = xm[u] + sigma * y;
+        }
+    }
+    for (; e < n; e += kWave) {
         const double y = inj ? sgn * dy[e] : dvec[e] * (z[e] + coef * (t * vn[e]));
-        ary[row * (int64_t)n + e] = y;
-        arx[row * (int64_t)n + e] = xmean[e] + sigma * y;
+        yo[e] = y;
+        xo[e] = xmean[e] + sigma * y;
     }
 }
 }  // namespace
@@ -395,6 +421,93 @@ extern "C" int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, 
     hipLaunchKernelGGL(vd_sample_kernel, dim3((unsigned)((P + rows_per_block - 1) / rows_per_block)),
                        dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, row0, dvec, vn, coef, xmean, sigma,
                        dy, ary, arx);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// VD-CMA moment sums (stochopy/optimize/vdcma/_vdcma.py:289-295 weighted mean of the selected candidates, :317 the
+// weighted step w . y, :331-339 + :428-444 the rank-mu moments p, q under the model D (I + v v^T) D): everything
+// that is O(mu n).  Only four n-vectors go back to the host per generation.
+//   t_k   = (ary[idx_k] / dvec) . vn                                   (vd_t_kernel, one wavefront per selected row)
+//   wx    = sum_k w_k arx[idx_k]            wy = sum_k w_k ary[idx_k]
+//   p_mu  = sum_k w_k (y_k^2 - shrink * t_k * y_k * vn - 1)           with y_k = ary[idx_k] / dvec
+//   q_mu  = sum_k w_k (t_k * y_k - 0.5 (t_k^2 + 1 + |v|^2) * vn)
+// as 64 partial rows (k mod 64) per output, then a fixed-order finish.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kVdPart = 64;
+
+__global__ __launch_bounds__(256) void vd_t_kernel(const double *__restrict__ ary, const int64_t *__restrict__ idx, int mu,
+                                                   int n, const double *__restrict__ dvec, const double *__restrict__ vn,
+                                                   double *__restrict__ tk) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int k = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (k >= mu) return;
+    const double *y = ary + idx[k] * (int64_t)n;
+    double t = 0.0;
+    int e = lane;
+    for (; e + 7 * kWave < n; e += 8 * kWave) {  // 8 row loads per lane in flight
+        double yy[8], dd[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) yy[u] = y[e + u * kWave], dd[u] = dvec[e + u * kWave], vv[u] = vn[e + u * kWave];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += (yy[u] / dd[u]) * vv[u];
+    }
+    for (; e < n; e += kWave) t += (y[e] / dvec[e]) * vn[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+    if (lane == 0) tk[k] = t;
+}
+
+// grid: ceil(n/64) x 16; part[o][q][e], o = 0..3 (wx, wy, p, q), q = k mod 64
+__global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *__restrict__ arx, const double *__restrict__ ary,
+                                                                 const int64_t *__restrict__ idx, const double *__restrict__ w,
+                                                                 const double *__restrict__ tk, int mu, int n,
+                                                                 const double *__restrict__ dvec, const double *__restrict__ vn,
+                                                                 double norm_v2, double *__restrict__ part) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    const int q = blockIdx.y * 4 + ty;
+    if (col >= n) return;
+    const double shrink = norm_v2 / (1.0 + norm_v2);
+    const double dv = dvec[col], v = vn[col];
+    double awx = 0.0, awy = 0.0, ap = 0.0, aq = 0.0;
+    for (int k = q; k < mu; k += kVdPart) {
+        const int64_t row = idx[k] * (int64_t)n + col;
+        const double wk = w[k], t = tk[k], ax = arx[row], ay = ary[row];
+        const double y = ay / dv;
+        awx += wk * ax;
+        awy += wk * ay;
+        ap += wk * (y * y - shrink * (t * (y * v)) - 1.0);
+        aq += wk * (t * y - (0.5 * (t * t + 1.0 + norm_v2)) * v);
+    }
+    const int64_t o = (int64_t)q * n + col, plane = (int64_t)kVdPart * n;
+    part[o] = awx, part[plane + o] = awy, part[2 * plane + o] = ap, part[3 * plane + o] = aq;
+}
+
+__global__ __launch_bounds__(256) void vd_moments_finish_kernel(const double *__restrict__ part, int n, double *__restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int64_t plane = (int64_t)kVdPart * n;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        double s = 0.0;
+        for (int q = 0; q < kVdPart; ++q) s += part[o * plane + (int64_t)q * n + e];
+        out[(int64_t)o * n + e] = s;
+    }
+}
+}  // namespace
+
+extern "C" int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
+                                const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream) {
+    SX_REQUIRE(arx && ary && idx && w && dvec && vn && ws && out && mu >= 1 && n >= 1, "sx_vdcma_moments: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    double *tk = ws, *part = ws + ((mu + 7) / 8) * 8;
+    hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
+    hipLaunchKernelGGL(vd_moments_partial_kernel, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
+                       w, tk, mu, n, dvec, vn, norm_v2, part);
+    hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, n, out);
     SX_LAUNCH_CHECK();
     return 0;
 }

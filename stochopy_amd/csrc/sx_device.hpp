@@ -140,6 +140,7 @@ enum : uint32_t {
     kPurposePsoR2 = 4,
     kPurposePsoRestart = 5,
     kPurposeCmaNormal = 6,
+    kPurposeNaUniform = 7,  // NA: the double behind uniform(low, high) of (sample, axis)
 };
 
 // Element e of a row sits in lane l = e % LPR of the row's lanes at step q = e / LPR (LPR a power of two).

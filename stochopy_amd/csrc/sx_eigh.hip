@@ -637,20 +637,20 @@ __global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double
 }
 
 // per column j of V: |v_j|^2 and the sign of its largest-magnitude component (lowest row on ties);
-// lam[j] = M_jj / |v_j|^2, scl[j] = sign / |v_j|.  One workgroup per 64 columns, 4 row strips.
+// lam[j] = M_jj / |v_j|^2, scl[j] = sign / |v_j|.  One workgroup per 16 columns, 16 row strips (rows of 128 bytes).
 __global__ __launch_bounds__(256) void eigh_colstats_kernel(const double *__restrict__ M0, const double *__restrict__ M1,
                                                             const double *__restrict__ V0, const double *__restrict__ V1,
                                                             int n, int npad, const EighInfo *info,
                                                             double *__restrict__ lam, double *__restrict__ scl) {
-    __shared__ double s_n2[4][64], s_mx[4][64], s_sg[4][64];
-    __shared__ int s_ix[4][64];
+    __shared__ double s_n2[16][16], s_mx[16][16], s_sg[16][16];
+    __shared__ int s_ix[16][16];
     const double *M = info->parity ? M1 : M0, *V = info->parity ? V1 : V0;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + tx;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + tx;
     double n2 = 0.0, mx = -1.0, sg = 1.0;
     int ix = 0;
     if (j < n) {
-        for (int i = ty; i < n; i += 4) {
+        for (int i = ty; i < n; i += 16) {
             const double v = V[(int64_t)i * npad + j];
             n2 += v * v;
             const double a = fabs(v);
@@ -661,11 +661,11 @@ __global__ __launch_bounds__(256) void eigh_colstats_kernel(const double *__rest
     __syncthreads();
     if (ty == 0) {
         if (j < n) {
-            double tot = (s_n2[0][tx] + s_n2[1][tx]) + (s_n2[2][tx] + s_n2[3][tx]);
-            double bm = s_mx[0][tx], bs = s_sg[0][tx];
-            int bi = s_ix[0][tx];
+            double tot = 0.0, bm = -1.0, bs = 1.0;
+            int bi = 0;
 #pragma unroll
-            for (int k = 1; k < 4; ++k) {
+            for (int k = 0; k < 16; ++k) {
+                tot += s_n2[k][tx];
                 const double m = s_mx[k][tx];
                 if (m > bm || (m == bm && s_ix[k][tx] < bi)) bm = m, bi = s_ix[k][tx], bs = s_sg[k][tx];
             }
@@ -678,18 +678,34 @@ __global__ __launch_bounds__(256) void eigh_colstats_kernel(const double *__rest
     }
 }
 
-// ascending rank of every eigenvalue (ties: lower position first); inv[rank] = position, w[rank] = value
+// ascending rank of every eigenvalue (ties: lower position first); inv[rank] = position, w[rank] = value.
+// The values pass through LDS 4096 at a time.
 __global__ __launch_bounds__(1024) void eigh_rank_kernel(const double *__restrict__ lam, int n, int *__restrict__ inv,
                                                          double *__restrict__ w) {
-    for (int j = threadIdx.x; j < n; j += 1024) {
-        const double lj = lam[j];
+    constexpr int CH = 4096;
+    __shared__ double keys[CH];
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        const int j = j0 + threadIdx.x;
+        const double lj = j < n ? lam[j] : 0.0;
         int rank = 0;
-        for (int k = 0; k < n; ++k) {
-            const double lk = lam[k];
-            rank += (lk < lj || (lk == lj && k < j)) ? 1 : 0;
+        for (int c0 = 0; c0 < n; c0 += CH) {
+            const int len = n - c0 < CH ? n - c0 : CH;
+            __syncthreads();
+            for (int e = threadIdx.x; e < len; e += 1024) keys[e] = lam[c0 + e];
+            __syncthreads();
+            if (j < n) {
+                const int jj = j - c0;  // position of this value inside the chunk (ties: lower position first)
+#pragma unroll 16
+                for (int k = 0; k < len; ++k) {
+                    const double lk = keys[k];
+                    rank += (lk < lj || (lk == lj && k < jj)) ? 1 : 0;
+                }
+            }
         }
-        inv[rank] = j;
-        w[rank] = lj;
+        if (j < n) {
+            inv[rank] = j;
+            w[rank] = lj;
+        }
     }
 }
 
@@ -800,7 +816,7 @@ extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, doub
         hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, max_sweeps, cur, tol);
         SX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 63) / 64)), dim3(256), 0, st, L.M[0], L.M[1], L.V[0],
+    hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 15) / 16)), dim3(256), 0, st, L.M[0], L.M[1], L.V[0],
                        L.V[1], n, npad, L.info, L.lam, L.scl);
     hipLaunchKernelGGL(eigh_rank_kernel, dim3(1), dim3(1024), 0, st, L.lam, n, L.inv, w);
     hipLaunchKernelGGL(eigh_write_kernel, dim3((unsigned)n), dim3(256), 0, st, L.V[0], L.V[1], n, npad, L.info, L.inv,

@@ -134,7 +134,8 @@ class _CmaDeviceRun:
                 Z=ctx.empty((P, n)), arx=ctx.empty((P, n)), fit=ctx.empty((P,)), xmean=ctx.upload(xmean),
                 xold=ctx.zeros((n,)), ps=ctx.zeros((n,)), pc=ctx.zeros((n,)), C=ctx.upload(np.eye(n)),
                 B=ctx.upload(np.eye(n)), D=ctx.upload(np.ones(n)), eigw=eig.w, w=ctx.upload(w), Y=ctx.empty((mu, n)),
-                part=ctx.empty((64, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
+                part=ctx.empty((64, n)), step=ctx.empty((n,)), isc=ctx.empty((n,)), xnew=ctx.empty((n,)),
+                ypart=ctx.empty((8, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
                 xbest=ctx.zeros((n,)), order=ctx.empty((P,), dtype=t.int64), eigh_ws=eig.ws)
             st = _lib.SxCmaState(it=0, nfev=0, best_row=0, fbest=0.0, sigma=sigma, sigma_next=sigma, tmp_coef=0.0,
                                  psnorm=0.0, status=_lib.SX_STATUS_NONE, done=0, stop_it=0)
@@ -159,7 +160,7 @@ class _CmaDeviceRun:
                     if state.done:
                         break
                     used, ok, _off = eig.info()
-                    a.eig_sweeps = min(60, used + 2) if ok else 60
+                    a.eig_sweeps = min(60, used + 1) if ok else 60
                     now = time.perf_counter()
                     if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
                         look *= 2

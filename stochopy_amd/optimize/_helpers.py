@@ -43,11 +43,12 @@ def minimize(fun, bounds, x0=None, args=(), method="de", options=None, callback=
 
     Same signature and dispatch as the reference (``_helpers.py:44-94``):
     ``options`` is splatted into the per-method function.  Methods offered:
-    ``"de"``, ``"pso"``, ``"cpso"``, ``"cmaes"``, ``"vdcma"``.  Options added by this backend:
+    ``"de"``, ``"pso"``, ``"cpso"``, ``"cmaes"``, ``"vdcma"``, ``"na"``.  Options added by this backend:
     ``backend="hip"`` (the default here), ``workers`` = number of GPUs (-1 = every rank of the process group),
-    ``rng`` in {"numpy-legacy", "philox"}, ``strict_updating`` (honour ``updating="immediate"`` with the
-    reference's serial semantics), and for DE with several GPUs ``exchange`` / ``donors``.  ``fun`` is a
-    ``stochopy_amd.factory`` objective, or a caller's own device objective tagged with ``factory.batched``.
+    ``rng`` in {"numpy-legacy", "philox"}, ``strict_updating`` (insist on / opt out of the ordered sweep of
+    ``updating="immediate"``), and for DE with several GPUs ``exchange`` / ``donors``.  ``fun`` is a
+    ``stochopy_amd.factory`` objective (fused kernels), a caller's own device objective tagged with
+    ``factory.batched``, or any other Python callable ``fun(x, *args)`` (evaluated per individual on the host).
     """
     options = options if options else {}
     try:

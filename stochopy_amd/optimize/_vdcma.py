@@ -157,6 +157,10 @@ class _VdRun:
         d_fit_loc = d_fit if self.world is None else ctx.empty((Pl,))
         d_dvec, d_vn, d_xmean, d_dy = ctx.empty((n,)), ctx.empty((n,)), ctx.empty((n,)), ctx.empty((n,))
         d_zinj = ctx.empty((1, n))
+        d_sel = ctx.empty((mu,), dtype=t.int64)
+        d_w = ctx.upload(w)
+        d_mws = ctx.empty((((mu + 7) // 8) * 8 + 4 * 64 * n,))
+        d_mout = ctx.empty((4, n))
         h_Z = t.empty((P, n), dtype=t.float64).pin_memory() if self.rng == "numpy-legacy" else None
         if self.penalize:
             bweights = _BoundaryWeights(n)
@@ -230,11 +234,14 @@ class _VdRun:
                     xall[it - 1] = seen(d_arx[k].cpu().numpy())
                     funall[it - 1] = arfit[k]
             # ---- rank, mean shift (:289-295): the mu selected rows of y and x come to the host ----
+            # ---- rank (host argsort), then every O(mu n) sum of the update on the device: the weighted means of the
+            # selected x and y and the rank-mu moments (:289-295, :317, :331-339); four n-vectors come back ----
             order = np.argsort(arfit)
-            sel = t.from_numpy(np.ascontiguousarray(order[:mu], dtype=np.int64)).to(ctx.device)
-            arx_sel = d_arx.index_select(0, sel).cpu().numpy()
-            ary_sel = d_ary.index_select(0, sel).cpu().numpy()
-            dx = np.dot(w, arx_sel) - w.sum() * xmean
+            d_sel.copy_(t.from_numpy(np.ascontiguousarray(order[:mu], dtype=np.int64)))
+            _lib.check(L.sx_vdcma_moments(ptr(d_arx), ptr(d_ary), ptr(d_sel), ptr(d_w), mu, n, ptr(d_dvec), ptr(d_vn),
+                                          float(norm_v2), ptr(d_mws), ptr(d_mout), sp), "sx_vdcma_moments")
+            wx, wy, p_mu_dev, q_mu_dev = d_mout.cpu().numpy()
+            dx = wx - w.sum() * xmean
             xold = xmean.copy()
             xmean = xmean + dx
             besthist[it - 1] = arfit[order[0]]
@@ -250,7 +257,7 @@ class _VdRun:
             # ---- evolution path, model constants (:309-328) ----
             pc *= 1.0 - cc
             if cond:
-                pc += np.sqrt(cc * (2.0 - cc) * mueff) * np.dot(w, ary_sel)
+                pc += np.sqrt(cc * (2.0 - cc) * mueff) * wy
             gamma = 1.0 / np.sqrt(1.0 + norm_v2)
             alpha = np.sqrt(norm_v2**2 + (1.0 + norm_v2) / vnn.max() * (2.0 - gamma)) / (2.0 + norm_v2)
             if alpha < 1.0:
@@ -261,7 +268,7 @@ class _VdRun:
             avec = 2.0 - (bsca + 2.0 * alpha**2) * vnn
             invavnn = vnn / avec
             # ---- moments, natural gradient, update of v and d (:331-378) ----
-            p_mu, q_mu = (np.zeros(n), np.zeros(n)) if cmu == 0.0 else _moments(vn, norm_v2, ary_sel / dvec, w)
+            p_mu, q_mu = (np.zeros(n), np.zeros(n)) if cmu == 0.0 else (p_mu_dev, q_mu_dev)
             p_one, q_one = (np.zeros(n), np.zeros(n)) if c1 == 0.0 else _moments(vn, norm_v2, pc / dvec)
             p = cmu * p_mu
             q = cmu * q_mu

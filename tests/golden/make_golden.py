@@ -17,6 +17,7 @@ Reference entry points exercised (paths relative to /root/reference):
     stochopy/optimize/cpso/_cpso.py:12     cpso.minimize
     stochopy/optimize/pso/_pso.py:9        pso.minimize
     stochopy/optimize/cmaes/_cmaes.py:12   cmaes.minimize
+    stochopy/optimize/na/_na.py:11         na.minimize
     stochopy/factory/benchmark.py:14-156   the seven objectives
     numpy legacy global RNG (np.random.seed/rand/permutation/randint/randn/uniform)
 """
@@ -444,8 +445,49 @@ def immediate():
     print("wrote immediate_xall.npz", os.path.getsize(os.path.join(HERE, "immediate_xall.npz")))
 
 
+# --------------------------------------------------------------------------- #
+# 8. Neighbourhood Algorithm (na/_na.py:131-305): the reference's own test row (tests/test_optimize.py:89-92) and
+#    coverage cases (more axes, x0, a fixed axis, early stop, history options)
+# --------------------------------------------------------------------------- #
+def na():
+    out = dict(STAMP)
+    cases = []
+    arrays = {}
+
+    def add(tag, fun, n, opts, bounds=None, x0=None, xref=None):
+        o = dict(opts, return_all=True)
+        entry, res, pops = run_ref(fun, n, "na", o, x0=x0, bounds=bounds, full=True)
+        entry["tag"] = tag
+        if xref is not None:
+            entry["xref_from_reference_tests"] = xref
+            assert np.allclose(xref, res.x), (tag, xref, res.x)
+        arrays[tag + "__xall"] = res.xall
+        arrays[tag + "__funall"] = res.funall
+        cases.append(entry)
+        print(" ", tag, "fun", float(res.fun), "nit", res.nit, "status", res.status)
+
+    suite_opts = {"maxiter": 128, "popsize": 8, "seed": 42, "nrperc": 0.5}
+    add("na_suite", "rosenbrock", 2, suite_opts, xref=[1.14849912, 1.31885465])
+    rs = np.random.RandomState(11)
+    add("na_suite_x0", "rosenbrock", 2, suite_opts, x0=rs.uniform(-5.12, 5.12, (8, 2)))
+    add("na_sphere_n5_p12", "sphere", 5, {"maxiter": 40, "popsize": 12, "seed": 3, "nrperc": 0.25})
+    add("na_rastrigin_n3_p20", "rastrigin", 3, {"maxiter": 30, "popsize": 20, "seed": 9, "nrperc": 1.0})
+    add("na_rosen_n12_p16", "rosenbrock", 12, {"maxiter": 20, "popsize": 16, "seed": 5, "nrperc": 0.5})
+    add("na_fixed_axis", "sphere", 4, {"maxiter": 25, "popsize": 10, "seed": 2, "nrperc": 0.3},
+        bounds=[[-5.12, 5.12], [1.5, 1.5], [-2.0, 3.0], [-5.12, 5.12]])
+    add("na_sphere_ftol", "sphere", 2, {"maxiter": 400, "popsize": 16, "seed": 7, "nrperc": 0.5, "ftol": 1e-4})
+    add("na_best_only_history", "rosenbrock", 3, {"maxiter": 25, "popsize": 9, "seed": 4, "nrperc": 0.4, "verbosity": 0.0})
+    add("na_half_history", "ackley", 4, {"maxiter": 20, "popsize": 10, "seed": 6, "nrperc": 0.5, "verbosity": 0.5})
+    out["cases"] = cases
+    dump("na.json", out)
+    np.savez_compressed(os.path.join(HERE, "na_xall.npz"), **arrays)
+    print("wrote na_xall.npz", os.path.getsize(os.path.join(HERE, "na_xall.npz")))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "factory", "suite", "configs", "penalize", "vdcma", "immediate"]
+    which = sys.argv[1:] or ["rng", "factory", "suite", "configs", "penalize", "vdcma", "immediate", "na"]
+    if "na" in which:
+        na()
     if "immediate" in which:
         immediate()
     if "vdcma" in which:

@@ -302,7 +302,7 @@ def test_api_surface_and_validation():
     with pytest.raises(ValueError):
         sa.optimize.minimize(f, b, options={"backend": "loky"})
     with pytest.raises(KeyError):
-        sa.optimize.minimize(f, b, method="na")
+        sa.optimize.minimize(f, b, method="sampler")  # not an optimizer of the reference's registry
 
 
 def test_optimize_result_surface():

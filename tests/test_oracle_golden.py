@@ -189,3 +189,29 @@ def test_philox_stream_properties():
     a = s.pso_generation(3, 64, 19)[0]
     b = s.pso_generation(3, 16, 19, row0=32)[0]
     assert np.array_equal(a[32:48], b)
+
+
+NA_CASES = load_golden("na.json")["cases"]
+
+
+@pytest.mark.parametrize("case", NA_CASES, ids=lambda c: c["tag"])
+def test_na_oracle_matches_reference_bit_for_bit(case):
+    """Neighbourhood Algorithm (na/_na.py:131-305): result, per-generation best-f, the full history and the
+    populations handed to the callback equal the reference's, bit for bit -- including the reference's scalar
+    `** 2` (libm pow) in the cell walk, the normalised rows it stores at iteration 1, and fixed axes."""
+    trace, pops = [], []
+    res = oracle.minimize(case["objective"], case_bounds(case), x0=case["x0"], method="na", options=dict(case["options"]),
+                          callback=lambda X, r: (trace.append(float(r.fun)), pops.append(np.array(X, copy=True))))
+    ref = case["result"]
+    assert (res.nit, res.nfev, res.status, res.success, res.message) == (
+        ref["nit"], ref["nfev"], ref["status"], ref["success"], ref["message"])
+    assert np.array_equal(res.x, unhex(ref["x"])) and res.fun == unhex(ref["fun"])
+    assert np.array_equal(np.array(trace), unhex(case["fun_trace"]))
+    arrays = np.load(os.path.join(GOLDEN, "na_xall.npz"))
+    assert np.array_equal(res.xall, arrays[case["tag"] + "__xall"])
+    assert np.array_equal(res.funall, arrays[case["tag"] + "__funall"])
+    import hashlib
+
+    assert hashlib.sha256(np.ascontiguousarray(pops[-1]).tobytes()).hexdigest() == case["pop_last_sha"]
+    if "xref_from_reference_tests" in case:
+        assert np.allclose(case["xref_from_reference_tests"], res.x)
