@@ -29,7 +29,10 @@ constexpr int kMaxDim = 4096; // leaves hold > 64 terms, so n <= 4096 has at mos
 // Rows of more than 256 elements form their objective terms inside the reduction (row_reduce_leaves_fused:
 // one leaf of <= 128 terms per 8-lane group, so >= 3 of the 8 groups are busy); shorter rows have too few
 // leaves for that and stage the terms, computed by all lanes, in LDS first.
-__host__ __device__ inline bool fused_terms(int n) { return n > 256; }
+#ifndef SX_FUSED_ABOVE
+#define SX_FUSED_ABOVE 256  // (a build-time knob for A/B measurements: tools/ab_fused.sh)
+#endif
+__host__ __device__ inline bool fused_terms(int n) { return n > SX_FUSED_ABOVE; }
 // doubles of LDS per row.  staged: U[n+8] | A[n] | B[n] | stack[24] | leaf sums [2][n/64+2];
 // fused: U[n+8] | leaf sums [2][n/64+2]
 __host__ __device__ inline int leaf_cap(int n) { return n / 64 + 2; }

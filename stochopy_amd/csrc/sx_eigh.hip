@@ -191,20 +191,33 @@ __device__ void jacobi_sweep(const JacobiView &L, int &cur, const int tid) {
     const int o00 = (2 * kp) * LD + 2 * kq, o10 = o00 + LD;
     const int dr0 = sys_perm<MODE>(2 * kp, M2) * LD, dr1 = sys_perm<MODE>(2 * kp + 1, M2) * LD;
     const int dc0 = sys_perm<MODE>(2 * kq, M2), dc1 = sys_perm<MODE>(2 * kq + 1, M2);
-    // rotation lanes: lane k prepares pair k of the next round = old positions (i, j)
+    // Rotation lanes.  With a wave of their own (OWN_WAVE) FOUR lanes serve pair k of the next round -- its old
+    // positions (i, j) = perm^-1(2k, 2k+1) -- and work out one pivot element each (lane 0: (i,i), 1: (j,j), 2 and 3:
+    // (i,j)) with the very operations the updating threads apply, so the predicted pivot IS the next matrix's; a DPP
+    // quad broadcast collects the three values and every lane forms the rotation (lane 0 of the quad stores it).
+    // Without room for an extra wave (M2 = 64) lane k of wave 0 does the three elements one after the other.
     const int dl = OWN_WAVE ? tid - NREG : tid;
-    const bool duty = dl >= 0 && dl < NP;
-    const int k2 = duty ? dl : 0;
+    const bool duty = dl >= 0 && dl < (OWN_WAVE ? 4 * NP : NP);
+    const int k2 = duty ? (OWN_WAVE ? dl >> 2 : dl) : 0, part = OWN_WAVE ? (dl & 3) : 0;
     const int i = sys_perm_inv<MODE>(2 * k2, M2), j = sys_perm_inv<MODE>(2 * k2 + 1, M2);
-    const int ki = i >> 1, kj = j >> 1;
-    const bool pi = i & 1, pj = j & 1;
-    const int qi = (2 * ki) * LD + 2 * ki, qj = (2 * kj) * LD + 2 * kj, qx = (2 * ki) * LD + 2 * kj;
+    // element (ea, eb) this lane predicts
+    const int ea = part == 1 ? j : i, eb = part == 0 ? i : j;
+    const int ka = ea >> 1, kb = eb >> 1;
+    const bool pa = ea & 1, pb = eb & 1;
+    const int qab = (2 * ka) * LD + 2 * kb;
+    auto predicted = [&](const double *S, const double *rc, const double *rs, int ka_, bool pa_, int kb_, bool pb_, int q_) {
+        const double ca = rc[ka_], sa = rs[ka_], cb = rc[kb_], sb = rs[kb_];
+        const double b00 = S[q_], b01 = S[q_ + 1], b10 = S[q_ + LD], b11 = S[q_ + LD + 1];
+        const double r0 = pa_ ? fma(sa, b00, ca * b10) : fma(ca, b00, -(sa * b10));
+        const double r1 = pa_ ? fma(sa, b01, ca * b11) : fma(ca, b01, -(sa * b11));
+        return pb_ ? fma(sb, r0, cb * r1) : fma(cb, r0, -(sb * r1));
+    };
     if (duty) {
         const double *S = cur ? L.S1 : L.S0;
         const int o = (2 * k2) * LD + 2 * k2;
         double c, s;
         rotation(S[o], S[o + LD + 1], S[o + 1], c, s);
-        L.c[k2] = c, L.s[k2] = s;
+        if (part == 0) L.c[k2] = c, L.s[k2] = s;
     }
     __syncthreads();
     for (int r = 0; r < ROUNDS; ++r) {
@@ -214,24 +227,26 @@ __device__ void jacobi_sweep(const JacobiView &L, int &cur, const int tid) {
         double *Wn = cur ? L.W0 : L.W1;
         const double *rc = L.c + (r & 1) * NP, *rs = L.s + (r & 1) * NP;
         SX_ETQ(r == 5 && tid == 0, 6);
-        SX_ETQ(r == 5 && duty && k2 == 0, 10);
+        SX_ETQ(r == 5 && duty && dl == 0, 10);
         if (duty && r + 1 < ROUNDS) {
-            const double ci = rc[ki], si = rs[ki], cj = rc[kj], sj = rs[kj];
-            // diagonal element of member pi of pair ki after the two-sided rotation of its 2x2 block [[a, b], [b, d]]
-            const double ai = S[qi], bi = S[qi + 1], di = S[qi + LD + 1];
-            const double aj = S[qj], bj = S[qj + 1], dj = S[qj + LD + 1];
-            const double b00 = S[qx], b01 = S[qx + 1], b10 = S[qx + LD], b11 = S[qx + LD + 1];
-            const double ti = 2.0 * (ci * si) * bi, tj = 2.0 * (cj * sj) * bj;
-            const double nii = pi ? fma(si * si, ai, fma(ci * ci, di, ti)) : fma(ci * ci, ai, fma(si * si, di, -ti));
-            const double njj = pj ? fma(sj * sj, aj, fma(cj * cj, dj, tj)) : fma(cj * cj, aj, fma(sj * sj, dj, -tj));
-            const double r0 = pi ? fma(si, b00, ci * b10) : fma(ci, b00, -(si * b10));
-            const double r1 = pi ? fma(si, b01, ci * b11) : fma(ci, b01, -(si * b11));
-            const double nij = pj ? fma(sj, r0, cj * r1) : fma(cj, r0, -(sj * r1));
-            SX_ETQ(r == 5 && k2 == 0 && nij != 12345.0, 11);
+            double nii, njj, nij;
+            if (OWN_WAVE) {
+                const double v = predicted(S, rc, rs, ka, pa, kb, pb, qab);
+                nii = dpp_f64<0x00>(v);  // quad_perm:[0,0,0,0]
+                njj = dpp_f64<0x55>(v);  // quad_perm:[1,1,1,1]
+                nij = dpp_f64<0xAA>(v);  // quad_perm:[2,2,2,2]
+            } else {
+                const int ki = i >> 1, kj = j >> 1;
+                const bool pi = i & 1, pj = j & 1;
+                nii = predicted(S, rc, rs, ki, pi, ki, pi, (2 * ki) * LD + 2 * ki);
+                njj = predicted(S, rc, rs, kj, pj, kj, pj, (2 * kj) * LD + 2 * kj);
+                nij = predicted(S, rc, rs, ki, pi, kj, pj, (2 * ki) * LD + 2 * kj);
+            }
+            SX_ETQ(r == 5 && dl == 0 && nij != 12345.0, 11);
             double c, s;
             rotation(nii, njj, nij, c, s);
-            SX_ETQ(r == 5 && k2 == 0 && c != 12345.0, 12);
-            L.c[((r + 1) & 1) * NP + k2] = c, L.s[((r + 1) & 1) * NP + k2] = s;
+            SX_ETQ(r == 5 && dl == 0 && c != 12345.0, 12);
+            if (part == 0) L.c[((r + 1) & 1) * NP + k2] = c, L.s[((r + 1) & 1) * NP + k2] = s;
         }
         if (reg) {
             const double c1 = rc[kp], s1 = rs[kp], c2 = rc[kq], s2 = rs[kq];
@@ -251,10 +266,10 @@ __device__ void jacobi_sweep(const JacobiView &L, int &cur, const int tid) {
             Wn[(2 * kp + 1) * LD + dc1] = fma(s2, w10, c2 * w11);
         }
         SX_ETQ(r == 5 && tid == 0, 7);
-        SX_ETQ(r == 5 && duty && k2 == 0, 13);
+        SX_ETQ(r == 5 && duty && dl == 0, 13);
         __syncthreads();
         SX_ETQ(r == 5 && tid == 0, 8);
-        SX_ETQ(r == 5 && duty && k2 == 0, 14);
+        SX_ETQ(r == 5 && duty && dl == 0, 14);
         cur ^= 1;
     }
 }
