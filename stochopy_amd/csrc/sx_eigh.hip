@@ -379,19 +379,23 @@ constexpr int LDY = kBS;       // 32x16 intermediate
 // acc (16x16, rows i0.., cols j0..) = A[i0.., 0:32] * B[0:32, j0..];  A row-major stride lda, B row-major stride ldb
 __device__ __forceinline__ v4d mma_ab(const double *A, int lda, int i0, const double *B, int ldb, int j0, int lane) {
     const int lr = lane & 15, lk = lane >> 4;
+    double av[kM2 / 4], bv[kM2 / 4];  // all sixteen LDS operand reads in flight before the first MFMA
+#pragma unroll
+    for (int k = 0; k < kM2 / 4; ++k) av[k] = A[(i0 + lr) * lda + 4 * k + lk], bv[k] = B[(4 * k + lk) * ldb + j0 + lr];
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k0 = 0; k0 < kM2; k0 += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(i0 + lr) * lda + k0 + lk], B[(k0 + lk) * ldb + j0 + lr], acc, 0, 0, 0);
+    for (int k = 0; k < kM2 / 4; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
     return acc;
 }
 // acc (16x16) = A[0:32, i0..]^T * B[0:32, j0..]
 __device__ __forceinline__ v4d mma_atb(const double *A, int lda, int i0, const double *B, int ldb, int j0, int lane) {
     const int lr = lane & 15, lk = lane >> 4;
+    double av[kM2 / 4], bv[kM2 / 4];
+#pragma unroll
+    for (int k = 0; k < kM2 / 4; ++k) av[k] = A[(4 * k + lk) * lda + i0 + lr], bv[k] = B[(4 * k + lk) * ldb + j0 + lr];
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k0 = 0; k0 < kM2; k0 += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(k0 + lk) * lda + i0 + lr], B[(k0 + lk) * ldb + j0 + lr], acc, 0, 0, 0);
+    for (int k = 0; k < kM2 / 4; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
     return acc;
 }
 
@@ -471,7 +475,8 @@ struct RoundLds {
 // One launch per round.  blockIdx < np: pair workgroups (rotation U_cur of the round rcur from the current pivot);
 // then np*np tiles of M and nr*np tiles of V, which apply the rotations U_prev of the round rprev.
 // flush != 0: no pair workgroups' sweeps (the last rotations are applied and the run is closed by the host).
-constexpr int kRoundThreads = jacobi_threads<kM2>();  // 256 updating threads + the rotation wave of the pivot sweep
+constexpr int kRoundThreads = jacobi_threads<kM2>() + 64;  // 256 updating threads + the rotation wave of the pivot
+                                                            // sweep + a sixth wave: the pivot products split six ways
 
 __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double *__restrict__ Min, const double *__restrict__ Vin,
                                                          double *__restrict__ Mout, double *__restrict__ Vout, int npad,
@@ -589,22 +594,21 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
     // (I-member, J-member) -- over the rounds of a sweep every off-diagonal element is then targeted exactly once,
     // and the mass met (all off-diagonal entries in the full round, the I x J block otherwise) adds up to off(M)^2.
     const bool full = rcur == 0;
-    if (wave < 3) {
-        const double *UR = wave == 0 ? L.p.UA : L.p.UB;
-        const int cR = 16 * (wave == 0 ? posI : posJ);
+    {   // first products, six ways: wave w forms half h = w & 1 of Y_b = X_b * A_right, b = w >> 1
+        const int b = wave >> 1, h = wave & 1;
+        const double *UR = b == 0 ? L.p.UA : L.p.UB;
+        const int cR = 16 * (b == 0 ? posI : posJ);
+        const v4d a = mma_ab(L.p.X[b], LDX, 16 * h, UR, LDU, cR, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.p.Y[b][(16 * h + lk + 4 * r) * LDY + lr] = a[r];
+    }
+    __syncthreads();
+    double m2 = 0.0;  // off-diagonal mass of this wave's sub-block (added to the sweep's total at the very end)
+    if (wave < 3) {  // second products: T_b = A_left^T Y_b (16x16), one sub-block per wave
         const double *UL = wave == 2 ? L.p.UB : L.p.UA;
         const int cL = 16 * (wave == 2 ? posJ : posI);
-        double *Y = L.p.Y[wave];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {  // Y (32x16) = X * UR[:, cR:cR+16]
-            const v4d a = mma_ab(L.p.X[wave], LDX, 16 * h, UR, LDU, cR, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Y[(16 * h + lk + 4 * r) * LDY + lr] = a[r];
-        }
-        __builtin_amdgcn_wave_barrier();  // Y is private to this wave: its LDS stores are ordered before its reads
-        const v4d tt = mma_atb(UL, LDU, cL, Y, LDY, 0, lane);  // 16x16
+        const v4d tt = mma_atb(UL, LDU, cL, L.p.Y[wave], LDY, 0, lane);
         const int ro = wave == 2 ? 1 : 0, co = wave == 0 ? 0 : 1;  // odd positions: block J
-        double m2 = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = lk + 4 * r, j = lr;
@@ -619,9 +623,6 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
                 if (full && i < j) m2 = fma(2.0 * tt[r], tt[r], m2);
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
-        if (lane == 0 && m2 != 0.0) atomicAdd(&info->acc[sweep], m2);
     }
     __syncthreads();  // stage 1 is over: its LDS is reused for the sweep
     SX_ETP(3);
@@ -640,6 +641,10 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
         const int pi = i < kBS ? 2 * i : 2 * (i - kBS) + 1, pj = j < kBS ? 2 * j : 2 * (j - kBS) + 1;
         Uo[e] = Wf[pi * LD + pj];
     }
+    // (the global atomic waits for nothing here; before a barrier it would stall the whole pivot phase)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
+    if (wave < 3 && lane == 0 && m2 != 0.0) atomicAdd(&info->acc[sweep], m2);
     SX_ETP(5);
 }
 

@@ -160,7 +160,7 @@ class _CmaDeviceRun:
                     if state.done:
                         break
                     used, ok, _off = eig.info()
-                    a.eig_sweeps = min(60, used + 1) if ok else 60
+                    a.eig_sweeps = min(60, used + 2) if ok else 60  # (launches beyond convergence are no-ops of ~2 us each)
                     now = time.perf_counter()
                     if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
                         look *= 2
