@@ -440,11 +440,14 @@ typedef struct sx_cma_args {
     double *besthist;           /* (maxiter) zero-initialised                                         */
     const double *xm, *xstd;    /* (n) un-standardisation x * xstd + xm (:167-173)                    */
     double *xbest;              /* (n) result: best candidate of the stopping generation              */
+    double *hist_x, *hist_f;    /* return_all history (maxiter, rows, n) / (maxiter, rows), un-standardised candidates
+                                 * (:262-269), or NULL; rows = hist_rows, or 1 when hist_rows == 0 (best candidate only) */
     int64_t *order;             /* (P) argsort of fit                                                 */
     void *state;                /* sx_cma_state                                                       */
     void *eigh_ws;              /* sx_eigh workspace                                                  */
     int64_t eigh_ws_bytes;
     int64_t P;
+    int64_t hist_rows;          /* ceil(verbosity * popsize)                                          */
     int32_t n, mu, fun_id, maxiter, ilim, eig_sweeps;
     double cs, cc, c1, cmu, damps, chind, mueff, xtol, ftol, insigma;
     uint32_t key0, key1;

@@ -79,8 +79,8 @@ class SxCmaArgs(C.Structure):
         ("Z", vp), ("arx", vp), ("fit", vp), ("xmean", vp), ("xold", vp), ("ps", vp), ("pc", vp), ("C", vp), ("B", vp),
         ("D", vp), ("eigw", vp), ("w", vp), ("Y", vp), ("part", vp), ("step", vp), ("isc", vp), ("xnew", vp),
         ("ypart", vp), ("besthist", vp), ("xm", vp), ("xstd", vp),
-        ("xbest", vp), ("order", vp), ("state", vp), ("eigh_ws", vp),
-        ("eigh_ws_bytes", i64), ("P", i64),
+        ("xbest", vp), ("hist_x", vp), ("hist_f", vp), ("order", vp), ("state", vp), ("eigh_ws", vp),
+        ("eigh_ws_bytes", i64), ("P", i64), ("hist_rows", i64),
         ("n", i32), ("mu", i32), ("fun_id", i32), ("maxiter", i32), ("ilim", i32), ("eig_sweeps", i32),
         ("cs", f64), ("cc", f64), ("c1", f64), ("cmu", f64), ("damps", f64), ("chind", f64), ("mueff", f64),
         ("xtol", f64), ("ftol", f64), ("insigma", f64),

@@ -104,6 +104,22 @@ __global__ __launch_bounds__(256) void cma_mean_partial_kernel(const double *__r
     part[(int64_t)q * n + col] = acc;
 }
 
+// return_all (cmaes/_cmaes.py:262-269): the first `rows` candidates of the generation, un-standardised, and their
+// fitness -- or, with rows == 0, the generation's best candidate -- into the device-side history
+__global__ __launch_bounds__(256) void cma_history_kernel(const sx_cma_args a, int64_t gen) {
+    const sx_cma_state *state = (const sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n;
+    const int64_t rows = a.hist_rows > 0 ? a.hist_rows : 1;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * n) return;
+    const int64_t r = t / n;
+    const int e = (int)(t % n);
+    const int64_t src = a.hist_rows > 0 ? r : state->best_row;
+    a.hist_x[((gen - 1) * rows + r) * n + e] = a.arx[src * n + e] * a.xstd[e] + a.xm[e];
+    if (e == 0) a.hist_f[(gen - 1) * rows + r] = a.fit[src];
+}
+
 template <class F>
 __device__ double block_reduce(double v, double *red, F op) {  // all threads get the result; 1024 threads
 #pragma unroll
@@ -336,6 +352,11 @@ extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eig
     if ((rc = sx_eval(a->fun_id, a->arx, P, n, n, a->xm, a->xstd, a->fit, nullptr, nullptr, stream))) return rc;
     hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, a->fit, P, a->order, state,
                        a->besthist, gen);
+    if (a->hist_x) {
+        SX_REQUIRE(a->hist_f != nullptr && a->hist_rows >= 0 && a->hist_rows <= P, "sx_cmaes_generation: bad history arguments");
+        const int64_t tot = (a->hist_rows > 0 ? a->hist_rows : 1) * n;
+        hipLaunchKernelGGL(cma_history_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *a, gen);
+    }
     hipLaunchKernelGGL(cma_mean_partial_kernel, dim3((unsigned)((n + 63) / 64), kPartRows / 4), dim3(256), 0, st, a->arx,
                        a->order, a->w, a->mu, n, a->part);
     hipLaunchKernelGGL(cma_step_bt_kernel, dim3((unsigned)((n + 63) / 64), kYSlices), dim3(256), 0, st, *a);

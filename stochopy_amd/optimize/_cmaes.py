@@ -82,10 +82,10 @@ def minimize(
     if eigh not in ("host", "device"):
         raise ValueError("eigh must be 'host' or 'device'")
     if (rng == "philox" and eigh == "device" and isinstance(fun_id, int) and workers == 1 and constraints is None
-            and callback is None and not return_all):
-        # nothing the host has to see between generations: the whole loop stays on the device
+            and callback is None):
+        # nothing the host has to see between generations: the whole loop (and the history) stays on the device
         return _CmaDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
-                             float(xtol), float(ftol), seed).result()
+                             float(xtol), float(ftol), seed, bool(return_all), float(verbosity)).result()
     run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                   float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh, workers,
                   penalize=constraints == "Penalize")
@@ -116,7 +116,8 @@ class _CmaDeviceRun:
 
     LOOK = 16
 
-    def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed):
+    def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
+                 verbosity=1.0):
         import ctypes as C
         import time
 
@@ -137,11 +138,16 @@ class _CmaDeviceRun:
                 part=ctx.empty((64, n)), step=ctx.empty((n,)), isc=ctx.empty((n,)), xnew=ctx.empty((n,)),
                 ypart=ctx.empty((8, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
                 xbest=ctx.zeros((n,)), order=ctx.empty((P,), dtype=t.int64), eigh_ws=eig.ws)
+            nout = int(np.ceil(verbosity * P)) if return_all else 0
+            if return_all:  # device-side history slabs, read back once at the end
+                keep["hist_x"] = ctx.empty((maxiter, max(1, nout), n))
+                keep["hist_f"] = ctx.empty((maxiter, max(1, nout)))
             st = _lib.SxCmaState(it=0, nfev=0, best_row=0, fbest=0.0, sigma=sigma, sigma_next=sigma, tmp_coef=0.0,
                                  psnorm=0.0, status=_lib.SX_STATUS_NONE, done=0, stop_it=0)
             d_state = keep["state"] = ctx.upload(np.frombuffer(bytes(st), dtype=np.float64))
             a = _lib.SxCmaArgs(**{k: ptr(v) for k, v in keep.items()})
             a.eigh_ws_bytes, a.P, a.n, a.mu, a.fun_id, a.maxiter = eig.bytes, P, n, mu, fun_id, maxiter
+            a.hist_rows = nout
             a.ilim, a.eig_sweeps = int(10.0 + 30.0 * n / P), 24
             a.cs, a.cc, a.c1, a.cmu, a.damps, a.chind, a.mueff = cs, cc, c1, cmu, damps, chind, mueff
             a.xtol, a.ftol, a.insigma, a.key0, a.key1 = xtol, ftol, sigma, key0, key1
@@ -171,6 +177,8 @@ class _CmaDeviceRun:
             self._res = OptimizeResult(x=keep["xbest"].cpu().numpy(), success=state.status >= 0, status=int(state.status),
                                        message=_common.messages[int(state.status)], fun=float(state.fbest),
                                        nfev=nit * P, nit=nit)
+            if return_all:
+                self._res.update({"xall": keep["hist_x"][:nit].cpu().numpy(), "funall": keep["hist_f"][:nit].cpu().numpy()})
             ctx.sync()
 
     def result(self):

@@ -262,6 +262,20 @@ def test_cmaes_device_resident_loop_vs_oracle(sa, cfg):
     assert (via_host.nit, via_host.status) == (got.nit, got.status) and np.isclose(via_host.fun, got.fun, rtol=1e-6)
 
 
+@pytest.mark.parametrize("verbosity", [1.0, 0.4, 0.0])
+def test_cmaes_device_resident_loop_history(sa, verbosity):
+    """return_all without a callback stays on the device (history slabs written by a kernel, read back once): same
+    shapes and values as the oracle's history (LAPACK + canonical signs)."""
+    n, P = 12, 30
+    opts = {"maxiter": 15, "popsize": P, "seed": 8, "sigma": 0.25, "return_all": True, "verbosity": verbosity}
+    bounds = [[-2.0, 3.0]] * n
+    ref = oracle.minimize("rosenbrock", bounds, method="cmaes", options=dict(opts, eigh="canonical"), rng="philox")
+    got = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"))
+    assert got.xall.shape == ref.xall.shape and got.funall.shape == ref.funall.shape
+    assert np.allclose(got.funall, ref.funall, rtol=1e-6) and np.allclose(got.xall, ref.xall, rtol=1e-6, atol=1e-9)
+    assert (got.nit, got.status) == (ref.nit, ref.status)
+
+
 def test_cmaes_device_resident_loop_stop_rules(sa):
     """Stopping rules other than maxiter / ftol on the device: TolX-type stops on a flat objective region."""
     for obj, n, P, opts in (("sphere", 4, 8, {"maxiter": 3000, "ftol": -1.0, "xtol": 0.0, "sigma": 0.3}),
