@@ -69,6 +69,13 @@ def test_batched_objective_reproduces_the_fused_run(sa, method, objective, n, op
     if opts.get("constraints") == "Penalize":  # the penalty sum is a torch reduction here: same run up to rounding
         assert np.allclose(ext.x, fused.x, rtol=1e-9, atol=1e-12) and np.isclose(ext.fun, fused.fun, rtol=1e-9)
         return
+    if method == "cmaes" and rng == "philox":
+        # the fused run keeps the whole generation loop on the device (sx_cma_loop.hip), the external objective needs
+        # the host-driven one: same algorithm, the mean / path updates associate differently -> same run up to rounding
+        assert np.allclose(ext.x, fused.x, rtol=1e-8, atol=1e-11) and np.isclose(ext.fun, fused.fun, rtol=1e-8)
+        assert np.allclose(ext.xall, fused.xall, rtol=1e-8, atol=1e-11)
+        assert np.allclose(ext.funall, fused.funall, rtol=1e-8)
+        return
     assert np.array_equal(ext.x, fused.x) and ext.fun == fused.fun
     assert np.array_equal(ext.xall, fused.xall) and np.array_equal(ext.funall, fused.funall)
 
