@@ -282,6 +282,12 @@ typedef struct sx_pso_args {
     int64_t *part_i;        /* DEVICE (sx_num_partials(P,n))                          */
     const double *r1;       /* DEVICE (P,n) rand(P,n), cpso/_cpso.py:262  (SX_RNG_HOST) */
     const double *r2;       /* DEVICE (P,n) rand(P,n), cpso/_cpso.py:263  (SX_RNG_HOST) */
+    uint64_t *radius_gen;   /* DEVICE (2) or NULL.  CPSO on one GPU: [0] = max_i ||X_i - gbest||_2 as IEEE bits, taken by
+                             * sx_pso_generation from the positions it has just written and the gbest it moved them
+                             * with (atomic max; sx_pso_restart_select clears it), [1] = delta*sqrt(4n) as IEEE bits
+                             * (host-set).  With it sx_pso_radius / sx_pso_restart_select skip the pass over X when
+                             * gbest did not move this generation (state.dx == 0: [0] IS the swarm radius of
+                             * cpso/_cpso.py:410) or when [0] - dx already exceeds [1] (no restart either way). */
     int64_t P;
     int64_t ld;
     int64_t row0;           /* global index of local row 0 (Philox counters; shards)  */

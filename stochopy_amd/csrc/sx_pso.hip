@@ -28,9 +28,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
+    __shared__ double sr[kMaxRowsPerBlock];
     const sx_state *st = a.state;
     if (st->done) return;
     const uint32_t gen = (uint32_t)(st->it + 1);
+    const bool want_radius = a.radius_gen != nullptr;  // CPSO: ||X_new - gbest||^2 of the row, in pso_radius_kernel's order
+    double racc = 0.0;
     const int n = a.n;
     const int64_t P = a.P, ld = a.ld;
     const RowIds<LPR> id(P);
@@ -99,6 +102,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                         vr[e] = vn;
                         xr[e] = xn;
                     }
+                    if (want_radius) {
+                        const double dg = xn - g[t];
+                        racc += dg * dg;
+                    }
                 }
             }
         }
@@ -115,7 +122,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                 vr[e] = vn;
                 xr[e] = xn;
             }
+            if (want_radius) {
+                const double dg = xn - gb[e];
+                racc += dg * dg;
+            }
         }
+    }
+    if (want_radius) {
+        racc = sqrt(row_sum<LPR>(racc));
+        if (l == 0) sr[id.slot] = id.active ? racc : 0.0;
     }
     const double fc = row_objective<FUN, LPR>(U, n, plan, l);
     const bool better = fc < fold;  // _common.py:127 strict <
@@ -127,7 +142,33 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             if (a.candfit != nullptr) a.candfit[id.row] = fc;
         }
     }
-    block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+    block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);  // (a workgroup barrier inside)
+    if (want_radius && threadIdx.x == 0) {
+        double m = sr[0];
+        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+        for (int k = 1; k < rows_in_block; ++k) m = fmax(m, sr[k]);
+        // non-negative doubles order like their bit patterns
+        atomicMax((unsigned long long *)a.radius_gen, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// What the generation kernel's radius ([0] of radius_gen, see stochopy_hip.h) says after the best/termination step:
+// 0 = nothing (the pass over X is needed), 1 = it IS the swarm radius (gbest did not move), 2 = `bound` is a lower
+// bound of the radius that already rules a restart out (||X_i - g_new|| >= ||X_i - g_old|| - ||g_new - g_old||).
+__device__ __forceinline__ int radius_shortcut(const sx_pso_args &a, double &value) {
+    if (a.radius_gen == nullptr) return 0;
+    const double rg = __longlong_as_double((long long)a.radius_gen[0]);
+    const double thr = __longlong_as_double((long long)a.radius_gen[1]);
+    const double dx = a.state->dx;  // ||gbest_prev - gbest||_2 of this generation (_common.py:135)
+    if (dx == 0.0) {
+        value = rg;
+        return 1;
+    }
+    if (rg - dx > thr * (1.0 + 1.0e-9)) {
+        value = rg - dx;
+        return 2;
+    }
+    return 0;
 }
 
 typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
@@ -178,6 +219,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(co
                                                                               double *__restrict__ part_r) {
     __shared__ double sr[kMaxRowsPerBlock];
     if (a.state->done) return;
+    double shortcut;
+    if (radius_shortcut(a, shortcut)) return;  // uniform: the select kernel takes the same decision
     const RowIds<LPR> id(a.P);
     const double *__restrict__ xr = a.X + id.rowc * a.ld;
     double acc = 0.0;
@@ -266,14 +309,18 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         return;
     }
     double m = 0.0;
-    for (int64_t k = tid; k < npart; k += kSelThreads) {
-        const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
-        m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
-    }
+    const int shortcut = radius_shortcut(a, m);  // uniform; pso_radius_kernel skipped its pass in the same cases
+    if (!shortcut) {
+        for (int64_t k = tid; k < npart; k += kSelThreads) {
+            const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
+            m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
+    }
     if (lane == 0) smax[wv] = m;
-    __syncthreads();
+    __syncthreads();  // (every thread has read radius_gen[0] by now)
+    if (a.radius_gen != nullptr && tid == 0) a.radius_gen[0] = 0ull;  // the next generation starts its maximum afresh
     m = smax[0];
     for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
     const double radius = m / sqrt(4.0 * (double)a.n);

@@ -11,6 +11,8 @@ best/termination kernel; the competitive restart (:405-426) is three small kerne
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from .. import _device, _lib, _rng
@@ -231,6 +233,14 @@ class _PsoRun:
         a.maxiter = self.maxiter
         a.w, a.c1, a.c2, a.xtol, a.ftol = self.w, self.c1, self.c2, self.xtol, self.ftol
         a.key0, a.key1 = key0, key1
+        if (self.gamma and self.world is None and self.rng == "philox" and self.external is None and not self.immediate
+                and os.environ.get("SX_CPSO_GEN_RADIUS") != "0"):
+            # the generation kernel records max_i ||X_i - gbest|| itself (stochopy_hip.h, sx_pso_args.radius_gen): the
+            # restart test's pass over X (cpso/_cpso.py:410) is then only run when gbest moved AND the swarm is small
+            rg = np.zeros(2, dtype=np.int64)
+            rg[1:].view(np.float64)[0] = self.delta * np.sqrt(4.0 * n)
+            self.radius_gen = ctx.upload(rg)
+            a.radius_gen = self.radius_gen.data_ptr()
         self.args = a
         if self.rng == "numpy-legacy":
             self.h_r = [t.empty((P, n), dtype=t.float64).pin_memory() for _ in range(2)]

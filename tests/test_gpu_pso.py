@@ -121,3 +121,29 @@ def test_cpso_philox_restarts_fire_and_match_oracle(sa):
     # no callback => fully asynchronous device path; same final answer
     r_async = sa.optimize.minimize(sa.factory.sphere, bounds, method="cpso", options=dict(opts, backend="hip", rng="philox"))
     assert r_async.fun == r_ref.fun and np.array_equal(r_async.x, r_ref.x) and r_async.nit == r_ref.nit
+
+
+@pytest.mark.parametrize("objective,n,P,maxiter,shrink", [("sphere", 16, 256, 120, None), ("ackley", 32, 1024, 150, None),
+                                                          ("rosenbrock", 130, 512, 80, "Shrink"), ("sphere", 8, 4000, 40, None)])
+def test_cpso_generation_side_radius_takes_the_same_decisions(sa, monkeypatch, objective, n, P, maxiter, shrink):
+    """The generation kernel records max_i ||X_i - gbest|| itself and the restart test only passes over X again when
+    gbest moved while the swarm is small (sx_pso_args.radius_gen).  With that shortcut (default) and without it
+    (SX_CPSO_GEN_RADIUS=0: every generation runs the pass) a run is the same bit for bit -- through replayed graphs (no
+    callback) and generation by generation (history)."""
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 21, "updating": "deferred", "backend": "hip", "rng": "philox",
+            "constraints": shrink}
+    bounds = [[-5.12, 5.12]] * n
+    fun = getattr(sa.factory, objective)
+    runs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("SX_CPSO_GEN_RADIUS", knob)
+        runs[knob] = (sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts)),
+                      sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts, return_all=True)))
+    for a, b in zip(runs["1"], runs["0"]):
+        assert a.fun == b.fun and np.array_equal(a.x, b.x) and (a.nit, a.status) == (b.nit, b.status)
+    assert np.array_equal(runs["1"][1].xall, runs["0"][1].xall) and np.array_equal(runs["1"][1].funall, runs["0"][1].funall)
+    assert runs["1"][0].fun == runs["1"][1].fun
+    if objective == "sphere" and P == 256:  # restarts do fire in this run (the oracle counts them)
+        ref = oracle.minimize("sphere", bounds, method="cpso", rng="philox",
+                              options={k: v for k, v in opts.items() if k not in ("backend", "rng")})
+        assert len(ref["_restarts"]) > 3 and ref.fun == runs["1"][0].fun and np.array_equal(ref.x, runs["1"][0].x)
