@@ -512,11 +512,12 @@ def eigh_canonical(C):
 
 
 def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, sigma=0.1, muperc=0.5,
-              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, eigh="lapack", **_ignored):
-    """eigh="lapack": the reference's call as is (pinned to the goldens); eigh="canonical": the same
+              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, eigh="lapack", probe=None,
+              **_ignored):
+    """eigh="lapack" (or a callable wrapping it): the reference's call as is (pinned to the goldens); eigh="canonical": the same
     decomposition with the device eigensolver's sign rule (what eigh="device" runs of the HIP path are compared
     with)."""
-    if eigh not in ("lapack", "canonical"):
+    if not callable(eigh) and eigh not in ("lapack", "canonical"):
         raise ValueError(eigh)
     if constraints not in (None, "Penalize"):
         raise KeyError(constraints)
@@ -545,6 +546,9 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
     it = 0
     while True:
         it += 1
+        if probe is not None:  # tests: the model a generation starts from (copies)
+            before = dict(xmean=xmean.copy(), sigma=sigma, ps=ps.copy(), pc=pc.copy(), C=C.copy(), B=B.copy(), D=D.copy(),
+                          besthist=bestfit_hist.copy())
         Z = stream.cma_normals(it, P, n)
         arx = cma_sample(xmean, sigma, B, D, Z)
         arxvalid = arx
@@ -564,13 +568,14 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
         pc += np.sqrt(cc * (2.0 - cc) * mueff) * (xmean - xold) / sigma if cond else 0.0
         C = cma_covariance(C, arx[order[:mu], :], xold, sigma, w, pc, cond, c1, cmu, cc)
         sigma *= np.exp((cs / damps) * (np.linalg.norm(ps) / chind - 1.0))
-        if nfev - eigeneval > P / (c1 + cmu) / n / 10.0:
+        due = nfev - eigeneval > P / (c1 + cmu) / n / 10.0
+        if due:
             eigeneval = nfev
             C = np.triu(C) + np.triu(C, 1).T
             if eigh == "canonical":
                 D, B = eigh_canonical(C)
-            else:
-                D, B = np.linalg.eigh(C)
+            else:  # a callable: the same LAPACK call behind a recorder (tests replay the pairs into the HIP run)
+                D, B = eigh(C) if callable(eigh) else np.linalg.eigh(C)
                 o = np.argsort(D)
                 D = D[o]
                 B = B[:, o]
@@ -578,6 +583,10 @@ def run_cmaes(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
             invsqrtC = np.dot(np.dot(B, np.diag(1.0 / D)), B.T)
         status = cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, insigma, ilim, pc,
                           xtol, ftol, np.diag(C), B, D)
+        if probe is not None:
+            probe(it, before, dict(arx=arx.copy(), arfit=arfit.copy(), order=order.copy(), xmean=xmean.copy(), ps=ps.copy(),
+                                   pc=pc.copy(), C=C.copy(), sigma=sigma, B=B.copy(), D=D.copy(), due=bool(due),
+                                   status=status))
         if callback is not None:
             callback(unstd(arxvalid), Result(x=unstd(arxvalid[order[0]]), fun=arfit[order[0]], nfev=nfev, nit=it))
         if status is not None:

@@ -54,6 +54,9 @@ def minimize(
     eigenvalues and eigenvectors to rounding, signs by a stated rule (largest component positive), no
     2 x n^2 PCIe trip -- the default in the throughput mode ``rng="philox"``; the oracle reproduces such runs
     with ``eigh="canonical"`` (LAPACK + the same sign rule).
+    ``eigh=callable``: ``callable(C) -> (eigenvalues, eigenvectors)`` replaces the host decomposition (another solver,
+    or -- tests/test_gpu_cmaes.py -- the reference's own eigenpairs replayed, which makes same-seed parity checkable
+    for shapes whose covariance has a repeated eigenvalue, where no two solvers agree on a basis).
 
     ``workers > 1`` (one process per GPU) shards what the reference's parallel backends shard -- the
     candidates: every rank samples and evaluates ``popsize / workers`` rows (same draws: the legacy stream is
@@ -79,8 +82,8 @@ def minimize(
     workers = _common.resolve_workers(workers)
     if eigh is None:
         eigh = "host" if rng == "numpy-legacy" else "device"
-    if eigh not in ("host", "device"):
-        raise ValueError("eigh must be 'host' or 'device'")
+    if not callable(eigh) and eigh not in ("host", "device"):
+        raise ValueError("eigh must be 'host', 'device' or a callable C -> (eigenvalues, eigenvectors)")
     if (rng == "philox" and eigh == "device" and isinstance(fun_id, int) and workers == 1 and constraints is None
             and callback is None):
         # nothing the host has to see between generations: the whole loop (and the history) stays on the device
@@ -117,7 +120,9 @@ class _CmaDeviceRun:
     LOOK = 16
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
-                 verbosity=1.0):
+                 verbosity=1.0, run=True):
+        """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
+        with ``step`` from a state of their choosing."""
         import ctypes as C
         import time
 
@@ -151,7 +156,10 @@ class _CmaDeviceRun:
             a.ilim, a.eig_sweeps = int(10.0 + 30.0 * n / P), 24
             a.cs, a.cc, a.c1, a.cmu, a.damps, a.chind, a.mueff = cs, cc, c1, cmu, damps, chind, mueff
             a.xtol, a.ftol, a.insigma, a.key0, a.key1 = xtol, ftol, sigma, key0, key1
-            eig_every = P / (c1 + cmu) / n / 10.0  # :301
+            self.buffers, self.args, self.eig, self.P = keep, a, eig, P
+            self.eig_every = eig_every = P / (c1 + cmu) / n / 10.0  # :301
+            if not run:
+                return
             eigeneval, look, since, t0 = 0, 1, 0, time.perf_counter()
             state = st
             for gen in range(1, maxiter + 1):
@@ -180,6 +188,18 @@ class _CmaDeviceRun:
             if return_all:
                 self._res.update({"xall": keep["hist_x"][:nit].cpu().numpy(), "funall": keep["hist_f"][:nit].cpu().numpy()})
             ctx.sync()
+
+    def step(self, gen, due):
+        """Enqueue generation ``gen`` (``due``: 0 no decomposition, 1 cold, 2 started from the current B)."""
+        import ctypes as C
+
+        t = _device.torch()
+        with t.cuda.stream(self.ctx.stream):
+            _lib.check(self.ctx.L.sx_cmaes_generation(C.byref(self.args), int(gen), int(due), self.ctx.stream_ptr),
+                       "sx_cmaes_generation")
+
+    def read_state(self):
+        return _lib.SxCmaState.from_buffer_copy(self.buffers["state"].cpu().numpy().tobytes())
 
     def result(self):
         return self._res
@@ -449,7 +469,8 @@ class _CmaRun:
                         break
                     continue
                 Ch = d_C.cpu().numpy()
-                D, B = np.linalg.eigh(Ch)
+                D, B = self.eigh(Ch) if callable(self.eigh) else np.linalg.eigh(Ch)
+                D, B = np.asarray(D, dtype=np.float64), np.asarray(B, dtype=np.float64)
                 o = np.argsort(D)
                 D = D[o]
                 B = B[:, o]

@@ -133,6 +133,44 @@ def test_cmaes_matches_reference_golden(sa, case):
         assert res.fun <= max(10.0 * unhex(ref["fun"]), case["options"].get("ftol", 1e-8))
 
 
+@pytest.mark.parametrize("case", CMA_CASES, ids=lambda c: c["tag"])
+def test_cmaes_golden_with_the_references_eigenpairs_replayed(sa, case):
+    """Same-seed parity for EVERY CMA-ES golden, the two with a repeated eigenvalue (mu + 1 < n) included: the oracle
+    -- bit-identical to the reference on these cases (tests/test_oracle_golden.py) -- records the (C, eigenvalues,
+    eigenvectors) of each of its LAPACK calls, and the HIP run gets those pairs back through ``eigh=callable``
+    instead of decomposing its own C.  What is left to differ is everything the GPU computes -- normals upload,
+    sampling GEMM, objective, recombination, rank-mu update (checked here: its C against the oracle's at 1e-9) -- and
+    the run must follow the reference's per-generation best-f within 1e-6 to the last generation."""
+    recorded = []
+
+    def record(Cmat):
+        w, V = np.linalg.eigh(Cmat)
+        recorded.append((Cmat.copy(), w, V))
+        return w, V
+
+    oracle.minimize(case["objective"], case_bounds(case), x0=case["x0"], method="cmaes",
+                    options=dict(case["options"], eigh=record), rng="numpy-legacy")
+    calls = []
+
+    def replay(Cmat):
+        Cref, w, V = recorded[len(calls)]
+        calls.append(float(np.abs(Cmat - Cref).max() / np.abs(Cref).max()))
+        return w, V
+
+    trace = []
+    res = sa.optimize.minimize(getattr(sa.factory, case["objective"]), case_bounds(case), x0=case["x0"], method="cmaes",
+                               options=dict(case["options"], backend="hip", rng="numpy-legacy", eigh=replay),
+                               callback=lambda X, r: trace.append(float(r.fun)))
+    ref, want = case["result"], unhex(case["fun_trace"])
+    assert len(calls) == len(recorded) and max(calls) <= 1e-9
+    assert len(trace) == len(want) and np.allclose(trace, want, rtol=1e-6, atol=1e-300)
+    assert (res.nit, res.nfev, res.status, res.success, res.message) == (
+        ref["nit"], ref["nfev"], ref["status"], ref["success"], ref["message"])
+    assert np.isclose(res.fun, unhex(ref["fun"]), rtol=1e-6, atol=0)
+    xref = np.asarray(unhex(ref["x"]))  # (the C4 fixture keeps the leading coordinates only)
+    assert np.allclose(res.x[: xref.size], xref, rtol=1e-5, atol=1e-8)
+
+
 @pytest.mark.parametrize("tag", ["cmaes_none", "cmaes_none_x0"])
 def test_cmaes_reference_suite_xrefs(sa, tag):
     """reference tests/test_optimize.py:9-20 (constraints=None rows)."""
@@ -298,3 +336,75 @@ def test_cmaes_device_eigensolver_converges(sa):
     res = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * 2, method="cmaes",
                                options={"maxiter": 300, "popsize": 10, "seed": 0, "eigh": "device", "rng": "philox"})
     assert res.success and np.allclose(res.x, [1.0, 1.0], atol=1e-3)
+
+
+@pytest.mark.parametrize("objective,n,P,maxiter", [("rosenbrock", 20, 20, 300), ("sphere", 8, 12, 119), ("rosenbrock", 6, 12, 60),
+                                                   ("rastrigin", 40, 16, 80), ("sphere", 70, 10, 40)])
+def test_device_loop_generation_by_generation_from_the_oracles_state(sa, ctx, objective, n, P, maxiter):
+    """The device-resident CMA-ES generation (csrc/sx_cma_loop.hip) checked one generation at a time: every
+    generation starts from the ORACLE's model of that generation (mean, paths, C, B, D, sigma, best-f history) and
+    must arrive at the oracle's next model -- candidates, fitness, best row, mean, ps, pc, C, sigma, status -- to
+    rounding.  The new eigenvectors are checked by what is determined about them (eigenvalues, reconstruction,
+    orthonormality): with mu + 1 < n (four of the five shapes) C keeps a repeated eigenvalue, whose eigenspace has no
+    canonical basis, so whole-run traces of two solvers part ways there -- this form of the test does not care."""
+    import torch
+
+    from stochopy_amd import _lib
+    from stochopy_amd.optimize._cmaes import _CmaDeviceRun
+
+    seed, sigma0 = 4242, 0.3
+    bounds = np.array([[-3.0, 4.0]] * n)
+    steps = []
+    oracle.minimize(objective, bounds, method="cmaes", rng="philox",
+                    options=dict(maxiter=maxiter, popsize=P, sigma=sigma0, seed=seed, eigh="canonical", xtol=1e-12,
+                                 ftol=1e-30, probe=lambda it, before, after: steps.append((it, before, after))))
+    assert len(steps) >= min(maxiter, 30)
+    run = _CmaDeviceRun(getattr(sa.factory, objective).sx_id, bounds[:, 0].copy(), bounds[:, 1].copy(), None, maxiter, P,
+                        sigma0, 0.5, 1e-12, 1e-30, seed, run=False)
+    buf = run.buffers
+    mu = int(0.5 * P)
+
+    def put(name, value):
+        buf[name].copy_(torch.from_numpy(np.array(value, dtype=np.float64, order="C", copy=True)))
+
+    def close(a, b, tol):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-300)
+
+    decomposed = 0
+    with torch.cuda.stream(run.ctx.stream):
+        for it, before, after in steps:
+            for name in ("xmean", "ps", "pc", "C", "B", "D"):
+                put(name, before[name])
+            put("besthist", before["besthist"])
+            st = _lib.SxCmaState(it=it - 1, nfev=(it - 1) * P, best_row=0, fbest=0.0, sigma=before["sigma"],
+                                 sigma_next=before["sigma"], tmp_coef=0.0, psnorm=0.0, status=_lib.SX_STATUS_NONE, done=0,
+                                 stop_it=0)
+            put("state", np.frombuffer(bytes(st), dtype=np.float64))
+            due = (1 + decomposed % 2) if after["due"] else 0  # cold start / started from the current B, alternately
+            decomposed += bool(after["due"])
+            run.step(it, due)
+            got = run.read_state()
+            best = int(after["order"][0])
+            assert close(buf["arx"].cpu().numpy(), after["arx"], 1e-12), it
+            assert np.allclose(buf["fit"].cpu().numpy(), after["arfit"], rtol=1e-11, atol=1e-300), it
+            assert (got.it, got.nfev, got.best_row) == (it, it * P, best), it
+            assert np.isclose(got.fbest, after["arfit"][best], rtol=1e-11, atol=0), it
+            assert close(buf["xmean"].cpu().numpy(), after["xmean"], 1e-12), it
+            assert close(buf["ps"].cpu().numpy(), after["ps"], 1e-10), it
+            assert close(buf["pc"].cpu().numpy(), after["pc"], 1e-10), it
+            Cgot = buf["C"].cpu().numpy()
+            if not after["due"]:  # (the reference symmetrises only when it decomposes: compare the upper triangle)
+                assert close(np.triu(Cgot), np.triu(after["C"]), 1e-11), it
+            else:
+                assert close(Cgot, after["C"], 1e-11), it
+                Dg, Bg = buf["D"].cpu().numpy(), buf["B"].cpu().numpy()
+                assert close(Dg, after["D"], 1e-10), it
+                assert np.abs(Bg.T @ Bg - np.eye(n)).max() <= 1e-12, it
+                assert close((Bg * Dg**2) @ Bg.T, after["C"], 1e-11), it
+                k = np.abs(Bg).argmax(axis=0)  # canonical sign: the largest component of every eigenvector is positive
+                assert (Bg[k, np.arange(n)] > 0).all(), it
+            assert np.isclose(got.sigma, after["sigma"], rtol=1e-10, atol=0), it
+            want = _lib.SX_STATUS_NONE if after["status"] is None else after["status"]
+            assert (got.status, bool(got.done)) == (want, after["status"] is not None), it
+    assert decomposed >= 10
