@@ -288,6 +288,11 @@ typedef struct sx_pso_args {
                              * (host-set).  With it sx_pso_radius / sx_pso_restart_select skip the pass over X when
                              * gbest did not move this generation (state.dx == 0: [0] IS the swarm radius of
                              * cpso/_cpso.py:410) or when [0] - dx already exceeds [1] (no restart either way). */
+    const uint64_t *pending_restart; /* DEVICE (3) or NULL: an sx_pso_restart_select decision (its out3) of the
+                             * PREVIOUS generation that sx_pso_restart_apply has not carried out: the generation kernel
+                             * re-seeds those rows itself (same Philox positions, V = 0, pbest = X, pbestfit = 1e30,
+                             * cpso/_cpso.py:420-424) instead of loading them.  Set inside sx_pso_graph_create only
+                             * (in-kernel draws); callers pass NULL and apply restarts with sx_pso_restart_apply. */
     int64_t P;
     int64_t ld;
     int64_t row0;           /* global index of local row 0 (Philox counters; shards)  */

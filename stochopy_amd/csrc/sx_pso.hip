@@ -22,6 +22,12 @@ using namespace sx;
 
 namespace {
 
+// order-preserving map double -> uint64 (larger double <=> larger key)
+__device__ __forceinline__ unsigned long long sort_key(double f) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(f);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
 template <int FUN, int RNG, int LPR>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
                                                                                 const PlanArg plan) {
@@ -42,7 +48,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     double *U = lds + id.slot * lds_row_stride(n);
     double *Vn = U;  // Shrink: the raw velocity waits in U[e] until the owning lane replaces it by the position
 
-    const double fold = a.pbestfit[rowc];
+    double fold = a.pbestfit[rowc];
+    // CPSO inside a graph: the restart decided at the end of the previous generation is carried out here -- a selected
+    // row is not loaded but re-seeded (what pso_restart_apply_kernel would have written: same Philox positions, V = 0,
+    // pbest = X, pbestfit = 1e30), and then moved like any other
+    bool reseed = false;
+    if (RNG == SX_RNG_PHILOX && a.pending_restart != nullptr)
+        reseed = a.pending_restart[0] != 0ull && sort_key(fold) >= a.pending_restart[1];
+    if (reseed) fold = 1.0e30;
     double *__restrict__ xr = a.X + rowc * ld;
     double *__restrict__ vr = a.V + rowc * ld;
     double *__restrict__ pb = a.pbest + rowc * ld;
@@ -64,10 +77,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
 #pragma unroll
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
-            const bool in = e < n;
-            x[t] = in ? xr[e] : 0.0;
-            v[t] = in ? vr[e] : 0.0;
-            p[t] = in ? pb[e] : 0.0;
+            const bool in = e < n, ld_row = in && !reseed;
+            x[t] = ld_row ? xr[e] : 0.0;
+            v[t] = ld_row ? vr[e] : 0.0;
+            p[t] = ld_row ? pb[e] : 0.0;
             g[t] = in ? gb[e] : 0.0;
             r1[t] = (RNG == SX_RNG_HOST && in) ? r1row[e] : 0.0;
             r2[t] = (RNG == SX_RNG_HOST && in) ? r2row[e] : 0.0;
@@ -82,6 +95,29 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                 r2[t] = u32(wd.y);
                 r1[t + 1] = u32(wd.z);
                 r2[t + 1] = u32(wd.w);
+            }
+        }
+        if (RNG == SX_RNG_PHILOX && reseed) {  // X = uniform(lower, upper) keyed like pso_restart_apply_kernel's draws
+#pragma unroll
+            for (int t = 0; t < kStep; t += 2) {
+                const U4 wd = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen - 1u,
+                                            kPurposePsoRestart, a.key0, a.key1);
+                const double u[2] = {u53(wd.x, wd.y), u53(wd.z, wd.w)};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = (q0 + t + h) * LPR + l;
+                    if (e < n) {
+                        const double lo = a.lower[e];
+                        x[t + h] = lo + (a.upper[e] - lo) * u[h];
+                        p[t + h] = x[t + h];
+                        // pbest = X now (a row whose new fitness is not below 1e30 keeps it); Shrink's second pass
+                        // reads X back
+                        if (id.active) {
+                            pb[e] = x[t + h];
+                            if (shrink) xr[e] = x[t + h];
+                        }
+                    }
+                }
             }
         }
 #pragma unroll
@@ -138,7 +174,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
         if (better)
             for (int e = l; e < n; e += LPR) pb[e] = U[e];
         if (l == 0) {
-            if (better) a.pbestfit[id.row] = fc;
+            if (better)
+                a.pbestfit[id.row] = fc;
+            else if (reseed)
+                a.pbestfit[id.row] = 1.0e30;
             if (a.candfit != nullptr) a.candfit[id.row] = fc;
         }
     }
@@ -247,12 +286,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(co
         for (int k = 1; k < rows_in_block; ++k) m = fmax(m, sr[k]);
         part_r[blockIdx.x] = m;
     }
-}
-
-// order-preserving map double -> uint64 (larger double <=> larger key)
-__device__ __forceinline__ unsigned long long sort_key(double f) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(f);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
 // histogram increment for one key per lane (dig < 0: this lane has none).  Fitness values of a converged swarm
@@ -651,7 +684,13 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     sx_graph *gr = new sx_graph();
     SX_HIP(hipGraphCreate(&gr->graph, 0));
     sx_pso_args args = *a;
+    args.pending_restart = nullptr;
+    // generations 2..ngen of the graph carry out the previous generation's restart themselves (sx_pso_args.pending_restart);
+    // the last one is followed by the apply kernel, so the state a replay leaves behind is complete
+    sx_pso_args args_inline = args;
+    args_inline.pending_restart = sel3;
     void *gen_args[] = {&args, &plan};
+    void *gen_args_inline[] = {&args_inline, &plan};
     // restart kernels' arguments
     const double *fit = a->pbestfit;
     const double *pr = part_r;
@@ -670,7 +709,8 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
         if (int rc = add_kernel_node(gr->graph, &prev, (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n),
-                                     dim3(g.blocks), dim3(g.threads), (unsigned)g.lds, gen_args))
+                                     dim3(g.blocks), dim3(g.threads), (unsigned)g.lds,
+                                     (part_r != nullptr && i > 0) ? gen_args_inline : gen_args))
             return rc;
         if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n,
                                        a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
@@ -682,9 +722,10 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
                                          0, sel_args))
                 return rc;
             const int rpb = 4;
-            if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_apply_kernel,
-                                         dim3((unsigned)((a->P + rpb - 1) / rpb)), dim3(rpb * kWave), 0, app_args))
-                return rc;
+            if (i == ngen - 1)
+                if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_apply_kernel,
+                                             dim3((unsigned)((a->P + rpb - 1) / rpb)), dim3(rpb * kWave), 0, app_args))
+                    return rc;
         }
     }
     SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));

@@ -1,6 +1,8 @@
+"""One CPSO run at BASELINE config 3b (Ackley n=256, P=16384, Philox) for the profiler: python run_cpso_c3b.py [maxiter]"""
 import sys
 sys.path.insert(0, "/root/repo")
 import stochopy_amd as sa
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 r = sa.optimize.minimize(sa.factory.ackley, [[-5.12, 5.12]] * 256, method="cpso",
-                         options={"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "maxiter": 80, "updating": "deferred"})
+                         options={"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "maxiter": m, "updating": "deferred"})
 print(r.nit, r.fun)
