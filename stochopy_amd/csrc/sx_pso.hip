@@ -28,7 +28,9 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-template <int FUN, int RNG, int LPR>
+// FULL: n == 4 * LPR (64, 128 or 256 -- BASELINE config 3): the row length is a compile-time constant, a row is exactly
+// one batch, and every bound check and loop over the row folds away.
+template <int FUN, int RNG, int LPR, bool FULL>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
                                                                                 const PlanArg plan) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     const uint32_t gen = (uint32_t)(st->it + 1);
     const bool want_radius = a.radius_gen != nullptr;  // CPSO: ||X_new - gbest||^2 of the row, in pso_radius_kernel's order
     double racc = 0.0;
-    const int n = a.n;
+    const int n = FULL ? 4 * LPR : a.n;
     const int64_t P = a.P, ld = a.ld;
     const RowIds<LPR> id(P);
     const int l = id.l;  // lane within the row
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
 #pragma unroll
         for (int t = 0; t < kStep; ++t) {
             const int e = (q0 + t) * LPR + l;
-            const bool in = e < n, ld_row = in && !reseed;
+            const bool in = FULL || e < n, ld_row = in && !reseed;
             x[t] = ld_row ? xr[e] : 0.0;
             v[t] = ld_row ? vr[e] : 0.0;
             p[t] = ld_row ? pb[e] : 0.0;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
         racc = sqrt(row_sum<LPR>(racc));
         if (l == 0) sr[id.slot] = id.active ? racc : 0.0;
     }
-    const double fc = row_objective<FUN, LPR>(U, n, plan, l);
+    const double fc = row_objective<FUN, LPR, FULL>(U, n, plan, l);
     const bool better = fc < fold;  // _common.py:127 strict <
     if (id.active) {
         if (better)
@@ -212,27 +214,30 @@ __device__ __forceinline__ int radius_shortcut(const sx_pso_args &a, double &val
 
 typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
 
-template <int RNG, int LPR>
+template <int RNG, int LPR, bool FULL>
 pso_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR>;
-        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR>;
-        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR>;
-        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR>;
-        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR>;
-        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR>;
+        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL>;
+        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL>;
+        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL>;
+        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL>;
+        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL>;
+        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL>;
     }
     return nullptr;
 }
 
 template <int RNG>
 pso_kernel_t pick_kernel(int fun_id, int n) {
-    switch (lanes_per_row(n)) {
-        case 16: return pick_kernel_lpr<RNG, 16>(fun_id);
-        case 32: return pick_kernel_lpr<RNG, 32>(fun_id);
+    const int lpr = lanes_per_row(n);
+    // whole-batch rows with in-kernel draws get the constant-length form (host draws: the run is bound by the host)
+    const bool full = RNG == SX_RNG_PHILOX && n == 4 * lpr;
+    switch (lpr) {
+        case 16: return full ? pick_kernel_lpr<RNG, 16, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 16, false>(fun_id);
+        case 32: return full ? pick_kernel_lpr<RNG, 32, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 32, false>(fun_id);
     }
-    return pick_kernel_lpr<RNG, 64>(fun_id);
+    return full ? pick_kernel_lpr<RNG, 64, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 64, false>(fun_id);
 }
 
 int check_args(const sx_pso_args *a) {

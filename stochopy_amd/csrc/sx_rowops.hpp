@@ -99,7 +99,10 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     }
     lds_wave_fence();  // terms complete
     double sa, sb;
-    if (plan.nleaf > 1)  // uniform: n > 128, leaves reduced in parallel by the row's 8-lane groups
+    // uniform: n > 128, leaves reduced in parallel by the row's 8-lane groups.  (For FULL rows the choice is known at
+    // compile time, and dropping the other branch takes the two-stream PSO kernels from 106 to 81 VGPRs = 6 waves per
+    // SIMD instead of 4 -- measured SLOWER at BASELINE config 3, 48.2 vs 45.0 us: profiles/r2_pso_c3_variants.txt.)
+    if (plan.nleaf > 1)
         row_reduce_leaves<O::TWO, O::BMUL, LPR>(A, B, B + n, B + n + 24, leaf_cap(n), plan, l, sa, sb);
     else
         row_reduce2<O::TWO, O::BMUL>(A, B, B + n, plan, l, sa, sb);
