@@ -330,7 +330,9 @@ int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, const int64
 int sx_pso_restart_select_gathered(const sx_pso_args *a, const double *gathered, int world, double delta,
                                    double gamma, uint64_t *out3, void *stream);
 /* hipGraph of `ngen` generations of the cpso loop body (cpso/_cpso.py:257-307), single GPU + SX_RNG_PHILOX:
- * per generation sx_pso_generation(a, 1) and, when part_r/sel3 are given (CPSO), the three restart kernels.
+ * per generation sx_pso_generation(a, 1) and, when part_r/sel3 are given (CPSO), the radius and selection kernels; a
+ * decided restart is carried out by the next generation's kernel (sx_pso_args.pending_restart, set here), the apply
+ * kernel runs once after the last generation, so X / V / pbest are complete whenever a replay has finished.
  * Replay with sx_graph_launch; launches after convergence are no-ops. */
 int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_r, double delta, double gamma, uint64_t *sel3,
                         sx_graph **out);
