@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     const sx_state *st = a.state;
     if (st->done) return;
     const uint32_t gen = (uint32_t)(st->it + 1);
-    const bool want_radius = a.radius_gen != nullptr;  // CPSO: ||X_new - gbest||^2 of the row, in pso_radius_kernel's order
+    const bool want_radius = a.gen_part != nullptr;  // CPSO: ||X_new - gbest||^2 of the row, in pso_radius_kernel's order
     double racc = 0.0;
     const int n = FULL ? 4 * LPR : a.n;
     const int64_t P = a.P, ld = a.ld;
@@ -185,31 +185,37 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     }
     block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);  // (a workgroup barrier inside)
     if (want_radius && threadIdx.x == 0) {
-        double m = sr[0];
+        // per workgroup: max_i ||X_i - gbest|| (against the gbest the particles were moved with) and the largest
+        // personal-best fitness -- plain stores into arrays the restart kernels read (an atomic max on one word per
+        // quantity was measured first: 2048 workgroups on one address cost the kernel 9 us each)
+        double m = sr[0], fmaxv = -__builtin_huge_val();
         const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
         for (int k = 1; k < rows_in_block; ++k) m = fmax(m, sr[k]);
-        // non-negative doubles order like their bit patterns
-        atomicMax((unsigned long long *)a.radius_gen, (unsigned long long)__double_as_longlong(m));
+        for (int k = 0; k < rows_in_block; ++k)
+            if (si[k] != INT64_MAX) fmaxv = fmax(fmaxv, sf[k]);
+        a.gen_part[blockIdx.x] = m;
+        a.gen_part[gridDim.x + blockIdx.x] = fmaxv;
     }
 }
 
-// What the generation kernel's radius ([0] of radius_gen, see stochopy_hip.h) says after the best/termination step:
-// 0 = nothing (the pass over X is needed), 1 = it IS the swarm radius (gbest did not move), 2 = `bound` is a lower
-// bound of the radius that already rules a restart out (||X_i - g_new|| >= ||X_i - g_old|| - ||g_new - g_old||).
-__device__ __forceinline__ int radius_shortcut(const sx_pso_args &a, double &value) {
-    if (a.radius_gen == nullptr) return 0;
-    const double rg = __longlong_as_double((long long)a.radius_gen[0]);
-    const double thr = __longlong_as_double((long long)a.radius_gen[1]);
+// The generation kernel's radius of THIS workgroup's rows (gen_part, see stochopy_hip.h) after the best/termination
+// step: if gbest did not move it is exact; if it moved by dx, ||X_i - g_new|| >= ||X_i - g_old|| - dx, and a value
+// above delta*sqrt(4n) already rules a restart out whatever the other workgroups find.  In both cases the workgroup
+// passes it on instead of reading its rows again.
+__device__ __forceinline__ bool radius_known(const sx_pso_args &a, int64_t npart, double &value) {
+    if (a.gen_part == nullptr) return false;
+    const double mine = a.gen_part[blockIdx.x];
+    const double thr = a.gen_part[2 * npart];
     const double dx = a.state->dx;  // ||gbest_prev - gbest||_2 of this generation (_common.py:135)
     if (dx == 0.0) {
-        value = rg;
-        return 1;
+        value = mine;
+        return true;
     }
-    if (rg - dx > thr * (1.0 + 1.0e-9)) {
-        value = rg - dx;
-        return 2;
+    if (mine - dx > thr * (1.0 + 1.0e-9)) {
+        value = mine - dx;
+        return true;
     }
-    return 0;
+    return false;
 }
 
 typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
@@ -263,8 +269,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(co
                                                                               double *__restrict__ part_r) {
     __shared__ double sr[kMaxRowsPerBlock];
     if (a.state->done) return;
-    double shortcut;
-    if (radius_shortcut(a, shortcut)) return;  // uniform: the select kernel takes the same decision
+    double known;
+    if (radius_known(a, (int64_t)gridDim.x, known)) {  // uniform over the workgroup
+        if (threadIdx.x == 0) part_r[blockIdx.x] = known;
+        return;
+    }
     const RowIds<LPR> id(a.P);
     const double *__restrict__ xr = a.X + id.rowc * a.ld;
     double acc = 0.0;
@@ -346,21 +355,33 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         if (tid == 0) out[0] = 0;
         return;
     }
-    double m = 0.0;
-    const int shortcut = radius_shortcut(a, m);  // uniform; pso_radius_kernel skipped its pass in the same cases
-    if (!shortcut) {
-        for (int64_t k = tid; k < npart; k += kSelThreads) {
-            const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
-            m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
+    // the keys' range without a pass over them: the smallest personal best is state.gfit, the largest comes per
+    // workgroup from the generation kernel (one swarm segment only)
+    const bool range_known = a.gen_part != nullptr && nseg == 1;
+    __shared__ double sfmax[kSelThreads / kWave];
+    double m = 0.0, fmaxv = -__builtin_huge_val();
+    for (int64_t k = tid; k < npart; k += kSelThreads) {
+        const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
+        m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
+        if (range_known) fmaxv = fmax(fmaxv, a.gen_part[npart + k]);
     }
-    if (lane == 0) smax[wv] = m;
-    __syncthreads();  // (every thread has read radius_gen[0] by now)
-    if (a.radius_gen != nullptr && tid == 0) a.radius_gen[0] = 0ull;  // the next generation starts its maximum afresh
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmax(m, __shfl_xor(m, off, kWave));
+        fmaxv = fmax(fmaxv, __shfl_xor(fmaxv, off, kWave));
+    }
+    if (lane == 0) {
+        smax[wv] = m;
+        sfmax[wv] = fmaxv;
+    }
+    const double gfit = a.state->gfit;
+    __syncthreads();
     m = smax[0];
-    for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
+    fmaxv = sfmax[0];
+    for (int k = 1; k < kSelThreads / kWave; ++k) {
+        m = fmax(m, smax[k]);
+        fmaxv = fmax(fmaxv, sfmax[k]);
+    }
     const double radius = m / sqrt(4.0 * (double)a.n);
     int64_t nw = 0;
     if (radius < delta) {
@@ -398,7 +419,10 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
     //    same all over a converged swarm): find the highest bit in which any two keys differ
     __shared__ unsigned long long s_min[kSelThreads / kWave], s_max[kSelThreads / kWave];
     unsigned long long kmin = ~0ull, kmax = 0ull;
-    if (in_regs) {
+    if (range_known) {
+        kmin = sort_key(gfit);
+        kmax = sort_key(fmaxv);
+    } else if (in_regs) {
 #pragma unroll
         for (int k = 0; k < kSelPerThread; ++k) {
             const int64_t i = (int64_t)k * kSelThreads + tid;
@@ -414,20 +438,22 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
             kmax = kk > kmax ? kk : kmax;
         }
     }
+    if (!range_known) {  // uniform
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long omin = __shfl_xor(kmin, off, kWave), omax = __shfl_xor(kmax, off, kWave);
-        kmin = omin < kmin ? omin : kmin;
-        kmax = omax > kmax ? omax : kmax;
-    }
-    if (lane == 0) {
-        s_min[wv] = kmin;
-        s_max[wv] = kmax;
-    }
-    __syncthreads();
-    for (int k = 0; k < kSelThreads / kWave; ++k) {
-        kmin = s_min[k] < kmin ? s_min[k] : kmin;
-        kmax = s_max[k] > kmax ? s_max[k] : kmax;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long omin = __shfl_xor(kmin, off, kWave), omax = __shfl_xor(kmax, off, kWave);
+            kmin = omin < kmin ? omin : kmin;
+            kmax = omax > kmax ? omax : kmax;
+        }
+        if (lane == 0) {
+            s_min[wv] = kmin;
+            s_max[wv] = kmax;
+        }
+        __syncthreads();
+        for (int k = 0; k < kSelThreads / kWave; ++k) {
+            kmin = s_min[k] < kmin ? s_min[k] : kmin;
+            kmax = s_max[k] > kmax ? s_max[k] : kmax;
+        }
     }
     SEL_TP(3);
     if (kmin == kmax) {  // one value all over the swarm: it is the threshold

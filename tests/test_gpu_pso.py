@@ -130,7 +130,7 @@ def test_cpso_philox_restarts_fire_and_match_oracle(sa):
 def test_cpso_graph_path_equals_stepping_and_oracle(sa, monkeypatch, objective, n, P, maxiter, shrink):
     """Inside a replayed graph (no callback, no history) CPSO takes two shortcuts: the generation kernel records
     max_i ||X_i - gbest|| itself and the restart test only passes over X again when gbest moved while the swarm is small
-    (sx_pso_args.radius_gen; SX_CPSO_GEN_RADIUS=0 switches it off), and a decided restart is carried out by the NEXT
+    (sx_pso_args.gen_part; SX_CPSO_GEN_RADIUS=0 switches it off), and a decided restart is carried out by the NEXT
     generation kernel, which re-seeds the selected rows instead of loading them (sx_pso_args.pending_restart).  Either
     way the run is the generation-by-generation one (history: every restart applied by its own kernel) bit for bit,
     and -- for the +,-,* objectives -- the oracle's, restarts included."""

@@ -1,6 +1,6 @@
 """CPSO at BASELINE config 3b (Ackley n=256, P=16384, Philox): cost per generation over a long run (the restart test
 runs every generation, fires in some) and while the restart fires every generation (short maxiter), with and
-without the generation-side swarm radius (SX_CPSO_GEN_RADIUS, sx_pso_args.radius_gen).  Wall clock around whole
+without the generation-side swarm radius (SX_CPSO_GEN_RADIUS, sx_pso_args.gen_part).  Wall clock around whole
 minimize() calls, two run lengths, minimum of three."""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
