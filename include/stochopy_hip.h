@@ -544,6 +544,10 @@ void sx_mt_uniform_rows(sx_mt *g, const double *lo, const double *hi, int n, int
 void sx_mt_randn(sx_mt *g, double *out, int64_t count);   /* randn / normal(0,1) (polar, cached) */
 void sx_mt_randint(sx_mt *g, int64_t high, int64_t *out, int64_t count); /* randint(high,size=)  */
 void sx_mt_permutation(sx_mt *g, int64_t n, int64_t *out); /* permutation(n)                     */
+/* _common.py:109-120 lhs: rand(P,n) then n x permutation(P); out[i][j] = (x[perm_j[i]][j]) * scale[j] + shift[j] with
+ * x = rand / P + lin[i]; lin (P) = numpy's linspace(-1, 1, P, endpoint=False), scale / shift (n) = 0.5*(upper -/+ lower) */
+void sx_mt_latin_hypercube(sx_mt *g, int64_t P, int n, const double *lin, const double *scale, const double *shift,
+                           double *out);
 /* de/_de.py:304-311 delete_shuffle_sync: P permutations of P-1, first k rows kept: donors[k][P] */
 void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors);
 /* the per-individual draws of ONE de_async generation after r1 (de/_de.py:376-382): for i = 0..P-1

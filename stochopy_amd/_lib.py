@@ -160,6 +160,7 @@ PROTOTYPES = {
     "sx_mt_randn": (None, [vp, vp, i64]),
     "sx_mt_randint": (None, [vp, i64, vp, i64]),
     "sx_mt_permutation": (None, [vp, i64, vp]),
+    "sx_mt_latin_hypercube": (None, [vp, i64, C.c_int, vp, vp, vp, vp]),
     "sx_mt_de_donors": (None, [vp, i64, C.c_int, vp]),
     "sx_mt_de_async_draws": (None, [vp, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "sx_mt_get_state": (None, [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64)]),

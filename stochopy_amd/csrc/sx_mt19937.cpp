@@ -231,6 +231,24 @@ extern "C" void sx_mt_permutation(sx_mt *g, int64_t n, int64_t *out) {
     shuffle(g, out, n);
 }
 
+// _common.py:109-120 (lhs): x = rand(P, n) / P + linspace(-1, 1, P, endpoint=False)[:, None]; column j of the
+// population is column j of x taken in the order of its own permutation(P); then * scale[j] + shift[j].  The caller
+// passes numpy's own linspace / scale / shift vectors, so every number is formed by the operations numpy would use.
+extern "C" void sx_mt_latin_hypercube(sx_mt *g, int64_t P, int n, const double *lin, const double *scale,
+                                      const double *shift, double *out) {
+    std::vector<double> x((size_t)(P * n));
+    fill_doubles(g, x.data(), P * n);
+    const double dP = (double)P;
+    for (int64_t i = 0; i < P; ++i)
+        for (int c = 0; c < n; ++c) x[i * n + c] = x[i * n + c] / dP + lin[i];
+    std::vector<int64_t> perm((size_t)P);
+    for (int c = 0; c < n; ++c) {
+        for (int64_t i = 0; i < P; ++i) perm[i] = i;
+        shuffle(g, perm.data(), P);
+        for (int64_t i = 0; i < P; ++i) out[i * n + c] = x[perm[i] * n + c] * scale[c] + shift[c];
+    }
+}
+
 extern "C" void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors) {
     // individual i: permutation of arange(P) without i; entry t becomes donor t (de/_de.py:304-311)
     std::vector<int32_t> a((size_t)(P - 1));
