@@ -58,7 +58,7 @@ const char *sx_last_error(void);
 /* number of visible HIP devices (<0 on error); used by the loader to fail loudly */
 int sx_device_count(void);
 /* sizeof(sx_state / sx_de_args / sx_pso_args / sx_xchg_args) as compiled: lets a binding check its struct
- * mirror (which: 0 state, 1 DE args, 2 PSO args, 3 exchange args, 4 CMA state, 5 CMA args; -1 otherwise) */
+ * mirror (which: 0 state, 1 DE args, 2 PSO args, 3 exchange args, 4 CMA state, 5 CMA args, 6 VD-CMA args; -1 otherwise) */
 int sx_struct_size(int which);
 
 /* ------------------------------------------------------------------------- *
@@ -503,6 +503,35 @@ int sx_eigh_info(const void *ws, int *sweeps, int *converged, double *off_rel, v
  * (mu rounded up to 8) + 4*64*n doubles; out DEVICE (4,n).  The host keeps the O(n) natural-gradient step. */
 int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
                      const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream);
+
+/* VD-CMA, device-resident generation (csrc/sx_cma_loop.hip): the whole loop body of vdcma/_vdcma.py:232-425 between two
+ * looks of the host at the state -- normals, the mean-shift injection (:241-247), candidates, objective, ranking, the
+ * O(mu n) moment sums, and in ONE workgroup the O(n) part: mean / step (:292-295), the rank-gap step size (:298-306),
+ * the evolution path (:309-314), alpha / beta (:317-328), the moments of the path, the natural gradient and the update
+ * of v and d (:331-378), the stopping rules (cmaes/_cmaes.py:360-434 without the rules that need B, D).
+ * state: an sx_cma_state whose reserved[0..4] = {ps, |v|^2, |v|, injection flag, sqrt(1 + |v|^2) - 1}; sigma_next,
+ * tmp_coef, psnorm unused.  All vectors DEVICE; besthist zero-initialised; hist_x / hist_f as in sx_cma_args or NULL. */
+typedef struct sx_vd_args {
+    double *Z, *ary, *arx;      /* (P,n) normals / steps y / candidates x                              */
+    double *fit;                /* (P)                                                                */
+    double *xmean, *xold, *dx, *dvec, *vvec, *vn, *pc; /* (n)                                         */
+    double *zinj, *dy;          /* (n) the injection's normal row ("row P" of the generation) and +-dy */
+    const double *w;            /* (mu)                                                               */
+    double *mws, *mout;         /* sx_vdcma_moments' workspace and its (4,n) output                    */
+    double *besthist;           /* (maxiter)                                                          */
+    const double *xm, *xstd;    /* (n) un-standardisation                                             */
+    double *xbest;              /* (n) result                                                         */
+    double *hist_x, *hist_f;    /* return_all history slabs or NULL                                   */
+    int64_t *order;             /* (P) argsort of the generation's fitness                             */
+    void *state;                /* sx_cma_state                                                       */
+    int64_t P;
+    int64_t hist_rows;
+    int32_t n, mu, fun_id, maxiter, ilim, pad_;
+    double cs, ds, cc, c1, cmu, mueff, wsum, xtol, ftol, insigma;
+    uint32_t key0, key1;
+} sx_vd_args;
+
+int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Neighbourhood Algorithm: the resampling walk (csrc/sx_na.hip)

@@ -616,7 +616,7 @@ def vd_natural_gradient(dvec, vn, vnn, norm_v, norm_v2, alpha, avec, bsca, invav
 
 
 def run_vdcma(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=10, sigma=0.1, muperc=0.5,
-              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, **_ignored):
+              xtol=1e-8, ftol=1e-8, constraints=None, return_all=False, verbosity=1.0, probe=None, **_ignored):
     """VD-CMA (vdcma/_vdcma.py:144-425): covariance model D (I + v v^T) D, O(n) per sample."""
     if constraints not in (None, "Penalize"):
         raise KeyError(constraints)
@@ -655,6 +655,10 @@ def run_vdcma(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
     it = 0
     while True:
         it += 1
+        if probe is not None:  # tests: the model a generation starts from (copies)
+            before = dict(xmean=xmean.copy(), sigma=sigma, ps=ps, dx=dx.copy(), dvec=dvec.copy(), vvec=vvec.copy(),
+                          vn=vn.copy(), pc=pc.copy(), norm_v2=norm_v2, norm_v=norm_v, inject=inject,
+                          besthist=bestfit_hist.copy())
         arz = stream.cma_normals(it, P, n)                          # :236-247
         ary = dvec * (arz + (np.sqrt(1.0 + norm_v2) - 1.0) * np.outer(np.dot(arz, vn), vn))
         if inject:
@@ -724,6 +728,10 @@ def run_vdcma(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsiz
         vnn = vn**2
         status = cma_stop(it, n, maxiter, xmean, xold, bestfit_hist, arfit, order, sigma, insigma, ilim, pc,
                           xtol, ftol, diagC, None, None)
+        if probe is not None:
+            probe(it, before, dict(arx=arx.copy(), ary=ary.copy(), arfit=arfit.copy(), order=order.copy(), xmean=xmean.copy(),
+                                   dx=dx.copy(), sigma=sigma, ps=ps, pc=pc.copy(), dvec=dvec.copy(), vvec=vvec.copy(),
+                                   vn=vn.copy(), norm_v2=norm_v2, status=status))
         if callback is not None:
             callback(unstd(arxvalid), Result(x=unstd(arxvalid[order[0]]), fun=arfit[order[0]], nfev=nfev, nit=it))
         if status is not None:

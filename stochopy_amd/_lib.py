@@ -74,6 +74,18 @@ class SxCmaState(C.Structure):
                 ("reserved", f64 * 6)]
 
 
+class SxVdArgs(C.Structure):
+    _fields_ = [
+        ("Z", vp), ("ary", vp), ("arx", vp), ("fit", vp), ("xmean", vp), ("xold", vp), ("dx", vp), ("dvec", vp),
+        ("vvec", vp), ("vn", vp), ("pc", vp), ("zinj", vp), ("dy", vp), ("w", vp), ("mws", vp), ("mout", vp),
+        ("besthist", vp), ("xm", vp), ("xstd", vp), ("xbest", vp), ("hist_x", vp), ("hist_f", vp), ("order", vp),
+        ("state", vp), ("P", i64), ("hist_rows", i64),
+        ("n", i32), ("mu", i32), ("fun_id", i32), ("maxiter", i32), ("ilim", i32), ("pad", i32),
+        ("cs", f64), ("ds", f64), ("cc", f64), ("c1", f64), ("cmu", f64), ("mueff", f64), ("wsum", f64), ("xtol", f64),
+        ("ftol", f64), ("insigma", f64), ("key0", C.c_uint32), ("key1", C.c_uint32),
+    ]
+
+
 class SxCmaArgs(C.Structure):
     _fields_ = [
         ("Z", vp), ("arx", vp), ("fit", vp), ("xmean", vp), ("xold", vp), ("ps", vp), ("pc", vp), ("C", vp), ("B", vp),
@@ -148,6 +160,7 @@ PROTOTYPES = {
     "sx_na_uniforms": (C.c_int, [vp, i64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "sx_vdcma_moments": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, f64, vp, vp, vp]),
     "sx_cmaes_generation": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, vp]),
+    "sx_vdcma_generation": (C.c_int, [C.POINTER(SxVdArgs), i64, vp]),
     "sx_eigh_workspace_bytes": (i64, [C.c_int]),
     "sx_eigh": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, vp]),
     "sx_eigh_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64), vp]),

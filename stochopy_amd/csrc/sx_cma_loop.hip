@@ -334,6 +334,23 @@ __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_arg
 
 }  // namespace
 
+namespace sx {
+// shared with the VD-CMA generation (sx_vd_loop.hip)
+int cma_rank_launch(const double *fit, int64_t P, int64_t *order, sx_cma_state *state, double *besthist, int64_t gen,
+                    void *stream) {
+    hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, (hipStream_t)stream, fit, P, order,
+                       state, besthist, gen);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+int cma_history_launch(const sx_cma_args &h, int64_t gen, void *stream) {
+    const int64_t tot = (h.hist_rows > 0 ? h.hist_rows : 1) * h.n;
+    hipLaunchKernelGGL(cma_history_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, gen);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace sx
+
 extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
     SX_REQUIRE(a && a->Z && a->arx && a->fit && a->xmean && a->xold && a->ps && a->pc && a->C && a->B && a->D && a->w &&
                    a->Y && a->part && a->step && a->isc && a->ypart && a->xnew && a->besthist && a->xm && a->xstd && a->xbest && a->eigw && a->order && a->state &&

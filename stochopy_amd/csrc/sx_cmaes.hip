@@ -367,10 +367,16 @@ __global__ __launch_bounds__(256) void vd_sample_kernel(const double *__restrict
                                                         const double *__restrict__ dvec, const double *__restrict__ vn,
                                                         double coef, const double *__restrict__ xmean, double sigma,
                                                         const double *__restrict__ dy, double *__restrict__ ary,
-                                                        double *__restrict__ arx) {
+                                                        double *__restrict__ arx, const sx_cma_state *st) {
     const int lane = (int)(threadIdx.x & 63);
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= P) return;
+    if (st != nullptr) {  // device-resident loop: step size, model coefficient and injection flag live on the device
+        if (st->done) return;
+        sigma = st->sigma;
+        coef = st->reserved[4];
+        if (st->reserved[3] == 0.0) dy = nullptr;
+    }
     const double *z = Z + row * (int64_t)n;
     double t = 0.0;
     // 8 row loads per lane in flight (the row is streamed twice: the second pass hits L2)
@@ -420,10 +426,23 @@ extern "C" int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, 
     const int rows_per_block = 4;
     hipLaunchKernelGGL(vd_sample_kernel, dim3((unsigned)((P + rows_per_block - 1) / rows_per_block)),
                        dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, row0, dvec, vn, coef, xmean, sigma,
-                       dy, ary, arx);
+                       dy, ary, arx, (const sx_cma_state *)nullptr);
     SX_LAUNCH_CHECK();
     return 0;
 }
+
+namespace sx {
+// the same with sigma / coefficient / injection flag read from the device state (sx_vdcma_generation)
+int vd_sample_launch(const double *Z, int64_t P, int n, const double *dvec, const double *vn, const double *xmean,
+                     const double *dy, double *ary, double *arx, const sx_cma_state *st, void *stream) {
+    const int rows_per_block = 4;
+    hipLaunchKernelGGL(vd_sample_kernel, dim3((unsigned)((P + rows_per_block - 1) / rows_per_block)),
+                       dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, (int64_t)0, dvec, vn, 0.0, xmean, 0.0,
+                       dy, ary, arx, st);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace sx
 
 // ---------------------------------------------------------------------------
 // VD-CMA moment sums (stochopy/optimize/vdcma/_vdcma.py:289-295 weighted mean of the selected candidates, :317 the
@@ -465,7 +484,9 @@ __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *_
                                                                  const int64_t *__restrict__ idx, const double *__restrict__ w,
                                                                  const double *__restrict__ tk, int mu, int n,
                                                                  const double *__restrict__ dvec, const double *__restrict__ vn,
-                                                                 double norm_v2, double *__restrict__ part) {
+                                                                 double norm_v2, double *__restrict__ part,
+                                                                 const sx_cma_state *st) {
+    if (st != nullptr) norm_v2 = st->reserved[1];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + tx;
     const int q = blockIdx.y * 4 + ty;
@@ -499,15 +520,23 @@ __global__ __launch_bounds__(256) void vd_moments_finish_kernel(const double *__
 }
 }  // namespace
 
-extern "C" int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
-                                const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream) {
-    SX_REQUIRE(arx && ary && idx && w && dvec && vn && ws && out && mu >= 1 && n >= 1, "sx_vdcma_moments: bad arguments");
+namespace sx {
+int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
+                      const double *dvec, const double *vn, double norm_v2, const sx_cma_state *state, double *ws,
+                      double *out, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     double *tk = ws, *part = ws + ((mu + 7) / 8) * 8;
     hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
     hipLaunchKernelGGL(vd_moments_partial_kernel, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
-                       w, tk, mu, n, dvec, vn, norm_v2, part);
+                       w, tk, mu, n, dvec, vn, norm_v2, part, state);
     hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, n, out);
     SX_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace sx
+
+extern "C" int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
+                                const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream) {
+    SX_REQUIRE(arx && ary && idx && w && dvec && vn && ws && out && mu >= 1 && n >= 1, "sx_vdcma_moments: bad arguments");
+    return sx::vd_moments_launch(arx, ary, idx, w, mu, n, dvec, vn, norm_v2, nullptr, ws, out, stream);
 }

@@ -29,6 +29,7 @@ extern "C" int sx_struct_size(int which) {
         case 3: return (int)sizeof(sx_xchg_args);
         case 4: return (int)sizeof(sx_cma_state);
         case 5: return (int)sizeof(sx_cma_args);
+        case 6: return (int)sizeof(sx_vd_args);
     }
     return -1;
 }

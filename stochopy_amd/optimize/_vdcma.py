@@ -61,10 +61,116 @@ def minimize(
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
     workers = _common.resolve_workers(workers)
+    if (rng == "philox" and isinstance(fun_id, int) and workers == 1 and constraints is None and callback is None
+            and len(lower) <= 4096):
+        # nothing the host has to see between generations: the whole loop (and the history) stays on the device
+        return _VdDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
+                            float(xtol), float(ftol), seed, bool(return_all), float(verbosity)).result()
     run = _VdRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, workers,
                  constraints == "Penalize")
     return run.result()
+
+
+def _strategy_constants(n, P, muperc):
+    """Selection weights and learning rates (vdcma/_vdcma.py:185-199)."""
+    mu = int(muperc * P)
+    w = np.log(mu + 0.5) - np.log(np.arange(1, mu + 1))
+    w /= w.sum()
+    mueff = w.sum() ** 2 / np.square(w).sum()
+    cc = (4.0 + mueff / n) / (n + 4.0 + 2.0 * mueff / n)
+    cfactor = (n - 5.0) / 6.0
+    c1 = cfactor * 2.0 / ((n + 1.3) ** 2 + mueff)
+    cmu = min(1.0 - c1, cfactor * 2.0 * (mueff - 2.0 + 1.0 / mueff) / ((n + 2.0) ** 2 + mueff))
+    return mu, w, mueff, cc, c1, cmu
+
+
+class _VdDeviceRun:
+    """The reference's loop (vdcma/_vdcma.py:232-425) with every per-generation step on the device
+    (csrc/sx_cma_loop.hip, sx_vdcma_generation): the host enqueues generations and looks at the 128-byte state every
+    LOOK of them.  Draws: Philox normals keyed by (seed, generation, row); the injection's normal row is "row P"."""
+
+    LOOK = 16
+
+    def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
+                 verbosity=1.0, run=True):
+        """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
+        with ``step`` from a state of their choosing."""
+        import ctypes as C
+        import time
+
+        ctx = self.ctx = _device.Context()
+        t = _device.torch()
+        ptr, n = _device.ptr, len(lower)
+        with t.cuda.stream(ctx.stream):
+            init = _rng.make_init_stream("philox", seed)
+            key0, key1 = _rng.philox_key(seed)
+            xm, xstd = 0.5 * (upper + lower), 0.5 * (upper - lower)
+            xmean = init.uniform(-1.0, 1.0, n) if x0 is None else (np.asarray(x0, dtype=np.float64) - xm) / xstd
+            mu, w, mueff, cc, c1, cmu = _strategy_constants(n, P, muperc)
+            vvec = init.randn(n) / np.sqrt(n)  # the first direction comes right after the initial mean in the stream
+            norm_v2 = float(np.dot(vvec, vvec))
+            norm_v = float(np.sqrt(norm_v2))
+            keep = self.buffers = dict(
+                Z=ctx.empty((P, n)), ary=ctx.empty((P, n)), arx=ctx.empty((P, n)), fit=ctx.empty((P,)),
+                xmean=ctx.upload(xmean), xold=ctx.zeros((n,)), dx=ctx.zeros((n,)), dvec=ctx.upload(np.ones(n)),
+                vvec=ctx.upload(vvec), vn=ctx.upload(vvec / norm_v), pc=ctx.zeros((n,)), zinj=ctx.empty((n,)),
+                dy=ctx.zeros((n,)), w=ctx.upload(w), mws=ctx.empty((((mu + 7) // 8) * 8 + 4 * 64 * n,)),
+                mout=ctx.empty((4, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
+                xbest=ctx.zeros((n,)), order=ctx.empty((P,), dtype=t.int64))
+            nout = int(np.ceil(verbosity * P)) if return_all else 0
+            if return_all:  # device-side history slabs, read back once at the end
+                keep["hist_x"] = ctx.empty((maxiter, max(1, nout), n))
+                keep["hist_f"] = ctx.empty((maxiter, max(1, nout)))
+            st = _lib.SxCmaState(it=0, nfev=0, best_row=0, fbest=0.0, sigma=sigma, sigma_next=sigma, tmp_coef=0.0,
+                                 psnorm=0.0, status=_lib.SX_STATUS_NONE, done=0, stop_it=0)
+            st.reserved[0], st.reserved[1], st.reserved[2] = 0.0, norm_v2, norm_v           # ps, |v|^2, |v|
+            st.reserved[3], st.reserved[4] = 0.0, float(np.sqrt(1.0 + norm_v2) - 1.0)      # injection off, coefficient
+            d_state = keep["state"] = ctx.upload(np.frombuffer(bytes(st), dtype=np.float64))
+            a = _lib.SxVdArgs(**{k: ptr(v) for k, v in keep.items()})
+            a.P, a.hist_rows, a.n, a.mu, a.fun_id, a.maxiter = P, nout, n, mu, fun_id, maxiter
+            a.ilim = int(10 + 30 * n / P)
+            a.cs, a.ds, a.cc, a.c1, a.cmu, a.mueff, a.wsum = 0.3, float(np.sqrt(n)), cc, c1, cmu, mueff, float(w.sum())
+            a.xtol, a.ftol, a.insigma, a.key0, a.key1 = xtol, ftol, sigma, key0, key1
+            self.args, self.P = a, P
+            if not run:
+                return
+            look, since, t0 = 1, 0, time.perf_counter()
+            state = st
+            for gen in range(1, maxiter + 1):
+                _lib.check(ctx.L.sx_vdcma_generation(C.byref(a), gen, ctx.stream_ptr), "sx_vdcma_generation")
+                since += 1
+                if since >= look or gen == maxiter:
+                    state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
+                    if state.done:
+                        break
+                    now = time.perf_counter()
+                    if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
+                        look *= 2
+                    since, t0 = 0, now
+            if not state.done:  # cannot happen: generation maxiter sets status -1
+                raise RuntimeError("VD-CMA device loop ended without a status")
+            nit = int(state.stop_it)
+            self._res = OptimizeResult(x=keep["xbest"].cpu().numpy(), success=state.status >= 0, status=int(state.status),
+                                       message=_common.messages[int(state.status)], fun=float(state.fbest),
+                                       nfev=nit * P, nit=nit)
+            if return_all:
+                self._res.update({"xall": keep["hist_x"][:nit].cpu().numpy(), "funall": keep["hist_f"][:nit].cpu().numpy()})
+            ctx.sync()
+
+    def step(self, gen):
+        import ctypes as C
+
+        t = _device.torch()
+        with t.cuda.stream(self.ctx.stream):
+            _lib.check(self.ctx.L.sx_vdcma_generation(C.byref(self.args), int(gen), self.ctx.stream_ptr),
+                       "sx_vdcma_generation")
+
+    def read_state(self):
+        return _lib.SxCmaState.from_buffer_copy(self.buffers["state"].cpu().numpy().tobytes())
+
+    def result(self):
+        return self._res
 
 
 def _moments(vn, norm_v2, y, w=None):

@@ -2,6 +2,7 @@
 """Randomised parity of the round-2 paths against the oracle / LAPACK (GPU box):
   eigh   random symmetric matrices (sizes 1..600, several spectra, cold and warm) vs numpy.linalg.eigh
   cmaes  the device-resident loop vs the oracle with LAPACK + canonical signs (mu + 1 >= n shapes)
+  vdcma  the device-resident VD-CMA loop vs the oracle
   na     the Neighbourhood Algorithm vs the oracle, both rng modes (bit for bit on + - * objectives)
   host   plain Python objectives vs the fused run (bit for bit when the objective has the kernel's bits)
 usage: fuzz_round2.py [seconds per family]"""
@@ -82,6 +83,26 @@ def one_cmaes():
     return ok, f"{obj} n={n} P={P} {o}: got {got.fun!r}/{got.nit}/{got.status} ref {ref.fun!r}/{ref.nit}/{ref.status}"
 
 
+def one_vdcma():
+    n = int(rs.choice([6, 7, 9, 16, 33, 64, 100, 257, 700]))
+    P = int(rs.randint(4, 40))
+    obj = str(rs.choice(["rosenbrock", "sphere", "rastrigin"]))
+    o = {"maxiter": int(rs.randint(3, 80)), "popsize": P, "seed": int(rs.randint(1 << 30)), "sigma": float(rs.uniform(0.05, 0.5)),
+         "muperc": float(rs.choice([0.25, 0.5, 1.0]))}
+    if rs.rand() < 0.3:
+        o["return_all"] = True
+        o["verbosity"] = float(rs.choice([0.0, 0.5, 1.0]))
+    if rs.rand() < 0.3:
+        o["ftol"] = float(10 ** rs.uniform(-6, 2))
+    b = [[-float(rs.uniform(1, 6)), float(rs.uniform(1, 6))]] * n
+    ref = oracle.minimize(obj, b, method="vdcma", options=dict(o), rng="philox")
+    got = sa.optimize.minimize(getattr(sa.factory, obj), b, method="vdcma", options=dict(o, backend="hip", rng="philox"))
+    ok = (got.nit, got.status) == (ref.nit, ref.status) and np.isclose(got.fun, ref.fun, rtol=1e-5, atol=1e-12)
+    if ok and "return_all" in o:
+        ok = got.funall.shape == ref.funall.shape and np.allclose(got.funall, ref.funall, rtol=1e-5, atol=1e-12)
+    return ok, f"{obj} n={n} P={P} {o}: got {got.fun!r}/{got.nit}/{got.status} ref {ref.fun!r}/{ref.nit}/{ref.status}"
+
+
 def one_na():
     n = int(rs.randint(1, 9))
     P = int(rs.randint(2, 30))
@@ -116,7 +137,11 @@ def one_host():
 
 
 bad = 0
-for name, fn in (("eigh", one_eigh), ("cmaes device loop", one_cmaes), ("na", one_na), ("host callable", one_host)):
+only = os.environ.get("FUZZ_ONLY")
+for name, fn in (("eigh", one_eigh), ("cmaes device loop", one_cmaes), ("vdcma device loop", one_vdcma), ("na", one_na),
+                 ("host callable", one_host)):
+    if only and only not in name:
+        continue
     bad += family(name, fn)
 print("TOTAL mismatches:", bad)
 sys.exit(1 if bad else 0)
