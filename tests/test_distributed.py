@@ -362,8 +362,13 @@ def test_sharded_vdcma_matches_single_gpu(rng):
     n = 30
     opts = {"maxiter": 40, "popsize": 20, "seed": 8, "sigma": 0.25, "rng": rng}
     cfg = {"n": n, "objective": "rosenbrock", "method": "vdcma", "options": opts}
+    # the sharded run is driven by the host loop; with a callback so is the single-GPU run (bit-identical), without
+    # one the Philox run stays on the device (csrc/sx_vd_loop.hip: other summation orders, same run to rounding)
     one = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="vdcma",
-                               options=dict(opts, backend="hip"))
+                               options=dict(opts, backend="hip"), callback=lambda X, r: None)
+    resident = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="vdcma",
+                                    options=dict(opts, backend="hip"))
+    assert (resident.nit, resident.status) == (one.nit, one.status) and np.isclose(resident.fun, one.fun, rtol=1e-6)
     out = _spawn(gpu_minimize_worker, 2, cfg)
     for r in range(2):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
