@@ -249,13 +249,22 @@ __global__ __launch_bounds__(256) void cma_normals_kernel(double *__restrict__ Z
     if (row >= P) return;
     const uint32_t grow = (uint32_t)(row0 + row);
     const uint32_t lpr = (uint32_t)lanes_per_row(n);  // same element -> (slot, half) layout as the row kernels
-    for (int e = lane; e < n; e += kWave) {
-        const uint32_t q = (uint32_t)e / lpr, l = (uint32_t)e & (lpr - 1u);
-        const U4 w = philox4x32_10((q >> 1) * lpr + l, grow, gen, kPurposeCmaNormal, k0, k1);
+    // elements (2k)*lpr + l and (2k+1)*lpr + l are the cosine and the sine half of ONE call (slot k*lpr + l): a lane
+    // takes both, so the generator, the logarithm, the square root and the angle reduction run once per pair
+    const int npair = ((n + 2 * (int)lpr - 1) / (2 * (int)lpr)) * (int)lpr;
+    double *zr = Z + row * (int64_t)n;
+    for (int j = lane; j < npair; j += kWave) {
+        const uint32_t k = (uint32_t)j / lpr, l = (uint32_t)j & (lpr - 1u);
+        const int e0 = (int)(2u * k * lpr + l), e1 = e0 + (int)lpr;
+        if (e0 >= n) continue;
+        const U4 w = philox4x32_10(k * lpr + l, grow, gen, kPurposeCmaNormal, k0, k1);
         const double d0 = u53(w.x, w.y), d1 = u53(w.z, w.w);
         const double rad = sqrt(-2.0 * log(1.0 - d0));
         const double ang = 6.283185307179586 * d1;
-        Z[row * (int64_t)n + e] = (q & 1u) ? rad * sin(ang) : rad * cos(ang);
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        zr[e0] = rad * cs;
+        if (e1 < n) zr[e1] = rad * sn;
     }
 }
 
