@@ -516,16 +516,25 @@ __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *_
     part[o] = awx, part[plane + o] = awy, part[2 * plane + o] = ap, part[3 * plane + o] = aq;
 }
 
+// grid: ceil(n/64) x 4 outputs; the 64 partial rows of a column are added in their order (four slices of 16, then the
+// slices in order: the same value as one thread adding all 64 would NOT be bit-identical, and need not be -- the
+// device loop and the host loop are compared to rounding)
 __global__ __launch_bounds__(256) void vd_moments_finish_kernel(const double *__restrict__ part, int n, double *__restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    __shared__ double sl[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx, o = blockIdx.y;
     const int64_t plane = (int64_t)kVdPart * n;
+    double s = 0.0;
+    if (e < n) {
+        double v[kVdPart / 4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        double s = 0.0;
-        for (int q = 0; q < kVdPart; ++q) s += part[o * plane + (int64_t)q * n + e];
-        out[(int64_t)o * n + e] = s;
+        for (int q = 0; q < kVdPart / 4; ++q) v[q] = part[o * plane + (int64_t)(ty * (kVdPart / 4) + q) * n + e];
+#pragma unroll
+        for (int q = 0; q < kVdPart / 4; ++q) s += v[q];
     }
+    sl[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < n) out[(int64_t)o * n + e] = ((sl[0][tx] + sl[1][tx]) + sl[2][tx]) + sl[3][tx];
 }
 }  // namespace
 
@@ -538,7 +547,7 @@ int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, 
     hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
     hipLaunchKernelGGL(vd_moments_partial_kernel, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
                        w, tk, mu, n, dvec, vn, norm_v2, part, state);
-    hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, n, out);
+    hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 63) / 64), 4), dim3(256), 0, st, part, n, out);
     SX_LAUNCH_CHECK();
     return 0;
 }
