@@ -282,14 +282,6 @@ typedef struct sx_pso_args {
     int64_t *part_i;        /* DEVICE (sx_num_partials(P,n))                          */
     const double *r1;       /* DEVICE (P,n) rand(P,n), cpso/_cpso.py:262  (SX_RNG_HOST) */
     const double *r2;       /* DEVICE (P,n) rand(P,n), cpso/_cpso.py:263  (SX_RNG_HOST) */
-    double *gen_part;       /* DEVICE (2*sx_num_partials(P,n) + 1) or NULL.  CPSO on one GPU: sx_pso_generation also
-                             * stores, per workgroup b, [b] = max_i ||X_i - gbest||_2 over its rows (new positions, the
-                             * gbest they were moved with) and [npart + b] = the largest pbestfit of its rows;
-                             * [2*npart] = delta*sqrt(4n), host-set.  With it a workgroup of sx_pso_radius skips its
-                             * pass over X when gbest did not move this generation (state.dx == 0: its value IS the
-                             * radius of cpso/_cpso.py:410) or when value - dx already exceeds delta*sqrt(4n) (no
-                             * restart whatever the others find), and sx_pso_restart_select takes the keys' range from
-                             * state.gfit and [npart ..) instead of a min/max pass over pbestfit. */
     const uint64_t *pending_restart; /* DEVICE (3) or NULL: an sx_pso_restart_select decision (its out3) of the
                              * PREVIOUS generation that sx_pso_restart_apply has not carried out: the generation kernel
                              * re-seeds those rows itself (same Philox positions, V = 0, pbest = X, pbestfit = 1e30,

@@ -50,7 +50,7 @@ class SxDeArgs(C.Structure):
 class SxPsoArgs(C.Structure):
     _fields_ = [
         ("X", vp), ("V", vp), ("pbest", vp), ("pbestfit", vp), ("candfit", vp), ("gbest", vp), ("lower", vp),
-        ("upper", vp), ("state", vp), ("part_f", vp), ("part_i", vp), ("r1", vp), ("r2", vp), ("gen_part", vp), ("pending_restart", vp),
+        ("upper", vp), ("state", vp), ("part_f", vp), ("part_i", vp), ("r1", vp), ("r2", vp), ("pending_restart", vp),
         ("P", i64), ("ld", i64), ("row0", i64),
         ("n", i32), ("fun_id", i32), ("constraints", i32), ("rng", i32), ("maxiter", i32), ("pad", i32),
         ("w", f64), ("c1", f64), ("c2", f64), ("xtol", f64), ("ftol", f64),

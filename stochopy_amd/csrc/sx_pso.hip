@@ -36,12 +36,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
-    __shared__ double sr[kMaxRowsPerBlock];
     const sx_state *st = a.state;
     if (st->done) return;
     const uint32_t gen = (uint32_t)(st->it + 1);
-    const bool want_radius = a.gen_part != nullptr;  // CPSO: ||X_new - gbest||^2 of the row, in pso_radius_kernel's order
-    double racc = 0.0;
     const int n = FULL ? 4 * LPR : a.n;
     const int64_t P = a.P, ld = a.ld;
     const RowIds<LPR> id(P);
@@ -140,10 +137,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                         vr[e] = vn;
                         xr[e] = xn;
                     }
-                    if (want_radius) {
-                        const double dg = xn - g[t];
-                        racc += dg * dg;
-                    }
                 }
             }
         }
@@ -160,15 +153,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                 vr[e] = vn;
                 xr[e] = xn;
             }
-            if (want_radius) {
-                const double dg = xn - gb[e];
-                racc += dg * dg;
-            }
         }
-    }
-    if (want_radius) {
-        racc = sqrt(row_sum<LPR>(racc));
-        if (l == 0) sr[id.slot] = id.active ? racc : 0.0;
     }
     const double fc = row_objective<FUN, LPR, FULL>(U, n, plan, l);
     const bool better = fc < fold;  // _common.py:127 strict <
@@ -183,39 +168,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             if (a.candfit != nullptr) a.candfit[id.row] = fc;
         }
     }
-    block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);  // (a workgroup barrier inside)
-    if (want_radius && threadIdx.x == 0) {
-        // per workgroup: max_i ||X_i - gbest|| (against the gbest the particles were moved with) and the largest
-        // personal-best fitness -- plain stores into arrays the restart kernels read (an atomic max on one word per
-        // quantity was measured first: 2048 workgroups on one address cost the kernel 9 us each)
-        double m = sr[0], fmaxv = -__builtin_huge_val();
-        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
-        for (int k = 1; k < rows_in_block; ++k) m = fmax(m, sr[k]);
-        for (int k = 0; k < rows_in_block; ++k)
-            if (si[k] != INT64_MAX) fmaxv = fmax(fmaxv, sf[k]);
-        a.gen_part[blockIdx.x] = m;
-        a.gen_part[gridDim.x + blockIdx.x] = fmaxv;
-    }
-}
-
-// The generation kernel's radius of THIS workgroup's rows (gen_part, see stochopy_hip.h) after the best/termination
-// step: if gbest did not move it is exact; if it moved by dx, ||X_i - g_new|| >= ||X_i - g_old|| - dx, and a value
-// above delta*sqrt(4n) already rules a restart out whatever the other workgroups find.  In both cases the workgroup
-// passes it on instead of reading its rows again.
-__device__ __forceinline__ bool radius_known(const sx_pso_args &a, int64_t npart, double &value) {
-    if (a.gen_part == nullptr) return false;
-    const double mine = a.gen_part[blockIdx.x];
-    const double thr = a.gen_part[2 * npart];
-    const double dx = a.state->dx;  // ||gbest_prev - gbest||_2 of this generation (_common.py:135)
-    if (dx == 0.0) {
-        value = mine;
-        return true;
-    }
-    if (mine - dx > thr * (1.0 + 1.0e-9)) {
-        value = mine - dx;
-        return true;
-    }
-    return false;
+    block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
 }
 
 typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
@@ -269,11 +222,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(co
                                                                               double *__restrict__ part_r) {
     __shared__ double sr[kMaxRowsPerBlock];
     if (a.state->done) return;
-    double known;
-    if (radius_known(a, (int64_t)gridDim.x, known)) {  // uniform over the workgroup
-        if (threadIdx.x == 0) part_r[blockIdx.x] = known;
-        return;
-    }
     const RowIds<LPR> id(a.P);
     const double *__restrict__ xr = a.X + id.rowc * a.ld;
     double acc = 0.0;
@@ -355,33 +303,17 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         if (tid == 0) out[0] = 0;
         return;
     }
-    // the keys' range without a pass over them: the smallest personal best is state.gfit, the largest comes per
-    // workgroup from the generation kernel (one swarm segment only)
-    const bool range_known = a.gen_part != nullptr && nseg == 1;
-    __shared__ double sfmax[kSelThreads / kWave];
-    double m = 0.0, fmaxv = -__builtin_huge_val();
+    double m = 0.0;
     for (int64_t k = tid; k < npart; k += kSelThreads) {
         const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
         m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
-        if (range_known) fmaxv = fmax(fmaxv, a.gen_part[npart + k]);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m = fmax(m, __shfl_xor(m, off, kWave));
-        fmaxv = fmax(fmaxv, __shfl_xor(fmaxv, off, kWave));
-    }
-    if (lane == 0) {
-        smax[wv] = m;
-        sfmax[wv] = fmaxv;
-    }
-    const double gfit = a.state->gfit;
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
+    if (lane == 0) smax[wv] = m;
     __syncthreads();
     m = smax[0];
-    fmaxv = sfmax[0];
-    for (int k = 1; k < kSelThreads / kWave; ++k) {
-        m = fmax(m, smax[k]);
-        fmaxv = fmax(fmaxv, sfmax[k]);
-    }
+    for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
     const double radius = m / sqrt(4.0 * (double)a.n);
     int64_t nw = 0;
     if (radius < delta) {
@@ -419,10 +351,7 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
     //    same all over a converged swarm): find the highest bit in which any two keys differ
     __shared__ unsigned long long s_min[kSelThreads / kWave], s_max[kSelThreads / kWave];
     unsigned long long kmin = ~0ull, kmax = 0ull;
-    if (range_known) {
-        kmin = sort_key(gfit);
-        kmax = sort_key(fmaxv);
-    } else if (in_regs) {
+    if (in_regs) {
 #pragma unroll
         for (int k = 0; k < kSelPerThread; ++k) {
             const int64_t i = (int64_t)k * kSelThreads + tid;
@@ -438,22 +367,20 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
             kmax = kk > kmax ? kk : kmax;
         }
     }
-    if (!range_known) {  // uniform
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long omin = __shfl_xor(kmin, off, kWave), omax = __shfl_xor(kmax, off, kWave);
-            kmin = omin < kmin ? omin : kmin;
-            kmax = omax > kmax ? omax : kmax;
-        }
-        if (lane == 0) {
-            s_min[wv] = kmin;
-            s_max[wv] = kmax;
-        }
-        __syncthreads();
-        for (int k = 0; k < kSelThreads / kWave; ++k) {
-            kmin = s_min[k] < kmin ? s_min[k] : kmin;
-            kmax = s_max[k] > kmax ? s_max[k] : kmax;
-        }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long omin = __shfl_xor(kmin, off, kWave), omax = __shfl_xor(kmax, off, kWave);
+        kmin = omin < kmin ? omin : kmin;
+        kmax = omax > kmax ? omax : kmax;
+    }
+    if (lane == 0) {
+        s_min[wv] = kmin;
+        s_max[wv] = kmax;
+    }
+    __syncthreads();
+    for (int k = 0; k < kSelThreads / kWave; ++k) {
+        kmin = s_min[k] < kmin ? s_min[k] : kmin;
+        kmax = s_max[k] > kmax ? s_max[k] : kmax;
     }
     SEL_TP(3);
     if (kmin == kmax) {  // one value all over the swarm: it is the threshold

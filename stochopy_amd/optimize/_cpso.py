@@ -233,15 +233,6 @@ class _PsoRun:
         a.maxiter = self.maxiter
         a.w, a.c1, a.c2, a.xtol, a.ftol = self.w, self.c1, self.c2, self.xtol, self.ftol
         a.key0, a.key1 = key0, key1
-        if (self.gamma and self.world is None and self.rng == "philox" and self.external is None and not self.immediate
-                and os.environ.get("SX_CPSO_GEN_RADIUS") != "0"):
-            # the generation kernel records, per workgroup, max_i ||X_i - gbest|| and the largest pbestfit (stochopy_hip.h,
-            # sx_pso_args.gen_part): the restart test's pass over X (cpso/_cpso.py:410) is then only run where gbest
-            # moved AND the swarm is small, and the selection knows the range of its keys without a pass over them
-            gp = np.zeros(2 * npart + 1)
-            gp[2 * npart] = self.delta * np.sqrt(4.0 * n)
-            self.gen_part = ctx.upload(gp)
-            a.gen_part = self.gen_part.data_ptr()
         self.args = a
         if self.rng == "numpy-legacy":
             self.h_r = [t.empty((P, n), dtype=t.float64).pin_memory() for _ in range(2)]
@@ -484,6 +475,8 @@ class _PsoRun:
         t = _device.torch()
         try:
             self.ctx.sync()
+            if self.world is not None:
+                self.world.quiesce_for_capture(self.ctx)
             g = t.cuda.CUDAGraph()
             with t.cuda.graph(g, stream=self.ctx.stream):
                 for _ in range(self.GRAPH_CHUNK):

@@ -302,7 +302,7 @@ class _DeRun:
             return False
         t = _device.torch()
         try:
-            self.ctx.sync()
+            self.world.quiesce_for_capture(self.ctx)
             g = t.cuda.CUDAGraph()
             with t.cuda.graph(g, stream=self.ctx.stream):
                 for _ in range(self.GRAPH_CHUNK):
@@ -575,6 +575,8 @@ class _DeRun:
         it0 = self.it_enq
         try:
             self.ctx.sync()
+            if self.world is not None:
+                self.world.quiesce_for_capture(self.ctx)
             g = t.cuda.CUDAGraph()
             with t.cuda.graph(g, stream=self.ctx.stream):
                 for _ in range(self.EXT_CHUNK):

@@ -53,6 +53,20 @@ class World:
     def shard(self, popsize):
         return shard_bounds(popsize, self.size, self.rank)
 
+    def quiesce_for_capture(self, ctx):
+        """Call right before capturing collectives of this group into a graph.  torch's ProcessGroupNCCL runs a
+        watchdog thread that polls the completion events of outstanding collectives every 100 ms; if it polls one while
+        this thread is capturing, HIP answers hipErrorCapturedEvent ("operation not permitted on an event last recorded
+        in a capturing stream"), the watchdog throws and the process aborts -- seen once in ~20 captures on the GPU
+        box.  Draining the stream and then giving the watchdog three of its periods retires every outstanding work
+        from its list first, so it has nothing to poll while the (few ms) capture runs."""
+        if self.backend != "nccl":
+            return
+        import time
+
+        ctx.sync()
+        time.sleep(0.35)
+
     def all_gather_records(self, record, out):
         """out[(world, n+2)] <- every rank's record[(n+2,)].  Device tensors; asynchronous with "nccl"."""
         if self.backend == "nccl":

@@ -127,28 +127,20 @@ def test_cpso_philox_restarts_fire_and_match_oracle(sa):
                                                           ("rosenbrock", 130, 512, 80, "Shrink"), ("sphere", 8, 4000, 60, None),
                                                           ("sphere", 600, 48, 110, "Shrink"), ("rosenbrock", 300, 512, 60, None),
                                                           ("sphere", 40, 130, 170, "Shrink")])
-def test_cpso_graph_path_equals_stepping_and_oracle(sa, monkeypatch, objective, n, P, maxiter, shrink):
-    """Inside a replayed graph (no callback, no history) CPSO takes two shortcuts: the generation kernel records
-    max_i ||X_i - gbest|| itself and the restart test only passes over X again when gbest moved while the swarm is small
-    (sx_pso_args.gen_part; SX_CPSO_GEN_RADIUS=0 switches it off), and a decided restart is carried out by the NEXT
-    generation kernel, which re-seeds the selected rows instead of loading them (sx_pso_args.pending_restart).  Either
-    way the run is the generation-by-generation one (history: every restart applied by its own kernel) bit for bit,
-    and -- for the +,-,* objectives -- the oracle's, restarts included."""
+def test_cpso_graph_path_equals_stepping_and_oracle(sa, objective, n, P, maxiter, shrink):
+    """Inside a replayed graph (no callback, no history) a decided restart is carried out by the NEXT generation kernel,
+    which re-seeds the selected rows instead of loading them (sx_pso_args.pending_restart); the apply kernel runs once
+    at the end of a replay.  The run is the generation-by-generation one (history: every restart applied by its own
+    kernel) bit for bit, and -- for the +,-,* objectives -- the oracle's, restarts included."""
     opts = {"maxiter": maxiter, "popsize": P, "seed": 21, "updating": "deferred", "backend": "hip", "rng": "philox",
             "constraints": shrink}
     bounds = [[-5.12, 5.12]] * n
     fun = getattr(sa.factory, objective)
-    runs = {}
-    for knob in ("1", "0"):
-        monkeypatch.setenv("SX_CPSO_GEN_RADIUS", knob)
-        runs[knob] = (sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts)),
-                      sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts, return_all=True)))
-    for a, b in zip(runs["1"], runs["0"]):
-        assert a.fun == b.fun and np.array_equal(a.x, b.x) and (a.nit, a.status) == (b.nit, b.status)
-    assert np.array_equal(runs["1"][1].xall, runs["0"][1].xall) and np.array_equal(runs["1"][1].funall, runs["0"][1].funall)
-    assert runs["1"][0].fun == runs["1"][1].fun
+    graph = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
+    step = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts, return_all=True))
+    assert graph.fun == step.fun and np.array_equal(graph.x, step.x) and (graph.nit, graph.status) == (step.nit, step.status)
     if objective != "ackley":  # restarts do fire in these runs (the oracle counts them)
         ref = oracle.minimize(objective, bounds, method="cpso", rng="philox",
                               options={k: v for k, v in opts.items() if k not in ("backend", "rng")})
         assert len(ref["_restarts"]) > 3, len(ref["_restarts"])
-        assert ref.fun == runs["1"][0].fun and np.array_equal(ref.x, runs["1"][0].x) and ref.nit == runs["1"][0].nit
+        assert ref.fun == graph.fun and np.array_equal(ref.x, graph.x) and ref.nit == graph.nit

@@ -47,7 +47,7 @@ def test_struct_layouts_match_the_header(lib):
     assert C.sizeof(_lib.SxXchgArgs) == lib.sx_struct_size(3)
     # field offsets of the scalars that follow the pointer block
     assert _lib.SxDeArgs.P.offset == 14 * 8 and _lib.SxDeArgs.key0.offset == C.sizeof(_lib.SxDeArgs) - 8
-    assert _lib.SxPsoArgs.P.offset == 15 * 8 and _lib.SxPsoArgs.key0.offset == C.sizeof(_lib.SxPsoArgs) - 8
+    assert _lib.SxPsoArgs.P.offset == 14 * 8 and _lib.SxPsoArgs.key0.offset == C.sizeof(_lib.SxPsoArgs) - 8
 
 
 class Stream:

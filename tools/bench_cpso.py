@@ -1,8 +1,7 @@
 """CPSO at BASELINE config 3b (Ackley n=256, P=16384, Philox): cost per generation over a long run (the restart test
-runs every generation, fires in some) and while the restart fires every generation (short maxiter), with and
-without the generation-side swarm radius (SX_CPSO_GEN_RADIUS, sx_pso_args.gen_part).  Wall clock around whole
-minimize() calls, two run lengths, minimum of three."""
-import os, sys, time
+runs every generation, fires in some) and while the restart fires every generation (short maxiter), PSO next to it.
+Wall clock around whole minimize() calls, two run lengths, minimum of three."""
+import sys, time
 sys.path.insert(0, "/root/repo")
 import torch
 import stochopy_amd as sa
@@ -27,9 +26,8 @@ def per_gen(method, short, long):
 
 
 wall("cpso", 20)
-for knob in ("1", "0", "1", "0"):
-    os.environ["SX_CPSO_GEN_RADIUS"] = knob
-    print(f"generation-side radius {'on ' if knob == '1' else 'off'}: long run {per_gen('cpso', 200, 1200):6.1f} us/gen "
-          f"({16384 / per_gen('cpso', 200, 1200) * 1e6:.3e} evals/s)   restart firing every generation "
+for _ in range(2):
+    v = per_gen("cpso", 200, 1200)
+    print(f"cpso: long run {v:6.1f} us/gen ({16384 / v * 1e6:.3e} evals/s)   restart firing every generation "
           f"{per_gen('cpso', 20, 120):6.1f} us/gen", flush=True)
 print(f"pso (no restart test) for comparison: {per_gen('pso', 200, 1200):6.1f} us/gen")
