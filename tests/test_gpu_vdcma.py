@@ -179,3 +179,17 @@ def test_vdcma_device_loop_matches_oracle(sa, objective, n, P, maxiter, extra):
     cb = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="vdcma",
                               options=dict(opts, backend="hip", rng="philox"), callback=lambda X, r: trace.append(r.fun))
     assert (cb.nit, cb.status) == (got.nit, got.status) and np.isclose(cb.fun, got.fun, rtol=1e-6, atol=1e-300)
+
+
+def test_vdcma_device_loop_small_shapes_and_short_runs(sa):
+    """n = 2 ... 7 (n <= 5: the learning rates c1, cmu are zero or negative, so d and v stay put), popsize 2 ... 8,
+    1 ... 30 generations: the device-resident loop stops where the oracle stops, with its result."""
+    for n in (2, 3, 5, 6, 7):
+        for P in (2, 3, 8):
+            for maxiter in (1, 2, 5, 30):
+                o = dict(maxiter=maxiter, popsize=P, sigma=0.3, seed=3)
+                b = [[-2.0, 3.0]] * n
+                ref = oracle.minimize("sphere", b, method="vdcma", options=dict(o), rng="philox")
+                got = sa.optimize.minimize(sa.factory.sphere, b, method="vdcma", options=dict(o, backend="hip", rng="philox"))
+                assert (got.nit, got.status) == (ref.nit, ref.status), (n, P, maxiter)
+                assert np.isclose(got.fun, ref.fun, rtol=1e-6, atol=1e-12), (n, P, maxiter)
