@@ -346,6 +346,49 @@ __device__ __forceinline__ double row_lane_value(double v, int idx, int l) {
     return __shfl(v, (int)(threadIdx.x & 63) - l + idx, kWave);
 }
 
+// Rows of exactly M = 64, 128 or 256 terms (the PSO kernel's whole-batch rows with an objective that has one term per
+// element): numpy's plan is known when the kernel is compiled -- one leaf of M/8 blocks, or two leaves of 16 -- so
+// the chain, the tree and the leaf sum are straight-line code instead of loops over the plan arrays (scalar loads,
+// selects and bound checks per step).  Same additions in the same order as row_reduce2 / row_reduce_leaves: same bits.
+template <bool TWO, bool BMUL, int LPR, int M>
+__device__ __forceinline__ void row_reduce_fixed(const double *A, const double *B, int l, double &sa, double &sb) {
+    static_assert(M == 64 || M == 128 || M == 256, "one or two full leaves");
+    constexpr int NLEAF = M > 128 ? 2 : 1;
+    constexpr int BLK = M / NLEAF / kGroup;  // blocks per leaf: 8 or 16
+    const int j = l & (kGroup - 1), grp = l >> 3;
+    const int leaf = (NLEAF == 2 && grp == 1) ? 1 : 0;  // the other lane groups repeat leaf 0 (LDS broadcasts)
+    const double identB = BMUL ? 1.0 : 0.0;
+    const double *a = A + leaf * (BLK * kGroup) + j, *b = B + leaf * (BLK * kGroup) + j;
+    double chA = 0.0, chB = identB;
+#pragma unroll
+    for (int h = 0; h < BLK; h += 8) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            va[t] = a[(h + t) * kGroup];
+            vb[t] = TWO ? b[(h + t) * kGroup] : identB;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (h + t == 0) {
+                chA = va[0];
+                chB = vb[0];
+            } else {
+                chA = chA + va[t];
+                if (TWO) chB = combine<BMUL>(chB, vb[t]);
+            }
+        }
+    }
+    double curA = group_tree<false>(chA);
+    double curB = TWO ? group_tree<BMUL>(chB) : identB;
+    if (NLEAF == 2) {  // leaf 0 lives in lane group 0, leaf 1 in group 1
+        curA = row_lane_value<LPR>(curA, 0, l) + row_lane_value<LPR>(curA, kGroup, l);
+        if (TWO) curB = combine<BMUL>(row_lane_value<LPR>(curB, 0, l), row_lane_value<LPR>(curB, kGroup, l));
+    }
+    sa = 0.0 + curA;  // add.reduce starts from the identity
+    sb = (TWO && !BMUL) ? 0.0 + curB : curB;
+}
+
 // Rows with several leaves (n > 128): the leaves of numpy's recursion are independent, so the LPR/8
 // 8-lane groups of the row take one leaf each (chain + tree [+ tail]); the leaf sums meet in LDS and are
 // then merged in recursion order.  L: 2*leaf_cap doubles of LDS scratch (leaf sums), S: the merge stack.

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             }
         }
     }
-    const double fc = row_objective<FUN, LPR, FULL>(U, n, plan, l);
+    const double fc = row_objective<FUN, LPR, FULL, FULL ? 4 * LPR : 0>(U, n, plan, l);
     const bool better = fc < fold;  // _common.py:127 strict <
     if (id.active) {
         if (better)

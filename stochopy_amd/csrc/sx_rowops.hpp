@@ -65,7 +65,8 @@ __device__ __forceinline__ double row_sum(double v) {
 // Objective of the row staged in LDS at U[0..n): terms by the row's LPR lanes -> A/B (behind U),
 // then the numpy-order row sums (lanes l >= 8 repeat the chains of lanes l & 7: LDS broadcasts, same bits).
 // Every lane of the row returns the value.  Each row works on its own LDS slice (no workgroup barrier).
-template <int FUN, int LPR, bool FULL = false>
+// NFIX: the row length when it is a compile-time constant (the PSO kernel's whole-batch rows), else 0
+template <int FUN, int LPR, bool FULL = false, int NFIX = 0>
 __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg &plan, int l) {
     using O = Obj<FUN>;
     const int m = O::NEXT ? n - 1 : n;
@@ -99,6 +100,10 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     }
     lds_wave_fence();  // terms complete
     double sa, sb;
+    if constexpr (NFIX != 0 && !O::NEXT && NFIX <= 256) {
+        row_reduce_fixed<O::TWO, O::BMUL, LPR, NFIX>(A, B, l, sa, sb);
+        return O::finish(sa, sb, n);
+    }
     // uniform: n > 128, leaves reduced in parallel by the row's 8-lane groups.  (For FULL rows the choice is known at
     // compile time, and dropping the other branch takes the two-stream PSO kernels from 106 to 81 VGPRs = 6 waves per
     // SIMD instead of 4 -- measured SLOWER at BASELINE config 3, 48.2 vs 45.0 us: profiles/r2_pso_c3_variants.txt.)

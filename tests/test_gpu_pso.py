@@ -74,7 +74,7 @@ def test_pso_reference_suite_xrefs(sa, tag):
 
 @pytest.mark.parametrize("method", ["pso", "cpso"])
 @pytest.mark.parametrize("constraints", [None, "Shrink"])
-@pytest.mark.parametrize("shape", [(5, 12), (37, 100), (130, 256), (300, 64)])
+@pytest.mark.parametrize("shape", [(5, 12), (37, 100), (130, 256), (300, 64), (64, 40), (128, 33), (256, 70)])
 def test_pso_philox_matches_oracle(sa, method, constraints, shape):
     """Philox mode: device draws == oracle PhiloxStream; +,-,* objective => bit-identical traces."""
     n, P = shape
@@ -91,6 +91,23 @@ def test_pso_philox_matches_oracle(sa, method, constraints, shape):
         assert fa == fb
         assert np.array_equal(Xa, Xb)
     assert np.array_equal(r_ref.x, r_got.x) and r_ref.nit == r_got.nit and r_ref.status == r_got.status
+
+
+@pytest.mark.parametrize("objective", ["sphere", "quartic", "styblinski_tang"])
+@pytest.mark.parametrize("shape", [(64, 40), (128, 33), (256, 70), (256, 2048)])
+def test_pso_whole_batch_rows_match_oracle(sa, objective, shape):
+    """Rows of exactly 64 / 128 / 256 elements take the kernel in which the row length -- and with it numpy's summation
+    plan -- is a compile-time constant (csrc/sx_pso.hip FULL, sx_device.hpp row_reduce_fixed): bit-identical to the
+    oracle for the +,-,* objectives with one term per element, PSO and CPSO (Shrink for the larger swarm)."""
+    n, P = shape
+    for method in ("pso", "cpso"):
+        opts = {"maxiter": 25, "popsize": P, "seed": 5 + n, "updating": "deferred",
+                "constraints": "Shrink" if P > 1000 else None}
+        bounds = [[-2.0, 2.0]] * n
+        ref = oracle.minimize(objective, bounds, method=method, options=dict(opts), rng="philox")
+        got = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method=method,
+                                   options=dict(opts, backend="hip", rng="philox"))
+        assert got.fun == ref.fun and np.array_equal(got.x, ref.x) and (got.nit, got.status) == (ref.nit, ref.status)
 
 
 def test_cpso_restart_selection_above_32768_particles(sa):
