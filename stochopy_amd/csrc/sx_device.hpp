@@ -389,6 +389,64 @@ __device__ __forceinline__ void row_reduce_fixed(const double *A, const double *
     sb = (TWO && !BMUL) ? 0.0 + curB : curB;
 }
 
+// Any compile-time number of terms M >= 8 (whole-batch rows of an objective with n - 1 terms: 63, 127, 255): numpy's
+// recursion (loops_utils.h.src pairwise sum: up to 128 terms = eight accumulators over the 8-blocks, the tree, then the
+// tail; above, split at n/2 rounded down to a multiple of 8) unrolled by the compiler.  Every 8-lane group walks the
+// same chain (LDS broadcasts), the leaves one after the other: a few more chain steps than the leaves-in-parallel form,
+// none of its bookkeeping.  Same additions in the same order: same bits.
+template <bool TWO, bool BMUL, int OFF, int M>
+__device__ __forceinline__ void pairwise_static(const double *A, const double *B, int j, double &ra, double &rb) {
+    static_assert(M >= 8, "shorter sums are plain loops");
+    if constexpr (M <= 128) {
+        constexpr int BLK = M / kGroup, TAIL = M % kGroup;
+        double chA = A[OFF + j], chB = TWO ? B[OFF + j] : (BMUL ? 1.0 : 0.0);
+#pragma unroll
+        for (int h0 = 1; h0 < BLK; h0 += 8) {  // reads run up to 8 blocks ahead of the adds
+            double va[8], vb[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                va[t] = h0 + t < BLK ? A[OFF + (h0 + t) * kGroup + j] : 0.0;
+                vb[t] = (TWO && h0 + t < BLK) ? B[OFF + (h0 + t) * kGroup + j] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (h0 + t < BLK) {
+                    chA = chA + va[t];
+                    if (TWO) chB = combine<BMUL>(chB, vb[t]);
+                }
+            }
+        }
+        double ta[TAIL > 0 ? TAIL : 1], tb[TAIL > 0 ? TAIL : 1];
+#pragma unroll
+        for (int k = 0; k < TAIL; ++k) {
+            ta[k] = A[OFF + BLK * kGroup + k];
+            tb[k] = TWO ? B[OFF + BLK * kGroup + k] : 0.0;
+        }
+        ra = group_tree<false>(chA);
+        rb = TWO ? group_tree<BMUL>(chB) : chB;
+#pragma unroll
+        for (int k = 0; k < TAIL; ++k) {
+            ra = ra + ta[k];
+            if (TWO) rb = combine<BMUL>(rb, tb[k]);
+        }
+    } else {
+        constexpr int N2 = (M / 2) - ((M / 2) % kGroup);
+        double la, lb, qa, qb;
+        pairwise_static<TWO, BMUL, OFF, N2>(A, B, j, la, lb);
+        pairwise_static<TWO, BMUL, OFF + N2, M - N2>(A, B, j, qa, qb);
+        ra = la + qa;
+        rb = TWO ? combine<BMUL>(lb, qb) : lb;
+    }
+}
+
+template <bool TWO, bool BMUL, int M>
+__device__ __forceinline__ void row_reduce_static(const double *A, const double *B, int l, double &sa, double &sb) {
+    double ra, rb;
+    pairwise_static<TWO, BMUL, 0, M>(A, B, l & (kGroup - 1), ra, rb);
+    sa = 0.0 + ra;  // add.reduce starts from the identity
+    sb = !TWO ? (BMUL ? 1.0 : 0.0) : (BMUL ? rb : 0.0 + rb);
+}
+
 // Rows with several leaves (n > 128): the leaves of numpy's recursion are independent, so the LPR/8
 // 8-lane groups of the row take one leaf each (chain + tree [+ tail]); the leaf sums meet in LDS and are
 // then merged in recursion order.  L: 2*leaf_cap doubles of LDS scratch (leaf sums), S: the merge stack.

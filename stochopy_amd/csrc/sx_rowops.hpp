@@ -100,8 +100,11 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     }
     lds_wave_fence();  // terms complete
     double sa, sb;
-    if constexpr (NFIX != 0 && !O::NEXT && NFIX <= 256) {
-        row_reduce_fixed<O::TWO, O::BMUL, LPR, NFIX>(A, B, l, sa, sb);
+    if constexpr (NFIX != 0 && NFIX <= 256) {  // the number of terms, and with it numpy's plan, is known at compile time
+        if constexpr (!O::NEXT)
+            row_reduce_fixed<O::TWO, O::BMUL, LPR, NFIX>(A, B, l, sa, sb);
+        else
+            row_reduce_static<O::TWO, O::BMUL, NFIX - 1>(A, B, l, sa, sb);
         return O::finish(sa, sb, n);
     }
     // uniform: n > 128, leaves reduced in parallel by the row's 8-lane groups.  (For FULL rows the choice is known at
