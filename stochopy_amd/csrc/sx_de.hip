@@ -205,7 +205,9 @@ constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its l
 
 // FULL: n is a whole number of batches (n % (kStep*LPR) == 0) and P a whole number of workgroups, so
 // every bounds test folds away (the P = 4096, n = 128 headline shape).
-template <int FUN, int RNG, int XM, int LPR, bool FULL>
+// NFIX: FULL with n == kStep * LPR exactly (64, 128 -- the headline shape -- or 256): the row length, and with it numpy's
+// summation plan, is a compile-time constant (row_reduce_fixed / row_reduce_static in sx_device.hpp); 0 otherwise.
+template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_de_args a,
                                                                                  const PlanArg plan,
                                                                                  const int chain_p, const int mode,
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     __shared__ int64_t s_gi;
     __shared__ int s_winner;
     SX_TP(0);
-    const int n = a.n;
+    const int n = NFIX ? NFIX : a.n;
     const int64_t P = a.P, ld = a.ld;
     const RowIds<LPR> id(P, P2P ? 1 : 0);
     const int l = id.l;  // lane within the row
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     }
 
     SX_TP(2);
-    const double fc = row_objective<FUN, LPR, FULL>(U, n, plan, l);
+    const double fc = row_objective<FUN, LPR, FULL, NFIX>(U, n, plan, l);
     SX_TP(3);
     const bool better = fc < fold;  // _common.py:127 strict <
     if (FULL || id.active) {
@@ -562,16 +564,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
 typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t,
                             const sx_xchg_args);
 
-template <int RNG, int XM, int LPR, bool FULL>
+template <int RNG, int XM, int LPR, bool FULL, int NFIX = 0>
 de_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL>;
-        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL>;
-        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL>;
-        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL>;
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL, NFIX>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL, NFIX>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL, NFIX>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL, NFIX>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL, NFIX>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL, NFIX>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL, NFIX>;
     }
     return nullptr;
 }
@@ -582,10 +584,18 @@ de_kernel_t pick_kernel(int fun_id, int n, int64_t P) {
     constexpr bool CH = XM >= 1;
     const int lpr = lanes_per_row(n);
     const bool full = CH && n % (kStep * lpr) == 0 && P % rows_per_block(n) == 0;
+    // one batch per row exactly (n = 64, 128, 256) with in-kernel draws: the compile-time row length
+    constexpr bool FX = CH && RNG == SX_RNG_PHILOX;
+    const bool fix = FX && full && n == kStep * lpr;
     switch (lpr) {
-        case 16: return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 16, false>(fun_id);
-        case 32: return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 32, false>(fun_id);
+        case 16:
+            if (fix) return pick_kernel_lpr<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id);
+            return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 16, false>(fun_id);
+        case 32:
+            if (fix) return pick_kernel_lpr<RNG, XM, 32, CH, FX ? kStep * 32 : 0>(fun_id);
+            return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 32, false>(fun_id);
     }
+    if (fix) return pick_kernel_lpr<RNG, XM, 64, CH, FX ? kStep * 64 : 0>(fun_id);
     return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 64, false>(fun_id);
 }
 
