@@ -87,7 +87,9 @@ __device__ __forceinline__ void publish(sx_state *st, int64_t it, double gfit, i
     st->done = status != SX_STATUS_NONE;
 }
 
-template <int FUN, int RNG, int LPR>
+// NFIX: the row length when it is exactly 4 * LPR (64, 128, 256) and the draws are made in the kernel -- a compile-time
+// constant, and with it numpy's summation plan (sx_device.hpp row_reduce_fixed / row_reduce_static); 0 otherwise.
+template <int FUN, int RNG, int LPR, int NFIX = 0>
 __global__ __launch_bounds__(kSweepWaves *kWave) void de_async_kernel(const sx_de_args a, const PlanArg plan) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sfc[kSweepSlots], sfold[kSweepSlots];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void de_async_kernel(const sx_d
     sx_state *st = a.state;
     if (st->done) return;
     constexpr int RPW = kWave / LPR;
-    const int n = a.n, lane = (int)(threadIdx.x & 63), l = lane & (LPR - 1);
+    const int n = NFIX ? NFIX : a.n, lane = (int)(threadIdx.x & 63), l = lane & (LPR - 1);
     const int slot = (int)(threadIdx.x >> 6) * RPW + lane / LPR, B = (int)(blockDim.x >> 6) * RPW;
     const int64_t P = a.P, ld = a.ld;
     const int stride = lds_row_stride(n);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void de_async_kernel(const sx_d
             U[e] = cand;
             }
         }
-        return row_objective<FUN, LPR>(U, n, plan, l);
+        return row_objective<FUN, LPR, false, NFIX>(U, n, plan, l);
     };
 
     for (int64_t i0 = 0; i0 < P; i0 += B) {
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void de_async_kernel(const sx_d
     if (threadIdx.x == 0) publish(st, it, gfit, status, a.maxiter);
 }
 
-template <int FUN, int RNG, int LPR>
+template <int FUN, int RNG, int LPR, int NFIX = 0>
 __global__ __launch_bounds__(kSweepWaves *kWave) void pso_async_kernel(const sx_pso_args a, const PlanArg plan) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sfc[kSweepSlots], sfold[kSweepSlots];
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void pso_async_kernel(const sx_
     sx_state *st = a.state;
     if (st->done) return;
     constexpr int RPW = kWave / LPR;
-    const int n = a.n, lane = (int)(threadIdx.x & 63), l = lane & (LPR - 1);
+    const int n = NFIX ? NFIX : a.n, lane = (int)(threadIdx.x & 63), l = lane & (LPR - 1);
     const int slot = (int)(threadIdx.x >> 6) * RPW + lane / LPR, B = (int)(blockDim.x >> 6) * RPW;
     const int64_t P = a.P, ld = a.ld;
     const int stride = lds_row_stride(n) + n;  // staging row + the new velocity
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void pso_async_kernel(const sx_
                 U[e] = xr[e] + vn;
             }
         }
-        return row_objective<FUN, LPR>(U, n, plan, l);
+        return row_objective<FUN, LPR, false, NFIX>(U, n, plan, l);
     };
 
     for (int64_t i0 = 0; i0 < P; i0 += B) {
@@ -376,29 +378,29 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void pso_async_kernel(const sx_
 typedef void (*de_async_t)(const sx_de_args, const PlanArg);
 typedef void (*pso_async_t)(const sx_pso_args, const PlanArg);
 
-template <int RNG, int LPR>
+template <int RNG, int LPR, int NFIX = 0>
 de_async_t pick_de(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_async_kernel<SX_FUN_ACKLEY, RNG, LPR>;
-        case SX_FUN_GRIEWANK: return de_async_kernel<SX_FUN_GRIEWANK, RNG, LPR>;
-        case SX_FUN_QUARTIC: return de_async_kernel<SX_FUN_QUARTIC, RNG, LPR>;
-        case SX_FUN_RASTRIGIN: return de_async_kernel<SX_FUN_RASTRIGIN, RNG, LPR>;
-        case SX_FUN_ROSENBROCK: return de_async_kernel<SX_FUN_ROSENBROCK, RNG, LPR>;
-        case SX_FUN_SPHERE: return de_async_kernel<SX_FUN_SPHERE, RNG, LPR>;
-        case SX_FUN_STYBLINSKI_TANG: return de_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR>;
+        case SX_FUN_ACKLEY: return de_async_kernel<SX_FUN_ACKLEY, RNG, LPR, NFIX>;
+        case SX_FUN_GRIEWANK: return de_async_kernel<SX_FUN_GRIEWANK, RNG, LPR, NFIX>;
+        case SX_FUN_QUARTIC: return de_async_kernel<SX_FUN_QUARTIC, RNG, LPR, NFIX>;
+        case SX_FUN_RASTRIGIN: return de_async_kernel<SX_FUN_RASTRIGIN, RNG, LPR, NFIX>;
+        case SX_FUN_ROSENBROCK: return de_async_kernel<SX_FUN_ROSENBROCK, RNG, LPR, NFIX>;
+        case SX_FUN_SPHERE: return de_async_kernel<SX_FUN_SPHERE, RNG, LPR, NFIX>;
+        case SX_FUN_STYBLINSKI_TANG: return de_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, NFIX>;
     }
     return nullptr;
 }
-template <int RNG, int LPR>
+template <int RNG, int LPR, int NFIX = 0>
 pso_async_t pick_pso(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return pso_async_kernel<SX_FUN_ACKLEY, RNG, LPR>;
-        case SX_FUN_GRIEWANK: return pso_async_kernel<SX_FUN_GRIEWANK, RNG, LPR>;
-        case SX_FUN_QUARTIC: return pso_async_kernel<SX_FUN_QUARTIC, RNG, LPR>;
-        case SX_FUN_RASTRIGIN: return pso_async_kernel<SX_FUN_RASTRIGIN, RNG, LPR>;
-        case SX_FUN_ROSENBROCK: return pso_async_kernel<SX_FUN_ROSENBROCK, RNG, LPR>;
-        case SX_FUN_SPHERE: return pso_async_kernel<SX_FUN_SPHERE, RNG, LPR>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR>;
+        case SX_FUN_ACKLEY: return pso_async_kernel<SX_FUN_ACKLEY, RNG, LPR, NFIX>;
+        case SX_FUN_GRIEWANK: return pso_async_kernel<SX_FUN_GRIEWANK, RNG, LPR, NFIX>;
+        case SX_FUN_QUARTIC: return pso_async_kernel<SX_FUN_QUARTIC, RNG, LPR, NFIX>;
+        case SX_FUN_RASTRIGIN: return pso_async_kernel<SX_FUN_RASTRIGIN, RNG, LPR, NFIX>;
+        case SX_FUN_ROSENBROCK: return pso_async_kernel<SX_FUN_ROSENBROCK, RNG, LPR, NFIX>;
+        case SX_FUN_SPHERE: return pso_async_kernel<SX_FUN_SPHERE, RNG, LPR, NFIX>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, NFIX>;
     }
     return nullptr;
 }
@@ -431,7 +433,8 @@ extern "C" int sx_de_async_generation(const sx_de_args *a, void *stream) {
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     de_async_t kern = nullptr;
     if (a->rng == SX_RNG_PHILOX) {
-        SX_DISPATCH_LPR(a->n, kern = (pick_de<SX_RNG_PHILOX, LPR>(a->fun_id)))
+        SX_DISPATCH_LPR(a->n, kern = a->n == 4 * LPR ? (pick_de<SX_RNG_PHILOX, LPR, 4 * LPR>(a->fun_id))
+                                                      : (pick_de<SX_RNG_PHILOX, LPR>(a->fun_id)))
     } else {
         SX_DISPATCH_LPR(a->n, kern = (pick_de<SX_RNG_HOST, LPR>(a->fun_id)))
     }
@@ -455,7 +458,8 @@ extern "C" int sx_pso_async_generation(const sx_pso_args *a, void *stream) {
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     pso_async_t kern = nullptr;
     if (a->rng == SX_RNG_PHILOX) {
-        SX_DISPATCH_LPR(a->n, kern = (pick_pso<SX_RNG_PHILOX, LPR>(a->fun_id)))
+        SX_DISPATCH_LPR(a->n, kern = a->n == 4 * LPR ? (pick_pso<SX_RNG_PHILOX, LPR, 4 * LPR>(a->fun_id))
+                                                      : (pick_pso<SX_RNG_PHILOX, LPR>(a->fun_id)))
     } else {
         SX_DISPATCH_LPR(a->n, kern = (pick_pso<SX_RNG_HOST, LPR>(a->fun_id)))
     }
