@@ -122,3 +122,21 @@ def test_de_graph_equals_stepwise(sa):
     ref = oracle.minimize("rosenbrock", bounds, method="de", options={k: v for k, v in o.items() if k not in ("backend", "rng")} | {"maxiter": 12}, rng="philox")
     c = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="de", options=dict(o, maxiter=12))
     assert ref.fun == c.fun and np.array_equal(ref.x, c.x)
+
+
+@pytest.mark.parametrize("objective", ["rosenbrock", "sphere"])
+@pytest.mark.parametrize("shape", [(64, 64), (128, 256), (256, 64), (128, 4096)])
+def test_de_one_batch_rows_through_replayed_graphs_match_oracle(sa, objective, shape):
+    """Rows of exactly 64 / 128 / 256 elements with a population that fills whole workgroups take the chained kernel in
+    which the row length -- and numpy's summation plan with it -- is a compile-time constant (csrc/sx_de.hip NFIX,
+    sx_device.hpp row_reduce_fixed / pairwise_static).  No callback: the generations run as replayed graphs of that
+    kernel.  Bit-identical to the oracle for every strategy."""
+    n, P = shape
+    for strategy, constraints in (("best1bin", None), ("rand1bin", "Random"), ("best2bin", None), ("rand2bin", None)):
+        opts = {"maxiter": 120 if P <= 256 else 12, "popsize": P, "seed": 77 + n, "strategy": strategy, "constraints": constraints,
+                "mutation": 0.6, "recombination": 0.8, "updating": "deferred"}
+        bounds = [[-2.0, 2.0]] * n
+        ref = oracle.minimize(objective, bounds, method="de", options=dict(opts), rng="philox")
+        got = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="de",
+                                   options=dict(opts, backend="hip", rng="philox"))
+        assert got.fun == ref.fun and np.array_equal(got.x, ref.x) and (got.nit, got.status) == (ref.nit, ref.status), strategy

@@ -93,12 +93,13 @@ def test_pso_philox_matches_oracle(sa, method, constraints, shape):
     assert np.array_equal(r_ref.x, r_got.x) and r_ref.nit == r_got.nit and r_ref.status == r_got.status
 
 
-@pytest.mark.parametrize("objective", ["sphere", "quartic", "styblinski_tang"])
+@pytest.mark.parametrize("objective", ["sphere", "rosenbrock"])
 @pytest.mark.parametrize("shape", [(64, 40), (128, 33), (256, 70), (256, 2048)])
 def test_pso_whole_batch_rows_match_oracle(sa, objective, shape):
     """Rows of exactly 64 / 128 / 256 elements take the kernel in which the row length -- and with it numpy's summation
     plan -- is a compile-time constant (csrc/sx_pso.hip FULL, sx_device.hpp row_reduce_fixed): bit-identical to the
-    oracle for the +,-,* objectives with one term per element, PSO and CPSO (Shrink for the larger swarm)."""
+    oracle for the +,-,* objectives (one term per element: row_reduce_fixed; n - 1 terms: pairwise_static), PSO and CPSO
+    (Shrink for the larger swarm)."""
     n, P = shape
     for method in ("pso", "cpso"):
         opts = {"maxiter": 25, "popsize": P, "seed": 5 + n, "updating": "deferred",
