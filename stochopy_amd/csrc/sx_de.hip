@@ -207,7 +207,10 @@ constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its l
 // every bounds test folds away (the P = 4096, n = 128 headline shape).
 // NFIX: FULL with n == kStep * LPR exactly (64, 128 -- the headline shape -- or 256): the row length, and with it numpy's
 // summation plan, is a compile-time constant (row_reduce_fixed / row_reduce_static in sx_device.hpp); 0 otherwise.
-template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0>
+// STRAT: with NFIX, the strategy as a compile-time constant too (its donor count, the best-row fetch and the mutant's
+// formula are otherwise uniform branches inside the row's dependent chain: 9.03 -> 8.52 us per generation at the
+// headline shape); -1 = read from the arguments.
+template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_de_args a,
                                                                                  const PlanArg plan,
                                                                                  const int chain_p, const int mode,
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const double fold = a.fit[rowc];
     const double *__restrict__ xi = cur + rowc * ld;
     const uint32_t grow = (uint32_t)(a.row0 + rowc);
-    const int strategy = a.strategy;
+    const int strategy = STRAT >= 0 ? STRAT : a.strategy;
     const int k = donors_of(strategy);
     const bool repair = a.constraints != 0;
     const bool use_best = strategy == SX_DE_BEST1BIN || strategy == SX_DE_BEST2BIN;
@@ -564,23 +567,35 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
 typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t,
                             const sx_xchg_args);
 
-template <int RNG, int XM, int LPR, bool FULL, int NFIX = 0>
+template <int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
 de_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL, NFIX>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL, NFIX>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL, NFIX>;
-        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL, NFIX>;
-        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL, NFIX>;
-        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL, NFIX>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL, NFIX>;
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL, NFIX, STRAT>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL, NFIX, STRAT>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL, NFIX, STRAT>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL, NFIX, STRAT>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL, NFIX, STRAT>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL, NFIX, STRAT>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL, NFIX, STRAT>;
     }
     return nullptr;
 }
 
 // bounds-test-free variant only for the chained (throughput) kernels, to keep the build small
+// the one-batch kernels come per strategy
+template <int RNG, int XM, int LPR, bool FULL, int NFIX>
+de_kernel_t pick_kernel_fixed(int fun_id, int strategy) {
+    switch (strategy) {
+        case SX_DE_RAND1BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_RAND1BIN : -1>(fun_id);
+        case SX_DE_RAND2BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_RAND2BIN : -1>(fun_id);
+        case SX_DE_BEST1BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_BEST1BIN : -1>(fun_id);
+        case SX_DE_BEST2BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_BEST2BIN : -1>(fun_id);
+    }
+    return nullptr;
+}
+
 template <int RNG, int XM>
-de_kernel_t pick_kernel(int fun_id, int n, int64_t P) {
+de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy) {
     constexpr bool CH = XM >= 1;
     const int lpr = lanes_per_row(n);
     const bool full = CH && n % (kStep * lpr) == 0 && P % rows_per_block(n) == 0;
@@ -589,13 +604,13 @@ de_kernel_t pick_kernel(int fun_id, int n, int64_t P) {
     const bool fix = FX && full && n == kStep * lpr;
     switch (lpr) {
         case 16:
-            if (fix) return pick_kernel_lpr<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id);
+            if (fix) return pick_kernel_fixed<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id, strategy);
             return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 16, false>(fun_id);
         case 32:
-            if (fix) return pick_kernel_lpr<RNG, XM, 32, CH, FX ? kStep * 32 : 0>(fun_id);
+            if (fix) return pick_kernel_fixed<RNG, XM, 32, CH, FX ? kStep * 32 : 0>(fun_id, strategy);
             return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 32, false>(fun_id);
     }
-    if (fix) return pick_kernel_lpr<RNG, XM, 64, CH, FX ? kStep * 64 : 0>(fun_id);
+    if (fix) return pick_kernel_fixed<RNG, XM, 64, CH, FX ? kStep * 64 : 0>(fun_id, strategy);
     return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 64, false>(fun_id);
 }
 
@@ -616,8 +631,8 @@ int check_args(const sx_de_args *a) {
 }
 
 de_kernel_t kernel_for(const sx_de_args *a) {
-    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, 0>(a->fun_id, a->n, a->P)
-                                   : pick_kernel<SX_RNG_HOST, 0>(a->fun_id, a->n, a->P);
+    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, 0>(a->fun_id, a->n, a->P, a->strategy)
+                                   : pick_kernel<SX_RNG_HOST, 0>(a->fun_id, a->n, a->P, a->strategy);
 }
 
 Geometry geometry(const sx_de_args *a) { return row_geometry(a->P, a->n); }
@@ -709,8 +724,8 @@ static int chain_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, 
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    de_kernel_t kern = x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P)
-                         : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P);
+    de_kernel_t kern = x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P, a->strategy)
+                         : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P, a->strategy);
     const unsigned blocks = finalize_only ? 1u : g.blocks + (x ? 1u : 0u);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream, *a, plan, parity,
                        finalize_only ? 1 : 0, (int64_t)g.blocks, x ? *x : sx_xchg_args{});
@@ -736,8 +751,8 @@ static int chain_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ng
         int parity = (start_parity + i) & 1;
         void *kargs[] = {&args, &plan, &parity, &mode, &npart, &xa};
         hipKernelNodeParams kp = {};
-        kp.func = (void *)(x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P)
-                             : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P));
+        kp.func = (void *)(x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P, a->strategy)
+                             : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P, a->strategy));
         kp.gridDim = dim3(g.blocks + (x ? 1u : 0u));
         kp.blockDim = dim3(g.threads);
         kp.sharedMemBytes = (unsigned)g.lds;
