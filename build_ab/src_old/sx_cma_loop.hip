@@ -1,0 +1,396 @@
+// CMA-ES, device-resident generation: everything between two looks of the host at the 128-byte state.
+//
+// Reference code replaced (paths relative to the reference checkout), on top of the kernels of sx_cmaes.hip
+// (sampling :232-237, covariance update :290-295) and sx_eigh.hip (:303-305):
+//   stochopy/optimize/cmaes/_cmaes.py:272-277  arindex = argsort(arfitness); xold = xmean; xmean = w @ arx[arindex[:mu]]
+//   stochopy/optimize/cmaes/_cmaes.py:280-287  ps, cond, pc                  (evolution paths)
+//   stochopy/optimize/cmaes/_cmaes.py:298      sigma *= exp((cs/damps)(|ps|/chind - 1))
+//   stochopy/optimize/cmaes/_cmaes.py:306      D = sqrt(D)
+//   stochopy/optimize/cmaes/_cmaes.py:360-434  converge: the ten ordered stopping rules, incl. the reads of the
+//                                              zero-initialised history
+// One generation = sx_cmaes_generation(): normals -> sample (MFMA) -> objective -> rank -> mean partials ->
+// paths (one workgroup: mean, C^(-1/2) step as B((B^T step)/D), ps, cond, pc, sigma) -> covariance update (MFMA)
+// -> [symmetrise + eigendecomposition] -> stop rules.  Step size, `cond` coefficient, best row, status live in
+// sx_cma_state on the device; the host only decides WHEN the eigendecomposition is due (a function of the
+// generation number) and looks at the state every few generations.  Once a stopping rule fires the result
+// (best point of that generation, un-standardised) is copied aside and the bookkeeping kernels of later launches
+// do nothing.
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+
+using namespace sx;
+
+namespace sx {
+int cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, const double *B, const double *D,
+                      const double *Z, double *arx, int64_t P, int n, void *stream);
+int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
+                       const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
+                       const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream);
+}  // namespace sx
+
+namespace {
+
+constexpr int kPartRows = 64;    // partial sums of the recombination
+constexpr int kPathThreads = 1024;
+
+static_assert(sizeof(sx_cma_state) == 128, "sx_cma_state is 128 bytes");
+
+// numpy sorts NaN last: a < b in that order
+__device__ __forceinline__ bool key_less(double a, double b) { return a < b || (b != b && a == a); }
+
+// order = argsort(fit) (ties: lower index first); best row / value and the history entry of the generation.
+// 64 elements per workgroup, 4 slices of the key range per element; the keys pass through LDS 4096 at a time.
+__global__ __launch_bounds__(256) void cma_rank_kernel(const double *__restrict__ fit, int64_t P,
+                                                       int64_t *__restrict__ order, sx_cma_state *state,
+                                                       double *__restrict__ besthist, int64_t gen) {
+    constexpr int CH = 4096;
+    __shared__ double keys[CH];
+    __shared__ int part[4][64];
+    if (state->done) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+    const double fi = i < P ? fit[i] : 0.0;
+    int cnt = 0;
+    for (int64_t c0 = 0; c0 < P; c0 += CH) {
+        const int len = (int)(P - c0 < CH ? P - c0 : CH);
+        __syncthreads();
+        for (int e = threadIdx.x; e < len; e += 256) keys[e] = fit[c0 + e];
+        __syncthreads();
+        if (i < P) {
+            const int span = (len + 3) / 4, k0 = ty * span, k1 = k0 + span < len ? k0 + span : len;
+            const int64_t ii = i - c0;
+#pragma unroll 16
+            for (int k = k0; k < k1; ++k) {
+                const double fk = keys[k];
+                cnt += (key_less(fk, fi) || (!key_less(fi, fk) && k < ii)) ? 1 : 0;
+            }
+        }
+    }
+    part[ty][tx] = cnt;
+    __syncthreads();
+    if (ty == 0 && i < P) {
+        const int64_t rank = (int64_t)part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
+        order[rank] = i;
+        if (rank == 0) {
+            state->best_row = i;
+            state->fbest = fi;
+            besthist[gen - 1] = fi;
+        }
+    }
+}
+
+// part[q][e] = sum over k = q (mod 64) of w[k] * arx[order[k]][e]   (grid: ceil(n/64) x 16, 256 threads)
+__global__ __launch_bounds__(256) void cma_mean_partial_kernel(const double *__restrict__ arx,
+                                                               const int64_t *__restrict__ order,
+                                                               const double *__restrict__ w, int mu, int n,
+                                                               double *__restrict__ part) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    const int q = blockIdx.y * 4 + ty;
+    if (col >= n) return;
+    double acc = 0.0;
+    for (int k0 = q; k0 < mu; k0 += 4 * kPartRows) {
+        double v[4], ww[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * kPartRows;
+            const bool in = k < mu;
+            ww[u] = in ? w[k] : 0.0;
+            v[u] = in ? arx[order[k] * (int64_t)n + col] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += ww[u] * v[u];
+    }
+    part[(int64_t)q * n + col] = acc;
+}
+
+// return_all (cmaes/_cmaes.py:262-269): the first `rows` candidates of the generation, un-standardised, and their
+// fitness -- or, with rows == 0, the generation's best candidate -- into the device-side history
+__global__ __launch_bounds__(256) void cma_history_kernel(const sx_cma_args a, int64_t gen) {
+    const sx_cma_state *state = (const sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n;
+    const int64_t rows = a.hist_rows > 0 ? a.hist_rows : 1;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * n) return;
+    const int64_t r = t / n;
+    const int e = (int)(t % n);
+    const int64_t src = a.hist_rows > 0 ? r : state->best_row;
+    a.hist_x[((gen - 1) * rows + r) * n + e] = a.arx[src * n + e] * a.xstd[e] + a.xm[e];
+    if (e == 0) a.hist_f[(gen - 1) * rows + r] = a.fit[src];
+}
+
+template <class F>
+__device__ double block_reduce(double v, double *red, F op) {  // all threads get the result; 1024 threads
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, kWave));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < kPathThreads / 64; ++k) s = op(s, red[k]);
+    return s;
+}
+
+// The evolution-path step in three launches (the two products with B are spread over the chip):
+//   cma_step_bt_kernel   xold = xmean; xmean = sum of the 64 partial rows (:273-274); step = xmean - xold;
+//                        ypart[s][j] = sum over rows i of slice s of B[i][j] * step[i]          (grid n/64 x 8)
+//   cma_b_y_kernel       y = (sum_s ypart[s]) / D;  isc = B y  = C^(-1/2) step                  (4 rows per workgroup)
+//   cma_paths_kernel     ps, |ps|, cond, pc, sigma, tmp coefficient (:280-298), one workgroup
+constexpr int kYSlices = 8;
+
+__global__ __launch_bounds__(256) void cma_step_bt_kernel(const sx_cma_args a) {
+    __shared__ double st[512];       // step of this workgroup's row slice (slices are <= 512 rows: n <= 4096)
+    __shared__ double red[4][64];
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int span = (n + kYSlices - 1) / kYSlices, r0 = blockIdx.y * span, r1 = r0 + span < n ? r0 + span : n;
+    for (int i = r0 + tid; i < r1; i += 256) {
+        const double xo = a.xmean[i];  // (every column block reads the same old mean: only block x = 0 replaces it, below)
+        double xn = 0.0;
+#pragma unroll 8
+        for (int q = 0; q < kPartRows; ++q) xn += a.part[(int64_t)q * n + i];
+        st[i - r0] = xn - xo;
+        if (blockIdx.x == 0) a.step[i] = xn - xo, a.xold[i] = xo, a.xnew[i] = xn;
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 64 + tx;
+    double acc = 0.0;
+    if (col < n)
+        for (int i = r0 + ty; i < r1; i += 4) acc += a.B[(int64_t)i * n + col] * st[i - r0];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && col < n) a.ypart[(int64_t)blockIdx.y * n + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ __launch_bounds__(256) void cma_b_y_kernel(const sx_cma_args a) {
+    extern __shared__ double y[];  // n
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < n; j += 256) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < kYSlices; ++q) s += a.ypart[(int64_t)q * n + j];
+        y[j] = s / a.D[j];
+        if (blockIdx.x == 0) a.xmean[j] = a.xnew[j];  // the old mean has been consumed by every workgroup of the launch before
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) acc += a.B[(int64_t)i * n + j] * y[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if (lane == 0) a.isc[i] = acc;
+}
+
+__global__ __launch_bounds__(kPathThreads) void cma_paths_kernel(const sx_cma_args a, int64_t gen) {
+    __shared__ double red[16];
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x;
+    const double sigma = state->sigma;
+    // ps = (1-cs) ps + sqrt(cs (2-cs) mueff) * isc / sigma                                     :280-282
+    const double kps = sqrt(a.cs * (2.0 - a.cs) * a.mueff);
+    double q2 = 0.0;
+    for (int e = tid; e < n; e += kPathThreads) {
+        const double p = (1.0 - a.cs) * a.ps[e] + kps * a.isc[e] / sigma;
+        a.ps[e] = p;
+        q2 += p * p;
+    }
+    q2 = block_reduce(q2, red, [](double u, double v) { return u + v; });
+    const double psn = sqrt(q2);
+    // cond = |ps| / sqrt(1 - (1-cs)^(2 nfev / P)) / chind < 1.4 + 2/(n+1)   with nfev = gen * P      :283-285
+    const bool cond = psn / sqrt(1.0 - pow(1.0 - a.cs, 2.0 * (double)gen)) / a.chind < 1.4 + 2.0 / (n + 1.0);
+    const double kpc = sqrt(a.cc * (2.0 - a.cc) * a.mueff);
+    for (int e = tid; e < n; e += kPathThreads) {
+        double p = a.pc[e] * (1.0 - a.cc);                                                     // :286
+        if (cond) p += kpc * a.step[e] / sigma;                                                // :287
+        a.pc[e] = p;
+    }
+    if (tid == 0) {
+        state->tmp_coef = cond ? 0.0 : a.c1 * a.cc * (2.0 - a.cc);                             // :291
+        state->sigma_next = sigma * exp((a.cs / a.damps) * (psn / a.chind - 1.0));            // :298
+        state->psnorm = psn;
+    }
+}
+
+// D = sqrt(eigenvalues) when a decomposition was made, then the ten ordered stopping rules (:360-434), the
+// result copy when one fires, and the publication of the new step size / generation counter.  One workgroup.
+__global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_args a, int64_t gen, int did_eigh) {
+    __shared__ double red14[kPathThreads / 64][14];
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x;
+    if (did_eigh) {
+        for (int e = tid; e < n; e += kPathThreads) a.D[e] = sqrt(a.eigw[e]);                  // :306
+        __syncthreads();
+    }
+    const double sigma = state->sigma_next, fbest = state->fbest;
+    const int axis = (int)(gen % n);
+    const double dax = a.D[axis];
+    // per-dimension quantities.  "all(x < t)" is carried as the count of elements that FAIL (NaN fails, as in numpy)
+    double dx2 = 0.0, fail4 = 0.0, any5 = 0.0, dmax = -__builtin_inf(), dmin = __builtin_inf(), any8 = 0.0;
+    double sdmax = -__builtin_inf(), fail10 = 0.0, nan_sd = 0.0, nan_d = 0.0;
+    for (int e = tid; e < n; e += kPathThreads) {
+        const double d = a.xold[e] - a.xmean[e];
+        dx2 += d * d;
+        if (!(fabs(0.1 * sigma * a.B[(int64_t)e * n + axis] * dax) < 1.0e-10)) fail4 += 1.0;
+        const double sd = sqrt(a.C[(int64_t)e * n + e]);
+        if (0.2 * sigma * sd < 1.0e-10) any5 += 1.0;
+        const double de = a.D[e];
+        dmax = fmax(dmax, de), dmin = fmin(dmin, de);  // (numpy's max/min propagate NaN; rule 6 then compares False either way)
+        if (de != de) nan_d += 1.0;
+        if (sigma * sd > 1.0e3 * a.insigma) any8 += 1.0;
+        if (sd != sd) nan_sd += 1.0;
+        sdmax = fmax(sdmax, sd);
+        if (!(sigma * fabs(a.pc[e]) < 1.0e-11 * a.insigma)) fail10 += 1.0;
+    }
+    // histories: window [gen-ilim, gen] of the zero-initialised best-fitness array (entry `gen` is not written yet),
+    // and the whole array joined with this generation's fitness values
+    double wmax = -__builtin_inf(), wmin = __builtin_inf(), jmax = -__builtin_inf(), jmin = __builtin_inf();
+    if (gen >= a.ilim) {
+        const int64_t hi = gen + 1 < a.maxiter ? gen + 1 : a.maxiter;
+        for (int64_t k = gen - a.ilim + tid; k < hi; k += kPathThreads) {
+            const double v = a.besthist[k];
+            wmax = fmax(wmax, v), wmin = fmin(wmin, v);
+        }
+    }
+    for (int64_t k = tid; k < a.maxiter; k += kPathThreads) {
+        const double v = a.besthist[k];
+        jmax = fmax(jmax, v), jmin = fmin(jmin, v);
+    }
+    for (int64_t k = tid; k < a.P; k += kPathThreads) {
+        const double v = a.fit[k];
+        jmax = fmax(jmax, v), jmin = fmin(jmin, v);
+    }
+    // one combined reduction: 7 sums, 4 maxima, 3 minima
+    double vs[14] = {dx2, fail4, any5, any8, fail10, nan_sd, nan_d, dmax, sdmax, wmax, jmax, dmin, wmin, jmin};
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(vs[q], off, kWave);
+            vs[q] = q < 7 ? vs[q] + o : (q < 11 ? fmax(vs[q], o) : fmin(vs[q], o));
+        }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 14; ++q) red14[tid >> 6][q] = vs[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        double r = red14[0][q];
+        for (int wv = 1; wv < kPathThreads / 64; ++wv) {
+            const double o = red14[wv][q];
+            r = q < 7 ? r + o : (q < 11 ? fmax(r, o) : fmin(r, o));
+        }
+        vs[q] = r;
+    }
+    dx2 = vs[0], fail4 = vs[1], any5 = vs[2], any8 = vs[3], fail10 = vs[4], nan_sd = vs[5], nan_d = vs[6];
+    dmax = vs[7], sdmax = vs[8], wmax = vs[9], jmax = vs[10], dmin = vs[11], wmin = vs[12], jmin = vs[13];
+    int status = SX_STATUS_NONE;
+    if (gen >= a.maxiter)
+        status = -1;
+    else if (sqrt(dx2) <= a.xtol && fbest < a.ftol)
+        status = 0;
+    else if (fbest <= a.ftol)
+        status = 1;
+    else if (fail4 == 0.0)
+        status = -2;
+    else if (any5 > 0.0)
+        status = -3;
+    else if (nan_d == 0.0 && dmax > 1.0e7 * dmin)
+        status = -4;
+    else if (gen >= a.ilim && wmax - wmin < 1.0e-10)
+        status = -5;
+    else if (any8 > 0.0)
+        status = -6;
+    else if (gen > 2 && jmax - jmin < 1.0e-12)
+        status = -7;
+    else if (fail10 == 0.0 && nan_sd == 0.0 && sigma * sdmax < 1.0e-11 * a.insigma)
+        status = -8;
+    if (status != SX_STATUS_NONE) {  // the caller's result: best candidate of THIS generation, un-standardised (:345-353)
+        const double *row = a.arx + state->best_row * (int64_t)n;
+        for (int e = tid; e < n; e += kPathThreads) a.xbest[e] = row[e] * a.xstd[e] + a.xm[e];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        state->sigma = sigma;
+        state->it = gen;
+        state->nfev = gen * a.P;
+        if (status != SX_STATUS_NONE) {
+            state->status = status;
+            state->stop_it = gen;
+            __threadfence();
+            state->done = 1;
+        }
+    }
+}
+
+}  // namespace
+
+namespace sx {
+// shared with the VD-CMA generation (sx_vd_loop.hip)
+int cma_rank_launch(const double *fit, int64_t P, int64_t *order, sx_cma_state *state, double *besthist, int64_t gen,
+                    void *stream) {
+    hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, (hipStream_t)stream, fit, P, order,
+                       state, besthist, gen);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+int cma_history_launch(const sx_cma_args &h, int64_t gen, void *stream) {
+    const int64_t tot = (h.hist_rows > 0 ? h.hist_rows : 1) * h.n;
+    hipLaunchKernelGGL(cma_history_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, gen);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace sx
+
+extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
+    SX_REQUIRE(a && a->Z && a->arx && a->fit && a->xmean && a->xold && a->ps && a->pc && a->C && a->B && a->D && a->w &&
+                   a->Y && a->part && a->step && a->isc && a->ypart && a->xnew && a->besthist && a->xm && a->xstd && a->xbest && a->eigw && a->order && a->state &&
+                   a->eigh_ws,
+               "sx_cmaes_generation: null pointer");
+    SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->mu >= 1 && a->mu <= a->P && gen >= 1 && gen <= a->maxiter,
+               "sx_cmaes_generation: bad shape or generation number");
+    SX_REQUIRE(a->n <= 4096, "sx_cmaes_generation: n <= 4096");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = a->n;
+    const int64_t P = a->P;
+    sx_cma_state *state = (sx_cma_state *)a->state;
+    int rc;
+    if ((rc = sx_cmaes_normals(a->Z, P, n, 0, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
+    if ((rc = sx::cma_sample_launch(a->xmean, 0.0, &state->sigma, a->B, a->D, a->Z, a->arx, P, n, stream))) return rc;
+    if ((rc = sx_eval(a->fun_id, a->arx, P, n, n, a->xm, a->xstd, a->fit, nullptr, nullptr, stream))) return rc;
+    hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, a->fit, P, a->order, state,
+                       a->besthist, gen);
+    if (a->hist_x) {
+        SX_REQUIRE(a->hist_f != nullptr && a->hist_rows >= 0 && a->hist_rows <= P, "sx_cmaes_generation: bad history arguments");
+        const int64_t tot = (a->hist_rows > 0 ? a->hist_rows : 1) * n;
+        hipLaunchKernelGGL(cma_history_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *a, gen);
+    }
+    hipLaunchKernelGGL(cma_mean_partial_kernel, dim3((unsigned)((n + 63) / 64), kPartRows / 4), dim3(256), 0, st, a->arx,
+                       a->order, a->w, a->mu, n, a->part);
+    hipLaunchKernelGGL(cma_step_bt_kernel, dim3((unsigned)((n + 63) / 64), kYSlices), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(cma_b_y_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)n * sizeof(double), st, *a);
+    hipLaunchKernelGGL(cma_paths_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen);
+    SX_LAUNCH_CHECK();
+    if ((rc = sx::cma_rank_mu_launch(a->arx, a->order, a->w, a->mu, a->xold, 0.0, &state->sigma, a->pc, a->c1, a->cmu, 0.0,
+                                     &state->tmp_coef, a->C, a->Y, n, stream)))
+        return rc;
+    if (do_eigh) {
+        if ((rc = sx_symmetrize_upper(a->C, n, stream))) return rc;
+        // do_eigh == 2: start from the previous eigenvectors (B is both the starting basis and the output)
+        if ((rc = sx_eigh(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes,
+                          a->eig_sweeps, 0.0, stream)))
+            return rc;
+    }
+    hipLaunchKernelGGL(cma_stop_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, do_eigh ? 1 : 0);
+    SX_LAUNCH_CHECK();
+    return 0;
+}

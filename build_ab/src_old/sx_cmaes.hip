@@ -1,0 +1,560 @@
+// CMA-ES device kernels: sampling (m + sigma * B * (D o z)) and the covariance
+// update (rank-mu + rank-one) as LDS-tiled fp64 MFMA contractions, the weighted
+// recombination of the mean, Philox normals, and two small helpers.
+//
+// Reference code replaced (paths relative to the reference checkout):
+//   stochopy/optimize/cmaes/_cmaes.py:232-237  arx[i] = xmean + sigma * dot(B, D * randn(n))
+//   stochopy/optimize/cmaes/_cmaes.py:274      xmean = dot(weights, arx[arindex[:mu]])
+//   stochopy/optimize/cmaes/_cmaes.py:290-295  artmp, C *= 1-c1-cmu; C += cmu*A^T diag(w) A; C += c1*pc pc^T; C += tmp
+//   stochopy/optimize/cmaes/_cmaes.py:303      C = triu(C) + triu(C,1).T
+//
+// MFMA: v_mfma_f64_16x16x4_f64.  Operand layout (cdna_hip_programming.md section 3):
+//   A (16x4): lane l holds A[l & 15][l >> 4];  B (4x16): lane l holds B[l >> 4][l & 15];
+//   C/D: 4 doubles per lane, col = l & 15, row = (l >> 4) + 4 * reg.
+// Workgroup tiles 64x64 / 32x64 / 32x32 (chosen so the small CMA-ES shapes still give >= 256 workgroups),
+// four waves in a 2x2 grid, K chunk 32 staged through LDS with register prefetch of the next chunk.
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+
+using namespace sx;
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 32;        // K chunk
+constexpr int LDA = KC + 2;   // A tile [BM][LDA]: row stride 34 doubles -> conflict-free ds_read_b64 of a column slab
+constexpr int kGemmThreads = 256;
+
+struct SampleOp {  // arx = xmean + sigma * (Z o D) * B^T
+    const double *Z;      // (P,n)
+    const double *Bm;     // (n,n) eigenvectors, row-major
+    const double *D;      // (n)
+    const double *xmean;  // (n)
+    double *arx;          // (P,n)
+    double sigma;
+    const double *sigma_p;  // when set: the step size lives on the device (device-resident loop)
+    int64_t P;
+    int n;
+};
+
+struct RankMuOp {  // C = (1-c1-cmu)*C + cmu * Y^T diag(w) Y + c1 * pc pc^T + tmpc * C_old
+    const double *Y;      // (mu,n)  Y[k] = (arx[idx[k]] - xold)/sigma  (cma_y_kernel)
+    const double *w;      // (mu)
+    const double *pc;     // (n)
+    double *C;            // (n,n) in place
+    double decay, cmu, c1, tmpc;
+    const double *tmpc_p;  // when set: tmp coefficient on the device (0 when `cond` held, else c1*cc*(2-cc))
+    int mu, n;
+};
+
+// Y[k][:] = (arx[idx[k]][:] - xold) / sigma   (cmaes/_cmaes.py:290), once per generation
+__global__ __launch_bounds__(256) void cma_y_kernel(const double *__restrict__ arx, const int64_t *__restrict__ idx,
+                                                    const double *__restrict__ xold, double sigma,
+                                                    const double *__restrict__ sigma_p, int mu, int n,
+                                                    double *__restrict__ Y) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)mu * n) return;
+    if (sigma_p) sigma = *sigma_p;
+    const int k = (int)(t / n), e = (int)(t % n);
+    Y[t] = (arx[idx[k] * (int64_t)n + e] - xold[e]) / sigma;
+}
+
+// MODE 0: M = P rows, N = n, K = n.   MODE 1: M = N = n, K = mu.
+// Workgroup tile BM x BN, four waves in a 2x2 grid, wave tile (BM/2) x (BN/2) of 16x16 MFMA tiles.
+// The global loads of chunk k+1 are issued into registers before the MFMAs of chunk k.
+template <int MODE, int BM, int BN, class Op>
+__global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
+    constexpr int LDB = BN + 16;  // B tile [KC][LDB]: the two k-groups of a 32-lane half land 32 banks apart
+    constexpr int TM = BM / 32, TN = BN / 32;  // MFMA tiles per wave
+    constexpr int NA = BM * KC / kGemmThreads, NB = BN * KC / kGemmThreads;  // staged elements per thread
+    __shared__ __attribute__((aligned(16))) double As[BM * LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    int64_t M;
+    int N, K;
+    if (MODE == 0) {
+        const SampleOp &o = (const SampleOp &)op;
+        M = o.P, N = o.n, K = o.n;
+    } else {
+        const RankMuOp &o = (const RankMuOp &)op;
+        M = o.n, N = o.n, K = o.mu;
+    }
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    double ra[NA], rb[NB];
+    // thread -> staged elements.  MODE 0: A row i = tid / (KC/NA), NA contiguous k; B row j = tid / (KC/NB), NB contiguous k.
+    //                             MODE 1: k = tid / 8 for both; NA contiguous i, NB contiguous j.
+    auto fetch = [&](int k0) {
+        if (MODE == 0) {
+            const SampleOp &o = (const SampleOp &)op;
+            {
+                const int i = tid / (KC / NA), kk = (tid % (KC / NA)) * NA;
+                const int64_t gi = m0 + i;
+#pragma unroll
+                for (int u = 0; u < NA; ++u) {
+                    const int gk = k0 + kk + u;
+                    ra[u] = (gi < M && gk < K) ? o.D[gk] * o.Z[gi * (int64_t)o.n + gk] : 0.0;  // D * z (:234)
+                }
+            }
+            {
+                const int j = tid / (KC / NB), kk = (tid % (KC / NB)) * NB;
+                const int gj = n0 + j;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int gk = k0 + kk + u;
+                    rb[u] = (gj < N && gk < K) ? o.Bm[(int64_t)gj * o.n + gk] : 0.0;
+                }
+            }
+        } else {
+            const RankMuOp &o = (const RankMuOp &)op;
+            const int kk = tid >> 3, gk = k0 + kk;
+            const bool kin = gk < K;
+            const double wk = kin ? o.w[gk] : 0.0;
+            const double *yr = o.Y + (int64_t)(kin ? gk : 0) * o.n;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int64_t gi = m0 + (tid & 7) * NA + u;
+                ra[u] = (kin && gi < M) ? yr[gi] * wk : 0.0;  // artmp.T @ diag(w)
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int gj = n0 + (tid & 7) * NB + u;
+                rb[u] = (kin && gj < N) ? yr[gj] : 0.0;
+            }
+        }
+    };
+    auto stage = [&]() {
+        if (MODE == 0) {
+            {
+                const int i = tid / (KC / NA), kk = (tid % (KC / NA)) * NA;
+#pragma unroll
+                for (int u = 0; u < NA; ++u) As[i * LDA + kk + u] = ra[u];
+            }
+            {
+                const int j = tid / (KC / NB), kk = (tid % (KC / NB)) * NB;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) Bs[(kk + u) * LDB + j] = rb[u];
+            }
+        } else {
+            const int kk = tid >> 3;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) As[((tid & 7) * NA + u) * LDA + kk] = ra[u];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) Bs[kk * LDB + (tid & 7) * NB + u] = rb[u];
+        }
+    };
+
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        stage();
+        __syncthreads();
+        if (k0 + KC < K) fetch(k0 + KC);  // in flight while the MFMAs below run
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 4) {
+            const int kq = ks + (lane >> 4);
+            double af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[(wm + i * 16 + (lane & 15)) * LDA + kq];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[kq * LDB + wn + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C/D element (row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile ----
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gi = m0 + wm + ti * 16 + (lane >> 4) + 4 * r;
+                const int gj = n0 + wn + tj * 16 + (lane & 15);
+                if (gi >= M || gj >= N) continue;
+                const double g = acc[ti][tj][r];
+                if (MODE == 0) {
+                    const SampleOp &o = (const SampleOp &)op;
+                    const double sg = o.sigma_p ? *o.sigma_p : o.sigma;
+                    o.arx[gi * (int64_t)o.n + gj] = o.xmean[gj] + sg * g;  // xmean + sigma * dot(B, D*z)
+                } else {
+                    const RankMuOp &o = (const RankMuOp &)op;
+                    const double tmpc = o.tmpc_p ? *o.tmpc_p : o.tmpc;
+                    double *cp = o.C + gi * (int64_t)o.n + gj;
+                    const double cold = *cp;
+                    double c = cold * o.decay;             // C *= 1 - c1 - cmu
+                    c = c + o.cmu * g;                     // C += cmu * A^T diag(w) A
+                    c = c + o.c1 * (o.pc[gi] * o.pc[gj]);  // C += c1 * outer(pc, pc)
+                    c = c + tmpc * cold;                   // C += tmp  (tmp = c1*cc*(2-cc)*C_old, or 0)
+                    *cp = c;
+                }
+            }
+        }
+    }
+}
+
+// xmean[e] = sum_k w[k] * arx[idx[k]][e]   (one workgroup per 64 columns; 16 k-slices of 64 lanes each,
+// 4 rows in flight per thread, fixed combination order => reproducible)
+constexpr int kRecSlices = 16;
+__global__ __launch_bounds__(64 * kRecSlices) void cma_recombine_kernel(const double *__restrict__ arx,
+                                                                        const int64_t *__restrict__ idx,
+                                                                        const double *__restrict__ w, int mu, int n,
+                                                                        double *__restrict__ xmean) {
+    __shared__ double part[kRecSlices][64];
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 64 + lane;
+    const int slice = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (col < n) {
+        for (int k0 = slice; k0 < mu; k0 += 4 * kRecSlices) {
+            double v[4], ww[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * kRecSlices;
+                const bool in = k < mu;
+                ww[u] = in ? w[k] : 0.0;
+                v[u] = in ? arx[idx[k] * (int64_t)n + col] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += ww[u] * v[u];
+        }
+    }
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && col < n) {
+        double s = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < kRecSlices; ++k) s += part[k][lane];
+        xmean[col] = s;
+    }
+}
+
+// Z[i][e] ~ N(0,1): Box-Muller on the two 53-bit uniforms of a call, half 0 -> cos, half 1 -> sin
+// (oracle/streams.py PhiloxStream.cma_normals)
+__global__ __launch_bounds__(256) void cma_normals_kernel(double *__restrict__ Z, int64_t P, int n, int64_t row0,
+                                                          uint32_t gen, uint32_t k0, uint32_t k1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= P) return;
+    const uint32_t grow = (uint32_t)(row0 + row);
+    const uint32_t lpr = (uint32_t)lanes_per_row(n);  // same element -> (slot, half) layout as the row kernels
+    // elements (2k)*lpr + l and (2k+1)*lpr + l are the cosine and the sine half of ONE call (slot k*lpr + l): a lane
+    // takes both, so the generator, the logarithm, the square root and the angle reduction run once per pair
+    const int npair = ((n + 2 * (int)lpr - 1) / (2 * (int)lpr)) * (int)lpr;
+    double *zr = Z + row * (int64_t)n;
+    for (int j = lane; j < npair; j += kWave) {
+        const uint32_t k = (uint32_t)j / lpr, l = (uint32_t)j & (lpr - 1u);
+        const int e0 = (int)(2u * k * lpr + l), e1 = e0 + (int)lpr;
+        if (e0 >= n) continue;
+        const U4 w = philox4x32_10(k * lpr + l, grow, gen, kPurposeCmaNormal, k0, k1);
+        const double d0 = u53(w.x, w.y), d1 = u53(w.z, w.w);
+        const double rad = sqrt(-2.0 * log(1.0 - d0));
+        const double ang = 6.283185307179586 * d1;
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        zr[e0] = rad * cs;
+        if (e1 < n) zr[e1] = rad * sn;
+    }
+}
+
+// C = triu(C) + triu(C,1).T
+__global__ __launch_bounds__(256) void symmetrize_upper_kernel(double *__restrict__ C, int n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * n) return;
+    const int i = (int)(t / n), j = (int)(t % n);
+    if (i > j) C[t] = C[(int64_t)j * n + i];
+}
+
+}  // namespace
+
+// tile choice: enough workgroups to cover the 256 CUs on the (small) CMA-ES shapes
+namespace sx {
+int cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, const double *B, const double *D,
+                      const double *Z, double *arx, int64_t P, int n, void *stream);
+int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
+                       const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
+                       const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream);
+}  // namespace sx
+
+extern "C" int sx_cmaes_sample(const double *xmean, double sigma, const double *B, const double *D, const double *Z,
+                               double *arx, int64_t P, int n, void *stream) {
+    return sx::cma_sample_launch(xmean, sigma, nullptr, B, D, Z, arx, P, n, stream);
+}
+
+int sx::cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, const double *B, const double *D,
+                          const double *Z, double *arx, int64_t P, int n, void *stream) {
+    SX_REQUIRE(xmean && B && D && Z && arx && P >= 1 && n >= 1, "sx_cmaes_sample: bad arguments");
+    SampleOp op{Z, B, D, xmean, arx, sigma, sigma_p, P, n};
+    const int64_t big = ((P + 63) / 64) * ((n + 63) / 64);
+    if (big >= 512) {
+        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((P + 63) / 64));
+        hipLaunchKernelGGL((cma_gemm_kernel<0, 64, 64, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    } else if (big >= 256) {
+        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((P + 31) / 32));
+        hipLaunchKernelGGL((cma_gemm_kernel<0, 32, 64, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    } else {  // small problems: more, smaller workgroups (2+ waves per SIMD hide the per-chunk latency)
+        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((P + 31) / 32));
+        hipLaunchKernelGGL((cma_gemm_kernel<0, 32, 32, SampleOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    }
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold,
+                                double sigma, const double *pc, double c1, double cmu, double tmp_coef, double *C,
+                                double *ws_y, int n, void *stream) {
+    return sx::cma_rank_mu_launch(arx, idx, w, mu, xold, sigma, nullptr, pc, c1, cmu, tmp_coef, nullptr, C, ws_y, n, stream);
+}
+
+int sx::cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
+                           const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
+                           const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream) {
+    SX_REQUIRE(arx && idx && w && xold && pc && C && ws_y && mu >= 1 && n >= 1, "sx_cmaes_rank_mu: bad arguments");
+    const int64_t total = (int64_t)mu * n;
+    hipLaunchKernelGGL(cma_y_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, arx, idx,
+                       xold, sigma, sigma_p, mu, n, ws_y);
+    SX_LAUNCH_CHECK();
+    RankMuOp op{ws_y, w, pc, C, 1.0 - c1 - cmu, cmu, c1, tmp_coef, tmp_coef_p, mu, n};
+    const int64_t big = ((int64_t)(n + 63) / 64) * ((n + 63) / 64);
+    if (big >= 512) {
+        dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
+        hipLaunchKernelGGL((cma_gemm_kernel<1, 64, 64, RankMuOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    } else {
+        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32));
+        hipLaunchKernelGGL((cma_gemm_kernel<1, 32, 32, RankMuOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+    }
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_cmaes_recombine(const double *arx, const int64_t *idx, const double *w, int mu, int n,
+                                  double *xmean, void *stream) {
+    SX_REQUIRE(arx && idx && w && xmean && mu >= 1 && n >= 1, "sx_cmaes_recombine: bad arguments");
+    hipLaunchKernelGGL(cma_recombine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * kRecSlices), 0, (hipStream_t)stream, arx, idx,
+                       w, mu, n, xmean);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_cmaes_normals(double *Z, int64_t P, int n, int64_t row0, uint32_t gen, uint32_t key0, uint32_t key1,
+                                void *stream) {
+    SX_REQUIRE(Z && P >= 1 && n >= 1, "sx_cmaes_normals: bad arguments");
+    hipLaunchKernelGGL(cma_normals_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Z, P, n,
+                       row0, gen, key0, key1);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_symmetrize_upper(double *C, int n, void *stream) {
+    SX_REQUIRE(C && n >= 1, "sx_symmetrize_upper: bad arguments");
+    const int64_t total = (int64_t)n * n;
+    hipLaunchKernelGGL(symmetrize_upper_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, C, n);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// VD-CMA sampling (stochopy/optimize/vdcma/_vdcma.py:236-248): with the covariance model D (I + v v^T) D a
+// candidate costs O(n):  y = d o (z + (sqrt(1 + |v|^2) - 1) (z . vn) vn),  x = xmean + sigma * y.
+// One wavefront per candidate; rows 0 and 1 of the generation are replaced by +dy / -dy when the mean-shift
+// injection is on (:241-247).  Both y (needed by the host's moment sums) and x are written.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void vd_sample_kernel(const double *__restrict__ Z, int64_t P, int n, int64_t row0,
+                                                        const double *__restrict__ dvec, const double *__restrict__ vn,
+                                                        double coef, const double *__restrict__ xmean, double sigma,
+                                                        const double *__restrict__ dy, double *__restrict__ ary,
+                                                        double *__restrict__ arx, const sx_cma_state *st) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= P) return;
+    if (st != nullptr) {  // device-resident loop: step size, model coefficient and injection flag live on the device
+        if (st->done) return;
+        sigma = st->sigma;
+        coef = st->reserved[4];
+        if (st->reserved[3] == 0.0) dy = nullptr;
+    }
+    const double *z = Z + row * (int64_t)n;
+    double t = 0.0;
+    // 8 row loads per lane in flight (the row is streamed twice: the second pass hits L2)
+    int e = lane;
+    for (; e + 7 * kWave < n; e += 8 * kWave) {
+        double zz[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) zz[u] = z[e + u * kWave], vv[u] = vn[e + u * kWave];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += zz[u] * vv[u];
+    }
+    for (; e < n; e += kWave) t += z[e] * vn[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+    const int64_t grow = row0 + row;
+    const bool inj = dy != nullptr && grow < 2;
+    const double sgn = grow == 0 ? 1.0 : -1.0;
+    double *yo = ary + row * (int64_t)n, *xo = arx + row * (int64_t)n;
+    e = lane;
+    for (; e + 3 * kWave < n; e += 4 * kWave) {
+        double zz[4], vv[4], dd[4], xm[4], dj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = e + u * kWave;
+            zz[u] = z[c], vv[u] = vn[c], dd[u] = dvec[c], xm[u] = xmean[c], dj[u] = inj ? dy[c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = e + u * kWave;
+            const double y = inj ? sgn * dj[u] : dd[u] * (zz[u] + coef * (t * vv[u]));
+            yo[c] = y;
+            xo[c] = xm[u] + sigma * y;
+        }
+    }
+    for (; e < n; e += kWave) {
+        const double y = inj ? sgn * dy[e] : dvec[e] * (z[e] + coef * (t * vn[e]));
+        yo[e] = y;
+        xo[e] = xmean[e] + sigma * y;
+    }
+}
+}  // namespace
+
+extern "C" int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, const double *dvec, const double *vn,
+                               double coef, const double *xmean, double sigma, const double *dy, double *ary,
+                               double *arx, void *stream) {
+    SX_REQUIRE(Z && dvec && vn && xmean && ary && arx && P >= 1 && n >= 1 && row0 >= 0, "sx_vdcma_sample: bad arguments");
+    const int rows_per_block = 4;
+    hipLaunchKernelGGL(vd_sample_kernel, dim3((unsigned)((P + rows_per_block - 1) / rows_per_block)),
+                       dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, row0, dvec, vn, coef, xmean, sigma,
+                       dy, ary, arx, (const sx_cma_state *)nullptr);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace sx {
+// the same with sigma / coefficient / injection flag read from the device state (sx_vdcma_generation)
+int vd_sample_launch(const double *Z, int64_t P, int n, const double *dvec, const double *vn, const double *xmean,
+                     const double *dy, double *ary, double *arx, const sx_cma_state *st, void *stream) {
+    const int rows_per_block = 4;
+    hipLaunchKernelGGL(vd_sample_kernel, dim3((unsigned)((P + rows_per_block - 1) / rows_per_block)),
+                       dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, (int64_t)0, dvec, vn, 0.0, xmean, 0.0,
+                       dy, ary, arx, st);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace sx
+
+// ---------------------------------------------------------------------------
+// VD-CMA moment sums (stochopy/optimize/vdcma/_vdcma.py:289-295 weighted mean of the selected candidates, :317 the
+// weighted step w . y, :331-339 + :428-444 the rank-mu moments p, q under the model D (I + v v^T) D): everything
+// that is O(mu n).  Only four n-vectors go back to the host per generation.
+//   t_k   = (ary[idx_k] / dvec) . vn                                   (vd_t_kernel, one wavefront per selected row)
+//   wx    = sum_k w_k arx[idx_k]            wy = sum_k w_k ary[idx_k]
+//   p_mu  = sum_k w_k (y_k^2 - shrink * t_k * y_k * vn - 1)           with y_k = ary[idx_k] / dvec
+//   q_mu  = sum_k w_k (t_k * y_k - 0.5 (t_k^2 + 1 + |v|^2) * vn)
+// as 64 partial rows (k mod 64) per output, then a fixed-order finish.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kVdPart = 64;
+
+__global__ __launch_bounds__(256) void vd_t_kernel(const double *__restrict__ ary, const int64_t *__restrict__ idx, int mu,
+                                                   int n, const double *__restrict__ dvec, const double *__restrict__ vn,
+                                                   double *__restrict__ tk) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int k = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (k >= mu) return;
+    const double *y = ary + idx[k] * (int64_t)n;
+    double t = 0.0;
+    int e = lane;
+    for (; e + 7 * kWave < n; e += 8 * kWave) {  // 8 row loads per lane in flight
+        double yy[8], dd[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) yy[u] = y[e + u * kWave], dd[u] = dvec[e + u * kWave], vv[u] = vn[e + u * kWave];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += (yy[u] / dd[u]) * vv[u];
+    }
+    for (; e < n; e += kWave) t += (y[e] / dvec[e]) * vn[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+    if (lane == 0) tk[k] = t;
+}
+
+// grid: ceil(n/64) x 16; part[o][q][e], o = 0..3 (wx, wy, p, q), q = k mod 64
+__global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *__restrict__ arx, const double *__restrict__ ary,
+                                                                 const int64_t *__restrict__ idx, const double *__restrict__ w,
+                                                                 const double *__restrict__ tk, int mu, int n,
+                                                                 const double *__restrict__ dvec, const double *__restrict__ vn,
+                                                                 double norm_v2, double *__restrict__ part,
+                                                                 const sx_cma_state *st) {
+    if (st != nullptr) norm_v2 = st->reserved[1];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    const int q = blockIdx.y * 4 + ty;
+    if (col >= n) return;
+    const double shrink = norm_v2 / (1.0 + norm_v2);
+    const double dv = dvec[col], v = vn[col];
+    double awx = 0.0, awy = 0.0, ap = 0.0, aq = 0.0;
+    for (int k = q; k < mu; k += kVdPart) {
+        const int64_t row = idx[k] * (int64_t)n + col;
+        const double wk = w[k], t = tk[k], ax = arx[row], ay = ary[row];
+        const double y = ay / dv;
+        awx += wk * ax;
+        awy += wk * ay;
+        ap += wk * (y * y - shrink * (t * (y * v)) - 1.0);
+        aq += wk * (t * y - (0.5 * (t * t + 1.0 + norm_v2)) * v);
+    }
+    const int64_t o = (int64_t)q * n + col, plane = (int64_t)kVdPart * n;
+    part[o] = awx, part[plane + o] = awy, part[2 * plane + o] = ap, part[3 * plane + o] = aq;
+}
+
+// grid: ceil(n/64) x 4 outputs; the 64 partial rows of a column are added in their order (four slices of 16, then the
+// slices in order: the same value as one thread adding all 64 would NOT be bit-identical, and need not be -- the
+// device loop and the host loop are compared to rounding)
+__global__ __launch_bounds__(256) void vd_moments_finish_kernel(const double *__restrict__ part, int n, double *__restrict__ out) {
+    __shared__ double sl[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx, o = blockIdx.y;
+    const int64_t plane = (int64_t)kVdPart * n;
+    double s = 0.0;
+    if (e < n) {
+        double v[kVdPart / 4];
+#pragma unroll
+        for (int q = 0; q < kVdPart / 4; ++q) v[q] = part[o * plane + (int64_t)(ty * (kVdPart / 4) + q) * n + e];
+#pragma unroll
+        for (int q = 0; q < kVdPart / 4; ++q) s += v[q];
+    }
+    sl[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < n) out[(int64_t)o * n + e] = ((sl[0][tx] + sl[1][tx]) + sl[2][tx]) + sl[3][tx];
+}
+}  // namespace
+
+namespace sx {
+int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
+                      const double *dvec, const double *vn, double norm_v2, const sx_cma_state *state, double *ws,
+                      double *out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    double *tk = ws, *part = ws + ((mu + 7) / 8) * 8;
+    hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
+    hipLaunchKernelGGL(vd_moments_partial_kernel, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
+                       w, tk, mu, n, dvec, vn, norm_v2, part, state);
+    hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 63) / 64), 4), dim3(256), 0, st, part, n, out);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace sx
+
+extern "C" int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
+                                const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream) {
+    SX_REQUIRE(arx && ary && idx && w && dvec && vn && ws && out && mu >= 1 && n >= 1, "sx_vdcma_moments: bad arguments");
+    return sx::vd_moments_launch(arx, ary, idx, w, mu, n, dvec, vn, norm_v2, nullptr, ws, out, stream);
+}

@@ -1,0 +1,520 @@
+// Core of the C ABI: error channel, summation plans, batched objective
+// evaluation, argmin and the best-of-generation / termination kernel.
+//
+// Reference code replaced (paths relative to the reference checkout):
+//   stochopy/factory/benchmark.py:14-156              the seven objectives
+//   stochopy/optimize/_common.py:34-90                population wrapper fun(X) -> f
+//   stochopy/optimize/_common.py:131-158              argmin + termination ladder
+#include <string>
+#include <vector>
+
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+#include "sx_rowops.hpp"
+
+namespace sx {
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" int sx_abi_version(void) { return SX_ABI_VERSION; }
+extern "C" const char *sx_last_error(void) { return g_error.c_str(); }
+extern "C" int sx_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(sx_state);
+        case 1: return (int)sizeof(sx_de_args);
+        case 2: return (int)sizeof(sx_pso_args);
+        case 3: return (int)sizeof(sx_xchg_args);
+        case 4: return (int)sizeof(sx_cma_state);
+        case 5: return (int)sizeof(sx_cma_args);
+        case 6: return (int)sizeof(sx_vd_args);
+    }
+    return -1;
+}
+extern "C" int sx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return -1;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// numpy pairwise-sum plan (host)
+// ---------------------------------------------------------------------------
+namespace {
+struct PlanBuilder {
+    std::vector<int> end_block, merges;
+    int blocks = 0;
+    int depth = 0, max_depth = 0;
+    void rec(int64_t m) {
+        if (m <= 128) {
+            blocks += (int)(m / 8);
+            end_block.push_back(blocks);
+            merges.push_back(0);
+            ++depth;
+            if (depth > max_depth) max_depth = depth;
+            return;
+        }
+        int64_t h = m / 2;
+        h -= h % 8;
+        rec(h);
+        rec(m - h);
+        merges.back() += 1;
+        --depth;
+    }
+};
+}  // namespace
+
+extern "C" int sx_sum_plan(int64_t m, int32_t *out, int cap) {
+    if (m < 0 || cap < 4) return -1;
+    if (m < 8) {
+        out[0] = 0;
+        out[1] = (int32_t)m;
+        out[2] = 0;
+        out[3] = 1;
+        return 4;
+    }
+    PlanBuilder b;
+    b.rec(m);
+    const int nleaf = (int)b.end_block.size();
+    const int need = 4 + 2 * nleaf;
+    if (cap < need) return -need;
+    out[0] = nleaf;
+    out[1] = (int32_t)(m % 8);
+    out[2] = (int32_t)(m / 8);
+    out[3] = b.max_depth;
+    for (int t = 0; t < nleaf; ++t) {
+        out[4 + 2 * t] = b.end_block[t];
+        out[5 + 2 * t] = b.merges[t];
+    }
+    return need;
+}
+
+extern "C" int64_t sx_fun_terms(int fun_id, int n) {
+    if (fun_id == SX_FUN_ROSENBROCK) return n > 0 ? n - 1 : 0;
+    return n;
+}
+
+extern "C" int64_t sx_num_partials(int64_t P, int n) { return (int64_t)row_geometry(P, n).blocks; }
+
+namespace sx {
+int make_plan_arg(int fun_id, int n, PlanArg *out) {
+    if (n > kMaxDim) {
+        set_error("dimension above the kernel limit (n <= 4096)");
+        return -1;
+    }
+    const int64_t m = sx_fun_terms(fun_id, n);
+    std::vector<int32_t> buf(4 + 2 * (size_t)(m / 64 + 2));
+    const int got = sx_sum_plan(m, buf.data(), (int)buf.size());
+    if (got < 0 || buf[0] > kMaxLeaf || buf[3] > 12) {
+        set_error("dimension too large for the kernel-argument summation plan");
+        return -1;
+    }
+    out->nleaf = buf[0];
+    out->tail = buf[1];
+    out->mb = buf[2];
+    out->depth = buf[3];
+    std::vector<int> stack;  // slots (leaf indices) of the pending partial sums
+    int nm = 0;
+    for (int t = 0; t < buf[0]; ++t) {
+        out->end[t] = buf[4 + 2 * t];
+        out->merges[t] = buf[5 + 2 * t];
+        stack.push_back(t);
+        for (int k = 0; k < buf[5 + 2 * t]; ++k) {
+            const int right = stack.back();
+            stack.pop_back();
+            out->mleft[nm] = stack.back();
+            out->mright[nm] = right;
+            ++nm;
+        }
+    }
+    return 0;
+}
+}  // namespace sx
+
+// ---------------------------------------------------------------------------
+// Batched evaluation kernel: one wavefront per individual.
+// ---------------------------------------------------------------------------
+template <int FUN, int LPR>
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
+    const double *__restrict__ X, int64_t P, int n, int64_t ldx, const double *__restrict__ xm,
+    const double *__restrict__ xstd, double *__restrict__ f, const PlanArg plan, double *__restrict__ part_f,
+    int64_t *__restrict__ part_i, const int clip, const double *__restrict__ pen_v, double *__restrict__ pen_out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sf[kMaxRowsPerBlock];
+    __shared__ int64_t si[kMaxRowsPerBlock];
+    const RowIds<LPR> id(P);
+    double *U = lds + id.slot * lds_row_stride(n);
+    const double *xr = X + id.rowc * ldx;
+    const bool affine = xm != nullptr;
+    double pacc = 0.0;
+    constexpr int kBatch = 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
+    for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
+        double xv[kBatch];
+#pragma unroll
+        for (int t = 0; t < kBatch; ++t) {
+            const int e = e0 + t * LPR;
+            xv[t] = e < n ? xr[e] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < kBatch; ++t) {
+            const int e = e0 + t * LPR;
+            if (e >= n) continue;
+            double v = xv[t];
+            if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
+                const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+                if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
+                v = c;
+            }
+            if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
+            U[e] = v;
+        }
+    }
+    if (pen_out != nullptr) {
+        pacc = row_sum<LPR>(pacc);
+        if (id.active && id.l == 0) pen_out[id.row] = pacc;
+    }
+    const double val = row_objective<FUN, LPR>(U, n, plan, id.l);
+    if (id.active && id.l == 0) f[id.row] = val;
+    if (part_f != nullptr) block_partial<LPR>(val, id, sf, si, part_f, part_i);
+}
+
+template <int FUN>
+static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
+                       const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s, int clip = 0,
+                       const double *pen_v = nullptr, double *pen_out = nullptr) {
+    const Geometry g = row_geometry(P, n);
+    SX_DISPATCH_LPR(n, hipLaunchKernelGGL((eval_kernel<FUN, LPR>), dim3(g.blocks), dim3(g.threads), g.lds, s, X, P, n,
+                                          ldx, xm, xstd, f, plan, part_f, part_i, clip, pen_v, pen_out))
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm,
+                       const double *xstd, double *f, double *part_f, int64_t *part_i, void *stream) {
+    SX_REQUIRE(X && f, "sx_eval: null pointer");
+    SX_REQUIRE(P >= 1 && n >= 1 && ldx >= n, "sx_eval: bad shape");
+    SX_REQUIRE(fun_id >= 0 && fun_id < SX_FUN_COUNT, "sx_eval: unknown fun_id");
+    SX_REQUIRE((xm == nullptr) == (xstd == nullptr), "sx_eval: xm and xstd must be given together");
+    SX_REQUIRE((part_f == nullptr) == (part_i == nullptr), "sx_eval: part_f and part_i must be given together");
+    hipStream_t s = (hipStream_t)stream;
+    PlanArg plan;
+    if (make_plan_arg(fun_id, n, &plan)) return -1;
+    switch (fun_id) {
+#define SX_CASE(ID) \
+    case ID:        \
+        return launch_eval<ID>(X, P, n, ldx, xm, xstd, f, plan, part_f, part_i, s);
+        SX_CASE(SX_FUN_ACKLEY)
+        SX_CASE(SX_FUN_GRIEWANK)
+        SX_CASE(SX_FUN_QUARTIC)
+        SX_CASE(SX_FUN_RASTRIGIN)
+        SX_CASE(SX_FUN_ROSENBROCK)
+        SX_CASE(SX_FUN_SPHERE)
+        SX_CASE(SX_FUN_STYBLINSKI_TANG)
+#undef SX_CASE
+    }
+    return -1;
+}
+
+// CMA-ES "Penalize" boundary handling (cmaes/_constraints.py:4-82), device part: candidates are clipped to the
+// standardised box [-1, 1]^n before the objective (f_raw), and pen[i] = sum_j (clip(x_ij) - x_ij)^2 * v[j]
+// (v = bnd_weights / bnd_scale from the host; NULL = no penalty term wanted).  One kernel.
+extern "C" int sx_cmaes_eval_penalized(int fun_id, const double *X, int64_t P, int n, const double *xm,
+                                       const double *xstd, const double *v, double *f_raw, double *pen, void *stream) {
+    SX_REQUIRE(X && f_raw && xm && xstd, "sx_cmaes_eval_penalized: null pointer");
+    SX_REQUIRE(P >= 1 && n >= 1, "sx_cmaes_eval_penalized: bad shape");
+    SX_REQUIRE(fun_id >= 0 && fun_id < SX_FUN_COUNT, "sx_cmaes_eval_penalized: unknown fun_id");
+    SX_REQUIRE((v == nullptr) == (pen == nullptr), "sx_cmaes_eval_penalized: v and pen must be given together");
+    hipStream_t s = (hipStream_t)stream;
+    PlanArg plan;
+    if (make_plan_arg(fun_id, n, &plan)) return -1;
+    switch (fun_id) {
+#define SX_CASE(ID) \
+    case ID:        \
+        return launch_eval<ID>(X, P, n, n, xm, xstd, f_raw, plan, nullptr, nullptr, s, 1, v, pen);
+        SX_CASE(SX_FUN_ACKLEY)
+        SX_CASE(SX_FUN_GRIEWANK)
+        SX_CASE(SX_FUN_QUARTIC)
+        SX_CASE(SX_FUN_RASTRIGIN)
+        SX_CASE(SX_FUN_ROSENBROCK)
+        SX_CASE(SX_FUN_SPHERE)
+        SX_CASE(SX_FUN_STYBLINSKI_TANG)
+#undef SX_CASE
+    }
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// argmin: stage 1 (grid) -> partials, stage 2 (one workgroup) -> result
+// ---------------------------------------------------------------------------
+constexpr int kFinalThreads = 256;
+
+__device__ __forceinline__ void block_argmin(double &bf, int64_t &bi, double *sf, int64_t *si) {
+    wave_argmin_all(bf, bi);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sf[w] = bf;
+        si[w] = bi;
+    }
+    __syncthreads();
+    bf = sf[0];
+    bi = si[0];
+    for (int k = 1; k < kFinalThreads / kWave; ++k) argmin_combine(bf, bi, sf[k], si[k]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFinalThreads) void argmin_stage1(const double *__restrict__ f, int64_t P,
+                                                               double *__restrict__ part_f,
+                                                               int64_t *__restrict__ part_i) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int64_t k = (int64_t)blockIdx.x * kFinalThreads + threadIdx.x; k < P; k += (int64_t)gridDim.x * kFinalThreads)
+        argmin_combine(bf, bi, f[k], k);
+    block_argmin(bf, bi, sf, si);
+    if (threadIdx.x == 0) {
+        part_f[blockIdx.x] = bf;
+        part_i[blockIdx.x] = bi;
+    }
+}
+
+__global__ __launch_bounds__(kFinalThreads) void argmin_stage2(const double *__restrict__ part_f,
+                                                               const int64_t *__restrict__ part_i, int64_t npart,
+                                                               int64_t *__restrict__ out_idx,
+                                                               double *__restrict__ out_val) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    for (int64_t k = threadIdx.x; k < npart; k += kFinalThreads) argmin_combine(bf, bi, part_f[k], part_i[k]);
+    block_argmin(bf, bi, sf, si);
+    if (threadIdx.x == 0) {
+        *out_idx = bi;
+        *out_val = bf;
+    }
+}
+
+extern "C" int sx_argmin(const double *f, int64_t P, double *ws_f, int64_t *ws_i, int64_t ws_len, int64_t *out_idx,
+                         double *out_val, void *stream) {
+    SX_REQUIRE(f && ws_f && ws_i && out_idx && out_val && P >= 1 && ws_len >= 1, "sx_argmin: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nblk = (P + kFinalThreads - 1) / kFinalThreads;
+    if (nblk > ws_len) nblk = ws_len;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(argmin_stage1, dim3((unsigned)nblk), dim3(kFinalThreads), 0, s, f, P, ws_f, ws_i);
+    SX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(kFinalThreads), 0, s, ws_f, ws_i, nblk, out_idx, out_val);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Best-of-generation + termination (stochopy/optimize/_common.py:131-158)
+// ---------------------------------------------------------------------------
+// best of the per-workgroup records, 8 records per thread and trip so their loads overlap
+__device__ __forceinline__ void scan_records(const double *__restrict__ part_f, const int64_t *__restrict__ part_i,
+                                             int64_t npart, double &bf, int64_t &bi) {
+    constexpr int kScan = 8;
+    for (int64_t k0 = threadIdx.x; k0 < npart; k0 += (int64_t)kFinalThreads * kScan) {
+        double f[kScan];
+        int64_t i[kScan];
+#pragma unroll
+        for (int u = 0; u < kScan; ++u) {
+            const int64_t k = k0 + (int64_t)u * kFinalThreads;
+            f[u] = k < npart ? part_f[k] : __builtin_huge_val();
+            i[u] = k < npart ? part_i[k] : INT64_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < kScan; ++u) argmin_combine(bf, bi, f[u], i[u]);
+    }
+}
+
+__global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
+    const double *__restrict__ part_f, const int64_t *__restrict__ part_i, int64_t npart,
+    const double *__restrict__ rows0, const double *__restrict__ rows1, int64_t ld, int n,
+    double *__restrict__ gbest, sx_state *__restrict__ state, int maxiter, double xtol, double ftol) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    scan_records(part_f, part_i, npart, bf, bi);  // the loads do not depend on the state word: issue them first
+    if (state->done) return;
+    const int64_t it = state->it + 1;  // the generation being finalised
+    block_argmin(bf, bi, sf, si);
+
+    // generation g lives in rows[g & 1] (double-buffered populations); rows0 == rows1 for in-place state
+    const double *src = ((it & 1) ? rows1 : rows0) + bi * ld;
+    // dx = ||xbest_prev - x[k]||_2 (np.linalg.norm, _common.py:135); all loads of a thread in flight together
+    constexpr int kPer = (kMaxDim + kFinalThreads - 1) / kFinalThreads;
+    double gv[kPer], sv[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = threadIdx.x + u * kFinalThreads;
+        gv[u] = e < n ? gbest[e] : 0.0;
+        sv[u] = e < n ? src[e] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        if (threadIdx.x + u * kFinalThreads < n) {
+            const double d = gv[u] - sv[u];
+            acc += d * d;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double ss = 0.0;
+    for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
+    const double dx = sqrt(ss);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u)
+        if (threadIdx.x + u * kFinalThreads < n) gbest[threadIdx.x + u * kFinalThreads] = sv[u];
+    if (threadIdx.x == 0) {
+        int status = SX_STATUS_NONE;
+        if (dx <= xtol && bf <= ftol)
+            status = 0;
+        else if (bf <= ftol)
+            status = 1;
+        else if (it >= maxiter)
+            status = -1;
+        state->it = it;
+        state->gbidx = bi;
+        state->gfit = bf;
+        state->dx = dx;
+        state->status = status;
+        state->done = status != SX_STATUS_NONE;
+    }
+}
+
+extern "C" int sx_select_finalize(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                                  const double *rows1, int64_t ld, int n, double *gbest, sx_state *state, int maxiter,
+                                  double xtol, double ftol, void *stream) {
+    SX_REQUIRE(part_f && part_i && rows0 && rows1 && gbest && state && npart >= 1 && n >= 1,
+               "sx_select_finalize: bad arguments");
+    hipLaunchKernelGGL(select_finalize_kernel, dim3(1), dim3(kFinalThreads), 0, (hipStream_t)stream, part_f, part_i,
+                       npart, rows0, rows1, ld, n, gbest, state, maxiter, xtol, ftol);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU: shard best -> record, and best-of-generation over the gathered records.
+// record = [ f, (double) global row, row[0..n) ]   (n + 2 doubles)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kFinalThreads) void shard_best_kernel(
+    const double *__restrict__ part_f, const int64_t *__restrict__ part_i, int64_t npart,
+    const double *__restrict__ rows0, const double *__restrict__ rows1, int64_t ld, int n,
+    const sx_state *__restrict__ state, int64_t row0, double *__restrict__ record) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    scan_records(part_f, part_i, npart, bf, bi);
+    const int64_t it = state->it + 1;  // the generation being finalised
+    block_argmin(bf, bi, sf, si);
+    const double *src = ((it & 1) ? rows1 : rows0) + bi * ld;
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) record[2 + e] = src[e];
+    if (threadIdx.x == 0) {
+        record[0] = bf;
+        record[1] = (double)(row0 + bi);  // exact below 2^53
+    }
+}
+
+__global__ __launch_bounds__(kFinalThreads) void gather_finalize_kernel(const double *__restrict__ records, int world,
+                                                                        int n, double *__restrict__ gbest,
+                                                                        sx_state *__restrict__ state, int maxiter,
+                                                                        double xtol, double ftol) {
+    __shared__ double sf[kFinalThreads / kWave];
+    if (state->done) return;
+    const int64_t stride = n + 2;
+    // every thread scans the (few) records: first minimum by (f, global row) = np.argmin over the whole population
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    int best = 0;
+    for (int w = 0; w < world; ++w) {
+        const double f = records[w * stride];
+        const int64_t gi = (int64_t)records[w * stride + 1];
+        if (f < bf || (f == bf && gi < bi)) {
+            bf = f;
+            bi = gi;
+            best = w;
+        }
+    }
+    const double *src = records + best * stride + 2;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) {
+        const double d = gbest[e] - src[e];
+        acc += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double ss = 0.0;
+    for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
+    const double dx = sqrt(ss);
+    for (int e = threadIdx.x; e < n; e += kFinalThreads) gbest[e] = src[e];
+    if (threadIdx.x == 0) {
+        const int64_t it = state->it + 1;
+        int status = SX_STATUS_NONE;
+        if (dx <= xtol && bf <= ftol)
+            status = 0;
+        else if (bf <= ftol)
+            status = 1;
+        else if (it >= maxiter)
+            status = -1;
+        state->it = it;
+        state->gbidx = bi;
+        state->gfit = bf;
+        state->dx = dx;
+        state->status = status;
+        state->done = status != SX_STATUS_NONE;
+    }
+}
+
+extern "C" int sx_shard_best(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
+                             const double *rows1, int64_t ld, int n, const sx_state *state, int64_t row0,
+                             double *record, void *stream) {
+    SX_REQUIRE(part_f && part_i && rows0 && rows1 && state && record && npart >= 1 && n >= 1,
+               "sx_shard_best: bad arguments");
+    hipLaunchKernelGGL(shard_best_kernel, dim3(1), dim3(kFinalThreads), 0, (hipStream_t)stream, part_f, part_i, npart,
+                       rows0, rows1, ld, n, state, row0, record);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_gather_finalize(const double *records, int world, int n, double *gbest, sx_state *state,
+                                  int maxiter, double xtol, double ftol, void *stream) {
+    SX_REQUIRE(records && gbest && state && world >= 1 && n >= 1, "sx_gather_finalize: bad arguments");
+    hipLaunchKernelGGL(gather_finalize_kernel, dim3(1), dim3(kFinalThreads), 0, (hipStream_t)stream, records, world, n,
+                       gbest, state, maxiter, xtol, ftol);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace sx {
+int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
+                      int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,
+                      sx_state *state, int maxiter, double xtol, double ftol) {
+    void *kargs[] = {&part_f, &part_i, &npart, &rows0, &rows1, &ld, &n, &gbest, &state, &maxiter, &xtol, &ftol};
+    hipKernelNodeParams kp = {};
+    kp.func = (void *)select_finalize_kernel;
+    kp.gridDim = dim3(1);
+    kp.blockDim = dim3(kFinalThreads);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = kargs;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    SX_HIP(hipGraphAddKernelNode(&node, graph, *prev ? prev : nullptr, *prev ? 1 : 0, &kp));
+    *prev = node;
+    return 0;
+}
+}  // namespace sx

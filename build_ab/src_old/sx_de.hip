@@ -207,9 +207,9 @@ constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its l
 // every bounds test folds away (the P = 4096, n = 128 headline shape).
 // NFIX: FULL with n == kStep * LPR exactly (64, 128 -- the headline shape -- or 256): the row length, and with it numpy's
 // summation plan, is a compile-time constant (row_reduce_fixed / row_reduce_static in sx_device.hpp); 0 otherwise.
-// STRAT: with NFIX and constraints=None, the strategy as a compile-time constant too (its donor count, the best-row
-// fetch and the mutant's formula are otherwise uniform branches inside the row's dependent chain: 9.03 -> 8.52 us per
-// generation at the headline shape), and no repair code; -1 = strategy and constraints read from the arguments.
+// STRAT: with NFIX, the strategy as a compile-time constant too (its donor count, the best-row fetch and the mutant's
+// formula are otherwise uniform branches inside the row's dependent chain: 9.03 -> 8.52 us per generation at the
+// headline shape); -1 = read from the arguments.
 template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_de_args a,
                                                                                  const PlanArg plan,
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const uint32_t grow = (uint32_t)(a.row0 + rowc);
     const int strategy = STRAT >= 0 ? STRAT : a.strategy;
     const int k = donors_of(strategy);
-    const bool repair = STRAT >= 0 ? false : a.constraints != 0;  // the per-strategy kernels are the constraints=None ones
+    const bool repair = a.constraints != 0;
     const bool use_best = strategy == SX_DE_BEST1BIN || strategy == SX_DE_BEST2BIN;
 
     int64_t d[kMaxDonors];
@@ -415,29 +415,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
         if (gdon) load_batch(0, B0);
     } else if (CHAIN) {
-        // (value, first row) over the records: the minimum value first (a tree per lane, then DPP over the wave), then
-        // the first record that holds it -- lanes own contiguous slices, so that is the first matching record of the
-        // first matching lane.  (A lexicographic compare-and-select chain over the 8 records, as the other kernels have
-        // it, is ~60 dependent instructions in front of the best row's address.)
-        double lm[kRecPerLane / 2];
+        double bf = pfv[0];
+        rec_t br = piv[0];
 #pragma unroll
-        for (int u = 0; u < kRecPerLane / 2; ++u) lm[u] = fmin(pfv[2 * u], pfv[2 * u + 1]);
-        const double lmin = fmin(fmin(lm[0], lm[1]), fmin(lm[2], lm[3]));
-        const double bf = wave_min_f64(lmin);
-        rec_t br = piv[0];  // (all NaN: record 0, as a sequential scan would)
-#pragma unroll
-        for (int u = kRecPerLane - 1; u >= 0; --u)
-            if (pfv[u] == bf) br = piv[u];
-        const unsigned long long hit = __ballot(lmin == bf);
-        const int src = hit ? (int)__ffsll((long long)hit) - 1 : 0;
-        int64_t bi;
-        if (LPR == kWave) {
-            bi = (int64_t)__builtin_amdgcn_readlane((int)br, src);
-        } else {
-            const int lo = __builtin_amdgcn_readlane((int)((int64_t)br & 0xffffffffll), src);
-            const int hi = __builtin_amdgcn_readlane((int)((int64_t)br >> 32), src);
-            bi = ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
-        }
+        for (int u = 1; u < kRecPerLane; ++u)
+            if (pfv[u] < bf || (pfv[u] == bf && piv[u] < br)) {
+                bf = pfv[u];
+                br = piv[u];
+            }
+        int64_t bi = br == kNoRec ? INT64_MAX : (int64_t)br;
+        wave_argmin_ordered(bf, bi);  // every wave on its own: no LDS, no workgroup barrier
         int status = SX_STATUS_NONE;
         if (it >= 2) {  // the reference does not test the initial population (de/_de.py:212-218)
             if (bf <= a.ftol)
@@ -468,7 +455,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     // ---- D. trial vector: mutation (de/_strategy.py, same association), crossover (de/_de.py:344 forced
     //      index OR r <= CR), Random repair (de/_constraints.py:21-26) -> LDS
     const int nq = (n + LPR - 1) / LPR;
-    double keep[kStep];  // NFIX (one batch per row): the trial stays in registers for the row store
     auto trial_batch = [&](int q0, const Batch &bt) {
         const double(&bx)[kStep] = bt.x;
         const double(&bd)[kMaxDonors][kStep] = bt.d;
@@ -532,7 +518,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
                 double cand = (e == irand || br[t] <= CR) ? v : bx[t];
                 if (repair && (cand < a.lower[e] || cand > a.upper[e])) cand = brs[t];
                 U[e] = cand;
-                if (NFIX) keep[t] = cand;
             }
         }
     };
@@ -560,19 +545,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const bool better = fc < fold;  // _common.py:127 strict <
     if (FULL || id.active) {
         double *__restrict__ xo = nxt + id.row * ld;
-        if constexpr (NFIX != 0) {  // both rows are in registers already: no load behind the objective
+        const double *__restrict__ src = better ? U : xi;  // LDS or global: generic loads
+        for (int e0 = l; e0 < n; e0 += kStep * LPR) {
+            double v[kStep];
 #pragma unroll
-            for (int t = 0; t < kStep; ++t) xo[l + t * LPR] = better ? keep[t] : B0.x[t];
-        } else {
-            const double *__restrict__ src = better ? U : xi;  // LDS or global: generic loads
-            for (int e0 = l; e0 < n; e0 += kStep * LPR) {
-                double v[kStep];
+            for (int t = 0; t < kStep; ++t) v[t] = (FULL || e0 + t * LPR < n) ? src[e0 + t * LPR] : 0.0;
 #pragma unroll
-                for (int t = 0; t < kStep; ++t) v[t] = (FULL || e0 + t * LPR < n) ? src[e0 + t * LPR] : 0.0;
-#pragma unroll
-                for (int t = 0; t < kStep; ++t)
-                    if (FULL || e0 + t * LPR < n) xo[e0 + t * LPR] = v[t];
-            }
+            for (int t = 0; t < kStep; ++t)
+                if (FULL || e0 + t * LPR < n) xo[e0 + t * LPR] = v[t];
         }
         if (l == 0) {
             if (better) a.fit[id.row] = fc;
@@ -604,8 +584,7 @@ de_kernel_t pick_kernel_lpr(int fun_id) {
 // bounds-test-free variant only for the chained (throughput) kernels, to keep the build small
 // the one-batch kernels come per strategy
 template <int RNG, int XM, int LPR, bool FULL, int NFIX>
-de_kernel_t pick_kernel_fixed(int fun_id, int strategy, int constraints) {
-    if (constraints != 0) return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX>(fun_id);
+de_kernel_t pick_kernel_fixed(int fun_id, int strategy) {
     switch (strategy) {
         case SX_DE_RAND1BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_RAND1BIN : -1>(fun_id);
         case SX_DE_RAND2BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_RAND2BIN : -1>(fun_id);
@@ -616,7 +595,7 @@ de_kernel_t pick_kernel_fixed(int fun_id, int strategy, int constraints) {
 }
 
 template <int RNG, int XM>
-de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy, int constraints) {
+de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy) {
     constexpr bool CH = XM >= 1;
     const int lpr = lanes_per_row(n);
     const bool full = CH && n % (kStep * lpr) == 0 && P % rows_per_block(n) == 0;
@@ -625,13 +604,13 @@ de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy, int constrai
     const bool fix = FX && full && n == kStep * lpr;
     switch (lpr) {
         case 16:
-            if (fix) return pick_kernel_fixed<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id, strategy, constraints);
+            if (fix) return pick_kernel_fixed<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id, strategy);
             return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 16, false>(fun_id);
         case 32:
-            if (fix) return pick_kernel_fixed<RNG, XM, 32, CH, FX ? kStep * 32 : 0>(fun_id, strategy, constraints);
+            if (fix) return pick_kernel_fixed<RNG, XM, 32, CH, FX ? kStep * 32 : 0>(fun_id, strategy);
             return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 32, false>(fun_id);
     }
-    if (fix) return pick_kernel_fixed<RNG, XM, 64, CH, FX ? kStep * 64 : 0>(fun_id, strategy, constraints);
+    if (fix) return pick_kernel_fixed<RNG, XM, 64, CH, FX ? kStep * 64 : 0>(fun_id, strategy);
     return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 64, false>(fun_id);
 }
 
@@ -652,8 +631,8 @@ int check_args(const sx_de_args *a) {
 }
 
 de_kernel_t kernel_for(const sx_de_args *a) {
-    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, 0>(a->fun_id, a->n, a->P, a->strategy, a->constraints)
-                                   : pick_kernel<SX_RNG_HOST, 0>(a->fun_id, a->n, a->P, a->strategy, a->constraints);
+    return a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX, 0>(a->fun_id, a->n, a->P, a->strategy)
+                                   : pick_kernel<SX_RNG_HOST, 0>(a->fun_id, a->n, a->P, a->strategy);
 }
 
 Geometry geometry(const sx_de_args *a) { return row_geometry(a->P, a->n); }
@@ -745,8 +724,8 @@ static int chain_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, 
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    de_kernel_t kern = x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P, a->strategy, a->constraints)
-                         : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P, a->strategy, a->constraints);
+    de_kernel_t kern = x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P, a->strategy)
+                         : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P, a->strategy);
     const unsigned blocks = finalize_only ? 1u : g.blocks + (x ? 1u : 0u);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream, *a, plan, parity,
                        finalize_only ? 1 : 0, (int64_t)g.blocks, x ? *x : sx_xchg_args{});
@@ -772,8 +751,8 @@ static int chain_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ng
         int parity = (start_parity + i) & 1;
         void *kargs[] = {&args, &plan, &parity, &mode, &npart, &xa};
         hipKernelNodeParams kp = {};
-        kp.func = (void *)(x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P, a->strategy, a->constraints)
-                             : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P, a->strategy, a->constraints));
+        kp.func = (void *)(x ? pick_kernel<SX_RNG_PHILOX, 2>(a->fun_id, a->n, a->P, a->strategy)
+                             : pick_kernel<SX_RNG_PHILOX, 1>(a->fun_id, a->n, a->P, a->strategy));
         kp.gridDim = dim3(g.blocks + (x ? 1u : 0u));
         kp.blockDim = dim3(g.threads);
         kp.sharedMemBytes = (unsigned)g.lds;

@@ -639,7 +639,7 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 __device__ __forceinline__ void wave_argmin_ordered(double &f, int64_t &i) {
     const double m = wave_min_f64(f);
     const unsigned long long mask = __ballot(f == m);
-    const int src = mask ? (int)__ffsll((long long)mask) - 1 : 0;  // all NaN: lane 0, as a sequential scan would
+    const int src = (int)__ffsll((long long)mask) - 1;
     const int lo = __builtin_amdgcn_readlane((int)(i & 0xffffffffll), src);
     const int hi = __builtin_amdgcn_readlane((int)(i >> 32), src);
     f = m;

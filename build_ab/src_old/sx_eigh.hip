@@ -1,0 +1,861 @@
+// Symmetric eigensolver for the CMA-ES model update, hand-written for gfx950: parallel two-sided block
+// Jacobi.  The matrix never leaves the GPU and nothing here calls a vendor solver.
+//
+// Reference code replaced (paths relative to the reference checkout):
+//   stochopy/optimize/cmaes/_cmaes.py:303-305   C = triu(C) + triu(C,1).T;  D, B = np.linalg.eigh(C);
+//                                               idx = argsort(D); D = D[idx]; B = B[:, idx]
+// (numpy.linalg.eigh is LAPACK dsyevd, a third-party call of the reference: SURVEY.md section 8c.)
+//
+// Method.  M = V^T C V is kept explicitly (V starts as I).  The index range is cut into nb blocks of 16; a
+// sweep is the nb-1 rounds of a round-robin tournament, each round pairing every block with one partner, and
+// a round is ONE kernel (eigh_round_kernel) whose workgroups all depend on the previous launch only:
+//   * pair workgroups (one per pair (I,J) of the round): the 32x32 pivot matrix [M_II M_IJ; M_JI M_JJ] of the
+//     CURRENT matrix is formed from the previous round's tiles and rotations (three small MFMA products), then
+//     one cyclic Jacobi sweep in LDS (31 rounds of 16 disjoint plane rotations; 256 threads = one 2x2 block of
+//     the two-sided update each) yields the orthogonal 32x32 U of the pair.
+//   * tile workgroups apply the PREVIOUS round's rotations to everything: tile (P,Q) of M becomes
+//     U_P^T (X U_Q) and tile (R,Q) of V becomes X U_Q, as fp64 MFMA (v_mfma_f64_16x16x4_f64) products, read
+//     from one buffer pair and written to the other.
+//   So the similarity updates (the flops) of round r-1 run beside the pivot sweeps (the latency) of round r,
+//   and a round costs one kernel boundary.
+// A sweep is accepted as the last one when the off-diagonal mass it leaves behind -- extrapolated from the
+// mass met during it and during the one before, eigh_last_sweep() -- is below tol * ||C||_F; the decision is
+// taken on the device and later launches of the run are no-ops, so the host never waits.
+// Finalisation: column norms of V (removes the drift of |v_j| over hundreds of rounds), eigenvalues
+// M_jj / |v_j|^2, ascending order (ties: lower position first), and the CANONICAL SIGN: the component of
+// largest magnitude of every eigenvector (lowest index on ties) is positive -- the rule
+// oracle/engine.py::eigh_canonical applies to LAPACK's vectors, so both sides of a parity test see the same basis.
+//
+// MFMA operand layout (cdna_hip_programming.md section 3): A (16x4): lane l holds A[l & 15][l >> 4];
+// B (4x16): lane l holds B[l >> 4][l & 15]; C/D: 4 doubles per lane, col = l & 15, row = (l >> 4) + 4 * reg.
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+
+#include <algorithm>
+
+using namespace sx;
+
+#ifdef SX_EIGH_TRACE
+// debug build only (tools/trace_eigh.py): shader-clock stamps of the pair workgroups of the LAST launch that ran them
+__device__ unsigned long long sx_eigh_trace_buf[64 * 16];
+#define SX_ETP(k)                                                                             \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 64) sx_eigh_trace_buf[blockIdx.x * 16 + (k)] = clock64(); \
+    } while (0)
+extern "C" int sx_eigh_trace_read(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sx_eigh_trace_buf), sizeof(unsigned long long) * 64 * 16);
+}
+#define SX_ETQ(cond, k)                                                                       \
+    do {                                                                                      \
+        if ((cond) && blockIdx.x < 64) sx_eigh_trace_buf[blockIdx.x * 16 + (k)] = clock64(); \
+    } while (0)
+#else
+#define SX_ETP(k) do {} while (0)
+#define SX_ETQ(cond, k) do {} while (0)
+#endif
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int kEighMaxSweeps = 60;
+constexpr int kBS = 16;        // block size of the outer method
+constexpr int kM2 = 2 * kBS;   // pivot matrices are 32x32
+constexpr int kUU = kM2 * kM2; // doubles per pair rotation
+
+struct EighInfo {  // first bytes of the workspace
+    int32_t done_seq;   // launch number at which the run ended (0: running); launches with a larger number do nothing
+    int32_t sweeps;     // sweeps carried out
+    int32_t parity;     // which (M, V) buffer pair holds the result
+    int32_t converged;  // 1: the stopping rule was met within max_sweeps
+    double norm2;       // ||C||_F^2 (upper triangle mirrored)
+    double thr2;        // tol^2 * norm2
+    double acc[kEighMaxSweeps];  // squared off-diagonal mass met during each sweep
+};
+
+// Stopping rule, evaluated from the off-diagonal mass a_s = sqrt(acc[s] / |C|_F^2) met DURING the sweeps so far:
+// the sweep s that just ended is the last one when a_s <= tol (nothing left), or when the iteration is in its
+// asymptotic regime (a_s <= 1e-10) and the mass it leaves behind, extrapolated as a_s * (a_s / a_{s-1}) -- exact
+// for linear convergence (multiple eigenvalues), pessimistic for quadratic -- is below tol.
+__device__ __forceinline__ bool eigh_last_sweep(const double *acc, int s, double norm2, double tol) {
+    const double a2 = acc[s], t2 = tol * tol * norm2;
+    if (a2 <= t2) return true;
+    if (a2 > 1.0e-20 * norm2) return false;
+    return s == 0 || a2 * a2 <= t2 * acc[s - 1];
+}
+
+// round-robin tournament of m (even) players: pair k of round r (0 <= r < m-1, 0 <= k < m/2)
+__host__ __device__ __forceinline__ void rr_pair(int k, int r, int m, int &a, int &b) {
+    const int q = m - 1;
+    if (k == 0) {
+        a = q;
+        b = r;
+        return;
+    }
+    int x = r + k;
+    if (x >= q) x -= q;
+    int y = r - k;
+    if (y < 0) y += q;
+    a = x;
+    b = y;
+}
+// inverse: the pair of player x in round r and whether x is its first (0) or second (1) member
+__device__ __forceinline__ void rr_find(int x, int r, int m, int &k, int &pos) {
+    const int q = m - 1;
+    if (x == q) {
+        k = 0, pos = 0;
+        return;
+    }
+    if (x == r) {
+        k = 0, pos = 1;
+        return;
+    }
+    int k1 = x - r;
+    if (k1 < 0) k1 += q;
+    if (k1 < m / 2) {
+        k = k1, pos = 0;
+    } else {
+        k = q - k1, pos = 1;
+    }
+}
+
+// Jacobi rotation J = [[c, s], [-s, c]] on the (p,q) plane that (nearly) annihilates a_pq, |angle| <= pi/4.
+// With d = a_qq - a_pp, h = 2 a_pq, r = hypot(d, h):  cos 2phi = |d| / r,  sin 2phi = sign(d) h / r,
+// c = sqrt((1 + cos 2phi) / 2),  s = sin 2phi / (2 c).  The ANGLE is worked out in single precision (two
+// v_rsq_f32, no division, no fp64 square root: this sits on the critical path of every inner round), then
+// (c, s) is renormalised in fp64 so that c^2 + s^2 = 1 to rounding: the transform is orthogonal to fp64
+// accuracy, and an angle that is off by 1e-7 relative only leaves 1e-7 of a_pq behind (every update below
+// applies the rotation that was actually chosen, nothing assumes an exact zero), which the quadratic
+// convergence of the sweeps absorbs.
+__device__ __forceinline__ void rotation(double app, double aqq, double apq, double &c, double &s) {
+    double d = aqq - app, h = 2.0 * apq;
+    const double mx = fmax(fabs(d), fabs(h));
+    if (h == 0.0 || !(mx < __builtin_inf())) {  // nothing to annihilate (or non-finite input: leave it alone)
+        c = 1.0, s = 0.0;
+        return;
+    }
+    int ex;
+    (void)frexp(mx, &ex);
+    const float df = (float)ldexp(d, -ex), hf = (float)ldexp(h, -ex);  // max(|d|, |h|) in [0.5, 1)
+    const float ir = __builtin_amdgcn_rsqf(fmaf(df, df, hf * hf));
+    const float x2 = fmaf(0.5f, fabsf(df) * ir, 0.5f);  // c^2 in [0.5, 1]
+    const float ic = __builtin_amdgcn_rsqf(x2);
+    const double cd = (double)(x2 * ic);
+    const double sd = (double)((0.5f * ((df < 0.0f ? -hf : hf) * ir)) * ic);
+    const double e = fma(-cd, cd, fma(-sd, sd, 1.0));  // 1 - (c^2 + s^2) ~ 1e-7
+    const double k = fma(e, fma(0.375, e, 0.5), 1.0);  // (1 - e)^(-1/2) to e^3
+    c = cd * k, s = sd * k;
+}
+
+// the LDS arrays one Jacobi sweep works on (the callers own the storage; everything is double-buffered)
+struct JacobiView {
+    double *S0, *S1;  // [M2][M2 + 1] each: the matrix
+    double *W0, *W1;  // [M2][M2 + 1] each: accumulated rotations (rows fixed, columns move with the matrix)
+    double *c, *s;    // [2][M2 / 2] rotation of every pair of the current / next inner round
+};
+
+// The sweep is systolic: position pair k is ALWAYS (2k, 2k+1), and after every round rows and columns move by
+// a fixed permutation, so every thread reads and writes at addresses that never change (no index arithmetic
+// inside the loop) and after the last round everything is back in place.
+//   MODE 0 (all pairs; M2-1 rounds): the round-robin tournament -- position 0 stays, the other M2-1 rotate by one
+//          place: 1 -> 2 -> 4 -> ... -> M2-2 -> M2-1 -> M2-3 -> ... -> 3 -> 1.
+//   MODE 1 (only pairs (even, odd) position = (block I, block J) of the outer method; M2/2 rounds): even
+//          positions stay, odd positions move on by one pair.
+template <int MODE>
+__host__ __device__ constexpr int sys_perm(int x, int m) {
+    if (MODE == 1) return (x & 1) ? (x + 2 >= m ? 1 : x + 2) : x;
+    return x == 0 ? 0 : (x == 1 ? 2 : ((x & 1) ? x - 2 : (x == m - 2 ? m - 1 : x + 2)));
+}
+template <int MODE>
+__host__ __device__ constexpr int sys_perm_inv(int y, int m) {
+    if (MODE == 1) return (y & 1) ? (y == 1 ? m - 1 : y - 2) : y;
+    return y == 0 ? 0 : (y == 2 ? 1 : ((y & 1) ? (y == m - 1 ? m - 2 : y + 2) : y - 2));
+}
+template <int M2>
+constexpr int jacobi_threads() {  // NP*NP updating threads, plus one wave that only prepares the next rotations
+    return (M2 / 2) * (M2 / 2) + 64 <= 1024 ? (M2 / 2) * (M2 / 2) + 64 : (M2 / 2) * (M2 / 2);
+}
+
+// one cyclic sweep on the M2 x M2 matrix in S0 (cur = 0) / S1; W <- W J for every rotation.
+// One barrier per inner round: while the NP*NP updating threads apply the rotations of round r to their 2x2
+// blocks (writing to the permuted places of the other buffer), NP rotation lanes -- a wave of their own when
+// the workgroup has room for one -- work out the pivot of their pair of round r+1 from the OLD matrix and the
+// rotations of round r, and from it the next rotation.
+template <int M2, int MODE>
+__device__ void jacobi_sweep(const JacobiView &L, int &cur, const int tid) {
+    constexpr int NP = M2 / 2, LD = M2 + 1, NREG = NP * NP, ROUNDS = MODE == 1 ? NP : M2 - 1;
+    constexpr bool OWN_WAVE = jacobi_threads<M2>() > NREG;
+    const bool reg = tid < NREG;
+    const int kp = reg ? tid / NP : 0, kq = reg ? tid % NP : 0;
+    // updating threads: source block (2kp, 2kp+1) x (2kq, 2kq+1), destination at the permuted places
+    const int o00 = (2 * kp) * LD + 2 * kq, o10 = o00 + LD;
+    const int dr0 = sys_perm<MODE>(2 * kp, M2) * LD, dr1 = sys_perm<MODE>(2 * kp + 1, M2) * LD;
+    const int dc0 = sys_perm<MODE>(2 * kq, M2), dc1 = sys_perm<MODE>(2 * kq + 1, M2);
+    // Rotation lanes.  With a wave of their own (OWN_WAVE) FOUR lanes serve pair k of the next round -- its old
+    // positions (i, j) = perm^-1(2k, 2k+1) -- and work out one pivot element each (lane 0: (i,i), 1: (j,j), 2 and 3:
+    // (i,j)) with the very operations the updating threads apply, so the predicted pivot IS the next matrix's; a DPP
+    // quad broadcast collects the three values and every lane forms the rotation (lane 0 of the quad stores it).
+    // Without room for an extra wave (M2 = 64) lane k of wave 0 does the three elements one after the other.
+    const int dl = OWN_WAVE ? tid - NREG : tid;
+    const bool duty = dl >= 0 && dl < (OWN_WAVE ? 4 * NP : NP);
+    const int k2 = duty ? (OWN_WAVE ? dl >> 2 : dl) : 0, part = OWN_WAVE ? (dl & 3) : 0;
+    const int i = sys_perm_inv<MODE>(2 * k2, M2), j = sys_perm_inv<MODE>(2 * k2 + 1, M2);
+    // element (ea, eb) this lane predicts
+    const int ea = part == 1 ? j : i, eb = part == 0 ? i : j;
+    const int ka = ea >> 1, kb = eb >> 1;
+    const bool pa = ea & 1, pb = eb & 1;
+    const int qab = (2 * ka) * LD + 2 * kb;
+    auto predicted = [&](const double *S, const double *rc, const double *rs, int ka_, bool pa_, int kb_, bool pb_, int q_) {
+        const double ca = rc[ka_], sa = rs[ka_], cb = rc[kb_], sb = rs[kb_];
+        const double b00 = S[q_], b01 = S[q_ + 1], b10 = S[q_ + LD], b11 = S[q_ + LD + 1];
+        const double r0 = pa_ ? fma(sa, b00, ca * b10) : fma(ca, b00, -(sa * b10));
+        const double r1 = pa_ ? fma(sa, b01, ca * b11) : fma(ca, b01, -(sa * b11));
+        return pb_ ? fma(sb, r0, cb * r1) : fma(cb, r0, -(sb * r1));
+    };
+    if (duty) {
+        const double *S = cur ? L.S1 : L.S0;
+        const int o = (2 * k2) * LD + 2 * k2;
+        double c, s;
+        rotation(S[o], S[o + LD + 1], S[o + 1], c, s);
+        if (part == 0) L.c[k2] = c, L.s[k2] = s;
+    }
+    __syncthreads();
+    for (int r = 0; r < ROUNDS; ++r) {
+        const double *S = cur ? L.S1 : L.S0;
+        double *Sn = cur ? L.S0 : L.S1;
+        const double *W = cur ? L.W1 : L.W0;
+        double *Wn = cur ? L.W0 : L.W1;
+        const double *rc = L.c + (r & 1) * NP, *rs = L.s + (r & 1) * NP;
+        SX_ETQ(r == 5 && tid == 0, 6);
+        SX_ETQ(r == 5 && duty && dl == 0, 10);
+        if (duty && r + 1 < ROUNDS) {
+            double nii, njj, nij;
+            if (OWN_WAVE) {
+                const double v = predicted(S, rc, rs, ka, pa, kb, pb, qab);
+                nii = dpp_f64<0x00>(v);  // quad_perm:[0,0,0,0]
+                njj = dpp_f64<0x55>(v);  // quad_perm:[1,1,1,1]
+                nij = dpp_f64<0xAA>(v);  // quad_perm:[2,2,2,2]
+            } else {
+                const int ki = i >> 1, kj = j >> 1;
+                const bool pi = i & 1, pj = j & 1;
+                nii = predicted(S, rc, rs, ki, pi, ki, pi, (2 * ki) * LD + 2 * ki);
+                njj = predicted(S, rc, rs, kj, pj, kj, pj, (2 * kj) * LD + 2 * kj);
+                nij = predicted(S, rc, rs, ki, pi, kj, pj, (2 * ki) * LD + 2 * kj);
+            }
+            SX_ETQ(r == 5 && dl == 0 && nij != 12345.0, 11);
+            double c, s;
+            rotation(nii, njj, nij, c, s);
+            SX_ETQ(r == 5 && dl == 0 && c != 12345.0, 12);
+            if (part == 0) L.c[((r + 1) & 1) * NP + k2] = c, L.s[((r + 1) & 1) * NP + k2] = s;
+        }
+        if (reg) {
+            const double c1 = rc[kp], s1 = rs[kp], c2 = rc[kq], s2 = rs[kq];
+            const double b00 = S[o00], b01 = S[o00 + 1], b10 = S[o10], b11 = S[o10 + 1];
+            const double w00 = W[o00], w01 = W[o00 + 1], w10 = W[o10], w11 = W[o10 + 1];
+            // rows: J^T B;  columns: (J^T B) J
+            const double r00 = fma(c1, b00, -(s1 * b10)), r01 = fma(c1, b01, -(s1 * b11));
+            const double r10 = fma(s1, b00, c1 * b10), r11 = fma(s1, b01, c1 * b11);
+            Sn[dr0 + dc0] = fma(c2, r00, -(s2 * r01));
+            Sn[dr0 + dc1] = fma(s2, r00, c2 * r01);
+            Sn[dr1 + dc0] = fma(c2, r10, -(s2 * r11));
+            Sn[dr1 + dc1] = fma(s2, r10, c2 * r11);
+            // W <- W J: rows 2kp, 2kp+1 (rows of W stay), columns (2kq, 2kq+1) move like the matrix's
+            Wn[(2 * kp) * LD + dc0] = fma(c2, w00, -(s2 * w01));
+            Wn[(2 * kp) * LD + dc1] = fma(s2, w00, c2 * w01);
+            Wn[(2 * kp + 1) * LD + dc0] = fma(c2, w10, -(s2 * w11));
+            Wn[(2 * kp + 1) * LD + dc1] = fma(s2, w10, c2 * w11);
+        }
+        SX_ETQ(r == 5 && tid == 0, 7);
+        SX_ETQ(r == 5 && duty && dl == 0, 13);
+        __syncthreads();
+        SX_ETQ(r == 5 && tid == 0, 8);
+        SX_ETQ(r == 5 && duty && dl == 0, 14);
+        cur ^= 1;
+    }
+}
+
+// sum over the workgroup (all threads get the result); NT threads, fixed order
+template <int NT>
+__device__ double block_sum(double v, double *red, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    constexpr int NW = (NT + 63) / 64;
+    static_assert(NW <= 17, "red[] holds 17 partial sums");
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// n <= 64: the whole decomposition in one workgroup (M2 = 16 / 32 / 64 by size), sweeps until the rule holds
+// ---------------------------------------------------------------------------------------------------
+template <int M2>
+__global__ __launch_bounds__(jacobi_threads<M2>()) void eigh_small_kernel(const double *__restrict__ C, int n,
+                                                                         double *__restrict__ Mout,
+                                                                         double *__restrict__ Vout, EighInfo *info,
+                                                                         int max_sweeps, double tol) {
+    constexpr int NP = M2 / 2, NT = jacobi_threads<M2>(), LD = M2 + 1;
+    __shared__ double sS[2][M2 * LD], sW[2][M2 * LD], sc[2 * NP], ss[2 * NP], sred[17];
+    const JacobiView L{sS[0], sS[1], sW[0], sW[1], sc, ss};
+    const int tid = threadIdx.x;
+    double n2 = 0.0;
+    for (int e = tid; e < M2 * M2; e += NT) {
+        const int i = e / M2, j = e % M2;
+        double v = 0.0;
+        if (i < n && j < n) v = i <= j ? C[(int64_t)i * n + j] : C[(int64_t)j * n + i];
+        sS[0][i * LD + j] = v;
+        sW[0][i * LD + j] = i == j ? 1.0 : 0.0;
+        n2 += v * v;
+    }
+    n2 = block_sum<NT>(n2, sred, tid);
+    const double thr2 = tol * tol * n2;
+    int cur = 0, sw = 0, conv = 0;
+    for (;;) {  // the off-diagonal mass is measured exactly before every sweep: stop as soon as it is below tol
+        double off2 = 0.0;
+        for (int e = tid; e < M2 * M2; e += NT) {
+            const int i = e / M2, j = e % M2;
+            const double v = sS[cur][i * LD + j];
+            if (i != j) off2 += v * v;
+        }
+        off2 = block_sum<NT>(off2, sred, tid);
+        if (tid == 0 && sw < kEighMaxSweeps) info->acc[sw] = off2;
+        if (off2 <= thr2) {
+            conv = 1;
+            break;
+        }
+        if (sw >= max_sweeps) break;
+        jacobi_sweep<M2, 0>(L, cur, tid);
+        ++sw;
+    }
+    for (int e = tid; e < M2 * M2; e += NT) {
+        const int i = e / M2, j = e % M2;
+        Mout[e] = sS[cur][i * LD + j];
+        Vout[e] = sW[cur][i * LD + j];
+    }
+    if (tid == 0) {
+        info->done_seq = 1, info->sweeps = sw, info->parity = 0, info->converged = conv;
+        info->norm2 = n2, info->thr2 = thr2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// n > 64
+// ---------------------------------------------------------------------------------------------------
+// M0 = C (upper triangle mirrored) padded with zeros to npad; V0 = I, or the caller's starting basis padded with
+// the identity; both rotation buffers = I; ||C||_F^2 into info->norm2 (info zeroed by the host beforehand)
+__global__ __launch_bounds__(256) void eigh_prepare_kernel(const double *__restrict__ C, int n, int npad,
+                                                           const double *__restrict__ Vstart, double *__restrict__ M0,
+                                                           double *__restrict__ V0, double *__restrict__ U,
+                                                           int64_t ucount, EighInfo *info) {
+    __shared__ double red[4];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (e < (int64_t)npad * npad) {
+        const int i = (int)(e / npad), j = (int)(e % npad);
+        const bool in = i < n && j < n;
+        if (in) v = i <= j ? C[(int64_t)i * n + j] : C[(int64_t)j * n + i];
+        M0[e] = v;
+        V0[e] = (in && Vstart) ? Vstart[(int64_t)i * n + j] : (i == j ? 1.0 : 0.0);
+    }
+    if (e < ucount) {
+        const int w = (int)(e % kUU);
+        U[e] = (w / kM2 == w % kM2) ? 1.0 : 0.0;
+    }
+    const double s = block_sum<256>(v * v, red, threadIdx.x);
+    if (threadIdx.x == 0 && s != 0.0) atomicAdd(&info->norm2, s);
+}
+
+// position i (0..31) of the pair (a, b) of 16-blocks -> matrix index
+__device__ __forceinline__ int pair_index(int i, int a, int b) { return (i < kBS ? a * kBS + i : b * kBS + i - kBS); }
+
+constexpr int LDX = kM2 + 2;   // X tile rows: the A-operand column-slab reads hit 32 distinct banks
+constexpr int LDU = kM2 + 16;  // U read transposed as an A operand: two k rows land 16 banks apart
+constexpr int LDY = kBS;       // 32x16 intermediate
+
+// acc (16x16, rows i0.., cols j0..) = A[i0.., 0:32] * B[0:32, j0..];  A row-major stride lda, B row-major stride ldb
+__device__ __forceinline__ v4d mma_ab(const double *A, int lda, int i0, const double *B, int ldb, int j0, int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    double av[kM2 / 4], bv[kM2 / 4];  // all sixteen LDS operand reads in flight before the first MFMA
+#pragma unroll
+    for (int k = 0; k < kM2 / 4; ++k) av[k] = A[(i0 + lr) * lda + 4 * k + lk], bv[k] = B[(4 * k + lk) * ldb + j0 + lr];
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < kM2 / 4; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
+    return acc;
+}
+// acc (16x16) = A[0:32, i0..]^T * B[0:32, j0..]
+__device__ __forceinline__ v4d mma_atb(const double *A, int lda, int i0, const double *B, int ldb, int j0, int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    double av[kM2 / 4], bv[kM2 / 4];
+#pragma unroll
+    for (int k = 0; k < kM2 / 4; ++k) av[k] = A[(4 * k + lk) * lda + i0 + lr], bv[k] = B[(4 * k + lk) * ldb + j0 + lr];
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < kM2 / 4; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
+    return acc;
+}
+
+// Out = alpha * op(A) B + diag * I on npad x npad matrices (npad a multiple of 32): the four products of a warm
+// start.  One workgroup per 32x32 tile, four waves = its four 16x16 quadrants, K in chunks of 32 through LDS with
+// the next chunk's global loads in flight during the MFMAs.
+template <bool TA>
+__global__ __launch_bounds__(256) void eigh_gemm_kernel(const double *__restrict__ A, const double *__restrict__ B,
+                                                        double *__restrict__ Out, int npad, double alpha, double diag) {
+    __shared__ double As[kM2 * LDX], Bs[kM2 * LDU];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * kM2, j0 = blockIdx.x * kM2;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int lr = lane & 15, lk = lane >> 4;
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, r = e / kM2, c = e % kM2;
+            // As[i][k]: TA reads A[k0 + r][i0 + c] (r = k, c = i: coalesced along i), else A[i0 + r][k0 + c]
+            ra[u] = TA ? A[(int64_t)(k0 + r) * npad + i0 + c] : A[(int64_t)(i0 + r) * npad + k0 + c];
+            rb[u] = B[(int64_t)(k0 + r) * npad + j0 + c];
+        }
+    };
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    fetch(0);
+    for (int k0 = 0; k0 < npad; k0 += kM2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, r = e / kM2, c = e % kM2;
+            if (TA)
+                As[c * LDX + r] = ra[u];
+            else
+                As[r * LDX + c] = ra[u];
+            Bs[r * LDU + c] = rb[u];
+        }
+        __syncthreads();
+        if (k0 + kM2 < npad) fetch(k0 + kM2);
+#pragma unroll
+        for (int kk = 0; kk < kM2; kk += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(wi + lr) * LDX + kk + lk], Bs[(kk + lk) * LDU + wj + lr], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + lk + 4 * r, gj = j0 + wj + lr;
+        Out[(int64_t)gi * npad + gj] = alpha * acc[r] + (gi == gj ? diag : 0.0);
+    }
+}
+
+struct RoundLds {
+    union {
+        struct {  // tile workgroups
+            double X[kM2 * LDX];
+            double UP[kM2 * LDU];
+            double UQ[kM2 * LDU];
+            double Y[kM2 * LDU];
+        } t;
+        struct {  // pair workgroups, stage 1: three source tiles, two rotations, the intermediates
+            double X[3][kM2 * LDX];
+            double UA[kM2 * LDU];
+            double UB[kM2 * LDU];
+            double Y[3][kM2 * LDY];
+        } p;
+        struct {  // pair workgroups, stage 2 (the sweep): second pivot buffer and the accumulated rotations
+            double S1[kM2 * (kM2 + 1)];
+            double W1[kM2 * (kM2 + 1)];
+        } j;
+    };
+    double S0[kM2 * (kM2 + 1)];  // the pivot matrix (written in stage 1, so outside the union)
+    double W0[kM2 * (kM2 + 1)];  // identity, written while the tiles are loaded
+    double rc[2 * kBS], rs[2 * kBS];  // rotation of every pair of the current / next inner round
+    double red[17];
+    int flag;
+};
+
+// One launch per round.  blockIdx < np: pair workgroups (rotation U_cur of the round rcur from the current pivot);
+// then np*np tiles of M and nr*np tiles of V, which apply the rotations U_prev of the round rprev.
+// flush != 0: no pair workgroups' sweeps (the last rotations are applied and the run is closed by the host).
+constexpr int kRoundThreads = jacobi_threads<kM2>() + 64;  // 256 updating threads + the rotation wave of the pivot
+                                                            // sweep + a sixth wave: the pivot products split six ways
+
+__global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double *__restrict__ Min, const double *__restrict__ Vin,
+                                                         double *__restrict__ Mout, double *__restrict__ Vout, int npad,
+                                                         int nb, const double *__restrict__ Uprev,
+                                                         double *__restrict__ Ucur, EighInfo *info, int sweep, int rprev,
+                                                         int rcur, int parity_out, double tol, int flush, int seq) {
+    __shared__ RoundLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = nb / 2;
+    // ---- run state: every workgroup derives the same decision from what earlier launches left ----
+    if (tid == 0) {
+        const int ended = info->done_seq;
+        int flag = (ended != 0 && ended < seq) ? 2 : 0;  // 2: the run ended in an EARLIER launch: nothing to do
+        if (!flag && rcur == 0 && sweep > 0 && !flush) {
+            if (eigh_last_sweep(info->acc, sweep - 1, info->norm2, tol)) {
+                flag = 1;  // apply the last rotations of the sweep that just ended, start no new ones
+                if (blockIdx.x == 0) {
+                    info->sweeps = sweep, info->parity = parity_out, info->converged = 1;
+                    info->thr2 = tol * tol * info->norm2;
+                    info->done_seq = seq;
+                }
+            }
+        }
+        L.flag = flag;
+    }
+    __syncthreads();
+    const int state = L.flag;
+    if (state == 2) return;
+    const int lr = lane & 15, lk = lane >> 4;
+    if ((int)blockIdx.x >= np) {
+        // =========================== tile workgroups ===========================
+        const int tile = (int)blockIdx.x - np;
+        const bool is_m = tile < np * np;
+        const int P = is_m ? tile / np : (tile - np * np) / np;  // M: pair of rprev; V: chunk of 32 rows
+        const int Q = is_m ? tile % np : (tile - np * np) % np;
+        int aq, bq, ap = 0, bp = 0;
+        rr_pair(Q, rprev, nb, aq, bq);
+        if (is_m) rr_pair(P, rprev, nb, ap, bp);
+        const double *src = is_m ? Min : Vin;
+        double *dst = is_m ? Mout : Vout;
+        for (int e = tid; e < kUU; e += kRoundThreads) {
+            const int i = e / kM2, j = e % kM2;
+            const int gi = is_m ? pair_index(i, ap, bp) : P * kM2 + i;
+            L.t.X[i * LDX + j] = src[(int64_t)gi * npad + pair_index(j, aq, bq)];
+            L.t.UQ[i * LDU + j] = Uprev[(int64_t)Q * kUU + e];
+            if (is_m) L.t.UP[i * LDU + j] = Uprev[(int64_t)P * kUU + e];
+        }
+        __syncthreads();
+        const int i0 = (wave >> 1) * 16, j0 = (wave & 1) * 16;  // waves 0..3: one 16x16 quadrant each
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (wave < 4) acc = mma_ab(L.t.X, LDX, i0, L.t.UQ, LDU, j0, lane);
+        if (is_m) {
+            if (wave < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L.t.Y[(i0 + lk + 4 * r) * LDU + j0 + lr] = acc[r];
+            }
+            __syncthreads();
+            if (wave < 4) acc = mma_atb(L.t.UP, LDU, i0, L.t.Y, LDU, j0, lane);
+        }
+        if (wave < 4) {
+            const int gj = pair_index(j0 + lr, aq, bq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + lk + 4 * r;
+                const int gi = is_m ? pair_index(i, ap, bp) : P * kM2 + i;
+                dst[(int64_t)gi * npad + gj] = acc[r];
+            }
+        }
+        return;
+    }
+    // =========================== pair workgroups ===========================
+    if (state == 1 || flush) return;
+    SX_ETP(0);
+    int I, Jb;
+    rr_pair((int)blockIdx.x, rcur, nb, I, Jb);
+    int PI, posI, PJ, posJ;
+    rr_find(I, rprev, nb, PI, posI);
+    rr_find(Jb, rprev, nb, PJ, posJ);
+    int aI, bI, aJ, bJ;
+    rr_pair(PI, rprev, nb, aI, bI);
+    rr_pair(PJ, rprev, nb, aJ, bJ);
+    // source tiles (pairs of rprev): 0: (PI,PI)  1: (PI,PJ)  2: (PJ,PJ); rotations of PI and PJ.
+    // 256 threads x 4 elements of each: 20 loads in flight per thread.
+    constexpr int LD = kM2 + 1;
+    if (tid < 256) {
+        double x0[4], x1[4], x2[4], ua[4], ub[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, i = e / kM2, j = e % kM2;
+            const int giI = pair_index(i, aI, bI), giJ = pair_index(i, aJ, bJ);
+            const int gjI = pair_index(j, aI, bI), gjJ = pair_index(j, aJ, bJ);
+            x0[u] = Min[(int64_t)giI * npad + gjI];
+            x1[u] = Min[(int64_t)giI * npad + gjJ];
+            x2[u] = Min[(int64_t)giJ * npad + gjJ];
+            ua[u] = Uprev[(int64_t)PI * kUU + e];
+            ub[u] = Uprev[(int64_t)PJ * kUU + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, i = e / kM2, j = e % kM2;
+            L.p.X[0][i * LDX + j] = x0[u];
+            L.p.X[1][i * LDX + j] = x1[u];
+            L.p.X[2][i * LDX + j] = x2[u];
+            L.p.UA[i * LDU + j] = ua[u];
+            L.p.UB[i * LDU + j] = ub[u];
+            L.W0[i * LD + j] = i == j ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    SX_ETP(1);
+    // The current pivot: T_II = A_I^T X0 A_I, T_IJ = A_I^T X1 A_J, T_JJ = A_J^T X2 A_J with A_X the 16 columns of the
+    // previous rotation that belong to block X.  Wave w < 3 forms sub-block w.  The pivot is stored INTERLEAVED:
+    // member i of block I at position 2i, member j of block J at position 2j+1 (what the systolic sweep expects).
+    // full != 0 (first round of a sweep): every pair of the 32 indices is rotated; otherwise only the pairs
+    // (I-member, J-member) -- over the rounds of a sweep every off-diagonal element is then targeted exactly once,
+    // and the mass met (all off-diagonal entries in the full round, the I x J block otherwise) adds up to off(M)^2.
+    const bool full = rcur == 0;
+    {   // first products, six ways: wave w forms half h = w & 1 of Y_b = X_b * A_right, b = w >> 1
+        const int b = wave >> 1, h = wave & 1;
+        const double *UR = b == 0 ? L.p.UA : L.p.UB;
+        const int cR = 16 * (b == 0 ? posI : posJ);
+        const v4d a = mma_ab(L.p.X[b], LDX, 16 * h, UR, LDU, cR, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.p.Y[b][(16 * h + lk + 4 * r) * LDY + lr] = a[r];
+    }
+    __syncthreads();
+    double m2 = 0.0;  // off-diagonal mass of this wave's sub-block (added to the sweep's total at the very end)
+    if (wave < 3) {  // second products: T_b = A_left^T Y_b (16x16), one sub-block per wave
+        const double *UL = wave == 2 ? L.p.UB : L.p.UA;
+        const int cL = 16 * (wave == 2 ? posJ : posI);
+        const v4d tt = mma_atb(UL, LDU, cL, L.p.Y[wave], LDY, 0, lane);
+        const int ro = wave == 2 ? 1 : 0, co = wave == 0 ? 0 : 1;  // odd positions: block J
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = lk + 4 * r, j = lr;
+            const int pi = 2 * i + ro, pj = 2 * j + co;
+            if (wave == 1) {
+                L.S0[pi * LD + pj] = tt[r];
+                L.S0[pj * LD + pi] = tt[r];
+                m2 = fma(2.0 * tt[r], tt[r], m2);
+            } else if (i <= j) {  // diagonal sub-blocks: upper triangle mirrored
+                L.S0[pi * LD + pj] = tt[r];
+                L.S0[pj * LD + pi] = tt[r];
+                if (full && i < j) m2 = fma(2.0 * tt[r], tt[r], m2);
+            }
+        }
+    }
+    __syncthreads();  // stage 1 is over: its LDS is reused for the sweep
+    SX_ETP(3);
+    const JacobiView view{L.S0, L.j.S1, L.W0, L.j.W1, L.rc, L.rs};
+    int cur = 0;
+    if (full)
+        jacobi_sweep<kM2, 0>(view, cur, tid);
+    else
+        jacobi_sweep<kM2, 1>(view, cur, tid);
+    SX_ETP(4);
+    // U in the order the tiles use (block I first, then block J): gathered index g <-> position 2g or 2(g-16)+1
+    const double *Wf = cur ? L.j.W1 : L.W0;
+    double *Uo = Ucur + (int64_t)blockIdx.x * kUU;
+    for (int e = tid; e < kUU; e += kRoundThreads) {
+        const int i = e / kM2, j = e % kM2;
+        const int pi = i < kBS ? 2 * i : 2 * (i - kBS) + 1, pj = j < kBS ? 2 * j : 2 * (j - kBS) + 1;
+        Uo[e] = Wf[pi * LD + pj];
+    }
+    // (the global atomic waits for nothing here; before a barrier it would stall the whole pivot phase)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
+    if (wave < 3 && lane == 0 && m2 != 0.0) atomicAdd(&info->acc[sweep], m2);
+    SX_ETP(5);
+}
+
+// the run ends without the rule having fired: record where the result lives
+__global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double tol) {
+    if (threadIdx.x != 0 || info->done_seq) return;
+    info->sweeps = sweeps, info->parity = parity, info->thr2 = tol * tol * info->norm2;
+    info->converged = (sweeps > 0 && eigh_last_sweep(info->acc, sweeps - 1, info->norm2, tol)) ? 1 : 0;
+    info->done_seq = 1;
+}
+
+// per column j of V: |v_j|^2 and the sign of its largest-magnitude component (lowest row on ties);
+// lam[j] = M_jj / |v_j|^2, scl[j] = sign / |v_j|.  One workgroup per 16 columns, 16 row strips (rows of 128 bytes).
+__global__ __launch_bounds__(256) void eigh_colstats_kernel(const double *__restrict__ M0, const double *__restrict__ M1,
+                                                            const double *__restrict__ V0, const double *__restrict__ V1,
+                                                            int n, int npad, const EighInfo *info,
+                                                            double *__restrict__ lam, double *__restrict__ scl) {
+    __shared__ double s_n2[16][16], s_mx[16][16], s_sg[16][16];
+    __shared__ int s_ix[16][16];
+    const double *M = info->parity ? M1 : M0, *V = info->parity ? V1 : V0;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + tx;
+    double n2 = 0.0, mx = -1.0, sg = 1.0;
+    int ix = 0;
+    if (j < n) {
+        for (int i = ty; i < n; i += 16) {
+            const double v = V[(int64_t)i * npad + j];
+            n2 += v * v;
+            const double a = fabs(v);
+            if (a > mx) mx = a, ix = i, sg = v < 0.0 ? -1.0 : 1.0;
+        }
+    }
+    s_n2[ty][tx] = n2, s_mx[ty][tx] = mx, s_sg[ty][tx] = sg, s_ix[ty][tx] = ix;
+    __syncthreads();
+    if (ty == 0) {
+        if (j < n) {
+            double tot = 0.0, bm = -1.0, bs = 1.0;
+            int bi = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                tot += s_n2[k][tx];
+                const double m = s_mx[k][tx];
+                if (m > bm || (m == bm && s_ix[k][tx] < bi)) bm = m, bi = s_ix[k][tx], bs = s_sg[k][tx];
+            }
+            lam[j] = M[(int64_t)j * npad + j] / tot;
+            scl[j] = bs / sqrt(tot);
+        } else if (j < npad) {
+            lam[j] = __builtin_inf();
+            scl[j] = 0.0;
+        }
+    }
+}
+
+// ascending rank of every eigenvalue (ties: lower position first); inv[rank] = position, w[rank] = value.
+// The values pass through LDS 4096 at a time.
+__global__ __launch_bounds__(1024) void eigh_rank_kernel(const double *__restrict__ lam, int n, int *__restrict__ inv,
+                                                         double *__restrict__ w) {
+    constexpr int CH = 4096;
+    __shared__ double keys[CH];
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        const int j = j0 + threadIdx.x;
+        const double lj = j < n ? lam[j] : 0.0;
+        int rank = 0;
+        for (int c0 = 0; c0 < n; c0 += CH) {
+            const int len = n - c0 < CH ? n - c0 : CH;
+            __syncthreads();
+            for (int e = threadIdx.x; e < len; e += 1024) keys[e] = lam[c0 + e];
+            __syncthreads();
+            if (j < n) {
+                const int jj = j - c0;  // position of this value inside the chunk (ties: lower position first)
+#pragma unroll 16
+                for (int k = 0; k < len; ++k) {
+                    const double lk = keys[k];
+                    rank += (lk < lj || (lk == lj && k < jj)) ? 1 : 0;
+                }
+            }
+        }
+        if (j < n) {
+            inv[rank] = j;
+            w[rank] = lj;
+        }
+    }
+}
+
+// B[i][r] = V[i][inv[r]] * scl[inv[r]]   (eigenvectors in columns, row-major like numpy's)
+__global__ __launch_bounds__(256) void eigh_write_kernel(const double *__restrict__ V0, const double *__restrict__ V1,
+                                                         int n, int npad, const EighInfo *info,
+                                                         const int *__restrict__ inv, const double *__restrict__ scl,
+                                                         double *__restrict__ B) {
+    const double *V = info->parity ? V1 : V0;
+    const int i = blockIdx.x;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const int j = inv[r];
+        B[(int64_t)i * n + r] = V[(int64_t)i * npad + j] * scl[j];
+    }
+}
+
+inline int eigh_npad(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 64 ? 64 : ((n + kM2 - 1) / kM2) * kM2)); }
+
+struct EighWs {
+    EighInfo *info;
+    double *M[2], *V[2], *U[2], *lam, *scl;
+    int *inv;
+    int64_t ucount;  // doubles in both rotation buffers
+    int64_t bytes;
+};
+
+inline EighWs eigh_layout(void *ws, int n) {
+    const int64_t np = eigh_npad(n);
+    char *p = (char *)ws;
+    EighWs w;
+    int64_t off = 1024;  // EighInfo
+    static_assert(sizeof(EighInfo) <= 1024, "info block");
+    w.info = (EighInfo *)p;
+    for (int k = 0; k < 2; ++k) w.M[k] = (double *)(p + off), off += np * np * 8;
+    for (int k = 0; k < 2; ++k) w.V[k] = (double *)(p + off), off += np * np * 8;
+    const int64_t pairs = np / kM2 + 1;
+    w.ucount = 2 * pairs * kUU;
+    for (int k = 0; k < 2; ++k) w.U[k] = (double *)(p + off), off += pairs * kUU * 8;
+    w.lam = (double *)(p + off), off += np * 8;
+    w.scl = (double *)(p + off), off += np * 8;
+    w.inv = (int *)(p + off), off += np * 8;
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int64_t sx_eigh_workspace_bytes(int n) {
+    if (n < 1) return -1;
+    return eigh_layout(nullptr, n).bytes;
+}
+
+extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
+                       int max_sweeps, double tol, void *stream) {
+    SX_REQUIRE(C && w && B && ws && n >= 1, "sx_eigh: bad arguments");
+    const EighWs L = eigh_layout(ws, n);
+    SX_REQUIRE(ws_bytes >= L.bytes, "sx_eigh: workspace too small (sx_eigh_workspace_bytes)");
+    if (max_sweeps <= 0) max_sweeps = 24;
+    if (max_sweeps > kEighMaxSweeps) max_sweeps = kEighMaxSweeps;
+    if (!(tol > 0.0)) tol = 1.0e-14;
+    hipStream_t st = (hipStream_t)stream;
+    const int npad = eigh_npad(n);
+    SX_HIP(hipMemsetAsync(L.info, 0, sizeof(EighInfo), st));
+    if (n <= 64) {
+        if (npad == 16)
+            hipLaunchKernelGGL((eigh_small_kernel<16>), dim3(1), dim3(jacobi_threads<16>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
+        else if (npad == 32)
+            hipLaunchKernelGGL((eigh_small_kernel<32>), dim3(1), dim3(jacobi_threads<32>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
+        else
+            hipLaunchKernelGGL((eigh_small_kernel<64>), dim3(1), dim3(jacobi_threads<64>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
+        SX_LAUNCH_CHECK();
+    } else {
+        const int64_t tot = std::max<int64_t>((int64_t)npad * npad, L.ucount);
+        if (V0 == nullptr) {
+            hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, n, npad,
+                               (const double *)nullptr, L.M[0], L.V[0], L.U[0], L.ucount, L.info);
+        } else {
+            // Warm start from a nearly orthonormal basis (the previous generation's eigenvectors):
+            //   V <- V0 (3 I - V0^T V0) / 2   one Newton-Schulz step: orthonormal to rounding, so that a basis handed
+            //                                 from decomposition to decomposition cannot drift
+            //   M <- V^T (C V)
+            // Four n^3 products on the matrix cores (~1 % of a cold decomposition); the sweeps then start from a
+            // nearly diagonal M and the stopping rule ends them after the few that are needed.
+            const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
+            hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, n, npad, V0,
+                               L.M[1], L.V[1], L.U[0], L.ucount, L.info);                       // M1 = C, V1 = V0
+            hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[1], L.V[1], L.M[0], npad, -0.5, 1.5);
+            hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.V[1], L.M[0], L.V[0], npad, 1.0, 0.0);
+            hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.M[1], L.V[0], L.V[1], npad, 1.0, 0.0);
+            hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[0], L.V[1], L.M[0], npad, 1.0, 0.0);
+        }
+        SX_LAUNCH_CHECK();
+        const int nb = npad / kBS, np = nb / 2;
+        const unsigned grid = (unsigned)(np + np * np + (npad / kM2) * np);
+        int cur = 0, ucur = 0, rprev = 0, seq = 0;  // the very first "previous rotations" are identities under any pairing
+        for (int sw = 0; sw < max_sweeps; ++sw) {
+            for (int r = 0; r < nb - 1; ++r) {
+                hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
+                                   L.V[cur ^ 1], npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, sw, rprev, r, cur ^ 1, tol, 0, ++seq);
+                cur ^= 1, ucur ^= 1, rprev = r;
+            }
+        }
+        // apply the last rotations, then close
+        hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1], L.V[cur ^ 1],
+                           npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, max_sweeps, rprev, 0, cur ^ 1, tol, 1, ++seq);
+        cur ^= 1;
+        SX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, max_sweeps, cur, tol);
+        SX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 15) / 16)), dim3(256), 0, st, L.M[0], L.M[1], L.V[0],
+                       L.V[1], n, npad, L.info, L.lam, L.scl);
+    hipLaunchKernelGGL(eigh_rank_kernel, dim3(1), dim3(1024), 0, st, L.lam, n, L.inv, w);
+    hipLaunchKernelGGL(eigh_write_kernel, dim3((unsigned)n), dim3(256), 0, st, L.V[0], L.V[1], n, npad, L.info, L.inv,
+                       L.scl, B);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// sweeps carried out / converged flag of the last sx_eigh on this workspace (synchronises the stream)
+extern "C" int sx_eigh_info(const void *ws, int *sweeps, int *converged, double *off_rel, void *stream) {
+    SX_REQUIRE(ws, "sx_eigh_info: bad arguments");
+    EighInfo h;
+    SX_HIP(hipMemcpyAsync(&h, ws, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (sweeps) *sweeps = h.sweeps;
+    if (converged) *converged = h.converged;
+    if (off_rel) {
+        const int k = h.sweeps > 0 ? h.sweeps - 1 : 0;
+        *off_rel = h.norm2 > 0.0 ? sqrt(h.acc[k] / h.norm2) : 0.0;
+    }
+    return 0;
+}

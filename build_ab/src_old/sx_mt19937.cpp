@@ -1,0 +1,297 @@
+// numpy-legacy random stream, host side (parity mode).
+//
+// The reference seeds numpy's *legacy global* generator (np.random.seed, at
+// stochopy/optimize/de/_de.py:148-149, cpso/_cpso.py:153-154,
+// cmaes/_cmaes.py:116-117) and draws through rand / uniform / randn / randint /
+// permutation.  numpy is a third-party dependency of the reference (unpinned,
+// setup.cfg:27-30; 2.2.6 in the build container); its legacy stream is the
+// published MT19937 of Matsumoto & Nishimura plus five small derivations, which
+// are restated here from their specification:
+//   double     ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two consecutive words
+//   uniform    lo + (hi - lo) * double
+//   gauss      Marsaglia polar method, second variate cached across calls
+//   bounded    mask = next_pow2(max) - 1; redraw (word & mask) until <= max
+//   shuffle    Fisher-Yates from the end, j = bounded(i)
+// Pinned bit-for-bit against numpy by tests/test_host_cpu.py and
+// tests/golden/rng_stream.json.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/stochopy_hip.h"
+
+struct sx_mt {
+    uint32_t mt[624];
+    int pos;
+    int has_gauss;
+    double gauss;
+    uint32_t out[624];  // the tempered words of the current block (filled by mt_twist; not part of the state)
+    int out_valid;      // out[] matches mt[] (cleared whenever mt[] is set from outside)
+};
+
+namespace {
+
+inline void mt_seed(sx_mt *g, uint32_t s) {
+    g->mt[0] = s;
+    for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->pos = 624;
+    g->has_gauss = 0;
+    g->gauss = 0.0;
+    g->out_valid = 0;
+}
+
+inline uint32_t temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+inline void mt_temper_block(sx_mt *g) {  // one vectorisable pass instead of 624 dependent call sites
+    for (int k = 0; k < 624; ++k) g->out[k] = temper(g->mt[k]);
+    g->out_valid = 1;
+}
+
+inline void mt_twist(sx_mt *g) {
+    uint32_t *mt = g->mt;
+    const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    int k = 0;
+    for (; k < 624 - 397; ++k) {
+        const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
+        mt[k] = mt[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    for (; k < 623; ++k) {
+        const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
+        mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    const uint32_t y = (mt[623] & UP) | (mt[0] & LO);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    g->pos = 0;
+    mt_temper_block(g);
+}
+
+inline uint32_t next32(sx_mt *g) {
+    if (g->pos == 624) mt_twist(g);
+    else if (!g->out_valid) mt_temper_block(g);
+    return g->out[g->pos++];
+}
+
+inline double next_double(sx_mt *g) {
+    const uint32_t a = next32(g) >> 5, b = next32(g) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+inline uint64_t mask_for(uint64_t mx) {
+    uint64_t m = mx;
+    m |= m >> 1;
+    m |= m >> 2;
+    m |= m >> 4;
+    m |= m >> 8;
+    m |= m >> 16;
+    m |= m >> 32;
+    return m;
+}
+
+// value in [0, mx]; mx == 0 consumes nothing
+inline uint64_t bounded(sx_mt *g, uint64_t mx, uint64_t mask) {
+    if (mx == 0) return 0;
+    uint64_t v;
+    if (mx <= 0xffffffffull) {
+        if (mx == 0xffffffffull) return next32(g);
+        do {
+            v = next32(g) & mask;
+        } while (v > mx);
+    } else {
+        do {
+            const uint64_t hi = next32(g), lo = next32(g);
+            v = ((hi << 32) | lo) & mask;
+        } while (v > mx);
+    }
+    return v;
+}
+
+// Fisher-Yates from the end for n <= 2^31 elements (the DE donor permutations, 16.8 million steps per
+// generation at P = 4096): same words, same rejections as shuffle(), with the mask held per power-of-two range
+// of i and 32-bit arithmetic throughout.
+template <class T>
+inline void shuffle_small(sx_mt *g, T *a, int32_t n) {
+    int32_t i = n - 1;
+    while (i >= 1) {
+        uint32_t mask = (uint32_t)i;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        const int32_t lo = (int32_t)(mask >> 1) + 1;  // smallest i with this mask
+        // one word per trip, no data-dependent branch: a rejected word (v > i) swaps a[i] with itself and
+        // leaves i where it is (the rejection branch of the textbook loop mispredicts ~30 % of the time)
+        while (i >= lo) {
+            const uint32_t v = next32(g) & mask;
+            const int32_t take = v <= (uint32_t)i;
+            const int32_t j = take ? (int32_t)v : i;
+            const T t = a[i];
+            a[i] = a[j];
+            a[j] = t;
+            i -= take;
+        }
+    }
+}
+
+template <class T>
+inline void shuffle(sx_mt *g, T *a, int64_t n) {
+    if (n <= 0x7fffffff) {
+        shuffle_small(g, a, (int32_t)n);
+        return;
+    }
+    for (int64_t i = n - 1; i >= 1; --i) {
+        const uint64_t j = bounded(g, (uint64_t)i, mask_for((uint64_t)i));
+        const T t = a[i];
+        a[i] = a[j];
+        a[j] = t;
+    }
+}
+
+inline double next_gauss(sx_mt *g) {
+    if (g->has_gauss) {
+        const double t = g->gauss;
+        g->has_gauss = 0;
+        g->gauss = 0.0;
+        return t;
+    }
+    double x1, x2, r2;
+    do {
+        x1 = 2.0 * next_double(g) - 1.0;
+        x2 = 2.0 * next_double(g) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+    g->gauss = f * x1;
+    g->has_gauss = 1;
+    return f * x2;
+}
+
+}  // namespace
+
+extern "C" sx_mt *sx_mt_create(uint32_t seed) {
+    sx_mt *g = new sx_mt();
+    mt_seed(g, seed);
+    return g;
+}
+extern "C" void sx_mt_destroy(sx_mt *g) { delete g; }
+extern "C" void sx_mt_seed(sx_mt *g, uint32_t seed) { mt_seed(g, seed); }
+
+// count doubles, two consecutive words each: whole pairs of the current tempered block are converted in one
+// vectorisable loop; a pair that straddles a block boundary goes through next_double()
+static void fill_doubles(sx_mt *g, double *out, int64_t count) {
+    int64_t i = 0;
+    while (i < count) {
+        if (g->pos >= 624 || !g->out_valid || 624 - g->pos < 2) {
+            out[i++] = next_double(g);
+            continue;
+        }
+        const int64_t pairs = (624 - g->pos) / 2;
+        const int64_t take = pairs < count - i ? pairs : count - i;
+        const uint32_t *w = g->out + g->pos;
+        for (int64_t k = 0; k < take; ++k)
+            out[i + k] = ((double)(w[2 * k] >> 5) * 67108864.0 + (double)(w[2 * k + 1] >> 6)) / 9007199254740992.0;
+        g->pos += (int)(2 * take);
+        i += take;
+    }
+}
+
+extern "C" void sx_mt_random(sx_mt *g, double *out, int64_t count) { fill_doubles(g, out, count); }
+
+extern "C" void sx_mt_uniform(sx_mt *g, double lo, double hi, double *out, int64_t count) {
+    const double range = hi - lo;
+    for (int64_t i = 0; i < count; ++i) out[i] = lo + range * next_double(g);
+}
+
+extern "C" void sx_mt_uniform_rows(sx_mt *g, const double *lo, const double *hi, int n, int64_t rows, double *out) {
+    std::vector<double> range((size_t)n);
+    for (int c = 0; c < n; ++c) range[c] = hi[c] - lo[c];
+    for (int64_t r = 0; r < rows; ++r)
+        for (int c = 0; c < n; ++c) out[r * n + c] = lo[c] + range[c] * next_double(g);
+}
+
+extern "C" void sx_mt_randn(sx_mt *g, double *out, int64_t count) {
+    for (int64_t i = 0; i < count; ++i) out[i] = next_gauss(g);
+}
+
+extern "C" void sx_mt_randint(sx_mt *g, int64_t high, int64_t *out, int64_t count) {
+    const uint64_t mx = (uint64_t)(high - 1);
+    const uint64_t mask = mask_for(mx);
+    for (int64_t i = 0; i < count; ++i) out[i] = (int64_t)bounded(g, mx, mask);
+}
+
+extern "C" void sx_mt_permutation(sx_mt *g, int64_t n, int64_t *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = i;
+    shuffle(g, out, n);
+}
+
+// _common.py:109-120 (lhs): x = rand(P, n) / P + linspace(-1, 1, P, endpoint=False)[:, None]; column j of the
+// population is column j of x taken in the order of its own permutation(P); then * scale[j] + shift[j].  The caller
+// passes numpy's own linspace / scale / shift vectors, so every number is formed by the operations numpy would use.
+extern "C" void sx_mt_latin_hypercube(sx_mt *g, int64_t P, int n, const double *lin, const double *scale,
+                                      const double *shift, double *out) {
+    std::vector<double> x((size_t)(P * n));
+    fill_doubles(g, x.data(), P * n);
+    const double dP = (double)P;
+    for (int64_t i = 0; i < P; ++i)
+        for (int c = 0; c < n; ++c) x[i * n + c] = x[i * n + c] / dP + lin[i];
+    std::vector<int64_t> perm((size_t)P);
+    for (int c = 0; c < n; ++c) {
+        for (int64_t i = 0; i < P; ++i) perm[i] = i;
+        shuffle(g, perm.data(), P);
+        for (int64_t i = 0; i < P; ++i) out[i * n + c] = x[perm[i] * n + c] * scale[c] + shift[c];
+    }
+}
+
+extern "C" void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors) {
+    // individual i: permutation of arange(P) without i; entry t becomes donor t (de/_de.py:304-311)
+    std::vector<int32_t> a((size_t)(P - 1));
+    for (int64_t i = 0; i < P; ++i) {
+        for (int64_t v = 0; v < P - 1; ++v) a[v] = (int32_t)v;
+        shuffle_small(g, a.data(), (int32_t)(P - 1));
+        for (int t = 0; t < k; ++t) {
+            const int32_t v = a[t];
+            donors[(int64_t)t * P + i] = v + (v >= i ? 1 : 0);
+        }
+    }
+}
+
+extern "C" void sx_mt_de_async_draws(sx_mt *g, int64_t P, int k, int n, int32_t *donors, int32_t *irand,
+                                     const double *lower, const double *upper, double *resample) {
+    // de_async, per individual (de/_de.py:376-382): donor permutation, forced crossover index, Random's block
+    std::vector<int32_t> a((size_t)(P - 1));
+    const uint64_t mx = (uint64_t)(n - 1);
+    const uint64_t mask = mask_for(mx);
+    for (int64_t i = 0; i < P; ++i) {
+        for (int64_t v = 0; v < P - 1; ++v) a[v] = (int32_t)v;
+        shuffle_small(g, a.data(), (int32_t)(P - 1));
+        for (int t = 0; t < k; ++t) {
+            const int32_t v = a[t];
+            donors[(int64_t)t * P + i] = v + (v >= i ? 1 : 0);
+        }
+        irand[i] = (int32_t)bounded(g, mx, mask);
+        if (resample != nullptr)
+            for (int c = 0; c < n; ++c) resample[i * n + c] = lower[c] + (upper[c] - lower[c]) * next_double(g);
+    }
+}
+
+// np.random.get_state() / set_state() interchange: key[624], pos, has_gauss, cached_gaussian
+extern "C" void sx_mt_get_state(sx_mt *g, uint32_t *key, int *pos, int *has_gauss, double *gauss) {
+    std::memcpy(key, g->mt, sizeof g->mt);
+    *pos = g->pos;
+    *has_gauss = g->has_gauss;
+    *gauss = g->gauss;
+}
+extern "C" void sx_mt_set_state(sx_mt *g, const uint32_t *key, int pos, int has_gauss, double gauss) {
+    std::memcpy(g->mt, key, sizeof g->mt);
+    g->out_valid = 0;
+    g->pos = pos;
+    g->has_gauss = has_gauss;
+    g->gauss = gauss;
+}

@@ -1,0 +1,692 @@
+// PSO / CPSO: one fused kernel per generation (velocity + position update, Shrink
+// clamp, objective, personal-best selection, per-workgroup best) and the
+// competitive-restart kernels (swarm radius, worst-nw selection, re-seeding).
+//
+// Reference code replaced (paths relative to the reference checkout):
+//   stochopy/optimize/cpso/_cpso.py:324-329   mutation (left-to-right association)
+//   stochopy/optimize/cpso/_cpso.py:332-361   pso_sync
+//   stochopy/optimize/cpso/_constraints.py:4-10, 44-53  NoConstraint / Shrink (sync form)
+//   stochopy/optimize/cpso/_cpso.py:405-426   restart (radius, nw, worst-nw reset)
+//   stochopy/optimize/_common.py:123-130      selection (strict <, in place)
+//   stochopy/factory/benchmark.py             objective, fused
+//
+// One wavefront per particle; X, V, pbest, pbestfit are row-local and updated in place.
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+#include "sx_rowops.hpp"
+
+namespace sx {
+int make_plan_arg(int fun_id, int n, PlanArg *out);
+}
+using namespace sx;
+
+namespace {
+
+// order-preserving map double -> uint64 (larger double <=> larger key)
+__device__ __forceinline__ unsigned long long sort_key(double f) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(f);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// FULL: n == 4 * LPR (64, 128 or 256 -- BASELINE config 3): the row length is a compile-time constant, a row is exactly
+// one batch, and every bound check and loop over the row folds away.
+template <int FUN, int RNG, int LPR, bool FULL>
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
+                                                                                const PlanArg plan) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sf[kMaxRowsPerBlock];
+    __shared__ int64_t si[kMaxRowsPerBlock];
+    const sx_state *st = a.state;
+    if (st->done) return;
+    const uint32_t gen = (uint32_t)(st->it + 1);
+    const int n = FULL ? 4 * LPR : a.n;
+    const int64_t P = a.P, ld = a.ld;
+    const RowIds<LPR> id(P);
+    const int l = id.l;  // lane within the row
+    const int64_t rowc = id.rowc;
+    double *U = lds + id.slot * lds_row_stride(n);
+    double *Vn = U;  // Shrink: the raw velocity waits in U[e] until the owning lane replaces it by the position
+
+    double fold = a.pbestfit[rowc];
+    // CPSO inside a graph: the restart decided at the end of the previous generation is carried out here -- a selected
+    // row is not loaded but re-seeded (what pso_restart_apply_kernel would have written: same Philox positions, V = 0,
+    // pbest = X, pbestfit = 1e30), and then moved like any other
+    bool reseed = false;
+    if (RNG == SX_RNG_PHILOX && a.pending_restart != nullptr)
+        reseed = a.pending_restart[0] != 0ull && sort_key(fold) >= a.pending_restart[1];
+    if (reseed) fold = 1.0e30;
+    double *__restrict__ xr = a.X + rowc * ld;
+    double *__restrict__ vr = a.V + rowc * ld;
+    double *__restrict__ pb = a.pbest + rowc * ld;
+    const double *__restrict__ gb = a.gbest;
+    const uint32_t grow = (uint32_t)(a.row0 + rowc);
+    const double w = a.w, c1 = a.c1, c2 = a.c2;
+    const bool shrink = a.constraints != 0;
+    const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
+    const double *r2row = RNG == SX_RNG_HOST ? a.r2 + rowc * (int64_t)n : nullptr;
+
+    // V = w*V + c1*r1*(pbest - X) + c2*r2*(gbest - X)   (cpso/_cpso.py:326), four row steps per batch so
+    // the 16 loads of a batch are in flight together.  Without Shrink the new position follows at once;
+    // with Shrink the raw velocity waits in LDS for the row-wide beta.
+    constexpr int kStep = 4;
+    double beta = __builtin_huge_val();
+    const int nq = (n + LPR - 1) / LPR;
+    for (int q0 = 0; q0 < nq; q0 += kStep) {
+        double x[kStep], v[kStep], p[kStep], g[kStep], r1[kStep], r2[kStep];
+#pragma unroll
+        for (int t = 0; t < kStep; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            const bool in = FULL || e < n, ld_row = in && !reseed;
+            x[t] = ld_row ? xr[e] : 0.0;
+            v[t] = ld_row ? vr[e] : 0.0;
+            p[t] = ld_row ? pb[e] : 0.0;
+            g[t] = in ? gb[e] : 0.0;
+            r1[t] = (RNG == SX_RNG_HOST && in) ? r1row[e] : 0.0;
+            r2[t] = (RNG == SX_RNG_HOST && in) ? r2row[e] : 0.0;
+        }
+        if (RNG == SX_RNG_PHILOX) {
+            // 32-bit uniforms, one call per 2 steps: words (0,1) -> (r1,r2) of even q, (2,3) of odd q
+#pragma unroll
+            for (int t = 0; t < kStep; t += 2) {
+                const U4 wd = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen,
+                                            kPurposePsoR1, a.key0, a.key1);
+                r1[t] = u32(wd.x);
+                r2[t] = u32(wd.y);
+                r1[t + 1] = u32(wd.z);
+                r2[t + 1] = u32(wd.w);
+            }
+        }
+        if (RNG == SX_RNG_PHILOX && reseed) {  // X = uniform(lower, upper) keyed like pso_restart_apply_kernel's draws
+#pragma unroll
+            for (int t = 0; t < kStep; t += 2) {
+                const U4 wd = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen - 1u,
+                                            kPurposePsoRestart, a.key0, a.key1);
+                const double u[2] = {u53(wd.x, wd.y), u53(wd.z, wd.w)};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = (q0 + t + h) * LPR + l;
+                    if (e < n) {
+                        const double lo = a.lower[e];
+                        x[t + h] = lo + (a.upper[e] - lo) * u[h];
+                        p[t + h] = x[t + h];
+                        // pbest = X now (a row whose new fitness is not below 1e30 keeps it); Shrink's second pass
+                        // reads X back
+                        if (id.active) {
+                            pb[e] = x[t + h];
+                            if (shrink) xr[e] = x[t + h];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kStep; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            if (e < n) {
+                const double vn = pso_velocity(w, v[t], c1, r1[t], p[t], x[t], c2, r2[t], g[t]);
+                if (shrink) {  // cpso/_constraints.py:22-50: beta = min over violated dims of (bound - x)/v
+                    Vn[e] = vn;
+                    const double xc = x[t] + vn;
+                    const double lo = a.lower[e], hi = a.upper[e];
+                    if (xc < lo) beta = fmin(beta, (lo - x[t]) / vn);
+                    if (xc > hi) beta = fmin(beta, (hi - x[t]) / vn);
+                } else {  // cpso/_constraints.py:4-10: X + V
+                    const double xn = x[t] + vn;
+                    U[e] = xn;
+                    if (id.active) {
+                        vr[e] = vn;
+                        xr[e] = xn;
+                    }
+                }
+            }
+        }
+    }
+    if (shrink) {
+        beta = row_min<LPR>(beta);
+        if (beta == __builtin_huge_val()) beta = 1.0;
+        lds_wave_fence();
+        for (int e = l; e < n; e += LPR) {
+            const double vn = Vn[e] * beta;  // V *= beta[:, None]
+            const double xn = xr[e] + vn;
+            U[e] = xn;
+            if (id.active) {
+                vr[e] = vn;
+                xr[e] = xn;
+            }
+        }
+    }
+    const double fc = row_objective<FUN, LPR, FULL, FULL ? 4 * LPR : 0>(U, n, plan, l);
+    const bool better = fc < fold;  // _common.py:127 strict <
+    if (id.active) {
+        if (better)
+            for (int e = l; e < n; e += LPR) pb[e] = U[e];
+        if (l == 0) {
+            if (better)
+                a.pbestfit[id.row] = fc;
+            else if (reseed)
+                a.pbestfit[id.row] = 1.0e30;
+            if (a.candfit != nullptr) a.candfit[id.row] = fc;
+        }
+    }
+    block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+}
+
+typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
+
+template <int RNG, int LPR, bool FULL>
+pso_kernel_t pick_kernel_lpr(int fun_id) {
+    switch (fun_id) {
+        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL>;
+        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL>;
+        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL>;
+        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL>;
+        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL>;
+        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL>;
+    }
+    return nullptr;
+}
+
+template <int RNG>
+pso_kernel_t pick_kernel(int fun_id, int n) {
+    const int lpr = lanes_per_row(n);
+    // whole-batch rows with in-kernel draws get the constant-length form (host draws: the run is bound by the host)
+    const bool full = RNG == SX_RNG_PHILOX && n == 4 * lpr;
+    switch (lpr) {
+        case 16: return full ? pick_kernel_lpr<RNG, 16, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 16, false>(fun_id);
+        case 32: return full ? pick_kernel_lpr<RNG, 32, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 32, false>(fun_id);
+    }
+    return full ? pick_kernel_lpr<RNG, 64, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 64, false>(fun_id);
+}
+
+int check_args(const sx_pso_args *a) {
+    SX_REQUIRE(a != nullptr, "sx_pso: null args");
+    SX_REQUIRE(a->X && a->V && a->pbest && a->pbestfit && a->gbest && a->state && a->part_f && a->part_i,
+               "sx_pso: null device pointer");
+    SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->ld >= a->n, "sx_pso: bad shape");
+    SX_REQUIRE(a->fun_id >= 0 && a->fun_id < SX_FUN_COUNT, "sx_pso: unknown objective");
+    SX_REQUIRE(a->rng == SX_RNG_HOST || a->rng == SX_RNG_PHILOX, "sx_pso: unknown rng mode");
+    SX_REQUIRE(a->rng != SX_RNG_HOST || (a->r1 && a->r2), "sx_pso: host draws missing");
+    SX_REQUIRE(a->constraints == 0 || (a->lower && a->upper), "sx_pso: bounds missing");
+    return 0;
+}
+
+Geometry geometry(int64_t P, int n) { return row_geometry(P, n); }
+
+// ---------------------------------------------------------------------------
+// Competitive restart, cpso/_cpso.py:405-426
+// ---------------------------------------------------------------------------
+// per-workgroup max_i ||X_i - gbest||_2  (:410)
+template <int LPR>
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(const sx_pso_args a,
+                                                                              double *__restrict__ part_r) {
+    __shared__ double sr[kMaxRowsPerBlock];
+    if (a.state->done) return;
+    const RowIds<LPR> id(a.P);
+    const double *__restrict__ xr = a.X + id.rowc * a.ld;
+    double acc = 0.0;
+    for (int e0 = id.l; e0 < a.n; e0 += 4 * LPR) {  // four row loads in flight per lane
+        double xv[4], gv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = e0 + t * LPR;
+            xv[t] = e < a.n ? xr[e] : 0.0;
+            gv[t] = e < a.n ? a.gbest[e] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double d = xv[t] - gv[t];
+            acc += d * d;
+        }
+    }
+    acc = sqrt(row_sum<LPR>(acc));
+    if (id.l == 0) sr[id.slot] = id.active ? acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = sr[0];
+        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+        for (int k = 1; k < rows_in_block; ++k) m = fmax(m, sr[k]);
+        part_r[blockIdx.x] = m;
+    }
+}
+
+// histogram increment for one key per lane (dig < 0: this lane has none).  Fitness values of a converged swarm
+// pile up in very few bins, where plain LDS atomics would serialise: the wave first looks for large groups of
+// equal digits (up to four) and adds one count per group; whatever is left is spread out and goes as plain atomics.
+__device__ __forceinline__ void hist_add(unsigned *bins, int dig, int lane) {
+    unsigned long long todo = __ballot(dig >= 0);
+    for (int r = 0; r < 4 && todo; ++r) {
+        const int leader = (int)__ffsll((long long)todo) - 1;
+        const int d = __shfl(dig, leader, kWave);
+        const unsigned long long same = __ballot(dig == d);
+        if (__popcll(same) < 4) break;
+        if (lane == leader) atomicAdd(&bins[d], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&bins[dig], 1u);
+}
+
+constexpr int kSelThreads = 1024;
+constexpr int kSelPerThread = 16;  // keys held in registers up to 16384 particles (larger swarms re-read them each step)
+
+// One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
+// and the nw-th largest pbestfit is found by a radix descent over keys held in registers, starting at the first bit in
+// which the keys differ at all (see below).
+// out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
+// The swarm is `nseg` segments (one per rank; 1 on a single GPU) of `seg_len` fitness values followed by
+// `seg_npart` partial radii, `seg_stride` doubles apart: fit = base, part_r = base + seg_len.
+__global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const sx_pso_args a,
+                                                                         const double *__restrict__ fit,
+                                                                         const double *__restrict__ part_r,
+                                                                         int nseg, int64_t seg_len, int64_t seg_npart,
+                                                                         int64_t seg_stride, double delta, double gamma,
+                                                                         unsigned long long *__restrict__ out) {
+    const int64_t Ptot = (int64_t)nseg * seg_len, npart = (int64_t)nseg * seg_npart;
+    // element i of the (segmented) fitness / radius arrays; 32-bit arithmetic (Ptot < 2^31), nothing for one segment
+    const unsigned useg = (unsigned)seg_len, unp = (unsigned)seg_npart;
+    auto fit_at = [&](int64_t i) -> double {
+        if (nseg == 1) return fit[i];
+        const unsigned sg = (unsigned)i / useg;
+        return fit[(int64_t)sg * seg_stride + ((unsigned)i - sg * useg)];
+    };
+    __shared__ double smax[kSelThreads / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef SX_SELTRACE
+#define SEL_TP(k) do { if (tid == 0) ((unsigned long long *)a.candfit)[k] = wall_clock64(); } while (0)
+#else
+#define SEL_TP(k) do {} while (0)
+#endif
+    SEL_TP(0);
+    const int done = a.state->done;
+    const int64_t it = a.state->it;  // (fetched together: every dependent load is a trip to L2)
+    if (done) {
+        if (tid == 0) out[0] = 0;
+        return;
+    }
+    double m = 0.0;
+    for (int64_t k = tid; k < npart; k += kSelThreads) {
+        const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
+        m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
+    if (lane == 0) smax[wv] = m;
+    __syncthreads();
+    m = smax[0];
+    for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
+    const double radius = m / sqrt(4.0 * (double)a.n);
+    int64_t nw = 0;
+    if (radius < delta) {
+        const double inorm = (double)it / (double)a.maxiter;
+        nw = (int64_t)(((double)Ptot - 1.0) / (1.0 + exp(1.0 / 0.09 * (inorm - gamma + 0.5))));
+    }
+    if (tid == 0) {
+        out[0] = (unsigned long long)(nw > 0 ? nw : 0);
+        out[2] = (unsigned long long)__double_as_longlong(radius);
+    }
+    SEL_TP(1);
+    if (nw <= 0) return;  // uniform
+    // up to 32768 particles the keys stay in registers for the 8 passes; larger swarms re-read them (L2)
+    const bool in_regs = Ptot <= (int64_t)kSelThreads * kSelPerThread;
+    unsigned long long key[kSelPerThread];
+    // (the loops over the register array are fully unrolled; `k * kSelThreads < Ptot` is uniform, so the
+    //  iterations past the swarm cost one scalar branch each)
+    // loads in batches of 8, unconditionally (indices past the swarm are clamped): one latency per batch, not per load
+#pragma unroll
+    for (int k0 = 0; k0 < kSelPerThread; k0 += 8) {
+        double fv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = (int64_t)(k0 + u) * kSelThreads + tid;
+            fv[u] = (in_regs && (int64_t)k0 * kSelThreads < Ptot) ? fit_at(i < Ptot ? i : Ptot - 1) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = (int64_t)(k0 + u) * kSelThreads + tid;
+            key[k0 + u] = (in_regs && i < Ptot) ? sort_key(fv[u]) : 0ull;  // 0 < real keys
+        }
+    }
+    SEL_TP(2);
+    // 1. the keys' common leading bits carry no information (sign, exponent and the first mantissa bits are the
+    //    same all over a converged swarm): find the highest bit in which any two keys differ
+    __shared__ unsigned long long s_min[kSelThreads / kWave], s_max[kSelThreads / kWave];
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kSelPerThread; ++k) {
+            const int64_t i = (int64_t)k * kSelThreads + tid;
+            if ((int64_t)k * kSelThreads < Ptot && i < Ptot) {
+                kmin = key[k] < kmin ? key[k] : kmin;
+                kmax = key[k] > kmax ? key[k] : kmax;
+            }
+        }
+    } else {
+        for (int64_t i = tid; i < Ptot; i += kSelThreads) {
+            const unsigned long long kk = sort_key(fit_at(i));
+            kmin = kk < kmin ? kk : kmin;
+            kmax = kk > kmax ? kk : kmax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long omin = __shfl_xor(kmin, off, kWave), omax = __shfl_xor(kmax, off, kWave);
+        kmin = omin < kmin ? omin : kmin;
+        kmax = omax > kmax ? omax : kmax;
+    }
+    if (lane == 0) {
+        s_min[wv] = kmin;
+        s_max[wv] = kmax;
+    }
+    __syncthreads();
+    for (int k = 0; k < kSelThreads / kWave; ++k) {
+        kmin = s_min[k] < kmin ? s_min[k] : kmin;
+        kmax = s_max[k] > kmax ? s_max[k] : kmax;
+    }
+    SEL_TP(3);
+    if (kmin == kmax) {  // one value all over the swarm: it is the threshold
+        if (tid == 0) out[1] = kmin;
+        return;
+    }
+    // 2. radix descent from that bit, up to 10 bits per step (one histogram bin per thread): histogram (LDS
+    //    atomics) of the digit over the keys that match the prefix found so far; the digit of the `remaining`-th
+    //    largest of them is where the suffix count crosses it.  As soon as at most 512 keys share the prefix --
+    //    after the first step, as a rule -- they are gathered and ranked against each other directly.
+    __shared__ unsigned bins[kSelThreads];
+    __shared__ unsigned wsum[kSelThreads / kWave];
+    __shared__ unsigned s_digit, s_above, s_count, s_ncand;
+    __shared__ unsigned long long cand[kSelThreads];
+    int top = 63 - __clzll((long long)(kmin ^ kmax));  // keys agree above this bit
+    unsigned long long prefix = top == 63 ? 0ull : (kmax >> (top + 1)) << (top + 1);
+    unsigned remaining = (unsigned)nw;
+    for (;;) {
+        const int shift = top >= 9 ? top - 9 : 0, width = top - shift + 1;
+        const unsigned dmask = (1u << width) - 1u;
+        const unsigned long long himask = top == 63 ? 0ull : (~0ull << (top + 1));
+        bins[tid] = 0u;
+        __syncthreads();
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kSelPerThread; ++k) {
+                const int64_t i = (int64_t)k * kSelThreads + tid;
+                if ((int64_t)k * kSelThreads < Ptot)
+                    hist_add(bins, (i < Ptot && (key[k] & himask) == prefix) ? (int)((unsigned)(key[k] >> shift) & dmask) : -1,
+                             lane);
+            }
+        } else {
+            for (int64_t i0 = tid; i0 < Ptot; i0 += (int64_t)kSelThreads * 8) {
+                unsigned long long kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kSelThreads;
+                    kk[u] = i < Ptot ? sort_key(fit_at(i)) : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kSelThreads;
+                    hist_add(bins, (i < Ptot && (kk[u] & himask) == prefix) ? (int)((unsigned)(kk[u] >> shift) & dmask) : -1, lane);
+                }
+            }
+        }
+        __syncthreads();
+        SEL_TP(4);
+        // thread t owns bin t: inclusive suffix sums over the bins >= t (wave scan, then the waves above)
+        const unsigned c = bins[tid];
+        unsigned suf = c;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned o = __shfl_down(suf, off, kWave);
+            if (lane + off < kWave) suf += o;
+        }
+        if (lane == 0) wsum[wv] = suf;  // the wave's total
+        __syncthreads();
+        for (int k = wv + 1; k < kSelThreads / kWave; ++k) suf += wsum[k];
+        const unsigned above = suf - c;  // keys (matching the prefix) with a larger digit than t
+        if (above < remaining && suf >= remaining) {  // exactly one thread
+            s_digit = (unsigned)tid;
+            s_above = above;
+            s_count = c;
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)s_digit << shift;
+        remaining -= s_above;
+        const unsigned cnt = s_count;
+        SEL_TP(5);
+        if (shift == 0) {  // every bit fixed: the candidates are all equal to the prefix
+            if (tid == 0) out[1] = prefix;
+            return;
+        }
+        if (cnt <= 512u) {  // ranking costs ~11 ns per candidate, a further histogram step ~6.5 us
+            const unsigned long long lomask = ~0ull << shift;
+            if (tid == 0) s_ncand = 0u;
+            __syncthreads();
+            if (in_regs) {
+#pragma unroll
+                for (int k = 0; k < kSelPerThread; ++k) {
+                    const int64_t i = (int64_t)k * kSelThreads + tid;
+                    if ((int64_t)k * kSelThreads < Ptot && i < Ptot && (key[k] & lomask) == prefix)
+                        cand[atomicAdd(&s_ncand, 1u)] = key[k];
+                }
+            } else {
+                for (int64_t i = tid; i < Ptot; i += kSelThreads) {
+                    const unsigned long long kk = sort_key(fit_at(i));
+                    if ((kk & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = kk;
+                }
+            }
+            __syncthreads();
+            SEL_TP(6);
+            if ((unsigned)tid < cnt) {  // the remaining-th largest candidate: `greater` < remaining <= greater + equal
+                const unsigned long long mine = cand[tid];
+                unsigned greater = 0u, equal = 0u;
+#pragma unroll 8
+                for (unsigned cc = 0; cc < cnt; ++cc) {
+                    const unsigned long long o = cand[cc];
+                    greater += o > mine;
+                    equal += o == mine;
+                }
+                if (greater < remaining && remaining <= greater + equal) out[1] = mine;  // same value from every tie
+            }
+            SEL_TP(7);
+            return;
+        }
+        top = shift - 1;
+    }
+}
+
+// rows whose pbestfit is among the nw worst: V = 0, X = uniform(lower, upper), pbest = X, pbestfit = 1e30 (:420-424)
+// host_rows != NULL (numpy-legacy): row ids in the reference's descending-fitness order + their new positions
+__global__ __launch_bounds__(256) void pso_restart_apply_kernel(
+    const sx_pso_args a, const unsigned long long *__restrict__ sel, const int64_t *__restrict__ host_rows,
+    const double *__restrict__ host_x, int64_t host_count) {
+    if (a.state->done) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t row;
+    if (host_rows != nullptr) {
+        if (slot >= host_count) return;
+        row = host_rows[slot];
+    } else {
+        if (slot >= a.P || sel[0] == 0) return;
+        row = slot;
+        if (sort_key(a.pbestfit[row]) < sel[1]) return;
+    }
+    const uint32_t gen = (uint32_t)a.state->it;  // the generation that just finished
+    const uint32_t grow = (uint32_t)(a.row0 + row);
+    double *__restrict__ xr = a.X + row * a.ld;
+    double *__restrict__ vr = a.V + row * a.ld;
+    double *__restrict__ pb = a.pbest + row * a.ld;
+    for (int e = lane; e < a.n; e += kWave) {
+        double x;
+        if (host_rows != nullptr)
+            x = host_x[slot * (int64_t)a.n + e];
+        else
+            x = a.lower[e] + (a.upper[e] - a.lower[e]) *
+                                 philox_u53(e, lanes_per_row(a.n), grow, gen, kPurposePsoRestart, a.key0, a.key1);
+        vr[e] = 0.0;
+        xr[e] = x;
+        pb[e] = x;
+    }
+    if (lane == 0) a.pbestfit[row] = 1.0e30;
+}
+
+}  // namespace
+
+extern "C" int sx_pso_generation(const sx_pso_args *a, int finalize, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a->P, a->n);
+    pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n)
+                                                 : pick_kernel<SX_RNG_HOST>(a->fun_id, a->n);
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan);
+    SX_LAUNCH_CHECK();
+    if (finalize)
+        return sx_select_finalize(a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n, a->gbest, a->state,
+                                  a->maxiter, a->xtol, a->ftol, stream);
+    return 0;
+}
+
+extern "C" int sx_pso_radius(const sx_pso_args *a, double *part_r, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(part_r != nullptr, "sx_pso_radius: null scratch");
+    const Geometry g = geometry(a->P, a->n);
+    SX_DISPATCH_LPR(a->n, hipLaunchKernelGGL(pso_radius_kernel<LPR>, dim3(g.blocks), dim3(g.threads), 0,
+                                             (hipStream_t)stream, *a, part_r))
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_pso_restart_select(const sx_pso_args *a, const double *part_r, double delta, double gamma,
+                                     uint64_t *out3, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(part_r && out3, "sx_pso_restart_select: null pointer");
+    const Geometry g = geometry(a->P, a->n);
+    hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a,
+                       (const double *)a->pbestfit, part_r, 1, a->P, (int64_t)g.blocks, a->P, delta, gamma,
+                       (unsigned long long *)out3);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// Sharded swarm: `gathered` = (world, P_local + npart) doubles, row r = rank r's [pbestfit | partial radii]
+// (one all-gather per generation); every rank derives the same radius / nw / threshold for the WHOLE swarm.
+extern "C" int sx_pso_restart_select_gathered(const sx_pso_args *a, const double *gathered, int world, double delta,
+                                              double gamma, uint64_t *out3, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(gathered && out3 && world >= 1, "sx_pso_restart_select_gathered: bad arguments");
+    const int64_t npart = (int64_t)geometry(a->P, a->n).blocks;
+    hipLaunchKernelGGL(pso_restart_select_kernel, dim3(1), dim3(kSelThreads), 0, (hipStream_t)stream, *a, gathered,
+                       gathered + a->P, world, a->P, npart, a->P + npart, delta, gamma, (unsigned long long *)out3);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_pso_restart_apply(const sx_pso_args *a, const uint64_t *sel3, const int64_t *host_rows,
+                                    const double *host_x, int64_t host_count, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE((sel3 != nullptr) != (host_rows != nullptr), "sx_pso_restart_apply: give sel3 OR host rows");
+    SX_REQUIRE(host_rows == nullptr || (host_x != nullptr && host_count >= 0), "sx_pso_restart_apply: host rows");
+    SX_REQUIRE(a->lower && a->upper, "sx_pso_restart_apply: bounds missing");
+    const int64_t slots = host_rows ? host_count : a->P;
+    if (slots == 0) return 0;
+    const int rpb = 4;
+    hipLaunchKernelGGL(pso_restart_apply_kernel, dim3((unsigned)((slots + rpb - 1) / rpb)), dim3(rpb * kWave), 0,
+                       (hipStream_t)stream, *a, (const unsigned long long *)sel3, host_rows, host_x, host_count);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// hipGraph of `ngen` generations (single GPU, Philox draws): per generation the generation kernel, the
+// best/termination kernel and -- CPSO (part_r != NULL) -- the three restart kernels, all reading the
+// generation counter and the done flag from the device, so one instantiated graph is replayed.
+// ---------------------------------------------------------------------------
+namespace {
+int add_kernel_node(hipGraph_t graph, hipGraphNode_t *prev, void *func, dim3 grid, dim3 block, unsigned lds,
+                    void **kargs) {
+    hipKernelNodeParams kp = {};
+    kp.func = func;
+    kp.gridDim = grid;
+    kp.blockDim = block;
+    kp.sharedMemBytes = lds;
+    kp.kernelParams = kargs;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    SX_HIP(hipGraphAddKernelNode(&node, graph, *prev ? prev : nullptr, *prev ? 1 : 0, &kp));
+    *prev = node;
+    return 0;
+}
+
+template <int LPR>
+void *radius_kernel_ptr() {
+    return (void *)pso_radius_kernel<LPR>;
+}
+}  // namespace
+
+namespace sx {
+int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
+                      int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,
+                      sx_state *state, int maxiter, double xtol, double ftol);
+}
+
+extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_r, double delta, double gamma,
+                                   uint64_t *sel3, sx_graph **out) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(out != nullptr && ngen >= 1, "sx_pso_graph_create: bad arguments");
+    SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_pso_graph_create: graphs need in-kernel (Philox) draws");
+    SX_REQUIRE((part_r == nullptr) == (sel3 == nullptr), "sx_pso_graph_create: restart needs part_r AND sel3");
+    SX_REQUIRE(part_r == nullptr || (a->lower && a->upper), "sx_pso_graph_create: bounds missing");
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a->P, a->n);
+    sx_graph *gr = new sx_graph();
+    SX_HIP(hipGraphCreate(&gr->graph, 0));
+    sx_pso_args args = *a;
+    args.pending_restart = nullptr;
+    // generations 2..ngen of the graph carry out the previous generation's restart themselves (sx_pso_args.pending_restart);
+    // the last one is followed by the apply kernel, so the state a replay leaves behind is complete
+    sx_pso_args args_inline = args;
+    args_inline.pending_restart = sel3;
+    void *gen_args[] = {&args, &plan};
+    void *gen_args_inline[] = {&args_inline, &plan};
+    // restart kernels' arguments
+    const double *fit = a->pbestfit;
+    const double *pr = part_r;
+    int one = 1;
+    int64_t P = a->P, npart = g.blocks;
+    unsigned long long *sel = (unsigned long long *)sel3;
+    void *rad_args[] = {&args, &part_r};
+    void *sel_args[] = {&args, &fit, &pr, &one, &P, &npart, &P, &delta, &gamma, &sel};
+    const int64_t *no_rows = nullptr;
+    const double *no_x = nullptr;
+    int64_t zero = 0;
+    const unsigned long long *csel = sel;
+    void *app_args[] = {&args, &csel, &no_rows, &no_x, &zero};
+    void *radius_fn = nullptr;
+    SX_DISPATCH_LPR(a->n, radius_fn = radius_kernel_ptr<LPR>())
+    hipGraphNode_t prev = nullptr;
+    for (int i = 0; i < ngen; ++i) {
+        if (int rc = add_kernel_node(gr->graph, &prev, (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n),
+                                     dim3(g.blocks), dim3(g.threads), (unsigned)g.lds,
+                                     (part_r != nullptr && i > 0) ? gen_args_inline : gen_args))
+            return rc;
+        if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n,
+                                       a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
+            return rc;
+        if (part_r != nullptr) {
+            if (int rc = add_kernel_node(gr->graph, &prev, radius_fn, dim3(g.blocks), dim3(g.threads), 0, rad_args))
+                return rc;
+            if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_select_kernel, dim3(1), dim3(kSelThreads),
+                                         0, sel_args))
+                return rc;
+            const int rpb = 4;
+            if (i == ngen - 1)
+                if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_apply_kernel,
+                                             dim3((unsigned)((a->P + rpb - 1) / rpb)), dim3(rpb * kWave), 0, app_args))
+                    return rc;
+        }
+    }
+    SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
+    *out = gr;
+    return 0;
+}

@@ -126,16 +126,21 @@ __device__ __forceinline__ void block_partial(double val, const RowIds<LPR> &id,
         si[id.slot] = id.active ? id.row : INT64_MAX;
     }
     __syncthreads();
-    if (threadIdx.x < kWave) {  // wavefront 0: slot k in lane k (slots are in row order), one DPP minimum instead of a
-        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;  // 15-step chain in one lane
-        const int k = (int)threadIdx.x;
-        double bf = k < rows_in_block ? sf[k] : __builtin_huge_val();
-        int64_t bi = k < rows_in_block ? si[k] : INT64_MAX;
-        wave_argmin_ordered(bf, bi);
-        if (k == 0) {
-            part_f[id.block] = bf;
-            part_i[id.block] = bi;
+    if (threadIdx.x == 0) {
+        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+        double vf[kMaxRowsPerBlock];
+        int64_t vi[kMaxRowsPerBlock];
+#pragma unroll
+        for (int k = 0; k < kMaxRowsPerBlock; ++k) {  // all LDS reads in flight at once
+            vf[k] = k < rows_in_block ? sf[k] : __builtin_huge_val();
+            vi[k] = k < rows_in_block ? si[k] : INT64_MAX;
         }
+        double bf = vf[0];
+        int64_t bi = vi[0];
+#pragma unroll
+        for (int k = 1; k < kMaxRowsPerBlock; ++k) argmin_combine(bf, bi, vf[k], vi[k]);
+        part_f[id.block] = bf;
+        part_i[id.block] = bi;
     }
 }
 
