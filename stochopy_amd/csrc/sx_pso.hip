@@ -30,7 +30,9 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
 
 // FULL: n == 4 * LPR (64, 128 or 256 -- BASELINE config 3): the row length is a compile-time constant, a row is exactly
 // one batch, and every bound check and loop over the row folds away.
-template <int FUN, int RNG, int LPR, bool FULL>
+// PLAIN (with FULL): constraints=None and no restart pending (plain PSO, or the first generation of a CPSO graph): neither
+// the Shrink pass nor the re-seeding test is compiled in.
+template <int FUN, int RNG, int LPR, bool FULL, bool PLAIN = false>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
                                                                                 const PlanArg plan) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     // row is not loaded but re-seeded (what pso_restart_apply_kernel would have written: same Philox positions, V = 0,
     // pbest = X, pbestfit = 1e30), and then moved like any other
     bool reseed = false;
-    if (RNG == SX_RNG_PHILOX && a.pending_restart != nullptr)
+    if (!PLAIN && RNG == SX_RNG_PHILOX && a.pending_restart != nullptr)
         reseed = a.pending_restart[0] != 0ull && sort_key(fold) >= a.pending_restart[1];
     if (reseed) fold = 1.0e30;
     double *__restrict__ xr = a.X + rowc * ld;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     const double *__restrict__ gb = a.gbest;
     const uint32_t grow = (uint32_t)(a.row0 + rowc);
     const double w = a.w, c1 = a.c1, c2 = a.c2;
-    const bool shrink = a.constraints != 0;
+    const bool shrink = PLAIN ? false : a.constraints != 0;
     const double *r1row = RNG == SX_RNG_HOST ? a.r1 + rowc * (int64_t)n : nullptr;
     const double *r2row = RNG == SX_RNG_HOST ? a.r2 + rowc * (int64_t)n : nullptr;
 
@@ -173,30 +175,36 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
 
 typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
 
-template <int RNG, int LPR, bool FULL>
+template <int RNG, int LPR, bool FULL, bool PLAIN = false>
 pso_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL>;
-        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL>;
-        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL>;
-        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL>;
-        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL>;
-        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL>;
+        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL, PLAIN>;
+        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL, PLAIN>;
+        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL, PLAIN>;
+        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL, PLAIN>;
+        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL, PLAIN>;
+        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL, PLAIN>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL, PLAIN>;
     }
     return nullptr;
 }
 
 template <int RNG>
-pso_kernel_t pick_kernel(int fun_id, int n) {
+pso_kernel_t pick_kernel(int fun_id, int n, bool plain) {
+    constexpr bool PH = RNG == SX_RNG_PHILOX;
     const int lpr = lanes_per_row(n);
     // whole-batch rows with in-kernel draws get the constant-length form (host draws: the run is bound by the host)
-    const bool full = RNG == SX_RNG_PHILOX && n == 4 * lpr;
+    const bool full = PH && n == 4 * lpr;
     switch (lpr) {
-        case 16: return full ? pick_kernel_lpr<RNG, 16, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 16, false>(fun_id);
-        case 32: return full ? pick_kernel_lpr<RNG, 32, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 32, false>(fun_id);
+        case 16:
+            if (full) return plain ? pick_kernel_lpr<RNG, 16, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 16, PH>(fun_id);
+            return pick_kernel_lpr<RNG, 16, false>(fun_id);
+        case 32:
+            if (full) return plain ? pick_kernel_lpr<RNG, 32, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 32, PH>(fun_id);
+            return pick_kernel_lpr<RNG, 32, false>(fun_id);
     }
-    return full ? pick_kernel_lpr<RNG, 64, RNG == SX_RNG_PHILOX>(fun_id) : pick_kernel_lpr<RNG, 64, false>(fun_id);
+    if (full) return plain ? pick_kernel_lpr<RNG, 64, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 64, PH>(fun_id);
+    return pick_kernel_lpr<RNG, 64, false>(fun_id);
 }
 
 int check_args(const sx_pso_args *a) {
@@ -536,8 +544,9 @@ extern "C" int sx_pso_generation(const sx_pso_args *a, int finalize, void *strea
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a->P, a->n);
-    pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n)
-                                                 : pick_kernel<SX_RNG_HOST>(a->fun_id, a->n);
+    const bool plain = a->constraints == 0 && a->pending_restart == nullptr;
+    pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n, plain)
+                                                 : pick_kernel<SX_RNG_HOST>(a->fun_id, a->n, plain);
     hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan);
     SX_LAUNCH_CHECK();
     if (finalize)
@@ -666,9 +675,10 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     SX_DISPATCH_LPR(a->n, radius_fn = radius_kernel_ptr<LPR>())
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
-        if (int rc = add_kernel_node(gr->graph, &prev, (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n),
-                                     dim3(g.blocks), dim3(g.threads), (unsigned)g.lds,
-                                     (part_r != nullptr && i > 0) ? gen_args_inline : gen_args))
+        const bool inl = part_r != nullptr && i > 0;  // CPSO: generations 2.. carry out the restart decided before them
+        if (int rc = add_kernel_node(gr->graph, &prev,
+                                     (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n, a->constraints == 0 && !inl),
+                                     dim3(g.blocks), dim3(g.threads), (unsigned)g.lds, inl ? gen_args_inline : gen_args))
             return rc;
         if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n,
                                        a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
