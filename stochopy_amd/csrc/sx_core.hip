@@ -330,8 +330,14 @@ __device__ __forceinline__ void scan_records(const double *__restrict__ part_f, 
             f[u] = k < npart ? part_f[k] : __builtin_huge_val();
             i[u] = k < npart ? part_i[k] : INT64_MAX;
         }
+        // this trip's minimum (a tree), then the first record that holds it (k grows with u), then one lexicographic
+        // step into the running pair: a chain of 8 compare-and-select steps otherwise
+        const double m = fmin(fmin(fmin(f[0], f[1]), fmin(f[2], f[3])), fmin(fmin(f[4], f[5]), fmin(f[6], f[7])));
+        int64_t first = i[0];  // (all NaN: the first record, as a sequential scan)
 #pragma unroll
-        for (int u = 0; u < kScan; ++u) argmin_combine(bf, bi, f[u], i[u]);
+        for (int u = kScan - 1; u >= 0; --u)
+            if (f[u] == m) first = i[u];
+        argmin_combine(bf, bi, m, first);
     }
 }
 

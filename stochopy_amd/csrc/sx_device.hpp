@@ -646,13 +646,39 @@ __device__ __forceinline__ void wave_argmin_ordered(double &f, int64_t &i) {
     i = ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
 }
 
+// smallest of a 64-bit signed value over the wave, in every lane (DPP + readlanes, like wave_min_f64)
+template <int CTRL>
+__device__ __forceinline__ int64_t dpp_i64(int64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(v & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xf, 0xf, true);
+    return ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
+}
+__device__ __forceinline__ int64_t min_i64(int64_t a, int64_t b) { return b < a ? b : a; }
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
+    v = min_i64(v, dpp_i64<kDppXor1>(v));
+    v = min_i64(v, dpp_i64<kDppXor2>(v));
+    v = min_i64(v, dpp_i64<kDppHalfMirror>(v));
+    v = min_i64(v, dpp_i64<kDppRowMirror>(v));
+    const unsigned long long u = (unsigned long long)v;
+    const int64_t a = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 0) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)u, 0));
+    const int64_t b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 16) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)u, 16));
+    const int64_t c = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 32) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)u, 32));
+    const int64_t d = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 48) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)u, 48));
+    return min_i64(min_i64(a, b), min_i64(c, d));
+}
+
+// (min f, smallest index that holds it) over the wave for ANY assignment of indices to lanes, in every lane: the
+// minimum value, then the minimum index among the lanes that hold it -- two DPP reductions instead of six rounds of
+// ds_bpermute exchanges.  (All NaN: index 0, as np.argmin.)
 __device__ __forceinline__ void wave_argmin_all(double &f, int64_t &i) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const double f2 = __shfl_xor(f, off, kWave);
-        const int64_t i2 = __shfl_xor((long long)i, off, kWave);
-        argmin_combine(f, i, f2, i2);
-    }
+    const double m = wave_min_f64(f);
+    const int64_t r = wave_min_i64(f == m ? i : INT64_MAX);
+    f = m;
+    i = r == INT64_MAX ? 0 : r;
 }
 
 }  // namespace sx
