@@ -634,6 +634,15 @@ __device__ __forceinline__ double wave_min_f64(double v) {
     return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// maximum over the 64 lanes, returned to every lane
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_f64<kDppXor1>(v));
+    v = fmax(v, dpp_f64<kDppXor2>(v));
+    v = fmax(v, dpp_f64<kDppHalfMirror>(v));
+    v = fmax(v, dpp_f64<kDppRowMirror>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 // (min f, its index) over the wave when LOWER LANES HOLD LOWER INDICES: the first lane that holds the
 // minimum wins = np.argmin's first-minimum rule.  Result in every lane.
 __device__ __forceinline__ void wave_argmin_ordered(double &f, int64_t &i) {

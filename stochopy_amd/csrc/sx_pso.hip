@@ -38,8 +38,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
+    // the state word (a miss after every kernel boundary) is needed by the Philox counters and the stop test only: the
+    // PLAIN kernel issues the row loads of its batch before anything waits for it.  (Not the general one: with the
+    // re-seeding code behind it the late test made that kernel 31.5 -> 53 us, profiles/r2_pso_c3_variants.txt.)
     const sx_state *st = a.state;
-    if (st->done) return;
+    const int done = st->done;
+    if (!PLAIN && done) return;
     const uint32_t gen = (uint32_t)(st->it + 1);
     const int n = FULL ? 4 * LPR : a.n;
     const int64_t P = a.P, ld = a.ld;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             r1[t] = (RNG == SX_RNG_HOST && in) ? r1row[e] : 0.0;
             r2[t] = (RNG == SX_RNG_HOST && in) ? r2row[e] : 0.0;
         }
+        if (PLAIN && done) return;  // (uniform; nothing has been written yet)
         if (RNG == SX_RNG_PHILOX) {
             // 32-bit uniforms, one call per 2 steps: words (0,1) -> (r1,r2) of even q, (2,3) of odd q
 #pragma unroll
@@ -229,7 +234,7 @@ template <int LPR>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(const sx_pso_args a,
                                                                               double *__restrict__ part_r) {
     __shared__ double sr[kMaxRowsPerBlock];
-    if (a.state->done) return;
+    const int done = a.state->done;  // looked at behind the row loads (a miss after the kernel boundary)
     const RowIds<LPR> id(a.P);
     const double *__restrict__ xr = a.X + id.rowc * a.ld;
     double acc = 0.0;
@@ -247,14 +252,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_radius_kernel(co
             acc += d * d;
         }
     }
+    if (done) return;
     acc = sqrt(row_sum<LPR>(acc));
     if (id.l == 0) sr[id.slot] = id.active ? acc : 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = sr[0];
+    if (threadIdx.x < kWave) {  // wavefront 0: slot k in lane k
         const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
-        for (int k = 1; k < rows_in_block; ++k) m = fmax(m, sr[k]);
-        part_r[blockIdx.x] = m;
+        const double m = wave_max_f64((int)threadIdx.x < rows_in_block ? sr[threadIdx.x] : 0.0);
+        if (threadIdx.x == 0) part_r[blockIdx.x] = m;
     }
 }
 
@@ -306,21 +311,21 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 #endif
     SEL_TP(0);
     const int done = a.state->done;
-    const int64_t it = a.state->it;  // (fetched together: every dependent load is a trip to L2)
-    if (done) {
-        if (tid == 0) out[0] = 0;
-        return;
-    }
+    const int64_t it = a.state->it;  // (fetched together, and looked at behind the radii: every dependent load is a trip to L2)
     double m = 0.0;
     for (int64_t k = tid; k < npart; k += kSelThreads) {
         const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
         m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, kWave));
+    if (done) {
+        if (tid == 0) out[0] = 0;
+        return;
+    }
+    m = wave_max_f64(m);
     if (lane == 0) smax[wv] = m;
     __syncthreads();
     m = smax[0];
+#pragma unroll
     for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
     const double radius = m / sqrt(4.0 * (double)a.n);
     int64_t nw = 0;
