@@ -409,8 +409,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     } else if (CHAIN) {
         // (value, first row) over the records: the minimum value first (a tree per lane, then DPP over the wave), then
         // the first record that holds it -- lanes own contiguous slices, so that is the first matching record of the
-        // first matching lane.  (A lexicographic compare-and-select chain over the 8 records, as the other kernels have
-        // it, is ~60 dependent instructions in front of the best row's address.)
+        // first matching lane.  (A lexicographic compare-and-select chain over the 8 records is ~60 dependent
+        // instructions in front of the best row's address.)
         double lm[kRecPerLane / 2];
 #pragma unroll
         for (int u = 0; u < kRecPerLane / 2; ++u) lm[u] = fmin(pfv[2 * u], pfv[2 * u + 1]);
