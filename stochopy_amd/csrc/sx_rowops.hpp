@@ -126,8 +126,11 @@ __device__ __forceinline__ void block_partial(double val, const RowIds<LPR> &id,
         si[id.slot] = id.active ? id.row : INT64_MAX;
     }
     __syncthreads();
-    if (threadIdx.x < kWave) {  // wavefront 0: slot k in lane k (slots are in row order), one DPP minimum instead of a
-        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;  // 15-step chain in one lane
+    // wavefront 0 takes slot k in lane k (slots are in row order) and finds the record with one DPP minimum + ballot.
+    // (One lane folding the slots in a 15-step compare-and-select chain cost 0.8 us at the end of every workgroup of
+    // the metric shape -- 8.4 -> 7.6 us per generation.)
+    if (threadIdx.x < kWave) {
+        const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
         const int k = (int)threadIdx.x;
         double bf = k < rows_in_block ? sf[k] : __builtin_huge_val();
         int64_t bi = k < rows_in_block ? si[k] : INT64_MAX;
