@@ -177,6 +177,7 @@ class _DeRun:
                                    f'{self.exchange_note or "it was switched off"}')
         self._graph = None
         self._chain_graphs = {}
+        self._tail_seen = {}
         self._ext_graphs, self._ext_graph_note = {}, None
         self._shard_calls = None
         self._rccl_graph = None
@@ -265,12 +266,30 @@ class _DeRun:
 
     def _enqueue_chain(self, ngen):
         ctx = self.ctx
-        for size in (self.GRAPH_CHUNK, self.TAIL_CHUNK):
-            while ngen >= size:
-                par = self.launches & 1
-                _lib.check(ctx.L.sx_graph_launch(self._chain_graph(par, size), ctx.stream_ptr), "sx_graph_launch")
-                self.launches += size
+
+        def replay(size):
+            par = self.launches & 1
+            _lib.check(ctx.L.sx_graph_launch(self._chain_graph(par, size), ctx.stream_ptr), "sx_graph_launch")
+            self.launches += size
+
+        while ngen >= self.GRAPH_CHUNK:
+            replay(self.GRAPH_CHUNK)
+            ngen -= self.GRAPH_CHUNK
+        # the rest as ONE graph of exactly that (even) length once a caller asks for the same length again -- every
+        # replay costs about as much as one generation of the metric shape, so stepping in blocks of 20 becomes one
+        # replay per block instead of two of the 10-generation graph; a length seen once (the tail of a single
+        # minimize() call) is not worth an instantiation.  At most 20 lengths x 2 parities are ever instantiated.
+        size = ngen & ~1
+        if size > self.TAIL_CHUNK:
+            par = self.launches & 1
+            seen = self._tail_seen.get((par, size), 0)
+            self._tail_seen[(par, size)] = seen + 1
+            if seen >= 1:
+                replay(size)
                 ngen -= size
+        while ngen >= self.TAIL_CHUNK:
+            replay(self.TAIL_CHUNK)
+            ngen -= self.TAIL_CHUNK
         for _ in range(ngen):
             self._chain_launch(self.launches & 1, 0)
             self.launches += 1
