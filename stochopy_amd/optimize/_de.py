@@ -264,35 +264,37 @@ class _DeRun:
                        "sx_de_graph_create")
             self._graph = g
 
+    @staticmethod
+    def plan_chain(ngen, launches, seen, chunk, tail):
+        """How `ngen` generations of the chained kernel are enqueued after `launches` earlier ones: a list of graph
+        lengths (0 = one eager launch).  Whole `chunk`-generation graphs first; the rest as ONE graph of exactly that
+        (even) length once the same (parity, length) has been asked for before -- every replay costs about as much as
+        one generation of the metric shape, so stepping in blocks of 20 becomes one replay per block instead of two of
+        the `tail`-generation graph, while a length seen once (the tail of a single minimize() call) is not worth an
+        instantiation; at most chunk/2 lengths x 2 parities are ever instantiated.  `seen` counts the requests."""
+        plan = [chunk] * (ngen // chunk)
+        ngen -= chunk * len(plan)
+        size = ngen & ~1
+        if size > tail:
+            key = ((launches + sum(plan)) & 1, size)
+            seen[key] = seen.get(key, 0) + 1
+            if seen[key] >= 2:
+                plan.append(size)
+                ngen -= size
+        plan += [tail] * (ngen // tail)
+        ngen %= tail
+        return plan + [0] * ngen
+
     def _enqueue_chain(self, ngen):
         ctx = self.ctx
-
-        def replay(size):
+        for size in self.plan_chain(ngen, self.launches, self._tail_seen, self.GRAPH_CHUNK, self.TAIL_CHUNK):
             par = self.launches & 1
-            _lib.check(ctx.L.sx_graph_launch(self._chain_graph(par, size), ctx.stream_ptr), "sx_graph_launch")
-            self.launches += size
-
-        while ngen >= self.GRAPH_CHUNK:
-            replay(self.GRAPH_CHUNK)
-            ngen -= self.GRAPH_CHUNK
-        # the rest as ONE graph of exactly that (even) length once a caller asks for the same length again -- every
-        # replay costs about as much as one generation of the metric shape, so stepping in blocks of 20 becomes one
-        # replay per block instead of two of the 10-generation graph; a length seen once (the tail of a single
-        # minimize() call) is not worth an instantiation.  At most 20 lengths x 2 parities are ever instantiated.
-        size = ngen & ~1
-        if size > self.TAIL_CHUNK:
-            par = self.launches & 1
-            seen = self._tail_seen.get((par, size), 0)
-            self._tail_seen[(par, size)] = seen + 1
-            if seen >= 1:
-                replay(size)
-                ngen -= size
-        while ngen >= self.TAIL_CHUNK:
-            replay(self.TAIL_CHUNK)
-            ngen -= self.TAIL_CHUNK
-        for _ in range(ngen):
-            self._chain_launch(self.launches & 1, 0)
-            self.launches += 1
+            if size == 0:
+                self._chain_launch(par, 0)
+                self.launches += 1
+            else:
+                _lib.check(ctx.L.sx_graph_launch(self._chain_graph(par, size), ctx.stream_ptr), "sx_graph_launch")
+                self.launches += size
 
     def _sharded_generation(self):
         """One generation on this rank's shard + the global-best exchange (parallel.py): two host calls into

@@ -348,3 +348,34 @@ def test_workers_option_resolution():
     assert [_common.resolve_workers(w) for w in (None, 0, 1, -1, 4)] == [1, 1, 1, 1, 4]
     with pytest.raises(ValueError):
         _common.resolve_workers(-3)
+
+
+def test_chained_generations_are_planned_as_few_graph_replays():
+    """_DeRun.plan_chain (host logic of the chained DE engine): whole 50-generation graphs, a repeated remainder as one
+    graph of exactly that even length, a one-off remainder from the 10-generation graph, single launches for the rest;
+    the generations always add up and graphs start at the parity they were built for."""
+    from stochopy_amd.optimize._de import _DeRun
+
+    plan = _DeRun.plan_chain
+    assert plan(200, 0, {}, 50, 10) == [50] * 4
+    assert plan(137, 0, {}, 50, 10) == [50, 50, 10, 10, 10] + [0] * 7  # first request: no new graph for 36
+    assert plan(9, 3, {}, 50, 10) == [0] * 9
+    seen = {}
+    assert plan(20, 5, seen, 50, 10) == [10, 10]      # the driver's --steps 20 --warmup 5: first block ...
+    assert plan(20, 25, seen, 50, 10) == [20]         # ... and every later one (odd parity, same length)
+    assert plan(20, 45, seen, 50, 10) == [20]
+    assert plan(20, 64, seen, 50, 10) == [10, 10]     # the other parity is a different graph: counted on its own
+    assert plan(20, 84, seen, 50, 10) == [20]
+    assert plan(71, 0, seen, 50, 10) == [50, 20, 0]   # 21 left after the whole graph: the (parity 0, 20) graph exists
+    rs = np.random.RandomState(3)
+    seen, launches = {}, 0
+    for _ in range(300):
+        n = int(rs.randint(0, 260))
+        p = plan(n, launches, seen, 50, 10)
+        assert sum(s if s else 1 for s in p) == n
+        at = launches
+        for s in p:
+            assert s == 0 or (s % 2 == 0 and 10 <= s <= 50)
+            at += s if s else 1
+        launches += n
+    assert all(k[1] % 2 == 0 and 10 < k[1] < 50 for k in seen)
