@@ -597,9 +597,9 @@ de_kernel_t pick_kernel_lpr(int fun_id) {
 // the one-batch kernels come per strategy
 template <int RNG, int XM, int LPR, bool FULL, int NFIX>
 de_kernel_t pick_kernel_fixed(int fun_id, int strategy, int constraints) {
-    // per strategy only for the single-GPU chained kernel (the peer-exchange kernel at these row lengths is not a
-    // throughput shape, and its instantiations are the expensive ones to compile)
-    if constexpr (XM == 2) {
+    // per strategy for the single-GPU chained kernel; for the peer-exchange kernel (whose instantiations are the
+    // expensive ones to compile) only at the metric shape's row length, n = 128 -- what `bench.py --gpus N` runs
+    if constexpr (XM == 2 && LPR != 32) {
         return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX>(fun_id);
     } else {
         if (constraints != 0) return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX>(fun_id);
