@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     __shared__ int64_t si[kMaxRowsPerBlock];
     // the state word (a miss after every kernel boundary) is needed by the Philox counters and the stop test only: the
     // PLAIN kernel issues the row loads of its batch before anything waits for it.  (Not the general one: with the
-    // re-seeding code behind it the late test made that kernel 31.5 -> 53 us, profiles/r2_pso_c3_variants.txt.)
+    // re-seeding code behind it the late test costs 130 VGPRs instead of 80 -- 3 waves per SIMD instead of 6 -- and made
+    // that kernel 31.5 -> 53 us, profiles/r2_pso_c3_variants.txt.)
     const sx_state *st = a.state;
     const int done = st->done;
     if (!PLAIN && done) return;
