@@ -36,7 +36,17 @@ namespace {
 // The result is the sequential sweep's, bit for bit; conflicts are rare (k*B/(2P) donors per individual, a
 // handful of best-row improvements per generation), and each costs one more parallel proposal.
 // ---------------------------------------------------------------------------
-constexpr int kSweepWaves = 16;
+#ifndef SX_SWEEP_WAVES
+#define SX_SWEEP_WAVES 16  // (a build-time knob for A/B measurements)
+#endif
+constexpr int kSweepWaves = SX_SWEEP_WAVES;
+// Ackley's and Griewank's term code (fp64 cos, exp) does not fit the 128 VGPRs a 16-wave workgroup leaves a lane: those
+// kernels spilled 220-350 bytes per lane to scratch; with 8 waves (256 VGPRs) they do not, and half the slots per round
+// still make the faster sweep (DE Ackley n=128 P=4096 1.89 -> 1.52 ms per generation, PSO Ackley n=256 2.90 -> 2.54;
+// Rosenbrock, which spills 48 bytes, is 20 % slower with 8 waves and keeps 16)
+__host__ __device__ constexpr int sweep_waves(int fun_id) {
+    return (fun_id == SX_FUN_ACKLEY || fun_id == SX_FUN_GRIEWANK) ? (kSweepWaves + 1) / 2 : kSweepWaves;
+}
 constexpr int kSweepSlots = 64;  // <= 64: the "replaced in this round" set is one 64-bit mask
 
 struct SweepGeometry {
@@ -44,12 +54,12 @@ struct SweepGeometry {
     size_t lds;
 };
 // slot = staging row (+ `extra` more rows of n doubles); the best row G behind the slots
-inline SweepGeometry sweep_geometry(int n, int extra) {
+inline SweepGeometry sweep_geometry(int n, int extra, int fun_id) {
     const int rpw = kWave / lanes_per_row(n);
     const size_t slot_bytes = (size_t)(lds_row_stride(n) + extra * n) * sizeof(double);
     const size_t avail = 160 * 1024 - 4096 - (size_t)n * sizeof(double);  // 160 KB per CU, static arrays, G
     int waves = (int)(avail / slot_bytes) / rpw;
-    waves = waves < 1 ? 1 : (waves > kSweepWaves ? kSweepWaves : waves);
+    waves = waves < 1 ? 1 : (waves > sweep_waves(fun_id) ? sweep_waves(fun_id) : waves);
     return SweepGeometry{waves, waves * rpw, (size_t)waves * rpw * slot_bytes + (size_t)n * sizeof(double)};
 }
 
@@ -90,7 +100,7 @@ __device__ __forceinline__ void publish(sx_state *st, int64_t it, double gfit, i
 // NFIX: the row length when it is exactly 4 * LPR (64, 128, 256) and the draws are made in the kernel -- a compile-time
 // constant, and with it numpy's summation plan (sx_device.hpp row_reduce_fixed / row_reduce_static); 0 otherwise.
 template <int FUN, int RNG, int LPR, int NFIX = 0>
-__global__ __launch_bounds__(kSweepWaves *kWave) void de_async_kernel(const sx_de_args a, const PlanArg plan) {
+__global__ __launch_bounds__(sweep_waves(FUN) * kWave) void de_async_kernel(const sx_de_args a, const PlanArg plan) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sfc[kSweepSlots], sfold[kSweepSlots];
     __shared__ unsigned long long sdep[kSweepSlots];
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(kSweepWaves *kWave) void de_async_kernel(const sx_d
 }
 
 template <int FUN, int RNG, int LPR, int NFIX = 0>
-__global__ __launch_bounds__(kSweepWaves *kWave) void pso_async_kernel(const sx_pso_args a, const PlanArg plan) {
+__global__ __launch_bounds__(sweep_waves(FUN) * kWave) void pso_async_kernel(const sx_pso_args a, const PlanArg plan) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sfc[kSweepSlots], sfold[kSweepSlots];
     __shared__ int sstatus;
@@ -438,7 +448,7 @@ extern "C" int sx_de_async_generation(const sx_de_args *a, void *stream) {
     } else {
         SX_DISPATCH_LPR(a->n, kern = (pick_de<SX_RNG_HOST, LPR>(a->fun_id)))
     }
-    const SweepGeometry g = sweep_geometry(a->n, 0);
+    const SweepGeometry g = sweep_geometry(a->n, 0, a->fun_id);
     if (int rc = launch_sweep(kern, g, (hipStream_t)stream, a)) return rc;
     hipLaunchKernelGGL(kern, dim3(1), dim3(g.waves * kWave), g.lds, (hipStream_t)stream, *a, plan);
     SX_LAUNCH_CHECK();
@@ -463,7 +473,7 @@ extern "C" int sx_pso_async_generation(const sx_pso_args *a, void *stream) {
     } else {
         SX_DISPATCH_LPR(a->n, kern = (pick_pso<SX_RNG_HOST, LPR>(a->fun_id)))
     }
-    const SweepGeometry g = sweep_geometry(a->n, 1);
+    const SweepGeometry g = sweep_geometry(a->n, 1, a->fun_id);
     if (int rc = launch_sweep(kern, g, (hipStream_t)stream, a)) return rc;
     hipLaunchKernelGGL(kern, dim3(1), dim3(g.waves * kWave), g.lds, (hipStream_t)stream, *a, plan);
     SX_LAUNCH_CHECK();
