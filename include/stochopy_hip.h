@@ -475,11 +475,11 @@ int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *st
  * Newton-Schulz step) and the iteration starts from V0^T C V0 -- same result to rounding, fewer sweeps; ignored for
  * n <= 64 (one-workgroup path).  ws: DEVICE scratch of
  * sx_eigh_workspace_bytes(n) bytes; it starts with the run record read by sx_eigh_info.  max_sweeps <= 0: 24;
- * tol <= 0: 1e-14 (a sweep is the last one when the off-diagonal mass it leaves behind, extrapolated from the mass
- * met during the last two sweeps, is <= tol*|C|_F).
+ * tol <= 0: 1e-14 (a sweep is the last one when the off-diagonal mass it leaves behind -- measured on the device
+ * while its last rotations are applied -- is <= tol*|C|_F).
  * Asynchronous on `stream`; the host never waits: launches after convergence are no-ops.
- * sx_eigh_info (synchronises): sweeps carried out, whether the rule was met, off-diagonal mass / |C|_F met
- * during the last sweep.
+ * sx_eigh_info (synchronises): sweeps carried out, whether the rule was met, off-diagonal mass / |C|_F left
+ * behind by the last sweep.
  * ------------------------------------------------------------------------- */
 int64_t sx_eigh_workspace_bytes(int n);
 int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,

@@ -18,9 +18,12 @@
 //     from one buffer pair and written to the other.
 //   So the similarity updates (the flops) of round r-1 run beside the pivot sweeps (the latency) of round r,
 //   and a round costs one kernel boundary.
-// A sweep is accepted as the last one when the off-diagonal mass it leaves behind -- extrapolated from the
-// mass met during it and during the one before, eigh_last_sweep() -- is below tol * ||C||_F; the decision is
-// taken on the device and later launches of the run are no-ops, so the host never waits.
+// A sweep is the last one when the off-diagonal mass it leaves behind is below tol * ||C||_F.  That mass is MEASURED:
+// the tile workgroups of the launch that applies a sweep's last rotations add up the off-diagonal squares of what
+// they write, and the next launch (round 1 of the following sweep) ends the run if the sum is below the threshold --
+// one extra round instead of a verifying sweep (round 3; before, a sweep was only accepted from the mass met DURING
+// it, eigh_last_sweep(), which is kept as a second rule: 7 -> 6 sweeps per decomposition inside a CMA-ES run at
+// n=512).  The decision is taken on the device and later launches of the run are no-ops, so the host never waits.
 // Finalisation: column norms of V (removes the drift of |v_j| over hundreds of rounds), eigenvalues
 // M_jj / |v_j|^2, ascending order (ties: lower position first), and the CANONICAL SIGN: the component of
 // largest magnitude of every eigenvector (lowest index on ties) is positive -- the rule
@@ -32,6 +35,7 @@
 #include "sx_host.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 using namespace sx;
 
@@ -70,7 +74,9 @@ struct EighInfo {  // first bytes of the workspace
     int32_t converged;  // 1: the stopping rule was met within max_sweeps
     double norm2;       // ||C||_F^2 (upper triangle mirrored)
     double thr2;        // tol^2 * norm2
-    double acc[kEighMaxSweeps];  // squared off-diagonal mass met during each sweep
+    double acc[kEighMaxSweeps];   // squared off-diagonal mass met during each sweep
+    double offm[kEighMaxSweeps];  // squared off-diagonal mass of M AFTER each sweep, measured exactly by the tile
+                                  // workgroups that apply the sweep's last rotations
 };
 
 // Stopping rule, evaluated from the off-diagonal mass a_s = sqrt(acc[s] / |C|_F^2) met DURING the sweeps so far:
@@ -274,6 +280,173 @@ __device__ void jacobi_sweep(const JacobiView &L, int &cur, const int tid) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The pivot sweep of the round kernel (32 x 32), round 3.  Same systolic schedule and the same arithmetic as
+// jacobi_sweep<32, MODE> above, with the work cut differently (tools/trace_eigh.py, round 2: an inner round took
+// 950 cycles, 850 of them the LDS traffic of the 256 updating threads -- matrix AND accumulated rotations, both
+// read and written through LDS every round):
+//   * waves 0-3 (256 threads) update the MATRIX only, one 2x2 block each, through LDS as before;
+//   * wave 4 works out the next round's rotations from the old matrix (four lanes per pair), as before, with a
+//     shorter chain: the pivot arrives scaled by a power of two to entries below 1 (rotations do not depend on the
+//     scale), so the single-precision angle needs no frexp / ldexp;
+//   * wave 5 keeps the accumulated rotations W = J_1 J_2 ... in REGISTERS: a column rotation never mixes rows, so
+//     lane i owns row i of W (32 lanes, 32 doubles each) and never exchanges anything with another lane; the pair of
+//     position k is always columns (2k, 2k+1) and after every round the columns move by the systolic permutation --
+//     register moves with compile-time indices.  (c, s) of the round come as 16 broadcast reads; W reaches LDS once,
+//     after the last round.
+// (c, s) pairs are interleaved in LDS, one 16-byte read each.  One barrier per inner round.
+// ---------------------------------------------------------------------------------------------------
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// rotation for a pivot whose entries are below 2 in magnitude (see above); entries whose squares vanish in single
+// precision (< 3e-19 of the scale, i.e. of |C|_F) are left alone: far below any tolerance.  Branch-free: the identity
+// is selected at the end (an rsq of 0 / inf only produces values that are thrown away).
+__device__ __forceinline__ void rotation_scaled(double app, double aqq, double apq, double &c, double &s) {
+    const float df = (float)(aqq - app), hf = 2.0f * (float)apq;
+    const float r2 = fmaf(df, df, hf * hf);
+    const bool live = r2 >= 1.0e-37f && r2 < 1.0e30f;  // else: nothing to annihilate, or non-finite input
+    const float ir = __builtin_amdgcn_rsqf(r2);
+    const float x2 = fmaf(0.5f, fabsf(df) * ir, 0.5f);  // c^2 in [0.5, 1]
+    const float ic = __builtin_amdgcn_rsqf(x2);
+    const double cd = (double)(x2 * ic);
+    const double sd = (double)((0.5f * ((df < 0.0f ? -hf : hf) * ir)) * ic);
+    const double e = fma(-cd, cd, fma(-sd, sd, 1.0));  // 1 - (c^2 + s^2) ~ 1e-7
+    const double k = fma(e, fma(0.375, e, 0.5), 1.0);  // (1 - e)^(-1/2) to e^3
+    c = live ? cd * k : 1.0, s = live ? sd * k : 0.0;
+}
+
+struct SweepView {
+    double *S0, *S1;  // [kM2][kM2 + 1] each: the matrix, double-buffered (the sweep starts in S0)
+    double *cs;       // [2][kBS][2], 16-byte aligned: (c, s) of every pair of the current / next inner round
+    double *Wout;     // [kM2][kM2 + 1]: the accumulated rotations, written once at the end
+};
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double flip_sign(double v, unsigned mask_hi) {
+    return __hiloint2double(__double2hiint(v) ^ (int)mask_hi, __double2loint(v));
+}
+
+// 384 threads: tid < 256 matrix, 256..319 rotations, 320..383 accumulated rotations.  Returns 0 / 1: the final matrix is
+// in S0 / S1; W is in Wout (visible after the caller's next barrier).
+// Issue priorities: the rotation wave's chain (LDS read -> pivot -> angle -> LDS write) IS the inner round, so it goes
+// first; the wave of the accumulated rotations works one round BEHIND (it applies round r-1 while round r is worked
+// out, and fetches round r's (c, s) at the END of its turn, when the LDS pipe is idle), so nothing ever waits for it.
+template <int MODE>
+__device__ int pivot_sweep(const SweepView &L, const int tid) {
+    constexpr int M2 = kM2, NP = kBS, LD = M2 + 1, NREG = NP * NP, ROUNDS = MODE == 1 ? NP : M2 - 1;
+    const bool reg = tid < NREG;
+    const int kp = reg ? tid / NP : 0, kq = reg ? tid % NP : 0;
+    const int o00 = (2 * kp) * LD + 2 * kq, o10 = o00 + LD;
+    const int dr0 = sys_perm<MODE>(2 * kp, M2) * LD, dr1 = sys_perm<MODE>(2 * kp + 1, M2) * LD;
+    const int dc0 = sys_perm<MODE>(2 * kq, M2), dc1 = sys_perm<MODE>(2 * kq + 1, M2);
+    // rotation lanes: four per pair of the NEXT round (old positions (i, j) = perm^-1(2k, 2k+1)); lane 0: (i,i), 1: (j,j),
+    // 2 and 3: (i,j).  Element (ea, eb) of the next matrix = (row combination of block row ka) then (column
+    // combination of block column kb): x = alpha b0. + beta b1., v = gamma x0 + delta x1 with
+    // (alpha, beta) = (c, -s) for the even member of pair ka, (s, c) for the odd one -- picked by ADDRESS and a sign mask.
+    const int dl = tid - NREG;
+    const bool duty = dl >= 0 && dl < 4 * NP;
+    const int k2 = duty ? dl >> 2 : 0, part = dl & 3;
+    const int i = sys_perm_inv<MODE>(2 * k2, M2), j = sys_perm_inv<MODE>(2 * k2 + 1, M2);
+    const int ea = part == 1 ? j : i, eb = part == 0 ? i : j;
+    const int ka = ea >> 1, kb = eb >> 1;
+    const int pa = ea & 1, pb = eb & 1;
+    const int qab = (2 * ka) * LD + 2 * kb;
+    const int ia = 2 * ka + pa, ja = 2 * ka + 1 - pa, ib = 2 * kb + pb, jb = 2 * kb + 1 - pb;
+    const unsigned ma = pa ? 0u : 0x80000000u, mb = pb ? 0u : 0x80000000u;
+    // accumulated rotations: lane `wrow` of the last wave owns row wrow of W
+    const int wrow = tid - (NREG + 64);
+    const bool wduty = wrow >= 0 && wrow < M2;
+    double w[M2], cc[NP], ss[NP];
+#pragma unroll
+    for (int col = 0; col < M2; ++col) w[col] = col == wrow ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) cc[k] = 1.0, ss[k] = 0.0;
+    auto apply_w = [&]() {  // W <- W J on columns (2k, 2k+1), then the columns move like the matrix's
+        double wn[M2];
+        static_for<NP>([&](auto kc_) {
+            constexpr int k = decltype(kc_)::value;
+            const double w0 = w[2 * k], w1 = w[2 * k + 1];
+            wn[sys_perm<MODE>(2 * k, M2)] = fma(cc[k], w0, -(ss[k] * w1));
+            wn[sys_perm<MODE>(2 * k + 1, M2)] = fma(ss[k], w0, cc[k] * w1);
+        });
+#pragma unroll
+        for (int col = 0; col < M2; ++col) w[col] = wn[col];
+    };
+    if (duty) {
+        const int o = (2 * k2) * LD + 2 * k2;
+        double c, s;
+        rotation_scaled(L.S0[o], L.S0[o + LD + 1], L.S0[o + 1], c, s);
+        if (part == 0) *(v2d *)(L.cs + 2 * k2) = (v2d){c, s};
+        __builtin_amdgcn_s_setprio(3);
+    } else if (reg) {
+        __builtin_amdgcn_s_setprio(2);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int r = 0; r < ROUNDS; ++r) {
+        const double *S = cur ? L.S1 : L.S0;
+        double *Sn = cur ? L.S0 : L.S1;
+        const double *cs = L.cs + (r & 1) * 2 * NP;
+        SX_ETQ(r == 5 && tid == 0, 6);
+        SX_ETQ(r == 5 && duty && dl == 0, 10);
+        if (duty && r + 1 < ROUNDS) {
+            const double al = cs[ia], be = flip_sign(cs[ja], ma), ga = cs[ib], de = flip_sign(cs[jb], mb);
+            const double b00 = S[qab], b01 = S[qab + 1], b10 = S[qab + LD], b11 = S[qab + LD + 1];
+            const double x0 = fma(al, b00, be * b10), x1 = fma(al, b01, be * b11);
+            const double v = fma(ga, x0, de * x1);
+            const double nii = dpp_f64<0x00>(v);  // quad_perm:[0,0,0,0]
+            const double njj = dpp_f64<0x55>(v);  // quad_perm:[1,1,1,1]
+            const double nij = dpp_f64<0xAA>(v);  // quad_perm:[2,2,2,2]
+            SX_ETQ(r == 5 && dl == 0 && nij != 12345.0, 11);
+            double c, s;
+            rotation_scaled(nii, njj, nij, c, s);
+            SX_ETQ(r == 5 && dl == 0 && c != 12345.0, 12);
+            if (part == 0) *(v2d *)(L.cs + ((r + 1) & 1) * 2 * NP + 2 * k2) = (v2d){c, s};
+        }
+        if (reg) {
+            const v2d r1 = *(const v2d *)(cs + 2 * kp), r2 = *(const v2d *)(cs + 2 * kq);
+            const double c1 = r1[0], s1 = r1[1], c2 = r2[0], s2 = r2[1];
+            const double b00 = S[o00], b01 = S[o00 + 1], b10 = S[o10], b11 = S[o10 + 1];
+            // rows: J^T B;  columns: (J^T B) J
+            const double r00 = fma(c1, b00, -(s1 * b10)), r01 = fma(c1, b01, -(s1 * b11));
+            const double r10 = fma(s1, b00, c1 * b10), r11 = fma(s1, b01, c1 * b11);
+            Sn[dr0 + dc0] = fma(c2, r00, -(s2 * r01));
+            Sn[dr0 + dc1] = fma(s2, r00, c2 * r01);
+            Sn[dr1 + dc0] = fma(c2, r10, -(s2 * r11));
+            Sn[dr1 + dc1] = fma(s2, r10, c2 * r11);
+        }
+        if (wduty) {
+            if (r > 0) apply_w();  // the rotations of round r - 1, fetched at the end of the previous turn
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const v2d t = *(const v2d *)(cs + 2 * k);
+                cc[k] = t[0], ss[k] = t[1];
+            }
+        }
+        SX_ETQ(r == 5 && tid == 0, 7);
+        SX_ETQ(r == 5 && duty && dl == 0, 13);
+        __syncthreads();
+        SX_ETQ(r == 5 && tid == 0, 8);
+        SX_ETQ(r == 5 && duty && dl == 0, 14);
+        cur ^= 1;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (wduty) {  // the last round's rotations; after them every column is back in its place
+        apply_w();
+#pragma unroll
+        for (int col = 0; col < M2; ++col) L.Wout[wrow * LD + col] = w[col];
+    }
+    return cur;
+}
+
 // sum over the workgroup (all threads get the result); NT threads, fixed order
 template <int NT>
 __device__ double block_sum(double v, double *red, int tid) {
@@ -323,6 +496,7 @@ __global__ __launch_bounds__(jacobi_threads<M2>()) void eigh_small_kernel(const 
         }
         off2 = block_sum<NT>(off2, sred, tid);
         if (tid == 0 && sw < kEighMaxSweeps) info->acc[sw] = off2;
+        if (tid == 0 && sw > 0) info->offm[sw - 1] = off2;
         if (off2 <= thr2) {
             conv = 1;
             break;
@@ -460,15 +634,15 @@ struct RoundLds {
             double UB[kM2 * LDU];
             double Y[3][kM2 * LDY];
         } p;
-        struct {  // pair workgroups, stage 2 (the sweep): second pivot buffer and the accumulated rotations
+        struct {  // pair workgroups, stage 2 (the sweep): second pivot buffer; the accumulated rotations of the sweep
             double S1[kM2 * (kM2 + 1)];
-            double W1[kM2 * (kM2 + 1)];
+            double W0[kM2 * (kM2 + 1)];  // (written once, from registers, at its end)
         } j;
     };
     double S0[kM2 * (kM2 + 1)];  // the pivot matrix (written in stage 1, so outside the union)
-    double W0[kM2 * (kM2 + 1)];  // identity, written while the tiles are loaded
-    double rc[2 * kBS], rs[2 * kBS];  // rotation of every pair of the current / next inner round
+    alignas(16) double cs[4 * kBS];  // (c, s) of every pair of the current / next inner round, interleaved
     double red[17];
+    double scale;                // power of two that brings |C|_F (hence every pivot entry) below 1
     int flag;
 };
 
@@ -487,20 +661,74 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int np = nb / 2;
     // ---- run state: every workgroup derives the same decision from what earlier launches left ----
+    // The record is a miss in every cache after the kernel boundary (~1 us).  Nothing below waits for it before the
+    // pair workgroups' own loads are in flight: those do not depend on it (a launch that turns out to be a no-op has
+    // read a few valid tiles for nothing).
+    int ended = 0;
+    double nrm2 = 0.0, left = 0.0, met1 = 0.0, met0 = 0.0;
     if (tid == 0) {
-        const int ended = info->done_seq;
+        ended = info->done_seq, nrm2 = info->norm2;
+        if (sweep > 0) left = info->offm[sweep - 1], met1 = info->acc[sweep - 1];
+        if (sweep > 1) met0 = info->acc[sweep - 2];
+    }
+    // pair workgroups: source tiles (pairs of rprev) 0: (PI,PI)  1: (PI,PJ)  2: (PJ,PJ) and the rotations of PI and PJ.
+    // 256 threads x 4 elements of each: 20 loads in flight per thread.
+    const bool is_pair = (int)blockIdx.x < np && !flush;
+    int I = 0, Jb = 0, PI = 0, posI = 0, PJ = 0, posJ = 0;
+    double x0[4], x1[4], x2[4], ua[4], ub[4];
+    if (is_pair) {
+        rr_pair((int)blockIdx.x, rcur, nb, I, Jb);
+        rr_find(I, rprev, nb, PI, posI);
+        rr_find(Jb, rprev, nb, PJ, posJ);
+        int aI, bI, aJ, bJ;
+        rr_pair(PI, rprev, nb, aI, bI);
+        rr_pair(PJ, rprev, nb, aJ, bJ);
+        if (tid < 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + 256 * u, i = e / kM2, j = e % kM2;
+                const int giI = pair_index(i, aI, bI), giJ = pair_index(i, aJ, bJ);
+                const int gjI = pair_index(j, aI, bI), gjJ = pair_index(j, aJ, bJ);
+                x0[u] = Min[(int64_t)giI * npad + gjI];
+                x1[u] = Min[(int64_t)giI * npad + gjJ];
+                x2[u] = Min[(int64_t)giJ * npad + gjJ];
+                ua[u] = Uprev[(int64_t)PI * kUU + e];
+                ub[u] = Uprev[(int64_t)PJ * kUU + e];
+            }
+        }
+    }
+    if (tid == 0) {
+        const double thr2 = tol * tol * nrm2;
         int flag = (ended != 0 && ended < seq) ? 2 : 0;  // 2: the run ended in an EARLIER launch: nothing to do
+        if (!flag && rcur == 1 && sweep > 0 && !flush && left <= thr2) {
+            // The previous launch applied the last rotations of sweep `sweep - 1` and measured what that sweep left
+            // behind: nothing above the tolerance.  The matrix this launch would read IS the result; the rotations of
+            // round 0 that were worked out beside the measurement are dropped.  (Costs one round, not a whole
+            // verifying sweep.)
+            flag = 2;
+            if (blockIdx.x == 0) {
+                info->sweeps = sweep, info->parity = parity_out ^ 1, info->converged = 1;
+                info->thr2 = thr2;
+                info->done_seq = seq;
+            }
+        }
         if (!flag && rcur == 0 && sweep > 0 && !flush) {
-            if (eigh_last_sweep(info->acc, sweep - 1, info->norm2, tol)) {
+            // second rule, from the mass met DURING the last two sweeps (eigh_last_sweep)
+            const bool last = met1 <= thr2 || (met1 <= 1.0e-20 * nrm2 && (sweep == 1 || met1 * met1 <= thr2 * met0));
+            if (last) {
                 flag = 1;  // apply the last rotations of the sweep that just ended, start no new ones
                 if (blockIdx.x == 0) {
                     info->sweeps = sweep, info->parity = parity_out, info->converged = 1;
-                    info->thr2 = tol * tol * info->norm2;
+                    info->thr2 = thr2;
                     info->done_seq = seq;
                 }
             }
         }
         L.flag = flag;
+        int ex = 0;
+        const double nrm = sqrt(nrm2);
+        if (nrm > 0.0 && nrm < __builtin_inf()) (void)frexp(nrm, &ex);
+        L.scale = ldexp(1.0, -ex);
     }
     __syncthreads();
     const int state = L.flag;
@@ -536,6 +764,7 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
             __syncthreads();
             if (wave < 4) acc = mma_atb(L.t.UP, LDU, i0, L.t.Y, LDU, j0, lane);
         }
+        double m2 = 0.0;
         if (wave < 4) {
             const int gj = pair_index(j0 + lr, aq, bq);
 #pragma unroll
@@ -543,6 +772,19 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
                 const int i = i0 + lk + 4 * r;
                 const int gi = is_m ? pair_index(i, ap, bp) : P * kM2 + i;
                 dst[(int64_t)gi * npad + gj] = acc[r];
+                if (gi != gj) m2 = fma(acc[r], acc[r], m2);
+            }
+        }
+        // this launch applies the LAST rotations of sweep `sweep - 1`: what it writes is the matrix after that sweep,
+        // and its off-diagonal mass decides (in the next launch) whether the run is over
+        if (is_m && rcur == 0 && sweep > 0) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
+            if (lane == 0 && wave < 4) L.red[wave] = m2;
+            __syncthreads();
+            if (tid == 0) {
+                const double t = (L.red[0] + L.red[1]) + (L.red[2] + L.red[3]);
+                if (t != 0.0) atomicAdd(&info->offm[sweep - 1], t);
             }
         }
         return;
@@ -550,30 +792,8 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
     // =========================== pair workgroups ===========================
     if (state == 1 || flush) return;
     SX_ETP(0);
-    int I, Jb;
-    rr_pair((int)blockIdx.x, rcur, nb, I, Jb);
-    int PI, posI, PJ, posJ;
-    rr_find(I, rprev, nb, PI, posI);
-    rr_find(Jb, rprev, nb, PJ, posJ);
-    int aI, bI, aJ, bJ;
-    rr_pair(PI, rprev, nb, aI, bI);
-    rr_pair(PJ, rprev, nb, aJ, bJ);
-    // source tiles (pairs of rprev): 0: (PI,PI)  1: (PI,PJ)  2: (PJ,PJ); rotations of PI and PJ.
-    // 256 threads x 4 elements of each: 20 loads in flight per thread.
     constexpr int LD = kM2 + 1;
     if (tid < 256) {
-        double x0[4], x1[4], x2[4], ua[4], ub[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 256 * u, i = e / kM2, j = e % kM2;
-            const int giI = pair_index(i, aI, bI), giJ = pair_index(i, aJ, bJ);
-            const int gjI = pair_index(j, aI, bI), gjJ = pair_index(j, aJ, bJ);
-            x0[u] = Min[(int64_t)giI * npad + gjI];
-            x1[u] = Min[(int64_t)giI * npad + gjJ];
-            x2[u] = Min[(int64_t)giJ * npad + gjJ];
-            ua[u] = Uprev[(int64_t)PI * kUU + e];
-            ub[u] = Uprev[(int64_t)PJ * kUU + e];
-        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u, i = e / kM2, j = e % kM2;
@@ -582,7 +802,6 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
             L.p.X[2][i * LDX + j] = x2[u];
             L.p.UA[i * LDU + j] = ua[u];
             L.p.UB[i * LDU + j] = ub[u];
-            L.W0[i * LD + j] = i == j ? 1.0 : 0.0;
         }
     }
     __syncthreads();
@@ -608,33 +827,35 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
         const double *UL = wave == 2 ? L.p.UB : L.p.UA;
         const int cL = 16 * (wave == 2 ? posJ : posI);
         const v4d tt = mma_atb(UL, LDU, cL, L.p.Y[wave], LDY, 0, lane);
+        const double sc = L.scale;
         const int ro = wave == 2 ? 1 : 0, co = wave == 0 ? 0 : 1;  // odd positions: block J
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = lk + 4 * r, j = lr;
             const int pi = 2 * i + ro, pj = 2 * j + co;
+            const double ts = tt[r] * sc;  // (the sweep works on the scaled pivot: rotations are scale-free)
             if (wave == 1) {
-                L.S0[pi * LD + pj] = tt[r];
-                L.S0[pj * LD + pi] = tt[r];
+                L.S0[pi * LD + pj] = ts;
+                L.S0[pj * LD + pi] = ts;
                 m2 = fma(2.0 * tt[r], tt[r], m2);
             } else if (i <= j) {  // diagonal sub-blocks: upper triangle mirrored
-                L.S0[pi * LD + pj] = tt[r];
-                L.S0[pj * LD + pi] = tt[r];
+                L.S0[pi * LD + pj] = ts;
+                L.S0[pj * LD + pi] = ts;
                 if (full && i < j) m2 = fma(2.0 * tt[r], tt[r], m2);
             }
         }
     }
     __syncthreads();  // stage 1 is over: its LDS is reused for the sweep
     SX_ETP(3);
-    const JacobiView view{L.S0, L.j.S1, L.W0, L.j.W1, L.rc, L.rs};
-    int cur = 0;
+    const SweepView view{L.S0, L.j.S1, L.cs, L.j.W0};
     if (full)
-        jacobi_sweep<kM2, 0>(view, cur, tid);
+        (void)pivot_sweep<0>(view, tid);
     else
-        jacobi_sweep<kM2, 1>(view, cur, tid);
+        (void)pivot_sweep<1>(view, tid);
+    __syncthreads();  // the accumulated rotations have left the registers of the last wave
     SX_ETP(4);
     // U in the order the tiles use (block I first, then block J): gathered index g <-> position 2g or 2(g-16)+1
-    const double *Wf = cur ? L.j.W1 : L.W0;
+    const double *Wf = L.j.W0;
     double *Uo = Ucur + (int64_t)blockIdx.x * kUU;
     for (int e = tid; e < kUU; e += kRoundThreads) {
         const int i = e / kM2, j = e % kM2;
@@ -652,7 +873,8 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
 __global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double tol) {
     if (threadIdx.x != 0 || info->done_seq) return;
     info->sweeps = sweeps, info->parity = parity, info->thr2 = tol * tol * info->norm2;
-    info->converged = (sweeps > 0 && eigh_last_sweep(info->acc, sweeps - 1, info->norm2, tol)) ? 1 : 0;
+    info->converged = (sweeps > 0 && (info->offm[sweeps - 1] <= info->thr2 ||
+                                      eigh_last_sweep(info->acc, sweeps - 1, info->norm2, tol))) ? 1 : 0;
     info->done_seq = 1;
 }
 
@@ -853,9 +1075,9 @@ extern "C" int sx_eigh_info(const void *ws, int *sweeps, int *converged, double 
     SX_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (sweeps) *sweeps = h.sweeps;
     if (converged) *converged = h.converged;
-    if (off_rel) {
-        const int k = h.sweeps > 0 ? h.sweeps - 1 : 0;
-        *off_rel = h.norm2 > 0.0 ? sqrt(h.acc[k] / h.norm2) : 0.0;
+    if (off_rel) {  // what the last sweep left behind (no sweep: the off-diagonal mass of the input)
+        const double m = h.sweeps > 0 ? h.offm[h.sweeps - 1] : h.acc[0];
+        *off_rel = h.norm2 > 0.0 ? sqrt(m / h.norm2) : 0.0;
     }
     return 0;
 }

@@ -17,7 +17,7 @@ class Eigh:
     """``eig = Eigh(ctx, n); w, B = eig(Cdev)``: eigenvalues ascending, eigenvectors in the columns of B.
 
     Everything is enqueued on ``ctx.stream``; nothing waits for the device.  ``info()`` synchronises and returns
-    (sweeps, converged, off) of the last call, ``off`` = off-diagonal mass met during the last sweep / |C|_F.
+    (sweeps, converged, off) of the last call, ``off`` = off-diagonal mass the last sweep left behind / |C|_F.
     """
 
     def __init__(self, ctx, n):
@@ -27,6 +27,7 @@ class Eigh:
         if self.bytes <= 0:
             raise ValueError(f"sx_eigh_workspace_bytes({n}) = {self.bytes}")
         self.ws = t.empty((self.bytes + 7) // 8, dtype=t.float64, device=ctx.device)
+        self.ws[:128].zero_()  # the run record: info() before the first decomposition reads zeros, not stale memory
         self.w = ctx.empty((self.n,))
         self.B = ctx.empty((self.n, self.n))
 

@@ -118,6 +118,8 @@ class _CmaDeviceRun:
     canonical sign of csrc/sx_eigh.hip."""
 
     LOOK = 16
+    COLD_SWEEPS = 40   # launched for a decomposition started from the identity (n=512: 11-13 are carried out)
+    WARM_SWEEPS0 = 16  # launched for the first warm-started one; afterwards: what the last one needed + 1
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
                  verbosity=1.0, run=True):
@@ -125,6 +127,7 @@ class _CmaDeviceRun:
         with ``step`` from a state of their choosing."""
         import ctypes as C
         import time
+        import warnings
 
         ctx = self.ctx = _device.Context()
         t = _device.torch()
@@ -153,7 +156,7 @@ class _CmaDeviceRun:
             a = _lib.SxCmaArgs(**{k: ptr(v) for k, v in keep.items()})
             a.eigh_ws_bytes, a.P, a.n, a.mu, a.fun_id, a.maxiter = eig.bytes, P, n, mu, fun_id, maxiter
             a.hist_rows = nout
-            a.ilim, a.eig_sweeps = int(10.0 + 30.0 * n / P), 24
+            a.ilim, a.eig_sweeps = int(10.0 + 30.0 * n / P), self.COLD_SWEEPS
             a.cs, a.cc, a.c1, a.cmu, a.damps, a.chind, a.mueff = cs, cc, c1, cmu, damps, chind, mueff
             a.xtol, a.ftol, a.insigma, a.key0, a.key1 = xtol, ftol, sigma, key0, key1
             self.buffers, self.args, self.eig, self.P = keep, a, eig, P
@@ -162,19 +165,33 @@ class _CmaDeviceRun:
                 return
             eigeneval, look, since, t0 = 0, 1, 0, time.perf_counter()
             state = st
+            # Sweeps to LAUNCH per decomposition (launches beyond convergence are no-ops of ~2 us each, 2n/16 - 1 per
+            # sweep): a cold start gets the full allowance; a warm start what the last one needed + 1 -- inside a run
+            # the count moves by at most one between decompositions (tools/eigh_c4_sweeps.py).
+            warm_sweeps, launched, decomposed = self.WARM_SWEEPS0, 0, False
             for gen in range(1, maxiter + 1):
                 due = gen * P - eigeneval > eig_every
                 if due:  # 1: first decomposition; 2: start from the previous eigenvectors (C changes by O(c1 + cmu))
                     due = 2 if eigeneval else 1
                     eigeneval = gen * P
+                    a.eig_sweeps = launched = self.COLD_SWEEPS if due == 1 else warm_sweeps
+                    decomposed = True
                 _lib.check(L.sx_cmaes_generation(C.byref(a), gen, int(due), ctx.stream_ptr), "sx_cmaes_generation")
                 since += 1
                 if since >= look or gen == maxiter:
                     state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
                     if state.done:
                         break
-                    used, ok, _off = eig.info()
-                    a.eig_sweeps = min(60, used + 2) if ok else 60  # (launches beyond convergence are no-ops of ~2 us each)
+                    if decomposed:  # (the record is only meaningful once a decomposition has been enqueued)
+                        used, ok, _off = eig.info()
+                        if ok:
+                            warm_sweeps = min(60, used + 1)
+                        else:
+                            if launched >= 60:
+                                warnings.warn("stochopy_amd: the device eigensolver did not reach its tolerance in 60 "
+                                              "sweeps; the decomposition is used as it is", RuntimeWarning, stacklevel=3)
+                            warm_sweeps = 60
+                        decomposed = False
                     now = time.perf_counter()
                     if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
                         look *= 2
@@ -372,7 +389,7 @@ class _CmaRun:
 
         nfev = 0
         eigeneval = 0
-        eig, eig_sweeps, eig_warm = None, 24, False  # device eigensolver: launches beyond convergence are no-ops, but not free
+        eig, eig_sweeps, eig_warm = None, _CmaDeviceRun.COLD_SWEEPS, False  # launches beyond convergence are no-ops, but not free
         besthist = np.zeros(self.maxiter)
         ilim = int(10.0 + 30.0 * n / P)
         insigma = sigma
@@ -450,11 +467,14 @@ class _CmaRun:
                         eig = Eigh(ctx, n)
                     # ascending eigenvalues, eigenvectors in columns; from the second time on, started from the last ones
                     Dt, _ = eig(d_C, B=d_B, max_sweeps=eig_sweeps, start=d_B if eig_warm else None)
-                    eig_warm = True
+                    was_warm, eig_warm = eig_warm, True
                     t.sqrt(Dt, out=d_D)
                     D = d_D.cpu().numpy()
                     used, ok, _off = eig.info()
-                    eig_sweeps = min(60, used + 3) if ok else 60
+                    if not was_warm:  # what the cold start needed says nothing about the warm ones
+                        eig_sweeps = _CmaDeviceRun.WARM_SWEEPS0
+                    else:
+                        eig_sweeps = min(60, used + 1) if ok else 60
                     B = d_B.cpu().numpy()
                     diagC = d_C.diagonal().cpu().numpy()
                     status = _stop_status(it, n, self.maxiter, xmean, xold, besthist, arfit, order, sigma, insigma,

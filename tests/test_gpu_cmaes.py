@@ -300,6 +300,29 @@ def test_cmaes_device_resident_loop_vs_oracle(sa, cfg):
     assert (via_host.nit, via_host.status) == (got.nit, got.status) and np.isclose(via_host.fun, got.fun, rtol=1e-6)
 
 
+@pytest.mark.parametrize("n,P,maxiter", [(512, 1024, 20), (257, 520, 24)], ids=["c4_n512_p1024", "n257_p520"])
+def test_cmaes_device_resident_loop_block_eigensolver_vs_oracle(sa, n, P, maxiter):
+    """BASELINE config 4 (Rosenbrock n=512, P=1024) and an odd size that pads (n=257) through the path whose
+    throughput is quoted: device-resident loop, Philox draws, the BLOCK path of the eigensolver (n > 64:
+    eigh_round_kernel, warm start from the previous basis through eigh_gemm_kernel, the measured stopping rule) in
+    every generation.  Against the oracle with LAPACK + the canonical sign rule: same stopping generation and
+    status, best-f of EVERY generation (device-side history, read back once) and the final best-x within the
+    north-star tolerance.  mu >= n - 1 in both shapes, so the covariance has no exactly repeated eigenvalue and the
+    basis is determined."""
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 0, "sigma": 0.1, "ftol": -1.0, "xtol": 0.0, "return_all": True,
+            "verbosity": 0.0}
+    bounds = [[-5.12, 5.12]] * n
+    ref = oracle.minimize("rosenbrock", bounds, method="cmaes", options=dict(opts, eigh="canonical"), rng="philox")
+    got = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"))
+    assert (got.nit, got.nfev, got.status) == (ref.nit, ref.nfev, ref.status) == (maxiter, maxiter * P, -1)
+    assert got.funall.shape == ref.funall.shape
+    assert np.allclose(got.funall, ref.funall, rtol=1e-6, atol=0.0), np.abs(got.funall / ref.funall - 1.0).max()
+    assert np.isclose(got.fun, ref.fun, rtol=1e-6, atol=0.0)
+    # best-x: 1e-6 of the search range per coordinate (the spectrum is clustered in these generations -- gaps of 1e-6
+    # relative -- so eigenvector rounding differences of two solvers are amplified to ~1e-7 of the range by generation 20)
+    assert np.abs(got.x - ref.x).max() <= 1e-6 * 10.24, np.abs(got.x - ref.x).max()
+
+
 @pytest.mark.parametrize("verbosity", [1.0, 0.4, 0.0])
 def test_cmaes_device_resident_loop_history(sa, verbosity):
     """return_all without a callback stays on the device (history slabs written by a kernel, read back once): same
