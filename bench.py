@@ -11,8 +11,8 @@ xtol=0 so every step does the full work.  N>1: the same shard per GPU (weak
 scaling), one process per GPU, global best exchanged every generation.
 
 `value` = objective evaluations per second = N * popsize * (steps timed) / t, population resident in HBM
-before the timed region.  The K-step block is repeated back to back until the timed region lasts >= 50 ms
-(`blocks`; K steps alone take 0.2 ms at the default shape), bracketed by barrier + synchronize; the median block
+before the timed region.  The K-step block is repeated back to back until the timed region lasts >= 2 s
+(`blocks`; K steps alone take 0.15 ms at the driver's K = 20), bracketed by barrier + synchronize; the median block
 duration (HIP events between blocks) is reported next to it.  Also in the line:
 `minimize_wall` -- evals/s of a whole `minimize()` call after one warm-up call (host-side initial population
 included); `cpu_baseline` / `cpu_baseline_loky` with core count and CPU model; for N > 1 `c5` -- BASELINE config 5
@@ -174,6 +174,18 @@ def main():
     ap.add_argument("--kernel-timing-launches", type=int, default=400)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N bench.py ...`
+        # (one process per GPU, rendezvous on 127.0.0.1: the container hostname may not resolve)
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
+
     import torch
 
     import stochopy_amd as sa  # noqa: F401  (fails loudly here if the HIP library is missing)
@@ -184,8 +196,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         "(or call bench.py without a launcher: it starts torch.distributed.run itself)")
     # (test switches, one-GPU boxes only: SX_BENCH_DEVICE pins every rank to one device, SX_BENCH_BACKEND=gloo sets the
     #  process group up without RCCL, which refuses two ranks on one GPU; the driver uses neither)
     device_index = int(os.environ.get("SX_BENCH_DEVICE", local_rank))
@@ -194,6 +206,9 @@ def main():
     if world > 1 or ("RANK" in os.environ and os.environ.get("SX_FORCE_SHARDED") == "1"):
         import torch.distributed as dist
 
+        # torch's NCCL flight recorder on: graph captures of the RCCL transport wait for the watchdog to RETIRE earlier
+        # collectives by reading it (parallel.World.quiesce_for_capture) instead of sleeping
+        os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "256")
         backend = os.environ.get("SX_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
@@ -215,11 +230,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return tt.item()
 
-    MIN_TIMED_S = 0.05
+    MAX_BLOCKS = 1 << 20
+    MIN_TIMED_S = 2.0  # (the driver's GPU-busy sampler and timed-region check need seconds, not milliseconds)
 
     def measure(exchange, objective=objective, n=n, Ptotal=None, strategy=strategy, donors=os.environ.get("SX_DONORS"),
                 K=K, W=W, kernel_launches=args.kernel_timing_launches):
-        """One resident run: W warm-up steps, then blocks of K steps until >= 50 ms are timed.  Ptotal None: weak
+        """One resident run: W warm-up steps, then blocks of K steps until >= 2 s are timed.  Ptotal None: weak
         scaling (every GPU owns P rows of a global population of world*P; same seed on every rank)."""
         lower, upper = np.full(n, -5.12), np.full(n, 5.12)
         run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, Ptotal or world * P, 0.5, 0.9, strategy,
@@ -232,7 +248,7 @@ def main():
                 run.prepare_graphs()
                 run.enqueue(W)
                 ctx.sync()
-                # K-step blocks, back to back, until the timed region lasts >= 50 ms (every rank times the same number)
+                # K-step blocks, back to back, until the timed region lasts >= 2 s (every rank times the same number)
                 blocks, steps_done = 1, 0
                 while True:
                     # an event record costs the stream ~2.6 us: one every >= 200 steps (every block when K >= 200)
@@ -249,7 +265,7 @@ def main():
                     barrier()
                     t1 = time.perf_counter()
                     steps_done += blocks * K
-                    enough = t1 - t0 >= MIN_TIMED_S or blocks >= 8192
+                    enough = t1 - t0 >= MIN_TIMED_S or blocks >= MAX_BLOCKS
                     if dist is not None:
                         enough = reduce_max(0 if enough else 1, torch.int64) == 0  # all ranks or none
                     if enough:
@@ -258,7 +274,7 @@ def main():
                     blocks = max(2 * blocks, grow)
                     if dist is not None:
                         blocks = int(reduce_max(blocks, torch.int64))
-                    blocks = min(blocks, 8192)
+                    blocks = min(blocks, MAX_BLOCKS)
                 st = run.read_state()  # raises if a wait inside the peer exchange timed out
                 assert st.it == 1 + W + steps_done, (st.it, W, K, blocks, steps_done)
                 block_ms = sorted(evs[g].elapsed_time(evs[g + 1]) / group for g in range(blocks // group))
@@ -344,7 +360,7 @@ def main():
             "ms_per_step": dt / m["steps_timed"] * 1e3,
             "timed": {"blocks": m["blocks"], "steps_timed": m["steps_timed"], "seconds": dt,
                       "block_ms_median": m["block_ms_median"],
-                      "note": "the K-step block repeated back to back until >= 50 ms are timed (one barrier + "
+                      "note": "the K-step block repeated back to back until >= 2 s are timed (one barrier + "
                               "synchronize pair around the region); block_ms_median from HIP events between blocks (one event per "
                               "max(1, 200 // K) blocks, divided by that count)"},
             "higher_is_better": True,
@@ -378,6 +394,11 @@ def main():
                 "timing": "HIP events on the engine stream around %d generations (%d kernel(s) each)" % (nl, kernels_per_gen),
             },
         }
+        # what actually ran, at the top level (the driver's SCALE run reads this, not the nested blocks)
+        line["n_ranks_seen"] = dist.get_world_size() if dist is not None else 1
+        line["process_group"] = dist.get_backend() if dist is not None else None
+        line["transport"] = None if run.world is None else run.exchange
+        line["transport_fallback"] = getattr(run, "exchange_note", None)
         if c5 is not None:
             line["c5"] = c5
         if world == 1 and not args.no_minimize_wall:

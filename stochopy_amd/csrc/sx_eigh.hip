@@ -290,9 +290,9 @@ __device__ void jacobi_sweep(const JacobiView &L, int &cur, const int tid) {
 //     shorter chain: the pivot arrives scaled by a power of two to entries below 1 (rotations do not depend on the
 //     scale), so the single-precision angle needs no frexp / ldexp;
 //   * wave 5 keeps the accumulated rotations W = J_1 J_2 ... in REGISTERS: a column rotation never mixes rows, so
-//     lane i owns row i of W (32 lanes, 32 doubles each) and never exchanges anything with another lane; the pair of
-//     position k is always columns (2k, 2k+1) and after every round the columns move by the systolic permutation --
-//     register moves with compile-time indices.  (c, s) of the round come as 16 broadcast reads; W reaches LDS once,
+//     two adjacent lanes own one row of W (16 columns each); the pair of position k is always columns (2k, 2k+1) and
+//     after every round the columns move by the systolic permutation -- register moves with compile-time indices
+//     and ONE column swapped between the two lanes (DPP).  (c, s) of the round come as 8 reads; W reaches LDS once,
 //     after the last round.
 // (c, s) pairs are interleaved in LDS, one 16-byte read each.  One barrier per inner round.
 // ---------------------------------------------------------------------------------------------------
@@ -360,24 +360,43 @@ __device__ int pivot_sweep(const SweepView &L, const int tid) {
     const int qab = (2 * ka) * LD + 2 * kb;
     const int ia = 2 * ka + pa, ja = 2 * ka + 1 - pa, ib = 2 * kb + pb, jb = 2 * kb + 1 - pb;
     const unsigned ma = pa ? 0u : 0x80000000u, mb = pb ? 0u : 0x80000000u;
-    // accumulated rotations: lane `wrow` of the last wave owns row wrow of W
-    const int wrow = tid - (NREG + 64);
-    const bool wduty = wrow >= 0 && wrow < M2;
-    double w[M2], cc[NP], ss[NP];
+    // accumulated rotations: lanes (2 * row + h) of the last wave own row `row` of W, positions 16h .. 16h+15 (a pair
+    // (2k, 2k+1) never straddles the halves; the systolic move passes ONE column per round between the two lanes of a
+    // row: a DPP swap)
+    const int wl = tid - (NREG + 64);
+    const bool wduty = wl >= 0;
+    const int wrow = wl >> 1, wh = wl & 1;
+    constexpr int HW = M2 / 2, HP = NP / 2;  // columns / pairs per lane
+    double w[HW], cc[HP], ss[HP];
 #pragma unroll
-    for (int col = 0; col < M2; ++col) w[col] = col == wrow ? 1.0 : 0.0;
+    for (int col = 0; col < HW; ++col) w[col] = (HW * wh + col) == wrow ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) cc[k] = 1.0, ss[k] = 0.0;
+    for (int k = 0; k < HP; ++k) cc[k] = 1.0, ss[k] = 0.0;
     auto apply_w = [&]() {  // W <- W J on columns (2k, 2k+1), then the columns move like the matrix's
-        double wn[M2];
-        static_for<NP>([&](auto kc_) {
+        double t[HW];
+        static_for<HP>([&](auto kc_) {
             constexpr int k = decltype(kc_)::value;
             const double w0 = w[2 * k], w1 = w[2 * k + 1];
-            wn[sys_perm<MODE>(2 * k, M2)] = fma(cc[k], w0, -(ss[k] * w1));
-            wn[sys_perm<MODE>(2 * k + 1, M2)] = fma(ss[k], w0, cc[k] * w1);
+            t[2 * k] = fma(cc[k], w0, -(ss[k] * w1));
+            t[2 * k + 1] = fma(ss[k], w0, cc[k] * w1);
         });
+        if (MODE == 1) {  // even positions stay, odd ones move on by one pair: 15 -> 17, 31 -> 1
+            const double recv = dpp_f64<kDppXor1>(t[HW - 1]);
 #pragma unroll
-        for (int col = 0; col < M2; ++col) w[col] = wn[col];
+            for (int x = 0; x < HW; x += 2) w[x] = t[x];
+            w[1] = recv;
+#pragma unroll
+            for (int x = 3; x < HW; x += 2) w[x] = t[x - 2];
+        } else {  // 0 stays; 1 -> 2 -> 4 -> ... -> 30 -> 31 -> 29 -> ... -> 3 -> 1: 14 -> 16 and 17 -> 15 change lanes
+            const double recv = dpp_f64<kDppXor1>(wh ? t[1] : t[HW - 2]);
+            w[0] = wh ? recv : t[0];
+            w[2] = wh ? t[0] : t[1];
+#pragma unroll
+            for (int x = 4; x < HW; x += 2) w[x] = t[x - 2];
+#pragma unroll
+            for (int x = 1; x < HW - 1; x += 2) w[x] = t[x + 2];
+            w[HW - 1] = wh ? t[HW - 2] : recv;
+        }
     };
     if (duty) {
         const int o = (2 * k2) * LD + 2 * k2;
@@ -387,7 +406,7 @@ __device__ int pivot_sweep(const SweepView &L, const int tid) {
         __builtin_amdgcn_s_setprio(3);
     } else if (reg) {
         __builtin_amdgcn_s_setprio(2);
-    }
+    }  // (the wave of the accumulated rotations stays at the pair workgroup's base priority 1)
     __syncthreads();
     int cur = 0;
     for (int r = 0; r < ROUNDS; ++r) {
@@ -426,8 +445,8 @@ __device__ int pivot_sweep(const SweepView &L, const int tid) {
             if (r > 0) apply_w();  // the rotations of round r - 1, fetched at the end of the previous turn
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const v2d t = *(const v2d *)(cs + 2 * k);
+            for (int k = 0; k < HP; ++k) {
+                const v2d t = *(const v2d *)(cs + 2 * (HP * wh + k));
                 cc[k] = t[0], ss[k] = t[1];
             }
         }
@@ -438,11 +457,11 @@ __device__ int pivot_sweep(const SweepView &L, const int tid) {
         SX_ETQ(r == 5 && duty && dl == 0, 14);
         cur ^= 1;
     }
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(1);
     if (wduty) {  // the last round's rotations; after them every column is back in its place
         apply_w();
 #pragma unroll
-        for (int col = 0; col < M2; ++col) L.Wout[wrow * LD + col] = w[col];
+        for (int col = 0; col < HW; ++col) L.Wout[wrow * LD + HW * wh + col] = w[col];
     }
     return cur;
 }
@@ -791,6 +810,8 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
     }
     // =========================== pair workgroups ===========================
     if (state == 1 || flush) return;
+    // (a pair workgroup shares its CU with a tile workgroup of the same launch; the round waits for the pair)
+    __builtin_amdgcn_s_setprio(1);
     SX_ETP(0);
     constexpr int LD = kM2 + 1;
     if (tid < 256) {

@@ -19,6 +19,8 @@ from .. import _device, _lib, _rng
 from . import _common
 from ._helpers import OptimizeResult, register
 
+_CAPTURE_MODE = "thread_local"  # see parallel.World.CAPTURE_MODE: torch's NCCL watchdog may poll events while we capture
+
 __all__ = ["minimize"]
 
 
@@ -478,7 +480,7 @@ class _PsoRun:
             if self.world is not None:
                 self.world.quiesce_for_capture(self.ctx)
             g = t.cuda.CUDAGraph()
-            with t.cuda.graph(g, stream=self.ctx.stream):
+            with t.cuda.graph(g, stream=self.ctx.stream, capture_error_mode=_CAPTURE_MODE):
                 for _ in range(self.GRAPH_CHUNK):
                     self._generation()
                     if self.gamma:

@@ -17,6 +17,8 @@ from .. import _device, _lib, _rng
 from . import _common
 from ._helpers import OptimizeResult, register
 
+_CAPTURE_MODE = "thread_local"  # see parallel.World.CAPTURE_MODE: torch's NCCL watchdog may poll events while we capture
+
 __all__ = ["minimize"]
 
 
@@ -325,7 +327,7 @@ class _DeRun:
         try:
             self.world.quiesce_for_capture(self.ctx)
             g = t.cuda.CUDAGraph()
-            with t.cuda.graph(g, stream=self.ctx.stream):
+            with t.cuda.graph(g, stream=self.ctx.stream, capture_error_mode=_CAPTURE_MODE):
                 for _ in range(self.GRAPH_CHUNK):
                     self._sharded_generation()
             self._rccl_graph = g
@@ -599,7 +601,7 @@ class _DeRun:
             if self.world is not None:
                 self.world.quiesce_for_capture(self.ctx)
             g = t.cuda.CUDAGraph()
-            with t.cuda.graph(g, stream=self.ctx.stream):
+            with t.cuda.graph(g, stream=self.ctx.stream, capture_error_mode=_CAPTURE_MODE):
                 for _ in range(self.EXT_CHUNK):
                     self._external_generation()
             self._ext_graphs[parity] = g

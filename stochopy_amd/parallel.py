@@ -53,19 +53,50 @@ class World:
     def shard(self, popsize):
         return shard_bounds(popsize, self.size, self.rank)
 
+    # Graph captures that contain collectives of this group.  torch's ProcessGroupNCCL runs a watchdog thread that polls
+    # the completion events of outstanding collectives every 100 ms.  If it polls while this thread captures on the
+    # stream those events were recorded on, HIP answers hipErrorCapturedEvent ("operation not permitted on an event last
+    # recorded in a capturing stream"), the watchdog throws and the process aborts: 1 in ~20 captures in round 1.
+    # Round 3 measured (tools/stress_capture.sh, gpurun_out/r3e): capture_error_mode="thread_local" alone does NOT cure
+    # it -- 4 aborts in 40 fresh processes -- because the error is raised for the EVENT, whatever the capture mode.  What
+    # cures it is an empty watchdog list while the capture runs.  So: drain the stream, then wait until the watchdog has
+    # RETIRED every work (read from torch's flight recorder, no guessing); only if the recorder is unavailable, give the
+    # watchdog three of its periods (what round 2 always did: 0 aborts in 135 captures).  thread_local mode is kept: it
+    # removes the other, documented hazard (any unsafe call from another thread during a global-mode capture).
+    CAPTURE_MODE = "thread_local"
+
+    @staticmethod
+    def _watchdog_idle():
+        """True / False: every collective in the flight recorder is retired / some are not; None: cannot tell."""
+        try:
+            import pickle
+
+            from torch._C._distributed_c10d import _dump_nccl_trace
+
+            entries = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False,
+                                                    onlyActive=False)).get("entries", [])
+            if not entries or any("retired" not in e for e in entries):
+                return None
+            return all(bool(e["retired"]) for e in entries)
+        except Exception:  # noqa: BLE001  (recorder disabled / other torch version)
+            return None
+
     def quiesce_for_capture(self, ctx):
-        """Call right before capturing collectives of this group into a graph.  torch's ProcessGroupNCCL runs a
-        watchdog thread that polls the completion events of outstanding collectives every 100 ms; if it polls one while
-        this thread is capturing, HIP answers hipErrorCapturedEvent ("operation not permitted on an event last recorded
-        in a capturing stream"), the watchdog throws and the process aborts -- seen once in ~20 captures on the GPU
-        box.  Draining the stream and then giving the watchdog three of its periods retires every outstanding work
-        from its list first, so it has nothing to poll while the (few ms) capture runs."""
+        """Call right before capturing collectives of this group into a graph (see above)."""
+        ctx.sync()
         if self.backend != "nccl":
             return
         import time
 
-        ctx.sync()
-        time.sleep(0.35)
+        deadline = time.perf_counter() + 2.0
+        while True:
+            idle = self._watchdog_idle()
+            if idle is None:
+                time.sleep(0.35)
+                return
+            if idle or time.perf_counter() > deadline:
+                return
+            time.sleep(0.01)
 
     def all_gather_records(self, record, out):
         """out[(world, n+2)] <- every rank's record[(n+2,)].  Device tensors; asynchronous with "nccl"."""

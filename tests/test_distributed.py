@@ -419,7 +419,8 @@ def test_sharded_pso_rccl_graph_capture_single_rank(method):
     from _dist_workers import nccl_single_rank_worker
 
     opts = {"maxiter": 70, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
-    cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts, "env": {"SX_EXCHANGE": "rccl"}}
+    cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts, "env": {"SX_EXCHANGE": "rccl"},
+           "flight_recorder": method == "pso"}  # pso: the capture waits on torch's flight recorder; cpso: it sleeps
     out = _spawn(nccl_single_rank_worker, 1, cfg)
     ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts), rng="philox")
     fun, nit, nfev, status = np.load(os.path.join(out, "meta_0.npy"))
