@@ -90,6 +90,15 @@ int64_t sx_num_partials(int64_t P, int n);
 int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd,
             double *f, double *part_f, int64_t *part_i, void *stream);
 
+/* Initial population with in-kernel draws (rng="philox"): the Latin hypercube of
+ * _common.py:109-120 (strata of width 2/P, jitter of width 1/P, one stratum per row and column, scaled to the
+ * bounds with the reference's two-rounding arithmetic), every row computable on its own: stratum = keyed bijection
+ * of [0, P) per column (Philox keys), jitter = 53-bit Philox uniform keyed by (global row, element).  A rank of a
+ * sharded run draws only its rows [row0, row0 + rows) of the P-row population.  X DEVICE (rows, ld); lower/upper
+ * DEVICE (n).  Oracle counterpart: oracle/streams.py PhiloxStream.lhs_population. */
+int sx_philox_lhs(double *X, int64_t rows, int n, int64_t ld, int64_t row0, int64_t P, const double *lower,
+                  const double *upper, uint32_t key0, uint32_t key1, void *stream);
+
 /* argmin with numpy's first-minimum tie rule (np.argmin, _common.py:132, de/_de.py:216)
  * f DEVICE (P); ws_f/ws_i DEVICE scratch of ws_len >= 1 entries; out_idx/out_val DEVICE (1). */
 int sx_argmin(const double *f, int64_t P, double *ws_f, int64_t *ws_i, int64_t ws_len, int64_t *out_idx,

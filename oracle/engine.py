@@ -51,7 +51,10 @@ def make_stream(rng, seed):
 
 
 def latin_hypercube(stream, P, n, lower, upper):
-    """_common.py:109-120 (jitter is 1/P wide inside strata 2/P wide -- reproduced as is)."""
+    """_common.py:109-120 (jitter is 1/P wide inside strata 2/P wide -- reproduced as is).  Philox mode: the same
+    construction with counter-based draws (PhiloxStream.lhs_population), as the HIP path's philox_lhs_kernel."""
+    if hasattr(stream, "lhs_population"):
+        return stream.lhs_population(P, n, np.asarray(lower, dtype=np.float64), np.asarray(upper, dtype=np.float64))
     u, perms = stream.lhs_draws(P, n)
     x = u / P
     x += np.linspace(-1.0, 1.0, P, endpoint=False)[:, None]

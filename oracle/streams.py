@@ -27,6 +27,8 @@ PURPOSE_PSO_R2 = 4
 PURPOSE_PSO_RESTART = 5
 PURPOSE_CMA_NORMAL = 6
 PURPOSE_NA_UNIFORM = 7
+PURPOSE_INIT_JITTER = 8
+PURPOSE_INIT_PERM = 9
 
 _M0 = np.uint64(0xD2511F53)
 _M1 = np.uint64(0xCD9E8D57)
@@ -155,7 +157,8 @@ class PhiloxStream:
     slot = (q >> 1) * LPR + l, half = q & 1.
     32-bit uniforms (DE crossover decisions): word * 2^-32 with
     slot = (q >> 2) * LPR + l, word = q & 3.
-    Initial population / initial mean: the legacy stream (host-side init step).
+    Initial population: lhs_population (counter-based Latin hypercube, every row on its own); the CMA-ES / VD-CMA
+    initial mean (n numbers) comes from a private legacy stream.
     """
 
     kind = "philox"
@@ -170,6 +173,39 @@ class PhiloxStream:
 
     def lhs_draws(self, P, n):
         return self.init.lhs_draws(P, n)
+
+    def lhs_population(self, P, n, lower, upper, row0=0, rows=None):
+        """The initial population of the throughput mode (csrc/sx_core.hip philox_lhs_kernel): the reference's Latin
+        hypercube (_common.py:109-120: strata of width 2/P, jitter of width 1/P, the same scaling arithmetic) with
+        counter-based draws, so that rows [row0, row0 + rows) can be produced on their own (a rank draws only its
+        shard).  Row i of column j takes stratum sigma_j(i): three rounds of x -> (x*m + a) mod 2^b, x ^= x >> ceil(b/2)
+        on b = bit_length(P - 1) bits (m odd; keys = words of two Philox calls with slot j), cycle-walked into
+        [0, P); the jitter is a 53-bit uniform keyed by (global row, element)."""
+        rows = P - row0 if rows is None else rows
+        gi = np.arange(row0, row0 + rows, dtype=np.uint64)
+        cols = np.arange(n, dtype=np.uint64)
+        ka = philox4x32_10(cols, 0, 0, PURPOSE_INIT_PERM, self.k0, self.k1)
+        kb = philox4x32_10(cols, 1, 0, PURPOSE_INIT_PERM, self.k0, self.k1)
+        m = [(ka[k] | np.uint64(1))[None, :] for k in range(3)]
+        ad = [kb[k][None, :] for k in range(3)]
+        b = max(1, int(P - 1).bit_length())
+        mask = np.uint64((1 << b) - 1)
+        sh = np.uint64((b + 1) // 2)
+        x = np.broadcast_to(gi[:, None], (rows, n)).copy()
+        todo = np.ones((rows, n), dtype=bool)
+        while todo.any():
+            y = x
+            for k in range(3):
+                y = (y * m[k] + ad[k]) & mask  # (below 2^63: x < 2^31, m < 2^32)
+                y = y ^ (y >> sh)
+            x = np.where(todo, y, x)
+            todo &= x >= np.uint64(P)
+        u = self._uniform_block(gi, n, 0, PURPOSE_INIT_JITTER)
+        step = 2.0 / P  # np.linspace(-1, 1, P, endpoint=False) = arange(P) * step + (-1)
+        v = u / P + (x.astype(np.float64) * step + -1.0)
+        pop = v * (0.5 * (upper - lower))
+        pop += 0.5 * (upper + lower)
+        return pop
 
     def cma_initial_mean(self, n):
         return self.init.cma_initial_mean(n)

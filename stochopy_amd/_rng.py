@@ -129,3 +129,17 @@ def make_init_stream(rng, seed):
         return LegacyHostStream(int(seed) & 0xFFFFFFFF)
     finally:
         np.random.set_state(state)
+
+
+def philox_latin_hypercube(ctx, out, row0, Ptotal, d_lower, d_upper, seed):
+    """Rows [row0, row0 + len(out)) of the Philox-mode initial population, drawn ON THE DEVICE straight into ``out``
+    ((rows, n) device tensor): the reference's Latin hypercube (_common.py:109-120) with counter-based draws
+    (csrc/sx_core.hip philox_lhs_kernel; oracle counterpart oracle/streams.py PhiloxStream.lhs_population).  Nothing is
+    built on the host, and a rank of a sharded run draws only its own rows."""
+    from . import _device
+
+    key0, key1 = philox_key(seed)
+    rows, n = out.shape
+    _lib.check(ctx.L.sx_philox_lhs(_device.ptr(out), rows, n, out.stride(0), int(row0), int(Ptotal), _device.ptr(d_lower),
+                                   _device.ptr(d_upper), key0, key1, ctx.stream_ptr), "sx_philox_lhs")
+    return out

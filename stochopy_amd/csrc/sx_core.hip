@@ -524,3 +524,58 @@ int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part
     return 0;
 }
 }  // namespace sx
+
+// ---------------------------------------------------------------------------
+// Initial population in Philox mode: the reference's Latin hypercube (_common.py:109-120)
+//     u = rand(P, n) / P + linspace(-1, 1, P, endpoint=False)[:, None];  column j permuted by permutation(P);
+//     pop = u * 0.5 (upper - lower) + 0.5 (upper + lower)
+// with counter-based draws, so that every row can be produced anywhere (a rank draws only ITS rows; nothing is
+// built on the host): row i of column j takes stratum sigma_j(i), sigma_j a keyed bijection of [0, P) --
+// three rounds of x -> (x * m + a) mod 2^b, x ^= x >> ceil(b/2) on b = bit_length(P - 1) bits (m odd; keys from
+// Philox calls (slot j, purpose kPurposeInitPerm)), cycle-walked into [0, P) -- and a 53-bit uniform keyed by
+// (global row, element) inside the stratum.  Same strata, same half-cell jitter, same scaling arithmetic
+// (two roundings each) as the reference; oracle counterpart: oracle/streams.py PhiloxStream.lhs_population.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void philox_lhs_kernel(double *__restrict__ X, int64_t rows, int n, int64_t ld,
+                                                          int64_t row0, int64_t P, const double *__restrict__ lower,
+                                                          const double *__restrict__ upper, uint32_t k0, uint32_t k1) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * n) return;
+    const int64_t r = t / n;
+    const int e = (int)(t % n);
+    const uint64_t gi = (uint64_t)(row0 + r);
+    // the column's permutation keys
+    const U4 ka = philox4x32_10((uint32_t)e, 0u, 0u, kPurposeInitPerm, k0, k1);
+    const U4 kb = philox4x32_10((uint32_t)e, 1u, 0u, kPurposeInitPerm, k0, k1);
+    const uint64_t m[3] = {(uint64_t)(ka.x | 1u), (uint64_t)(ka.y | 1u), (uint64_t)(ka.z | 1u)};
+    const uint64_t ad[3] = {(uint64_t)kb.x, (uint64_t)kb.y, (uint64_t)kb.z};
+    int b = 1;
+    while (((uint64_t)1 << b) < (uint64_t)P) ++b;  // P >= 2: b = bit_length(P - 1)
+    const uint64_t mask = ((uint64_t)1 << b) - 1u;
+    const int sh = (b + 1) / 2;
+    uint64_t x = gi;
+    do {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            x = (x * m[k] + ad[k]) & mask;
+            x ^= x >> sh;
+        }
+    } while (x >= (uint64_t)P);
+    const double u = philox_u53(e, lanes_per_row(n), (uint32_t)gi, 0u, kPurposeInitJitter, k0, k1);
+    const double step = 2.0 / (double)P;                      // np.linspace(-1, 1, P, endpoint=False): arange * step + start
+    const double v = u / (double)P + ((double)x * step + -1.0);
+    const double lo = lower[e], hi = upper[e];
+    X[r * ld + e] = v * (0.5 * (hi - lo)) + 0.5 * (hi + lo);
+}
+
+extern "C" int sx_philox_lhs(double *X, int64_t rows, int n, int64_t ld, int64_t row0, int64_t P, const double *lower,
+                             const double *upper, uint32_t key0, uint32_t key1, void *stream) {
+    SX_REQUIRE(X && lower && upper, "sx_philox_lhs: null pointer");
+    SX_REQUIRE(rows >= 1 && n >= 1 && ld >= n && row0 >= 0 && P >= 2 && row0 + rows <= P && P < ((int64_t)1 << 31),
+               "sx_philox_lhs: bad shape");
+    const int64_t tot = rows * n;
+    hipLaunchKernelGGL(philox_lhs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, rows,
+                       n, ld, row0, P, lower, upper, key0, key1);
+    SX_LAUNCH_CHECK();
+    return 0;
+}

@@ -144,6 +144,8 @@ enum : uint32_t {
     kPurposePsoRestart = 5,
     kPurposeCmaNormal = 6,
     kPurposeNaUniform = 7,  // NA: the double behind uniform(low, high) of (sample, axis)
+    kPurposeInitJitter = 8, // initial population (Philox mode): the uniform inside the stratum, keyed by (row, element)
+    kPurposeInitPerm = 9,   // ... and the keys of column j's stratum permutation (slot = j)
 };
 
 // Element e of a row sits in lane l = e % LPR of the row's lanes at step q = e / LPR (LPR a power of two).

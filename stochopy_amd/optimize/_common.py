@@ -131,8 +131,30 @@ def resolve_updating(updating, strict_updating, workers, fun):
             warnings.warn('stochopy_amd: updating="immediate" is an ordered sweep on one GPU with a fused factory '
                           'objective; this run (workers > 1 or a caller-supplied objective) uses "deferred" updating, '
                           "as a parallel backend of the reference does (de/_de.py:142-145).", RuntimeWarning, stacklevel=3)
+        if possible:
+            _note_serial_sweep()
         return possible
-    return bool(strict_updating) and workers == 1
+    if strict_updating and not possible:
+        raise ValueError('strict_updating=True: updating="immediate" is an ordered sweep on ONE GPU with a fused factory '
+                         "objective; this call (workers > 1, a caller-supplied objective or a sharded process group) "
+                         "cannot run it")
+    return bool(strict_updating)
+
+
+_sweep_noted = False
+
+
+def _note_serial_sweep():
+    """Once per process: a DEFAULT call (updating="immediate", the reference's default) runs the ordered sweep -- the
+    reference's result for the same seed, on one workgroup -- which is orders of magnitude slower than the
+    deferred generation kernels.  Say so, so that nobody benchmarks the parity mode by accident."""
+    global _sweep_noted
+    if not _sweep_noted:
+        _sweep_noted = True
+        warnings.warn('stochopy_amd: updating="immediate" (the default, as in the reference) runs one ORDERED sweep per '
+                      'generation on a single workgroup -- the reference\'s semantics and, for the same seed, its result.  '
+                      'For throughput pass updating="deferred" (or strict_updating=False): whole-population generation '
+                      "kernels, 100x faster at large popsize.  (Shown once.)", UserWarning, stacklevel=4)
 
 
 def evaluate_rows(ctx, fun, X, n, f, xm=None, xstd=None, clip=False):

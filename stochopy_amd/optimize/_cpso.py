@@ -144,16 +144,23 @@ class _PsoRun:
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
+                ok = False
                 try:
                     self._run()
-                    if self.px is not None:
-                        # Peers may still be reading this rank's exchange / population memory (their last kernels,
-                        # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
-                        # stream.  On the success path only -- a rank that raised must not wait for the others.
-                        self.ctx.sync()
-                        self.world.barrier()
+                    ok = True
                 finally:
-                    self.close()
+                    try:
+                        if self.px is not None:
+                            # Peers may still be reading this rank's exchange / population memory (their last kernels,
+                            # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
+                            # stream.  The meeting point is reached by failing ranks too (it carries a success flag):
+                            # a rank whose objective / callback raised makes its peers raise, not hang in a barrier.
+                            if ok:
+                                self.ctx.sync()
+                            if not self.world.all_agree(ok) and ok:
+                                raise RuntimeError("a peer rank failed during the run (its own exception says why)")
+                    finally:
+                        self.close()
 
     def close(self):
         if self._rccl_graph is not None:
@@ -175,13 +182,20 @@ class _PsoRun:
         self.stream = _rng.make_init_stream(self.rng, self.seed)
         if self.gamma:  # cpso/_cpso.py:215-216 (depends on maxiter; the whole swarm's size)
             self.delta = np.log(1.0 + 0.003 * self.Ptotal) / np.max((0.2, np.log(0.01 * self.maxiter)))
-        if self.x0 is not None:
-            X0 = np.array(self.x0, dtype=np.float64)
+        self.d_lower = ctx.upload(self.lower)
+        self.d_upper = ctx.upload(self.upper)
+        if self.x0 is None and self.rng == "philox":
+            # in-kernel draws: the Latin hypercube is drawn on the device too, every rank its own rows (_rng.py)
+            self.X = _rng.philox_latin_hypercube(ctx, ctx.empty((P, n)), self.row0, self.Ptotal, self.d_lower,
+                                                 self.d_upper, self.seed)
         else:
-            X0 = self.stream.latin_hypercube(self.Ptotal, n, self.lower, self.upper)
-        if self.world is not None:
-            X0 = np.ascontiguousarray(X0[self.row0 : self.row0 + P])
-        self.X = ctx.upload(X0)
+            if self.x0 is not None:
+                X0 = np.array(self.x0, dtype=np.float64)
+            else:
+                X0 = self.stream.latin_hypercube(self.Ptotal, n, self.lower, self.upper)
+            if self.world is not None:
+                X0 = np.ascontiguousarray(X0[self.row0 : self.row0 + P])
+            self.X = ctx.upload(X0)
         self.V = ctx.zeros((P, n))
         self.pbest = self.X.clone()
         npart = int(ctx.L.sx_num_partials(P, n))
@@ -193,8 +207,6 @@ class _PsoRun:
         if self.world is not None and self.gamma:
             self.fit_radius_all = ctx.empty((self.world.size, P + npart))
         self.candfit = ctx.empty((P,))
-        self.d_lower = ctx.upload(self.lower)
-        self.d_upper = ctx.upload(self.upper)
         self.part_f = ctx.empty((npart,))
         self.part_i = ctx.empty((npart,), dtype=t.int64)
         self.sel3 = ctx.zeros((3,), dtype=t.int64)

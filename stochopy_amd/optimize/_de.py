@@ -187,16 +187,23 @@ class _DeRun:
         if autorun:
             t = _device.torch()
             with t.cuda.stream(self.ctx.stream):
+                ok = False
                 try:
                     self._run()
-                    if self.px is not None:
-                        # Peers may still be reading this rank's exchange / population memory (their last kernels,
-                        # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
-                        # stream.  On the success path only -- a rank that raised must not wait for the others.
-                        self.ctx.sync()
-                        self.world.barrier()
+                    ok = True
                 finally:
-                    self.close()
+                    try:
+                        if self.px is not None:
+                            # Peers may still be reading this rank's exchange / population memory (their last kernels,
+                            # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
+                            # stream.  The meeting point is reached by failing ranks too (it carries a success flag):
+                            # a rank whose objective / callback raised makes its peers raise, not hang in a barrier.
+                            if ok:
+                                self.ctx.sync()
+                            if not self.world.all_agree(ok) and ok:
+                                raise RuntimeError("a peer rank failed during the run (its own exception says why)")
+                    finally:
+                        self.close()
 
     def close(self):
         if self._rccl_graph is not None or self._ext_graphs:
@@ -371,22 +378,26 @@ class _DeRun:
         ctx, P, n = self.ctx, self.P, self.n
         t = _device.torch()
         self.stream = _rng.make_init_stream(self.rng, self.seed)
-        if self.x0 is not None:
-            X0 = np.array(self.x0, dtype=np.float64)
-        else:
-            X0 = self.stream.latin_hypercube(self.Ptotal, n, self.lower, self.upper)
-        if self.world is not None:  # every rank builds the same global population and keeps its rows
-            X0 = np.ascontiguousarray(X0[self.row0 : self.row0 + P])
+        self.d_lower = ctx.upload(self.lower)
+        self.d_upper = ctx.upload(self.upper)
         # generation g lives in bufs[g & 1]; the initial population is generation 1
         if self.global_donors:  # buffers every peer maps: donor rows are read from their owners over xGMI
             self.bufs = list(self.px.share_population(P, n))
-            self.bufs[1].copy_(ctx.upload(X0))
         else:
-            self.bufs = [ctx.empty((P, n)), ctx.upload(X0)]
+            self.bufs = [ctx.empty((P, n)), ctx.empty((P, n))]
+        if self.x0 is None and self.rng == "philox":
+            # in-kernel draws: the Latin hypercube is drawn on the device too, every rank its own rows (_rng.py)
+            _rng.philox_latin_hypercube(ctx, self.bufs[1], self.row0, self.Ptotal, self.d_lower, self.d_upper, self.seed)
+        else:
+            if self.x0 is not None:
+                X0 = np.array(self.x0, dtype=np.float64)
+            else:  # the reference's stream: sequential by construction, built whole (numpy-legacy runs on one GPU)
+                X0 = self.stream.latin_hypercube(self.Ptotal, n, self.lower, self.upper)
+            if self.world is not None:
+                X0 = np.ascontiguousarray(X0[self.row0 : self.row0 + P])
+            self.bufs[1].copy_(ctx.upload(X0))
         self.fit = ctx.empty((P,))
         self.candfit = ctx.empty((P,))
-        self.d_lower = ctx.upload(self.lower)
-        self.d_upper = ctx.upload(self.upper)
         npart = int(ctx.L.sx_num_partials(P, n))
         self.part_f = ctx.empty((npart,))
         self.part_i = ctx.empty((npart,), dtype=t.int64)

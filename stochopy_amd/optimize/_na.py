@@ -57,6 +57,8 @@ def minimize(
         raise ValueError()
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
+    if popsize > 65535:
+        raise ValueError("method 'na': popsize <= 65535 (one workgroup row of the cell-walk kernels per sample)")
     if _common.resolve_workers(workers) != 1:
         raise ValueError("method 'na' runs on one GPU (workers=1): every walk reads the whole model store")
     return _NaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(nrperc), float(xtol), float(ftol),
@@ -66,7 +68,7 @@ def minimize(
 class _NaRun:
     def __init__(self, fun, lower, upper, x0, maxiter, P, nrperc, xtol, ftol, return_all, verbosity, callback, rng, seed):
         n = len(lower)
-        cap = max(1, maxiter) * P
+        cap = max(2, maxiter) * P  # (generation 2 always runs before the maxiter test, as in the reference: na/_na.py:196-263)
         if 8 * cap * (n + P) > _MAX_BYTES:
             raise ValueError(f"method 'na': maxiter * popsize = {cap} models need {8 * cap * (n + P) / 2**30:.0f} GiB "
                              "for the model store and the cell distances (limit 64 GiB)")
@@ -90,7 +92,13 @@ class _NaRun:
         d_lower, d_span = ctx.upload(lower), ctx.upload(span)
         d_fixed = ctx.upload((~free).astype(np.int32))
         nr = max(1, int(nrperc * P))                                                # :160
-        X0 = np.asarray(x0, dtype=np.float64) if x0 is not None else stream.latin_hypercube(P, n, lower, upper)
+        if x0 is not None:
+            X0 = np.asarray(x0, dtype=np.float64)
+        elif rng == "philox":  # the counter-based Latin hypercube of the in-kernel mode (drawn on the device, _rng.py)
+            X0 = _rng.philox_latin_hypercube(ctx, ctx.empty((P, n)), 0, P, ctx.upload(lower), ctx.upload(upper),
+                                             seed).cpu().numpy()
+        else:
+            X0 = stream.latin_hypercube(P, n, lower, upper)
         Xn = np.ascontiguousarray(normalize(X0))
         # device state: the samples being built, personal bests, the model store (column-major) and cell distances
         d_X = ctx.upload(Xn)
@@ -124,8 +132,8 @@ class _NaRun:
         M = P
         if return_all:
             nout = int(np.ceil(verbosity * P))
-            xall = np.empty((maxiter, max(1, nout), n))
-            funall = np.empty((maxiter, max(1, nout)))
+            xall = np.empty((max(2, maxiter), max(1, nout), n))
+            funall = np.empty((max(2, maxiter), max(1, nout)))
             if nout > 0:  # NB the reference stores the NORMALISED rows at iteration 1 (:185-193)
                 xall[0], funall[0] = Xn[:nout], pfit[:nout]
             else:
