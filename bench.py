@@ -116,8 +116,59 @@ def minimize_wall(objective, n, P, strategy, maxiter=1000):
     return {"value": res.nit * P / wall, "unit": "evals/s", "wall_s": wall, "walls_s": walls, "nit": int(res.nit),
             "nfev": int(res.nfev),
             "note": "wall clock around stochopy_amd.optimize.minimize(method='de', updating='deferred', rng='philox'), "
-                    "best of three calls after one warm-up call; includes the host-side initial population (numpy-legacy "
-                    "LHS, ~4 ms of host work at this shape) and the result copy"}
+                    "best of three calls after one warm-up call; everything included: the initial population (drawn on the "
+                    "device since round 3), uploads, graph replays, the result copy"}
+
+
+def other_configs():
+    """BASELINE.json configs 2-4 from the same process: evals/s = popsize / (wall per generation),
+    wall per generation from TWO whole minimize() calls of different length (set-up and result copy cancel), best of
+    three; `frac` = algorithmic bytes (or flops) of one generation / that time / peak -- a whole-generation figure, all
+    kernels and gaps included, not a kernel figure."""
+    import torch
+
+    import stochopy_amd as sa
+
+    def per_gen(method, fun, n, opts, short, long_, reps=3):
+        bounds = [[-5.12, 5.12]] * n
+        o = dict(opts, seed=0, rng="philox", ftol=-1.0, xtol=0.0, backend="hip")
+
+        def wall(m):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = sa.optimize.minimize(fun, bounds, method=method, options=dict(o, maxiter=m))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, r.nit
+
+        wall(short)
+        best = None
+        for _ in range(reps):
+            (t1, n1), (t2, n2) = wall(short), wall(long_)
+            v = (t2 - t1) / (n2 - n1)
+            best = v if best is None or v < best else best
+        return best
+
+    out = {}
+    mfma_f64 = 78.6e12  # dense fp64 MFMA peak used by SURVEY.md section 8d
+    t = per_gen("de", sa.factory.rastrigin, 128, {"popsize": 4096, "updating": "deferred", "strategy": "best1bin"}, 200, 2200)
+    out["C2_de_rastrigin_n128_p4096"] = {"evals_per_s": 4096 / t, "us_per_generation": t * 1e6, "bound": "hbm",
+                                        "frac": 4112 * 4096 / t / (HBM_PEAK_GBS * 1e9)}
+    c3 = {"popsize": 16384, "updating": "deferred"}
+    t = per_gen("pso", sa.factory.ackley, 256, c3, 200, 1200)
+    out["C3a_pso_ackley_n256_p16384"] = {"evals_per_s": 16384 / t, "us_per_generation": t * 1e6, "bound": "hbm",
+                                        "frac": 12312 * 16384 / t / (HBM_PEAK_GBS * 1e9)}
+    t = per_gen("cpso", sa.factory.ackley, 256, c3, 200, 1200)
+    out["C3b_cpso_ackley_n256_p16384"] = {"evals_per_s": 16384 / t, "us_per_generation": t * 1e6, "bound": "hbm",
+                                         "frac": 12312 * 16384 / t / (HBM_PEAK_GBS * 1e9),
+                                         "note": "PSO's bytes per evaluation; the competitive restart's own traffic is extra"}
+    t = per_gen("cmaes", sa.factory.rosenbrock, 512, {"popsize": 1024}, 10, 50, reps=2)
+    flops = 2.0 * 1024 * 512**2 + 2.0 * 512 * 512**2
+    out["C4_cmaes_rosenbrock_n512_p1024"] = {
+        "evals_per_s": 1024 / t, "ms_per_generation": t * 1e3, "bound": "mfma", "frac": flops / t / mfma_f64,
+        "note": "generations 10-50 of a run (every generation decomposes the covariance: ~7 Jacobi sweeps there, 5 after "
+                "generation ~200); frac = sampling + rank-mu flops (8.05e8) / generation time / 78.6 TF -- the generation "
+                "is the eigendecomposition's latency chain, not these two contractions"}
+    return out
 
 
 def _one_row(objective, x):
@@ -170,6 +221,7 @@ def main():
     ap.add_argument("--workload", default="de_rosenbrock_n128_p4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-minimize-wall", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C3a / C3b / C4 block")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU work spent on the baseline sample")
     ap.add_argument("--kernel-timing-launches", type=int, default=400)
     args = ap.parse_args()
@@ -403,6 +455,11 @@ def main():
             line["c5"] = c5
         if world == 1 and not args.no_minimize_wall:
             line["minimize_wall"] = minimize_wall(objective, n, P, strategy)
+        if world == 1 and not args.no_configs:
+            try:
+                line["configs"] = other_configs()
+            except Exception as e:  # noqa: BLE001  (keep the headline line whatever happens here)
+                line["configs"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(objective, n, min(P, 4096), strategy, args.cpu_baseline_seconds)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

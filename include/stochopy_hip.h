@@ -311,6 +311,21 @@ typedef struct sx_pso_args {
 
 int sx_pso_generation(const sx_pso_args *a, int finalize, void *stream);
 
+/* PSO with ONE kernel per generation (round 3; the pattern of sx_de_chain_launch): the best / termination step of
+ * _common.py:131-158 for generation g runs in the prologue of the launch that produces generation g+1 -- every
+ * workgroup reduces the per-workgroup records (two levels) and derives the same best row and status.  Because the
+ * swarm is updated in place, each workgroup keeps a copy of its best row in best_rows (double-buffered; the record
+ * says which copy is current), which is where the next generation reads gbest from.
+ * Supported (sx_pso_chain_supported != 0): one GPU, SX_RNG_PHILOX, constraints none, no pending restart, whole-batch
+ * rows (n = 64, 128 or 256), sx_num_partials(P,n) <= 8 x the workgroup size.
+ * a->state: 3 sx_state words ([0], [1] ping-pong by launch parity, [2] written by finalize_only launches = the
+ * host's view; reserved[0] / reserved[1] = record of the previous / current best); a->part_f / a->part_i:
+ * 2 x npart records, record = 2 * row + q; best_rows DEVICE (2, npart, n); a->gbest unused.  status 1 is reported
+ * for `fun <= ftol`; whether it is 0 (best moved by <= xtol) the host settles from the two resident rows. */
+int sx_pso_chain_supported(const sx_pso_args *a);
+int sx_pso_chain_launch(const sx_pso_args *a, double *best_rows, int parity, int finalize_only, void *stream);
+int sx_pso_chain_graph_create(const sx_pso_args *a, double *best_rows, int ngen, int start_parity, sx_graph **out);
+
 /* Competitive restart, cpso/_cpso.py:405-426.
  * sx_pso_radius: part_r[b] = max over the rows of workgroup b of ||X_i - gbest||_2 (:410)
  *   part_r DEVICE (sx_num_partials(P,n)).

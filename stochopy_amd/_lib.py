@@ -137,6 +137,9 @@ PROTOTYPES = {
     "sx_graph_launch": (C.c_int, [vp, vp]),
     "sx_graph_destroy": (C.c_int, [vp]),
     "sx_pso_generation": (C.c_int, [C.POINTER(SxPsoArgs), C.c_int, vp]),
+    "sx_pso_chain_supported": (C.c_int, [C.POINTER(SxPsoArgs)]),
+    "sx_pso_chain_launch": (C.c_int, [C.POINTER(SxPsoArgs), vp, C.c_int, C.c_int, vp]),
+    "sx_pso_chain_graph_create": (C.c_int, [C.POINTER(SxPsoArgs), vp, C.c_int, C.c_int, C.POINTER(vp)]),
     "sx_pso_radius": (C.c_int, [C.POINTER(SxPsoArgs), vp, vp]),
     "sx_pso_restart_select": (C.c_int, [C.POINTER(SxPsoArgs), vp, f64, f64, vp, vp]),
     "sx_pso_restart_apply": (C.c_int, [C.POINTER(SxPsoArgs), vp, vp, vp, i64, vp]),

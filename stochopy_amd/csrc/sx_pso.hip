@@ -32,20 +32,39 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
 // one batch, and every bound check and loop over the row folds away.
 // PLAIN (with FULL): constraints=None and no restart pending (plain PSO, or the first generation of a CPSO graph): neither
 // the Shrink pass nor the re-seeding test is compiled in.
-template <int FUN, int RNG, int LPR, bool FULL, bool PLAIN = false>
+// CHAIN (with PLAIN; round 3): ONE kernel per generation, the way DE runs (sx_de_kernel.hpp).  Launch L (parity
+// chain_p = L & 1) first finalises the generation its predecessor produced -- every workgroup reduces the per-workgroup
+// records of parity chain_p (two levels: a slice per thread, DPP over the wave, the waves through LDS), derives the same
+// best / status, workgroup 0 publishes it in state[1 - chain_p] -- and then produces the next generation, writing its
+// record of parity 1 - chain_p.  The swarm is updated in place, so the best row cannot be read from pbest while other
+// workgroups overwrite theirs: every workgroup keeps a copy of ITS best row in best_rows[q][block] and its record says
+// which q (rec = 2 * row + q); the copy is rewritten -- into the buffer the current record does NOT point to -- only
+// when the workgroup's best row changed.  mode 1: one workgroup, finalise only, into state[2] (the host's view).
+constexpr int kChainRecPerThread = 8;
+
+template <int FUN, int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
-                                                                                const PlanArg plan) {
+                                                                                const PlanArg plan,
+                                                                                double *__restrict__ best_rows,
+                                                                                const int chain_p, const int mode,
+                                                                                const int64_t npart) {
+    static_assert(!CHAIN || (PLAIN && FULL), "the chained form exists for the whole-batch constraints=None kernel");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
+    __shared__ int sb[kMaxRowsPerBlock];          // CHAIN: the row's pbest changed in this generation
+    __shared__ double s_wf[kMaxWavesPerBlock];    // CHAIN: the waves' partial results of the record reduction
+    __shared__ int64_t s_wi[kMaxWavesPerBlock];
     // the state word (a miss after every kernel boundary) is needed by the Philox counters and the stop test only: the
     // PLAIN kernel issues the row loads of its batch before anything waits for it.  (Not the general one: with the
     // re-seeding code behind it the late test costs 130 VGPRs instead of 80 -- 3 waves per SIMD instead of 6 -- and made
     // that kernel 31.5 -> 53 us, profiles/r2_pso_c3_variants.txt.)
-    const sx_state *st = a.state;
+    const sx_state *st = CHAIN ? a.state + chain_p : a.state;
     const int done = st->done;
     if (!PLAIN && done) return;
-    const uint32_t gen = (uint32_t)(st->it + 1);
+    // CHAIN: st->it is the last FINALISED generation; the swarm holds st->it + 1, this launch produces st->it + 2
+    const int64_t it_held = CHAIN ? st->it + 1 : st->it;
+    const uint32_t gen = (uint32_t)(it_held + 1);
     const int n = FULL ? 4 * LPR : a.n;
     const int64_t P = a.P, ld = a.ld;
     const RowIds<LPR> id(P);
@@ -66,6 +85,27 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     double *__restrict__ vr = a.V + rowc * ld;
     double *__restrict__ pb = a.pbest + rowc * ld;
     const double *__restrict__ gb = a.gbest;
+    // CHAIN: the predecessor's records, a contiguous slice per thread (first-minimum rule), and this workgroup's own
+    double pfv[kChainRecPerThread];
+    int64_t piv[kChainRecPerThread];
+    int64_t myprev = 0;
+    double *part_f_out = a.part_f;
+    int64_t *part_i_out = a.part_i;
+    if (CHAIN) {
+        const double *pf = a.part_f + (int64_t)chain_p * npart;
+        const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
+        const int per = (int)((npart + blockDim.x - 1) / blockDim.x);
+        const int64_t k0 = (int64_t)threadIdx.x * per;
+#pragma unroll
+        for (int u = 0; u < kChainRecPerThread; ++u) {
+            const bool in = u < per && k0 + u < npart;
+            pfv[u] = in ? pf[k0 + u] : __builtin_huge_val();
+            piv[u] = in ? pi[k0 + u] : INT64_MAX;
+        }
+        myprev = pi[id.block];
+        part_f_out = a.part_f + (int64_t)(1 - chain_p) * npart;
+        part_i_out = a.part_i + (int64_t)(1 - chain_p) * npart;
+    }
     const uint32_t grow = (uint32_t)(a.row0 + rowc);
     const double w = a.w, c1 = a.c1, c2 = a.c2;
     const bool shrink = PLAIN ? false : a.constraints != 0;
@@ -87,11 +127,52 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             x[t] = ld_row ? xr[e] : 0.0;
             v[t] = ld_row ? vr[e] : 0.0;
             p[t] = ld_row ? pb[e] : 0.0;
-            g[t] = in ? gb[e] : 0.0;
+            if (!CHAIN) g[t] = in ? gb[e] : 0.0;
             r1[t] = (RNG == SX_RNG_HOST && in) ? r1row[e] : 0.0;
             r2[t] = (RNG == SX_RNG_HOST && in) ? r2row[e] : 0.0;
         }
-        if (PLAIN && done) return;  // (uniform; nothing has been written yet)
+        if (PLAIN && done) {  // (uniform; nothing has been written yet)
+            if (CHAIN && mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) a.state[2] = *st;
+            return;
+        }
+        if constexpr (CHAIN) {
+            // ---- finalise the generation the swarm holds: (min f, first row) over the records, two levels ----
+            double bf = pfv[0];
+            int64_t brec = piv[0];
+#pragma unroll
+            for (int u = 1; u < kChainRecPerThread; ++u)
+                if (pfv[u] < bf) bf = pfv[u], brec = piv[u];  // (slices are in row order: strict < keeps the first)
+            wave_argmin_ordered(bf, brec);
+            if (id.lane == 0) s_wf[id.wave] = bf, s_wi[id.wave] = brec;
+            __syncthreads();
+            bf = s_wf[0], brec = s_wi[0];
+            const int nw = (int)(blockDim.x >> 6);
+            for (int wv = 1; wv < nw; ++wv)
+                if (s_wf[wv] < bf) bf = s_wf[wv], brec = s_wi[wv];
+            int status = SX_STATUS_NONE;
+            if (it_held >= 2) {  // the reference does not test the initial swarm (cpso/_cpso.py:219-240)
+                if (bf <= a.ftol)
+                    status = 1;  // (0 if the best moved by <= xtol: settled by the host from the two resident rows)
+                else if (it_held >= a.maxiter)
+                    status = -1;
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                sx_state *so = a.state + (mode == 1 ? 2 : 1 - chain_p);
+                so->it = it_held;
+                so->gbidx = brec >> 1;
+                so->gfit = bf;
+                so->dx = 0.0;
+                so->status = status;
+                so->done = status != SX_STATUS_NONE;
+                so->reserved[0] = st->reserved[1];  // the record of the best of the generation before
+                so->reserved[1] = brec;
+            }
+            if (status != SX_STATUS_NONE || mode == 1) return;
+            const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+            const double *__restrict__ gbc = best_rows + ((brec & 1) * npart + (brec >> 1) / rows_in_block) * (int64_t)n;
+#pragma unroll
+            for (int t = 0; t < kStep; ++t) g[t] = gbc[(q0 + t) * LPR + l];
+        }
         if (RNG == SX_RNG_PHILOX) {
             // 32-bit uniforms, one call per 2 steps: words (0,1) -> (r1,r2) of even q, (2,3) of odd q
 #pragma unroll
@@ -176,23 +257,61 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             if (a.candfit != nullptr) a.candfit[id.row] = fc;
         }
     }
-    block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+    if constexpr (!CHAIN) {
+        block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+    } else {
+        // the workgroup's record AND, when its best row changed, the row itself (see the head of the kernel)
+        if (id.l == 0) {
+            sf[id.slot] = id.active ? (better ? fc : fold) : __builtin_huge_val();
+            si[id.slot] = id.active ? id.row : INT64_MAX;
+            sb[id.slot] = better ? 1 : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x < kWave) {
+            const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+            const int k = (int)threadIdx.x;
+            double bf = k < rows_in_block ? sf[k] : __builtin_huge_val();
+            int64_t bi = k < rows_in_block ? si[k] : INT64_MAX;
+            wave_argmin_ordered(bf, bi);
+            const int ks = (int)(bi - (int64_t)id.block * rows_in_block);  // the winning slot
+            const bool changed = sb[ks] != 0 || bi != (myprev >> 1);
+            const int64_t q = changed ? 1 - (myprev & 1) : (myprev & 1);
+            if (changed) {  // the new pbest of a row that improved is its position, still in LDS
+                const double *src = sb[ks] ? lds + ks * lds_row_stride(n) : a.pbest + bi * ld;
+                double *dst = best_rows + (q * npart + id.block) * (int64_t)n;
+                for (int e = k; e < n; e += kWave) dst[e] = src[e];
+            }
+            if (k == 0) {
+                part_f_out[id.block] = bf;
+                part_i_out[id.block] = 2 * bi + q;
+            }
+        }
+    }
 }
 
-typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg);
+typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg, double *, int, int, int64_t);
 
-template <int RNG, int LPR, bool FULL, bool PLAIN = false>
+template <int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false>
 pso_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL, PLAIN>;
-        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL, PLAIN>;
-        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL, PLAIN>;
-        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL, PLAIN>;
-        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL, PLAIN>;
-        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL, PLAIN>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL, PLAIN>;
+        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL, PLAIN, CHAIN>;
+        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL, PLAIN, CHAIN>;
+        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL, PLAIN, CHAIN>;
+        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL, PLAIN, CHAIN>;
+        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL, PLAIN, CHAIN>;
+        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL, PLAIN, CHAIN>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL, PLAIN, CHAIN>;
     }
     return nullptr;
+}
+
+// the chained form: whole-batch rows (n = 64, 128, 256), in-kernel draws, constraints=None, no restart
+pso_kernel_t pick_chain_kernel(int fun_id, int n) {
+    switch (lanes_per_row(n)) {
+        case 16: return pick_kernel_lpr<SX_RNG_PHILOX, 16, true, true, true>(fun_id);
+        case 32: return pick_kernel_lpr<SX_RNG_PHILOX, 32, true, true, true>(fun_id);
+    }
+    return pick_kernel_lpr<SX_RNG_PHILOX, 64, true, true, true>(fun_id);
 }
 
 template <int RNG>
@@ -553,7 +672,7 @@ extern "C" int sx_pso_generation(const sx_pso_args *a, int finalize, void *strea
     const bool plain = a->constraints == 0 && a->pending_restart == nullptr;
     pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n, plain)
                                                  : pick_kernel<SX_RNG_HOST>(a->fun_id, a->n, plain);
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan);
+    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan, (double *)nullptr, 0, 0, (int64_t)0);
     SX_LAUNCH_CHECK();
     if (finalize)
         return sx_select_finalize(a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n, a->gbest, a->state,
@@ -662,8 +781,11 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     // the last one is followed by the apply kernel, so the state a replay leaves behind is complete
     sx_pso_args args_inline = args;
     args_inline.pending_restart = sel3;
-    void *gen_args[] = {&args, &plan};
-    void *gen_args_inline[] = {&args_inline, &plan};
+    double *no_rows_buf = nullptr;
+    int izero = 0;
+    int64_t lzero = 0;
+    void *gen_args[] = {&args, &plan, &no_rows_buf, &izero, &izero, &lzero};
+    void *gen_args_inline[] = {&args_inline, &plan, &no_rows_buf, &izero, &izero, &lzero};
     // restart kernels' arguments
     const double *fit = a->pbestfit;
     const double *pr = part_r;
@@ -702,6 +824,62 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
                     return rc;
         }
     }
+    SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
+    *out = gr;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// PSO, one kernel per generation ("chained": the best / termination step of generation g runs in the prologue of
+// the launch that produces g + 1; see pso_generation_kernel<..., CHAIN>).  Single GPU, in-kernel draws,
+// constraints=None, whole-batch rows (n = 64, 128, 256), no competitive restart.
+//   a->state   3 sx_state words: [0], [1] ping-pong, [2] the host's view (finalize_only launches)
+//   a->part_f / part_i   2 x npart records (rec = 2 * row + q)
+//   best_rows  2 x npart x n doubles: every workgroup's copy of its best row, double-buffered by q
+// ---------------------------------------------------------------------------
+extern "C" int sx_pso_chain_supported(const sx_pso_args *a) {
+    if (check_args(a)) return 0;
+    const Geometry g = geometry(a->P, a->n);
+    return a->rng == SX_RNG_PHILOX && a->constraints == 0 && a->pending_restart == nullptr &&
+                   a->n == 4 * lanes_per_row(a->n) && (int64_t)g.blocks <= (int64_t)kChainRecPerThread * g.threads
+               ? 1
+               : 0;
+}
+
+extern "C" int sx_pso_chain_launch(const sx_pso_args *a, double *best_rows, int parity, int finalize_only, void *stream) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(best_rows != nullptr && (parity == 0 || parity == 1), "sx_pso_chain_launch: bad arguments");
+    SX_REQUIRE(sx_pso_chain_supported(a), "sx_pso_chain_launch: shape / mode not supported by the chained kernel");
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a->P, a->n);
+    hipLaunchKernelGGL(pick_chain_kernel(a->fun_id, a->n), dim3(finalize_only ? 1u : g.blocks), dim3(g.threads), g.lds,
+                       (hipStream_t)stream, *a, plan, best_rows, parity, finalize_only ? 1 : 0, (int64_t)g.blocks);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sx_pso_chain_graph_create(const sx_pso_args *a, double *best_rows, int ngen, int start_parity,
+                                         sx_graph **out) {
+    if (int rc = check_args(a)) return rc;
+    SX_REQUIRE(out != nullptr && ngen >= 1 && best_rows != nullptr && (start_parity == 0 || start_parity == 1),
+               "sx_pso_chain_graph_create: bad arguments");
+    SX_REQUIRE(sx_pso_chain_supported(a), "sx_pso_chain_graph_create: shape / mode not supported by the chained kernel");
+    PlanArg plan;
+    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    const Geometry g = geometry(a->P, a->n);
+    sx_graph *gr = new sx_graph();
+    SX_HIP(hipGraphCreate(&gr->graph, 0));
+    sx_pso_args args = *a;
+    int par[2] = {0, 1}, mode = 0;
+    int64_t npart = g.blocks;
+    void *kargs[2][6] = {{&args, &plan, &best_rows, &par[0], &mode, &npart}, {&args, &plan, &best_rows, &par[1], &mode, &npart}};
+    void *fn = (void *)pick_chain_kernel(a->fun_id, a->n);
+    hipGraphNode_t prev = nullptr;
+    for (int i = 0; i < ngen; ++i)
+        if (int rc = add_kernel_node(gr->graph, &prev, fn, dim3(g.blocks), dim3(g.threads), (unsigned)g.lds,
+                                     kargs[(start_parity + i) & 1]))
+            return rc;
     SX_HIP(hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0));
     *out = gr;
     return 0;

@@ -158,6 +158,24 @@ def gpu_minimize_worker(rank, world, port, cfg, out_dir):
         dist.destroy_process_group()
 
 
+def nccl_multi_gpu_worker(rank, world, port, cfg, out_dir):
+    """One rank per PHYSICAL GPU, backend nccl (= RCCL over xGMI): the deployment.  Needs >= world devices (the test
+    that uses it is skipped on one-GPU boxes)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = "256"
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        _minimize_and_save(rank, world, cfg, out_dir)
+    finally:
+        dist.destroy_process_group()
+
+
 def gpu_p2p_straggler_worker(rank, world, port, cfg, out_dir):
     """Rank 1 sets the exchange up and then never launches a generation; rank 0 must time out and raise."""
     import time

@@ -458,3 +458,47 @@ def test_p2p_path_single_rank_nccl_setup():
     from _dist_workers import nccl_single_rank_worker
 
     _check_sharded_de(1, _de_cfg(24, 128, 9, 2024, "p2p"), worker=nccl_single_rank_worker)
+
+
+def _n_gpus():
+    try:
+        import torch
+
+        return torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two physical GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+@pytest.mark.parametrize("gens", [9, 130])
+def test_two_physical_gpus_rccl_and_peer_exchange(exchange, gens):
+    """The first box with more than one GPU runs this: one rank per device, process group nccl (RCCL over xGMI), the
+    record exchange through RCCL all-gathers ("rccl": captured into a graph from 50 generations on) and through peer
+    writes into IPC-mapped HBM across a real link ("p2p", after its probe) -- == oracle.run_de_sharded bit for bit on
+    every rank.  Everywhere else these transports are only ever exercised with ranks sharing one device."""
+    from _dist_workers import nccl_multi_gpu_worker
+
+    world = min(_n_gpus(), 8)
+    world = 1 << (world.bit_length() - 1)  # 2, 4 or 8
+    _check_sharded_de(world, _de_cfg(24, 64 * world, gens, 2024 + gens, exchange), worker=nccl_multi_gpu_worker)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two physical GPUs")
+@pytest.mark.parametrize("method", ["pso", "cpso"])
+def test_two_physical_gpus_pso_is_exact(method):
+    """PSO / CPSO sharded over physical GPUs (nccl process group; best record by peer writes or all-gather, the
+    restart's [pbestfit | radii] gather over RCCL) == the unsharded oracle run."""
+    from _dist_workers import nccl_multi_gpu_worker
+
+    world = 2
+    opts = {"maxiter": 70, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
+    cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts}
+    out = _spawn(nccl_multi_gpu_worker, world, cfg)
+    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts), rng="philox")
+    for r in range(world):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)

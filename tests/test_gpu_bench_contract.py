@@ -30,9 +30,17 @@ def test_bench_line_has_the_contract_fields():
     assert d["vs_baseline"] is None and d["config"]["workload"] == "de_rosenbrock_n128_p4096"
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
     t = d["timed"]
-    assert t["seconds"] >= 0.05 and t["steps_timed"] == t["blocks"] * 150 and t["block_ms_median"] > 0
+    assert t["seconds"] >= 2.0 and t["steps_timed"] == t["blocks"] * 150 and t["block_ms_median"] > 0
     w = d["minimize_wall"]
-    assert w["nit"] == 1000 and w["nfev"] == 1000 * 4096 and 0 < w["value"] <= d["value"] * 1.05
+    # (round 3: the initial population is drawn on the device -- a whole minimize() call is within ~10 % of the resident
+    #  loop; round 2, host-side Latin hypercube: 62 %)
+    assert w["nit"] == 1000 and w["nfev"] == 1000 * 4096 and 0.75 * d["value"] < w["value"] <= d["value"] * 1.05
+    assert (d["n_ranks_seen"], d["transport"], d["process_group"]) == (1, None, None)
+    cf = d["configs"]
+    assert set(cf) == {"C2_de_rastrigin_n128_p4096", "C3a_pso_ackley_n256_p16384", "C3b_cpso_ackley_n256_p16384",
+                       "C4_cmaes_rosenbrock_n512_p1024"}, cf
+    assert all(v["evals_per_s"] > 1e5 and 0.0 < v["frac"] < 1.0 for v in cf.values()), cf
+    assert cf["C3a_pso_ackley_n256_p16384"]["evals_per_s"] > 3e8 and cf["C4_cmaes_rosenbrock_n512_p1024"]["evals_per_s"] > 2.5e5
     assert d["cpu_baseline"]["cpu_model"] and d["cpu_baseline_loky"].get("cores") == os.cpu_count()
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -44,7 +52,7 @@ def test_bench_line_has_the_contract_fields():
 
 
 def test_bench_other_workload_and_smoke():
-    d = _run_bench("--no-cpu-baseline", "--workload", "de_rosenbrock_n1024_p16384")
+    d = _run_bench("--no-cpu-baseline", "--no-configs", "--workload", "de_rosenbrock_n1024_p16384")
     assert "cpu_baseline" not in d and d["config"]["dim"] == 1024 and d["roofline"]["frac"] > 0.3
     import __graft_entry__
 
@@ -55,24 +63,21 @@ def test_bench_two_ranks_emits_the_c5_strong_scaling_figures():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank) -- here with both
     ranks on the one test GPU and gloo for the process group: the weak-scaled metric line plus BASELINE config 5
     (P = 131072 in total) through both donor modes, with the number of ranks the process group saw."""
-    import socket
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # NO external launcher: `python bench.py --gpus 2` re-executes itself under torch.distributed.run (VERDICT r2 #3: the
+    # driver's SCALE run calls it exactly like the N=1 run).
     # SX_EXCHANGE=rccl: two ranks SHARING one GPU must not wait for each other inside kernels at these sizes (a
     # rank's waiting workgroups can fill the device before the peer's are resident); on a node every rank has its
     # own GPU and the default exchange applies.  Global donors need the peer mapping: reported as unavailable here.
     env = dict(os.environ, SX_BENCH_DEVICE="0", SX_BENCH_BACKEND="gloo", SX_EXCHANGE="rccl")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--kernel-timing-launches", "50"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--kernel-timing-launches", "50"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["popsize_total"] == 8192
+    assert (d["n_ranks_seen"], d["transport"], d["process_group"]) == (2, "rccl", "gloo")
     c5 = d["c5"]
     assert c5["n_ranks_seen"] == 2 and c5["rows_per_gpu"] == 65536 and c5["scaling"] == "strong"
     assert c5["donors_shard"].get("value", 0) > 0, c5["donors_shard"]

@@ -140,3 +140,24 @@ def test_de_one_batch_rows_through_replayed_graphs_match_oracle(sa, objective, s
         got = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="de",
                                    options=dict(opts, backend="hip", rng="philox"))
         assert got.fun == ref.fun and np.array_equal(got.x, ref.x) and (got.nit, got.status) == (ref.nit, ref.status), strategy
+
+
+@pytest.mark.parametrize("P,n", [(2, 3), (7, 5), (100, 70), (513, 2), (4096, 128), (16384, 256), (1000, 1030)])
+def test_philox_latin_hypercube_kernel_vs_oracle(sa, P, n):
+    """sx_philox_lhs (the initial population of rng="philox" runs, drawn on the device) == oracle
+    PhiloxStream.lhs_population bit for bit, whole and in shards (row0 / rows as a rank of a sharded run uses them)."""
+    from stochopy_amd import _device, _rng
+
+    ctx = _device.Context()
+    seed = 2**40 + 12345 + P
+    lo, up = np.full(n, -5.12), np.linspace(1.0, 5.12, n)
+    want = oracle.PhiloxStream(seed).lhs_population(P, n, lo, up)
+    d_lo, d_up = ctx.upload(lo), ctx.upload(up)
+    got = _rng.philox_latin_hypercube(ctx, ctx.empty((P, n)), 0, P, d_lo, d_up, seed)
+    ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), want)
+    if P >= 7:
+        r0, rows = P // 3, P // 2
+        part = _rng.philox_latin_hypercube(ctx, ctx.empty((rows, n)), r0, P, d_lo, d_up, seed)
+        ctx.sync()
+        assert np.array_equal(part.cpu().numpy(), want[r0 : r0 + rows])

@@ -379,3 +379,25 @@ def test_chained_generations_are_planned_as_few_graph_replays():
             at += s if s else 1
         launches += n
     assert all(k[1] % 2 == 0 and 10 < k[1] < 50 for k in seen)
+
+
+@pytest.mark.parametrize("P,n", [(2, 3), (7, 5), (100, 70), (513, 2), (4096, 128)])
+def test_philox_latin_hypercube_oracle_properties(P, n):
+    """The counter-based initial population of the throughput mode (oracle side; the HIP kernel is compared with it bit
+    for bit in tests/test_gpu_de.py): it IS a Latin hypercube in the reference's sense (_common.py:109-120) -- every
+    column visits every stratum of width (upper - lower) / P exactly once, the jitter fills the LOWER HALF of the cell
+    (rand / P inside strata 2 / P wide) -- and any block of rows can be drawn on its own (sharded runs)."""
+    import oracle
+    from oracle import engine as oe
+
+    s = oracle.PhiloxStream(99)
+    lo, up = np.full(n, -5.12), np.linspace(1.0, 5.12, n)
+    X = s.lhs_population(P, n, lo, up)
+    cell = (X - lo) / (up - lo) * P
+    strata = np.floor(cell).astype(int)
+    assert all(sorted(strata[:, j]) == list(range(P)) for j in range(n))
+    assert (cell - strata < 0.5 + 1e-9).all()
+    parts = [s.lhs_population(P, n, lo, up, row0=r0, rows=min(3, P - r0)) for r0 in range(0, P, 3)]
+    assert np.array_equal(np.vstack(parts), X)
+    assert not np.array_equal(X, oracle.PhiloxStream(100).lhs_population(P, n, lo, up))
+    assert np.array_equal(oe.latin_hypercube(oracle.PhiloxStream(99), P, n, lo, up), X)  # what oracle.minimize starts from
