@@ -87,6 +87,7 @@ int64_t sx_fun_terms(int fun_id, int n);
  * records for sx_select_finalize.  16, 32 or 64 lanes evaluate one individual; n <= 4096.
  * ------------------------------------------------------------------------- */
 int64_t sx_num_partials(int64_t P, int n);
+int sx_rows_per_workgroup(int n); /* rows of one workgroup of the row kernels = rows behind one (part_f, part_i) record */
 int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd,
             double *f, double *part_f, int64_t *part_i, void *stream);
 

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "sx_sum_plan": (C.c_int, [i64, vp, C.c_int]),
     "sx_fun_terms": (i64, [C.c_int, C.c_int]),
     "sx_num_partials": (i64, [i64, C.c_int]),
+    "sx_rows_per_workgroup": (C.c_int, [C.c_int]),
     "sx_eval": (C.c_int, [C.c_int, vp, i64, C.c_int, i64, vp, vp, vp, vp, vp, vp]),
     "sx_philox_lhs": (C.c_int, [vp, i64, C.c_int, i64, i64, i64, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "sx_argmin": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp]),

@@ -101,6 +101,7 @@ extern "C" int64_t sx_fun_terms(int fun_id, int n) {
 }
 
 extern "C" int64_t sx_num_partials(int64_t P, int n) { return (int64_t)row_geometry(P, n).blocks; }
+extern "C" int sx_rows_per_workgroup(int n) { return rows_per_block(n); }
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out) {

@@ -170,6 +170,11 @@ class _PsoRun:
             self.ctx.sync()
             self.ctx.L.sx_graph_destroy(self._graph)
             self._graph = None
+        if getattr(self, "_chain_graphs", None):
+            self.ctx.sync()
+            for g in self._chain_graphs.values():
+                self.ctx.L.sx_graph_destroy(g)
+            self._chain_graphs = {}
         if self.px is not None:
             self.ctx.sync()
             self.px.close()
@@ -248,6 +253,40 @@ class _PsoRun:
         a.w, a.c1, a.c2, a.xtol, a.ftol = self.w, self.c1, self.c2, self.xtol, self.ftol
         a.key0, a.key1 = key0, key1
         self.args = a
+        # One kernel per generation (csrc/sx_pso.hip, CHAIN): plain PSO on one GPU with in-kernel draws and nothing to
+        # report per generation.  The best / termination step moves into the next launch's prologue; gbest is read from
+        # per-workgroup best-row copies (best_rows), the state becomes three words and the records two sets.
+        # OPT-IN (SX_PSO_CHAIN=1): bit-identical, but measured SLOWER than the generation + select_finalize pair at
+        # BASELINE config 3 -- 37.3 against 35.3 us per generation (profiles/r3_pso_chain.txt): unlike DE's 256
+        # workgroups, PSO's 2 048 make 2.7 rounds over the chip and each round pays the prologue's extra dependent trip
+        # to memory (records -> best row), which costs what the second kernel did.
+        self.chain = bool(self.world is None and self.rng == "philox" and self.external is None and not self.immediate
+                          and not self.gamma and self.callback is None and not self.return_all
+                          and os.environ.get("SX_PSO_CHAIN", "0") == "1" and ctx.L.sx_pso_chain_supported(C.byref(a)))
+        self.launches = 0
+        self._chain_graphs = {}
+        if self.chain:
+            rpb = int(ctx.L.sx_rows_per_workgroup(n))
+            # many cheap generations per look at the device (a look is a finalise-only launch + a synchronisation)
+            self.CHECK_EVERY, self.GRAPH_CHUNK = 256, 32
+            fit = self.pbestfit.cpu().numpy()
+            pf = np.full((2, npart), np.inf)
+            pi = np.full((2, npart), np.iinfo(np.int64).max, dtype=np.int64)
+            rows = np.empty(npart, dtype=np.int64)
+            for b in range(npart):
+                lo = b * rpb
+                k = lo + int(np.argmin(fit[lo : lo + rpb]))  # first minimum, like the kernel's record
+                rows[b], pf[0, b], pi[0, b] = k, fit[k], 2 * k
+            self.part_f, self.part_i = ctx.upload(pf), ctx.upload(pi)
+            self.best_rows = ctx.empty((2, npart, n))
+            self.best_rows[0].copy_(self.X[t.from_numpy(rows).to(ctx.device)])
+            self.rows_per_block = rpb
+            s0 = _lib.SxState(it=0, gbidx=g, gfit=gfit0, dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
+            s0.reserved[1] = 2 * g
+            st.reserved[0] = st.reserved[1] = 2 * g
+            self.state = ctx.upload(np.frombuffer(bytes(s0) + bytes(st) + bytes(st), dtype=np.int64).copy())
+            a.state, a.part_f, a.part_i = self.state.data_ptr(), self.part_f.data_ptr(), self.part_i.data_ptr()
+            # (a.gbest stays a valid pointer -- the chained kernel never touches it)
         if self.rng == "numpy-legacy":
             self.h_r = [t.empty((P, n), dtype=t.float64).pin_memory() for _ in range(2)]
             self.d_r = [ctx.empty((P, n)) for _ in range(2)]
@@ -421,14 +460,21 @@ class _PsoRun:
                 st = ctx.read_state(self.state)
             else:
                 self.enqueue(min(max(self.maxiter - st.it, 1), self.CHECK_EVERY))
-                st = ctx.read_state(self.state)
+                st = self.read_state()
                 if self.px is not None and self.px.failed():
                     raise RuntimeError("peer exchange timed out: a rank did not reach the generation the others "
                                        "were waiting for (SX_XCHG_TIMEOUT_S)")
         self.st = st
         status = int(st.status)
+        xbest = self.gbest.cpu().numpy()
+        if self.chain:
+            xbest = self._chain_row(st.reserved[1])
+            # the chained kernel stops on `fun <= ftol` with status 1; _common.py:135-140 calls it 0 when the best moved
+            # by <= xtol.  Both generations' best rows are still resident (nothing is produced after `done`).
+            if status == 1 and np.linalg.norm(self._chain_row(st.reserved[0]) - xbest) <= self.xtol:
+                status = 0
         res = OptimizeResult(
-            x=self.gbest.cpu().numpy(),
+            x=xbest,
             success=status >= 0,
             status=status,
             message=_common.messages[status],
@@ -448,10 +494,49 @@ class _PsoRun:
             self.world.barrier()  # no rank frees its exchange buffer while a peer may still write into it
         self._res = res
 
+    # ---- chained mode (one kernel per generation) ----
+    def _chain_launch(self, parity, finalize_only):
+        _lib.check(self.ctx.L.sx_pso_chain_launch(C.byref(self.args), _device.ptr(self.best_rows), parity, finalize_only,
+                                                  self.ctx.stream_ptr), "sx_pso_chain_launch")
+
+    def _chain_graph(self, par, size):
+        key = (par, size)
+        if key not in self._chain_graphs:
+            g = C.c_void_p()
+            _lib.check(self.ctx.L.sx_pso_chain_graph_create(C.byref(self.args), _device.ptr(self.best_rows), size, par,
+                                                            C.byref(g)), "sx_pso_chain_graph_create")
+            self._chain_graphs[key] = g
+        return self._chain_graphs[key]
+
+    def _enqueue_chain(self, ngen):
+        while ngen >= self.GRAPH_CHUNK:  # (GRAPH_CHUNK is even: a replay leaves the launch parity where it found it)
+            _lib.check(self.ctx.L.sx_graph_launch(self._chain_graph(self.launches & 1, self.GRAPH_CHUNK),
+                                                  self.ctx.stream_ptr), "sx_graph_launch")
+            self.launches += self.GRAPH_CHUNK
+            ngen -= self.GRAPH_CHUNK
+        for _ in range(ngen):
+            self._chain_launch(self.launches & 1, 0)
+            self.launches += 1
+
+    def read_state(self):
+        """Host view of the run: (chained mode) finalise the last generation into state[2], then read it."""
+        if not self.chain:
+            return self.ctx.read_state(self.state)
+        self._chain_launch(self.launches & 1, 1)
+        return self.ctx.read_state(self.state[16:24])
+
+    def _chain_row(self, rec):
+        """The best row a record points to: best_rows[q][workgroup of the row]."""
+        rec = int(rec)
+        return self.best_rows[rec & 1, (rec >> 1) // self.rows_per_block].cpu().numpy()
+
     def enqueue(self, ngen):
         """Enqueue `ngen` generations (and their restarts) without host synchronisation (Philox mode).
         Single GPU: full chunks replay one instantiated hipGraph of the loop body."""
         ctx = self.ctx
+        if self.chain:
+            self._enqueue_chain(ngen)
+            return
         if self.world is None:
             while ngen >= self.GRAPH_CHUNK:
                 if self._graph is None:

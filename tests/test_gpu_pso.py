@@ -162,3 +162,43 @@ def test_cpso_graph_path_equals_stepping_and_oracle(sa, objective, n, P, maxiter
                               options={k: v for k, v in opts.items() if k not in ("backend", "rng")})
         assert len(ref["_restarts"]) > 3, len(ref["_restarts"])
         assert ref.fun == graph.fun and np.array_equal(ref.x, graph.x) and ref.nit == graph.nit
+
+
+@pytest.mark.parametrize("objective,n,P,maxiter,ftol", [
+    ("sphere", 64, 40, 70, -1.0), ("rosenbrock", 128, 33, 45, -1.0), ("sphere", 256, 70, 301, -1.0),
+    ("ackley", 256, 2048, 90, -1.0), ("sphere", 64, 512, 4000, 1e-3), ("sphere", 128, 300, 4000, 30.0),
+    ("rastrigin", 256, 16384, 40, -1.0)])
+def test_pso_chained_kernel_equals_two_kernel_path_and_oracle(sa, objective, n, P, maxiter, ftol, monkeypatch):
+    """Plain PSO on whole-batch rows CAN run one kernel per generation (opt-in SX_PSO_CHAIN=1; csrc/sx_pso.hip CHAIN: best / termination in the next
+    launch's prologue, gbest read from per-workgroup best-row copies; replayed 32-generation graphs + eager tail + the
+    finalise-only looks).  Same run, bit for bit, as the generation + select_finalize pair (SX_PSO_CHAIN=0) and as the
+    oracle: fun, x, nit, status -- including stops on ftol (status 0 / 1 settled from the two resident best rows) and
+    run lengths that are no multiple of the graph length."""
+    from stochopy_amd.optimize import _cpso
+
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 31 + n, "updating": "deferred", "ftol": ftol, "xtol": 1e-9}
+    bounds = [[-3.0, 2.0]] * n
+    chained = []
+    orig = _cpso._PsoRun._setup
+
+    def spy(self):
+        orig(self)
+        chained.append(self.chain)
+
+    monkeypatch.setattr(_cpso._PsoRun, "_setup", spy)
+    monkeypatch.setenv("SX_PSO_CHAIN", "1")  # (opt-in: measured slower than the two-kernel path, see _cpso.py)
+    got = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="pso", options=dict(opts, backend="hip", rng="philox"))
+    monkeypatch.setenv("SX_PSO_CHAIN", "0")
+    two = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="pso", options=dict(opts, backend="hip", rng="philox"))
+    assert chained == [True, False]
+    assert (got.fun, got.nit, got.nfev, got.status, got.message) == (two.fun, two.nit, two.nfev, two.status, two.message)
+    assert np.array_equal(got.x, two.x)
+    if P <= 4096:
+        ref = oracle.minimize(objective, bounds, method="pso", options=dict(opts), rng="philox")
+        assert (got.nit, got.status) == (ref.nit, ref.status)
+        if objective in ("sphere", "rosenbrock"):
+            assert got.fun == ref.fun and np.array_equal(got.x, ref.x)
+        else:
+            assert np.isclose(got.fun, ref.fun, rtol=1e-6)
+    if ftol > 0:
+        assert got.status in (0, 1) and got.nit < maxiter
