@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C3a / C3b / C4 block")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU work spent on the baseline sample")
     ap.add_argument("--kernel-timing-launches", type=int, default=400)
+    ap.add_argument("--min-timed-seconds", type=float, default=2.0,
+                    help="the K-step block is repeated until the timed region lasts this long (profilers: pass less)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -283,7 +285,7 @@ def main():
         return tt.item()
 
     MAX_BLOCKS = 1 << 20
-    MIN_TIMED_S = 2.0  # (the driver's GPU-busy sampler and timed-region check need seconds, not milliseconds)
+    MIN_TIMED_S = args.min_timed_seconds  # (the driver's GPU-busy sampler and timed-region check need seconds)
 
     def measure(exchange, objective=objective, n=n, Ptotal=None, strategy=strategy, donors=os.environ.get("SX_DONORS"),
                 K=K, W=W, kernel_launches=args.kernel_timing_launches):
@@ -398,7 +400,7 @@ def main():
             try:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc.sh), with the
                 rec = json.load(open(pmc))  # commit they were measured at: not measured inside this run
                 traffic = rec.get(args.workload, {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc passes (tools/r2_profiles.sh) at commit %s" % rec.get(
+                traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc passes (tools/r3_profiles.sh) at commit %s" % rec.get(
                     "_commit", "unrecorded")
             except Exception:
                 traffic = None

@@ -15,6 +15,8 @@
 // generation number) and looks at the state every few generations.  Once a stopping rule fires the result
 // (best point of that generation, un-standardised) is copied aside and the bookkeeping kernels of later launches
 // do nothing.
+#include <algorithm>
+
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 
@@ -386,8 +388,11 @@ extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eig
     if (do_eigh) {
         if ((rc = sx_symmetrize_upper(a->C, n, stream))) return rc;
         // do_eigh == 2: start from the previous eigenvectors (B is both the starting basis and the output)
+        // tolerance: what LAPACK's own decomposition guarantees, a backward error of n * eps * |C|_F (never below the
+        // solver's default 1e-14): at n = 512 that is 5.7e-14 -- about one decomposition in two stops a sweep earlier
+        const double tol = std::max(1.0e-14, (double)n * 1.1102230246251565e-16);
         if ((rc = sx_eigh(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes,
-                          a->eig_sweeps, 0.0, stream)))
+                          a->eig_sweeps, tol, stream)))
             return rc;
     }
     hipLaunchKernelGGL(cma_stop_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, do_eigh ? 1 : 0);

@@ -466,7 +466,8 @@ class _CmaRun:
                     if eig is None:
                         eig = Eigh(ctx, n)
                     # ascending eigenvalues, eigenvectors in columns; from the second time on, started from the last ones
-                    Dt, _ = eig(d_C, B=d_B, max_sweeps=eig_sweeps, start=d_B if eig_warm else None)
+                    Dt, _ = eig(d_C, B=d_B, max_sweeps=eig_sweeps, start=d_B if eig_warm else None,
+                                tol=max(1.0e-14, n * 1.1102230246251565e-16))  # LAPACK's own backward error, n * eps
                     was_warm, eig_warm = eig_warm, True
                     t.sqrt(Dt, out=d_D)
                     D = d_D.cpu().numpy()
