@@ -477,6 +477,11 @@ typedef struct sx_cma_args {
     int64_t *order;             /* (P) argsort of fit                                                 */
     void *state;                /* sx_cma_state                                                       */
     void *eigh_ws;              /* sx_eigh workspace                                                  */
+    double *pen_ws;             /* constraints="Penalize" on the device (cmaes/_constraints.py:4-82), or NULL: doubles
+                                 * [weights n | v n | penalty P | spread history 256 | count, validfitval, iniphase, -];
+                                 * initialise weights = 0, history[0] = 1, count = 1, validfitval = 0, iniphase = 1.  Needs
+                                 * int(20 + 3n/P) + 1 <= 256 history entries (else: the host-driven loop)   */
+    int64_t *pen_order;         /* (P) argsort of the raw fitness (percentiles of :34-35), with pen_ws      */
     int64_t eigh_ws_bytes;
     int64_t P;
     int64_t hist_rows;          /* ceil(verbosity * popsize)                                          */
@@ -486,6 +491,13 @@ typedef struct sx_cma_args {
 } sx_cma_args;
 
 int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream);
+/* The same generation in two steps for candidates sharded over ranks (workers > 1; what the reference's parallel backends
+ * shard: _common.py:58-72).  stage 0: this rank's candidates [row0, row0 + rows) -- Philox normals keyed by the global
+ * row, sampling GEMM, objective -- into arx_loc (rows,n) / fit_loc (rows) (a->Z: scratch of >= rows x n); the caller
+ * all-gathers them into a->arx / a->fit; stage 1: everything else (ranking ... stop rules; Penalize's bookkeeping and
+ * penalty pass), replicated on every rank.  stage 0 with all rows + stage 1 == sx_cmaes_generation. */
+int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, int stage, int64_t row0, int64_t rows,
+                              double *arx_loc, double *fit_loc, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Symmetric eigendecomposition on the device (csrc/sx_eigh.hip): parallel two-sided block Jacobi, the

@@ -92,6 +92,7 @@ class SxCmaArgs(C.Structure):
         ("D", vp), ("eigw", vp), ("w", vp), ("Y", vp), ("part", vp), ("step", vp), ("isc", vp), ("xnew", vp),
         ("ypart", vp), ("besthist", vp), ("xm", vp), ("xstd", vp),
         ("xbest", vp), ("hist_x", vp), ("hist_f", vp), ("order", vp), ("state", vp), ("eigh_ws", vp),
+        ("pen_ws", vp), ("pen_order", vp),
         ("eigh_ws_bytes", i64), ("P", i64), ("hist_rows", i64),
         ("n", i32), ("mu", i32), ("fun_id", i32), ("maxiter", i32), ("ilim", i32), ("eig_sweeps", i32),
         ("cs", f64), ("cc", f64), ("c1", f64), ("cmu", f64), ("damps", f64), ("chind", f64), ("mueff", f64),
@@ -165,6 +166,7 @@ PROTOTYPES = {
     "sx_na_uniforms": (C.c_int, [vp, i64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "sx_vdcma_moments": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, f64, vp, vp, vp]),
     "sx_cmaes_generation": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, vp]),
+    "sx_cmaes_generation_stage": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, C.c_int, i64, i64, vp, vp, vp]),
     "sx_vdcma_generation": (C.c_int, [C.POINTER(SxVdArgs), i64, vp]),
     "sx_eigh_workspace_bytes": (i64, [C.c_int]),
     "sx_eigh": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, vp]),

@@ -42,6 +42,7 @@ __device__ __forceinline__ bool key_less(double a, double b) { return a < b || (
 
 // order = argsort(fit) (ties: lower index first); best row / value and the history entry of the generation.
 // 64 elements per workgroup, 4 slices of the key range per element; the keys pass through LDS 4096 at a time.
+// besthist == NULL: ranking only (the raw fitness behind Penalize's percentiles): no best row, no history entry
 __global__ __launch_bounds__(256) void cma_rank_kernel(const double *__restrict__ fit, int64_t P,
                                                        int64_t *__restrict__ order, sx_cma_state *state,
                                                        double *__restrict__ besthist, int64_t gen) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void cma_rank_kernel(const double *__restrict_
     if (ty == 0 && i < P) {
         const int64_t rank = (int64_t)part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
         order[rank] = i;
-        if (rank == 0) {
+        if (rank == 0 && besthist != nullptr) {
             state->best_row = i;
             state->fbest = fi;
             besthist[gen - 1] = fi;
@@ -118,8 +119,114 @@ __global__ __launch_bounds__(256) void cma_history_kernel(const sx_cma_args a, i
     const int64_t r = t / n;
     const int e = (int)(t % n);
     const int64_t src = a.hist_rows > 0 ? r : state->best_row;
-    a.hist_x[((gen - 1) * rows + r) * n + e] = a.arx[src * n + e] * a.xstd[e] + a.xm[e];
+    double x = a.arx[src * n + e];
+    if (a.pen_ws != nullptr) x = fmin(fmax(x, -1.0), 1.0);  // Penalize: the caller sees the clipped points (:238-256)
+    a.hist_x[((gen - 1) * rows + r) * n + e] = x * a.xstd[e] + a.xm[e];
     if (e == 0) a.hist_f[(gen - 1) * rows + r] = a.fit[src];
+}
+
+// constraints="Penalize", the bookkeeping of cmaes/_constraints.py:33-76 on the device (round 3; the host-driven loop
+// keeps its numpy form, optimize/_cmaes.py _BoundaryWeights): percentiles of the RAW fitness (np.percentile's linear rule
+// incl. its lerp), the sliding history of fitness-spread estimates and its median, the weight growth for coordinates of
+// the mean that sit outside the box, and v = weights / scale for the penalty pass.  One workgroup.
+constexpr int kPenHist = 256;
+
+__device__ __forceinline__ double np_lerp(double a, double b, double t) {  // numpy/lib/_function_base_impl.py _lerp
+    const double d = b - a;
+    return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+__device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : (x == 0.0 ? 0.0 : x)); }
+
+__global__ __launch_bounds__(kPathThreads) void cma_penalty_kernel(const sx_cma_args a, int64_t gen) {
+    __shared__ double red3[kPathThreads / 64][3];
+    __shared__ double s_fill, s_meanlog;
+    __shared__ int s_dofill, s_outside;
+    __shared__ double s_sort[kPenHist];
+    const sx_cma_state *state = (const sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x;
+    const int64_t P = a.P;
+    double *w = a.pen_ws, *v = w + n, *hist = w + 2 * (int64_t)n + P, *meta = hist + kPenHist;
+    const double sigma = state->sigma;
+    // sums over the diagonal of C, their logarithms, and "any coordinate of the mean outside [-1, 1]"
+    double sd = 0.0, sl = 0.0, so = 0.0;
+    for (int e = tid; e < n; e += kPathThreads) {
+        const double dc = a.C[(int64_t)e * n + e], xm = a.xmean[e];
+        sd += dc, sl += log(dc);
+        if (xm < -1.0 || xm > 1.0) so += 1.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sd += __shfl_xor(sd, off, kWave), sl += __shfl_xor(sl, off, kWave), so += __shfl_xor(so, off, kWave);
+    }
+    if ((tid & 63) == 0) red3[tid >> 6][0] = sd, red3[tid >> 6][1] = sl, red3[tid >> 6][2] = so;
+    __syncthreads();
+    if (tid == 0) {
+        sd = sl = so = 0.0;
+        for (int k = 0; k < kPathThreads / 64; ++k) sd += red3[k][0], sl += red3[k][1], so += red3[k][2];
+        // :34-35  q25, q75 = np.percentile(fit, [25, 75]): virtual index (P - 1) q, linear interpolation
+        double q[2];
+        for (int h = 0; h < 2; ++h) {
+            const double vi = (double)(P - 1) * (h ? 0.75 : 0.25);
+            const int64_t lo = (int64_t)floor(vi), hi = lo + 1 < P ? lo + 1 : P - 1;
+            q[h] = np_lerp(a.fit[a.pen_order[lo]], a.fit[a.pen_order[hi]], vi - (double)lo);
+        }
+        double delta = (q[1] - q[0]) / (double)n / (sd / (double)n) / (sigma * sigma);
+        int count = (int)meta[0], valid = (int)meta[1], ini = (int)meta[2];
+        if (delta == 0.0) {  // :38-42
+            double m = __builtin_huge_val();
+            for (int k = 0; k < count; ++k)
+                if (hist[k] > 0.0) m = fmin(m, hist[k]);
+            delta = m;
+        } else if (!valid) {
+            count = 0, valid = 1;
+        }
+        const double cap = 20.0 + (3.0 * (double)n) / (double)P;  // :45-48 sliding window
+        if ((double)count < cap) {
+            hist[count++] = delta;
+        } else {
+            for (int k = 1; k < count; ++k) hist[k - 1] = hist[k];
+            hist[count - 1] = delta;
+        }
+        const int outside = so > 0.0;
+        int dofill = 0;
+        if (ini && outside) {  // :56-59  weights = 2.0002 * median(history)
+            for (int k = 0; k < count; ++k) {  // insertion sort of a copy
+                const double x = hist[k];
+                int j = k;
+                while (j > 0 && s_sort[j - 1] > x) s_sort[j] = s_sort[j - 1], --j;
+                s_sort[j] = x;
+            }
+            const double med = (count & 1) ? s_sort[count / 2] : 0.5 * (s_sort[count / 2 - 1] + s_sort[count / 2]);
+            s_fill = 2.0002 * med;
+            dofill = 1;
+            if (valid && gen > 2) ini = 0;
+        }
+        meta[0] = (double)count, meta[1] = (double)valid, meta[2] = (double)ini;
+        s_dofill = dofill, s_outside = outside, s_meanlog = sl / (double)n;
+    }
+    __syncthreads();
+    const int dofill = s_dofill, outside = s_outside;
+    const double fill = s_fill, meanlog = s_meanlog;
+    const double kk = 3.0 * fmax(1.0, sqrt((double)n / a.mueff)) * sigma, fac = pow(1.2, fmin(1.0, a.mueff / 10.0 / (double)n));
+    for (int e = tid; e < n; e += kPathThreads) {
+        double we = dofill ? fill : w[e];
+        const double dc = a.C[(int64_t)e * n + e], xm = a.xmean[e];
+        if (outside) {  // :61-73 (the excess is measured against a mean clipped on the UPPER side only, as the reference does)
+            const double tx = xm - (xm > 1.0 ? 1.0 : xm);
+            const bool out = xm < -1.0 || xm > 1.0;
+            if (out && fabs(tx) > kk * sqrt(dc) && np_sign(tx) == np_sign(xm - a.xold[e])) we *= fac;
+        }
+        w[e] = we;
+        v[e] = we / exp(0.9 * (log(dc) - meanlog));  // :76
+    }
+}
+
+__global__ __launch_bounds__(256) void cma_add_penalty_kernel(const sx_cma_args a) {
+    const sx_cma_state *state = (const sx_cma_state *)a.state;
+    if (state->done) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.P) a.fit[i] = a.fit[i] + a.pen_ws[2 * (int64_t)a.n + i];  // :79
 }
 
 template <class F>
@@ -318,7 +425,11 @@ __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_arg
         status = -8;
     if (status != SX_STATUS_NONE) {  // the caller's result: best candidate of THIS generation, un-standardised (:345-353)
         const double *row = a.arx + state->best_row * (int64_t)n;
-        for (int e = tid; e < n; e += kPathThreads) a.xbest[e] = row[e] * a.xstd[e] + a.xm[e];
+        for (int e = tid; e < n; e += kPathThreads) {
+            double x = row[e];
+            if (a.pen_ws != nullptr) x = fmin(fmax(x, -1.0), 1.0);  // Penalize: the clipped point (:336-350)
+            a.xbest[e] = x * a.xstd[e] + a.xm[e];
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -353,7 +464,8 @@ int cma_history_launch(const sx_cma_args &h, int64_t gen, void *stream) {
 }
 }  // namespace sx
 
-extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
+namespace {
+int check_cma_args(const sx_cma_args *a, int64_t gen) {
     SX_REQUIRE(a && a->Z && a->arx && a->fit && a->xmean && a->xold && a->ps && a->pc && a->C && a->B && a->D && a->w &&
                    a->Y && a->part && a->step && a->isc && a->ypart && a->xnew && a->besthist && a->xm && a->xstd && a->xbest && a->eigw && a->order && a->state &&
                    a->eigh_ws,
@@ -361,14 +473,64 @@ extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eig
     SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->mu >= 1 && a->mu <= a->P && gen >= 1 && gen <= a->maxiter,
                "sx_cmaes_generation: bad shape or generation number");
     SX_REQUIRE(a->n <= 4096, "sx_cmaes_generation: n <= 4096");
+    SX_REQUIRE(a->pen_ws == nullptr || (a->pen_order != nullptr && 20.0 + 3.0 * a->n / (double)a->P + 1.0 <= (double)kPenHist),
+               "sx_cmaes_generation: Penalize needs pen_order and a spread history of at most 256 entries");
+    return 0;
+}
+
+// candidates [row0, row0 + rows) of generation `gen`: normals (keyed by the GLOBAL row), sampling GEMM, objective (of the
+// clipped points with Penalize) -> arx_out (rows, n), fit_out (rows); Z: scratch (rows, n)
+int cma_candidates(const sx_cma_args *a, int64_t gen, int64_t row0, int64_t rows, double *Z, double *arx_out,
+                   double *fit_out, void *stream) {
+    const int n = a->n;
+    sx_cma_state *state = (sx_cma_state *)a->state;
+    int rc;
+    if ((rc = sx_cmaes_normals(Z, rows, n, row0, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
+    if ((rc = sx::cma_sample_launch(a->xmean, 0.0, &state->sigma, a->B, a->D, Z, arx_out, rows, n, stream))) return rc;
+    if (a->pen_ws == nullptr) return sx_eval(a->fun_id, arx_out, rows, n, n, a->xm, a->xstd, fit_out, nullptr, nullptr, stream);
+    return sx_cmaes_eval_penalized(a->fun_id, arx_out, rows, n, a->xm, a->xstd, nullptr, fit_out, nullptr, stream);
+}
+int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream);
+}  // namespace
+
+extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
+    if (int rc = check_cma_args(a, gen)) return rc;
+    if (int rc = cma_candidates(a, gen, 0, a->P, a->Z, a->arx, a->fit, stream)) return rc;
+    return cma_model_update(a, gen, do_eigh, stream);
+}
+
+// The same generation in two steps, for candidates sharded over ranks (workers > 1: what the reference's parallel backends
+// shard, _common.py:58-72): stage 0 = this rank's candidates [row0, row0 + rows) into arx_loc / fit_loc (a->Z: scratch of at
+// least rows x n); the caller all-gathers them into a->arx / a->fit; stage 1 = everything else, replicated on every rank
+// (ranking, recombination, paths, covariance, decomposition, stop rules -- and Penalize's bookkeeping + penalty pass).
+extern "C" int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, int stage, int64_t row0,
+                                         int64_t rows, double *arx_loc, double *fit_loc, void *stream) {
+    if (int rc = check_cma_args(a, gen)) return rc;
+    if (stage == 0) {
+        SX_REQUIRE(arx_loc && fit_loc && row0 >= 0 && rows >= 1 && row0 + rows <= a->P, "sx_cmaes_generation_stage: bad shard");
+        return cma_candidates(a, gen, row0, rows, a->Z, arx_loc, fit_loc, stream);
+    }
+    return cma_model_update(a, gen, do_eigh, stream);
+}
+
+namespace {
+int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int n = a->n;
     const int64_t P = a->P;
     sx_cma_state *state = (sx_cma_state *)a->state;
     int rc;
-    if ((rc = sx_cmaes_normals(a->Z, P, n, 0, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
-    if ((rc = sx::cma_sample_launch(a->xmean, 0.0, &state->sigma, a->B, a->D, a->Z, a->arx, P, n, stream))) return rc;
-    if ((rc = sx_eval(a->fun_id, a->arx, P, n, n, a->xm, a->xstd, a->fit, nullptr, nullptr, stream))) return rc;
+    if (a->pen_ws != nullptr) {
+        // Penalize (cmaes/_constraints.py:4-82): a->fit holds the objective of the clipped candidates; the boundary-weight
+        // bookkeeping from its percentiles, then the weighted squared excess on top (the second pass recomputes the same raw values)
+        hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, a->fit, P, a->pen_order, state,
+                           (double *)nullptr, gen);
+        hipLaunchKernelGGL(cma_penalty_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen);
+        if ((rc = sx_cmaes_eval_penalized(a->fun_id, a->arx, P, n, a->xm, a->xstd, a->pen_ws + n, a->fit,
+                                          a->pen_ws + 2 * (int64_t)n, stream)))
+            return rc;
+        hipLaunchKernelGGL(cma_add_penalty_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, *a);
+    }
     hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, a->fit, P, a->order, state,
                        a->besthist, gen);
     if (a->hist_x) {
@@ -399,3 +561,4 @@ extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eig
     SX_LAUNCH_CHECK();
     return 0;
 }
+}  // namespace

@@ -84,11 +84,14 @@ def minimize(
         eigh = "host" if rng == "numpy-legacy" else "device"
     if not callable(eigh) and eigh not in ("host", "device"):
         raise ValueError("eigh must be 'host', 'device' or a callable C -> (eigenvalues, eigenvectors)")
-    if (rng == "philox" and eigh == "device" and isinstance(fun_id, int) and workers == 1 and constraints is None
-            and callback is None):
-        # nothing the host has to see between generations: the whole loop (and the history) stays on the device
+    if (rng == "philox" and eigh == "device" and isinstance(fun_id, int) and callback is None
+            and (constraints is None or 20.0 + 3.0 * len(lower) / int(popsize) + 1.0 <= 256.0)):
+        # nothing the host has to see between generations: the whole loop (and the history) stays on the device --
+        # since round 3 including constraints="Penalize" (its boundary-weight bookkeeping: cma_penalty_kernel) and
+        # workers > 1 (every rank samples and evaluates its share of the candidates, one all-gather, replicated model)
         return _CmaDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
-                             float(xtol), float(ftol), seed, bool(return_all), float(verbosity)).result()
+                             float(xtol), float(ftol), seed, bool(return_all), float(verbosity),
+                             penalize=constraints == "Penalize", workers=workers).result()
     run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                   float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh, workers,
                   penalize=constraints == "Penalize")
@@ -122,7 +125,7 @@ class _CmaDeviceRun:
     WARM_SWEEPS0 = 16  # launched for the first warm-started one; afterwards: what the last one needed + 1
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
-                 verbosity=1.0, run=True):
+                 verbosity=1.0, run=True, penalize=False, workers=1):
         """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
         with ``step`` from a state of their choosing."""
         import ctypes as C
@@ -132,6 +135,12 @@ class _CmaDeviceRun:
         ctx = self.ctx = _device.Context()
         t = _device.torch()
         L, ptr, n = ctx.L, _device.ptr, len(lower)
+        world, row0, Pl = None, 0, P
+        if workers != 1:
+            from ..parallel import require_world
+
+            world = require_world(workers)
+            row0, Pl = world.shard(P)  # popsize must divide evenly
         with t.cuda.stream(ctx.stream):
             init = _rng.make_init_stream("philox", seed)
             key0, key1 = _rng.philox_key(seed)
@@ -146,6 +155,12 @@ class _CmaDeviceRun:
                 part=ctx.empty((64, n)), step=ctx.empty((n,)), isc=ctx.empty((n,)), xnew=ctx.empty((n,)),
                 ypart=ctx.empty((8, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
                 xbest=ctx.zeros((n,)), order=ctx.empty((P,), dtype=t.int64), eigh_ws=eig.ws)
+            if penalize:  # cmaes/_constraints.py:4-82 on the device: weights 0, spread history [1.0], both phase flags as at :213-215
+                pw = np.zeros(2 * n + P + 256 + 4)
+                pw[2 * n + P] = 1.0
+                pw[2 * n + P + 256: 2 * n + P + 259] = (1.0, 0.0, 1.0)
+                keep["pen_ws"] = ctx.upload(pw)
+                keep["pen_order"] = ctx.empty((P,), dtype=t.int64)
             nout = int(np.ceil(verbosity * P)) if return_all else 0
             if return_all:  # device-side history slabs, read back once at the end
                 keep["hist_x"] = ctx.empty((maxiter, max(1, nout), n))
@@ -160,6 +175,8 @@ class _CmaDeviceRun:
             a.cs, a.cc, a.c1, a.cmu, a.damps, a.chind, a.mueff = cs, cc, c1, cmu, damps, chind, mueff
             a.xtol, a.ftol, a.insigma, a.key0, a.key1 = xtol, ftol, sigma, key0, key1
             self.buffers, self.args, self.eig, self.P = keep, a, eig, P
+            if world is not None:
+                arx_loc, fit_loc = ctx.empty((Pl, n)), ctx.empty((Pl,))
             self.eig_every = eig_every = P / (c1 + cmu) / n / 10.0  # :301
             if not run:
                 return
@@ -176,7 +193,16 @@ class _CmaDeviceRun:
                     eigeneval = gen * P
                     a.eig_sweeps = launched = self.COLD_SWEEPS if due == 1 else warm_sweeps
                     decomposed = True
-                _lib.check(L.sx_cmaes_generation(C.byref(a), gen, int(due), ctx.stream_ptr), "sx_cmaes_generation")
+                if world is None:
+                    _lib.check(L.sx_cmaes_generation(C.byref(a), gen, int(due), ctx.stream_ptr), "sx_cmaes_generation")
+                else:  # own candidates, one gather of candidates and fitness, the model update replicated on every rank
+                    _lib.check(L.sx_cmaes_generation_stage(C.byref(a), gen, int(due), 0, row0, Pl, ptr(arx_loc), ptr(fit_loc),
+                                                           ctx.stream_ptr), "sx_cmaes_generation_stage")
+                    world.all_gather_rows(arx_loc, keep["arx"])
+                    world.all_gather_rows(fit_loc, keep["fit"])
+                    _lib.check(L.sx_cmaes_generation_stage(C.byref(a), gen, int(due), 1, 0, 0, None, None, ctx.stream_ptr),
+                               "sx_cmaes_generation_stage")
+                    look = 1  # (every rank must stop enqueueing collectives at the same generation)
                 since += 1
                 if since >= look or gen == maxiter:
                     state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
@@ -193,7 +219,7 @@ class _CmaDeviceRun:
                             warm_sweeps = 60
                         decomposed = False
                     now = time.perf_counter()
-                    if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
+                    if world is None and now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
                         look *= 2
                     since, t0 = 0, now
             if not state.done:  # cannot happen: generation maxiter sets status -1

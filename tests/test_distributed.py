@@ -344,11 +344,15 @@ def test_sharded_cmaes_matches_single_gpu(rng):
     resident = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="cmaes",
                                     options=dict(opts, backend="hip"))
     assert (resident.nit, resident.status) == (one.nit, one.status) and np.isclose(resident.fun, one.fun, rtol=1e-6)
+    # round 3: the sharded Philox run stays on the device too (sx_cmaes_generation_stage: own candidates, one gather, the
+    # model update replicated) -- the SAME kernels as the one-GPU resident run, so bit-identical to it; legacy draws take
+    # the host-driven loop on any number of ranks
+    want = resident if rng == "philox" else one
     out = _spawn(gpu_minimize_worker, 2, cfg)
     for r in range(2):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
-        assert (fun, nit, nfev, status) == (one.fun, one.nit, one.nfev, one.status)
-        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), one.x)
+        assert (fun, nit, nfev, status) == (want.fun, want.nit, want.nfev, want.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), want.x)
 
 
 @pytest.mark.gpu

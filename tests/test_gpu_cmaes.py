@@ -228,6 +228,42 @@ def test_cmaes_penalize_philox_and_sharded_eval_shapes(sa):
     assert np.all(got.x >= 1.0 - 1e-15) and np.allclose(got.x, ref.x, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("obj,n,P,lo,hi,maxiter,verbosity", [
+    ("sphere", 6, 12, 1.0, 5.0, 80, 1.0),       # the optimum sits on the boundary: the mean leaves the box, weights grow
+    ("rosenbrock", 10, 24, -0.5, 0.8, 60, 0.5),  # optimum (1, .., 1) outside: active penalties throughout
+    ("sphere", 40, 82, 2.0, 3.0, 30, 0.0),       # blocks of the eigensolver's small path, mu + 1 >= n
+    ("rastrigin", 130, 264, 0.3, 5.12, 16, 1.0),  # the block eigensolver (n > 64)
+])
+def test_cmaes_penalize_in_the_device_resident_loop_vs_oracle(sa, obj, n, P, lo, hi, maxiter, verbosity, monkeypatch):
+    """constraints="Penalize" with Philox draws and no callback stays on the device since round 3:
+    clipped objective, percentiles of the raw fitness, spread history + median, boundary weights, weighted squared excess
+    (csrc/sx_cma_loop.hip cma_penalty_kernel; cmaes/_constraints.py:4-82).  Against the oracle (LAPACK + canonical
+    signs): stopping generation, status, the full history (clipped points and PENALISED fitness, as the reference
+    stores them) and the result within the north-star tolerance; every visible point inside the box."""
+    from stochopy_amd.optimize import _cmaes
+
+    taken = []
+    orig = _cmaes._CmaDeviceRun.__init__
+
+    def spy(self, *a, **k):
+        taken.append(k.get("penalize"))
+        orig(self, *a, **k)
+
+    monkeypatch.setattr(_cmaes._CmaDeviceRun, "__init__", spy)
+    bounds = [[lo, hi]] * n
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 2024 + n, "sigma": 0.3, "constraints": "Penalize", "return_all": True,
+            "verbosity": verbosity, "ftol": -1.0, "xtol": 0.0}
+    ref = oracle.minimize(obj, bounds, method="cmaes", options=dict(opts, eigh="canonical"), rng="philox")
+    got = sa.optimize.minimize(getattr(sa.factory, obj), bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"))
+    assert taken == [True]  # the device-resident loop ran, with the penalty bookkeeping on the device
+    assert (got.nit, got.nfev, got.status) == (ref.nit, ref.nfev, ref.status)
+    assert got.funall.shape == ref.funall.shape and got.xall.shape == ref.xall.shape
+    assert np.allclose(got.funall, ref.funall, rtol=1e-6, atol=1e-300), np.abs(got.funall / ref.funall - 1).max()
+    assert np.allclose(got.xall, ref.xall, rtol=1e-5, atol=1e-6 * (hi - lo))
+    assert np.isclose(got.fun, ref.fun, rtol=1e-6, atol=0) and np.allclose(got.x, ref.x, rtol=1e-5, atol=1e-6 * (hi - lo))
+    assert np.all(got.xall >= lo - 1e-15) and np.all(got.xall <= hi + 1e-15) and np.all(got.x >= lo - 1e-15)
+
+
 def test_cmaes_philox_vs_oracle(sa):
     n, P = 20, 48  # mu + 1 >= n: the eigenbasis is determined (see _eigenbasis_is_determined)
     opts = {"maxiter": 12, "popsize": P, "seed": 4242, "sigma": 0.2}
