@@ -66,16 +66,35 @@ def one_eigh():
     return ok, f"n={n} {kind} warm={start is not None} sweeps={sweeps} conv={conv} eig={e1:.1e} resid={e2:.1e} orth={e3:.1e}"
 
 
+tie_cases = 0
+
+
 def one_cmaes():
-    n = int(rs.randint(2, 40))
+    big = rs.rand() < 0.15  # round 3: now and then the block path of the eigensolver (n > 64) inside the loop
+    n = int(rs.randint(65, 160)) if big else int(rs.randint(2, 40))
     P = int(rs.randint(2 * n + 2, 4 * n + 8))  # mu + 1 >= n: the eigenbasis is determined
     obj = str(rs.choice(["rosenbrock", "sphere", "rastrigin", "ackley"]))
-    o = {"maxiter": int(rs.randint(3, 40)), "popsize": P, "seed": int(rs.randint(1 << 30)), "sigma": float(rs.uniform(0.05, 0.5))}
+    o = {"maxiter": int(rs.randint(3, 14 if big else 40)), "popsize": P, "seed": int(rs.randint(1 << 30)),
+         "sigma": float(rs.uniform(0.05, 0.5))}
     if rs.rand() < 0.3:
         o["return_all"] = True
         o["verbosity"] = float(rs.choice([0.0, 0.5, 1.0]))
     b = [[-float(rs.uniform(1, 6)), float(rs.uniform(1, 6))]] * n
+    if rs.rand() < 0.35:  # round 3: constraints="Penalize" stays in the device-resident loop; boxes the mean tends to leave
+        o["constraints"] = "Penalize"
+        lo = float(rs.uniform(-2, 2))
+        b = [[lo, lo + float(rs.uniform(0.5, 4))]] * n
     ref = oracle.minimize(obj, b, method="cmaes", options=dict(o, eigh="canonical"), rng="philox")
+    if "constraints" in o:
+        # Candidates clipped to the same corner of the box have EXACTLY equal fitness while the boundary weights are still
+        # zero.  The device ranks ties by index (stable); numpy's default argsort -- the reference's and the oracle's -- is
+        # the AVX-512 / AVX2 vectorised sort on x86, whose tie order is an accident of the build and the CPU.  Such runs have
+        # no defined reference trajectory: counted, not compared.
+        full = oracle.minimize(obj, b, method="cmaes", options=dict(o, eigh="canonical", return_all=True, verbosity=1.0), rng="philox")
+        if any(len(np.unique(row)) < len(row) for row in full.funall):
+            global tie_cases
+            tie_cases += 1
+            return True, "exact fitness ties (undefined order in the reference)"
     got = sa.optimize.minimize(getattr(sa.factory, obj), b, method="cmaes", options=dict(o, backend="hip", rng="philox"))
     ok = (got.nit, got.status) == (ref.nit, ref.status) and np.isclose(got.fun, ref.fun, rtol=1e-5, atol=1e-12)
     if ok and "return_all" in o:
@@ -143,5 +162,6 @@ for name, fn in (("eigh", one_eigh), ("cmaes device loop", one_cmaes), ("vdcma d
     if only and only not in name:
         continue
     bad += family(name, fn)
+print(f"(Penalize runs with exact fitness ties -- undefined argsort order in the reference, not compared: {tie_cases})")
 print("TOTAL mismatches:", bad)
 sys.exit(1 if bad else 0)
