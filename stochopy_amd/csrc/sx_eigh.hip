@@ -35,6 +35,7 @@
 #include "sx_host.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 using namespace sx;
@@ -842,7 +843,9 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
 #pragma unroll
         for (int r = 0; r < 4; ++r) L.p.Y[b][(16 * h + lk + 4 * r) * LDY + lr] = a[r];
     }
+    SX_ETP(2);
     __syncthreads();
+    SX_ETP(9);
     double m2 = 0.0;  // off-diagonal mass of this wave's sub-block (added to the sweep's total at the very end)
     if (wave < 3) {  // second products: T_b = A_left^T Y_b (16x16), one sub-block per wave
         const double *UL = wave == 2 ? L.p.UB : L.p.UA;
@@ -866,6 +869,7 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
             }
         }
     }
+    SX_ETP(15);
     __syncthreads();  // stage 1 is over: its LDS is reused for the sweep
     SX_ETP(3);
     const SweepView view{L.S0, L.j.S1, L.cs, L.j.W0};

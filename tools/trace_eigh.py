@@ -25,6 +25,8 @@ b = buf.reshape(64, 16).astype(np.int64)[: max(1, n // 32)]
 for nm, k0, k1 in (("load tiles+U", 0, 1), ("pivot (MFMA) + off2", 1, 3), ("sweep", 3, 4), ("store U", 4, 5)):
     d = b[:, k1] - b[:, k0]
     print(f"{nm:20s} mean {d.mean():9.0f} cycles  min {d.min()} max {d.max()}")
+print("pivot phase, wave 0: first products (LDS reads + 8 MFMAs + Y store)", (b[:, 2] - b[:, 1]).mean(), "barrier", (b[:, 9] - b[:, 2]).mean(),
+      "second products + pivot store", (b[:, 15] - b[:, 9]).mean(), "barrier", (b[:, 3] - b[:, 15]).mean())
 print("total", (b[:, 5] - b[:, 0]).mean(), "cycles (the last launch is a cross-only round: 16 inner rounds); per inner round",
       (b[:, 4] - b[:, 3]).mean() / 16)
 print("inner round 5, updating wave 0: work", (b[:, 7] - b[:, 6]).mean(), "barrier wait", (b[:, 8] - b[:, 7]).mean())
