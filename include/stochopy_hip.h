@@ -553,6 +553,9 @@ typedef struct sx_vd_args {
     double *hist_x, *hist_f;    /* return_all history slabs or NULL                                   */
     int64_t *order;             /* (P) argsort of the generation's fitness                             */
     void *state;                /* sx_cma_state                                                       */
+    double *pen_ws;             /* constraints="Penalize" on the device, or NULL: as sx_cma_args.pen_ws (the covariance
+                                 * diagonal is that of D (I + v v^T) D, vdcma/_vdcma.py:249-254)        */
+    int64_t *pen_order;         /* (P), with pen_ws                                                   */
     int64_t P;
     int64_t hist_rows;
     int32_t n, mu, fun_id, maxiter, ilim, pad_;

@@ -79,7 +79,7 @@ class SxVdArgs(C.Structure):
         ("Z", vp), ("ary", vp), ("arx", vp), ("fit", vp), ("xmean", vp), ("xold", vp), ("dx", vp), ("dvec", vp),
         ("vvec", vp), ("vn", vp), ("pc", vp), ("zinj", vp), ("dy", vp), ("w", vp), ("mws", vp), ("mout", vp),
         ("besthist", vp), ("xm", vp), ("xstd", vp), ("xbest", vp), ("hist_x", vp), ("hist_f", vp), ("order", vp),
-        ("state", vp), ("P", i64), ("hist_rows", i64),
+        ("state", vp), ("pen_ws", vp), ("pen_order", vp), ("P", i64), ("hist_rows", i64),
         ("n", i32), ("mu", i32), ("fun_id", i32), ("maxiter", i32), ("ilim", i32), ("pad", i32),
         ("cs", f64), ("ds", f64), ("cc", f64), ("c1", f64), ("cmu", f64), ("mueff", f64), ("wsum", f64), ("xtol", f64),
         ("ftol", f64), ("insigma", f64), ("key0", C.c_uint32), ("key1", C.c_uint32),

@@ -137,7 +137,10 @@ __device__ __forceinline__ double np_lerp(double a, double b, double t) {  // nu
 }
 __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : (x == 0.0 ? 0.0 : x)); }
 
-__global__ __launch_bounds__(kPathThreads) void cma_penalty_kernel(const sx_cma_args a, int64_t gen) {
+// dvec / vvec != NULL: the model is VD-CMA's D (I + v v^T) D and its diagonal (d (1 + v^2)) d (vdcma/_vdcma.py:249-254)
+__global__ __launch_bounds__(kPathThreads) void cma_penalty_kernel(const sx_cma_args a, int64_t gen,
+                                                                   const double *__restrict__ dvec,
+                                                                   const double *__restrict__ vvec) {
     __shared__ double red3[kPathThreads / 64][3];
     __shared__ double s_fill, s_meanlog;
     __shared__ int s_dofill, s_outside;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(kPathThreads) void cma_penalty_kernel(const sx_cma_
     // sums over the diagonal of C, their logarithms, and "any coordinate of the mean outside [-1, 1]"
     double sd = 0.0, sl = 0.0, so = 0.0;
     for (int e = tid; e < n; e += kPathThreads) {
-        const double dc = a.C[(int64_t)e * n + e], xm = a.xmean[e];
+        const double dc = dvec ? (dvec[e] * (1.0 + vvec[e] * vvec[e])) * dvec[e] : a.C[(int64_t)e * n + e], xm = a.xmean[e];
         sd += dc, sl += log(dc);
         if (xm < -1.0 || xm > 1.0) so += 1.0;
     }
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kPathThreads) void cma_penalty_kernel(const sx_cma_
     const double kk = 3.0 * fmax(1.0, sqrt((double)n / a.mueff)) * sigma, fac = pow(1.2, fmin(1.0, a.mueff / 10.0 / (double)n));
     for (int e = tid; e < n; e += kPathThreads) {
         double we = dofill ? fill : w[e];
-        const double dc = a.C[(int64_t)e * n + e], xm = a.xmean[e];
+        const double dc = dvec ? (dvec[e] * (1.0 + vvec[e] * vvec[e])) * dvec[e] : a.C[(int64_t)e * n + e], xm = a.xmean[e];
         if (outside) {  // :61-73 (the excess is measured against a mean clipped on the UPPER side only, as the reference does)
             const double tx = xm - (xm > 1.0 ? 1.0 : xm);
             const bool out = xm < -1.0 || xm > 1.0;
@@ -456,6 +459,22 @@ int cma_rank_launch(const double *fit, int64_t P, int64_t *order, sx_cma_state *
     SX_LAUNCH_CHECK();
     return 0;
 }
+// Penalize for a loop that shares these kernels (sx_vd_loop.hip): h carries fit (raw, of the clipped candidates), arx, xm,
+// xstd, xmean, xold, state, pen_ws, pen_order, n, P, mueff, fun_id; leaves the penalised fitness in h.fit
+int cma_penalize_launch(const sx_cma_args &h, int64_t gen, const double *dvec, const double *vvec, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SX_REQUIRE(h.pen_ws && h.pen_order && 20.0 + 3.0 * h.n / (double)h.P + 1.0 <= (double)kPenHist,
+               "Penalize on the device needs pen_order and a spread history of at most 256 entries");
+    hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((h.P + 63) / 64)), dim3(256), 0, st, (const double *)h.fit, h.P, h.pen_order,
+                       (sx_cma_state *)h.state, (double *)nullptr, gen);
+    hipLaunchKernelGGL(cma_penalty_kernel, dim3(1), dim3(kPathThreads), 0, st, h, gen, dvec, vvec);
+    if (int rc = sx_cmaes_eval_penalized(h.fun_id, h.arx, h.P, h.n, h.xm, h.xstd, h.pen_ws + h.n, h.fit,
+                                         h.pen_ws + 2 * (int64_t)h.n, stream))
+        return rc;
+    hipLaunchKernelGGL(cma_add_penalty_kernel, dim3((unsigned)((h.P + 255) / 256)), dim3(256), 0, st, h);
+    SX_LAUNCH_CHECK();
+    return 0;
+}
 int cma_history_launch(const sx_cma_args &h, int64_t gen, void *stream) {
     const int64_t tot = (h.hist_rows > 0 ? h.hist_rows : 1) * h.n;
     hipLaunchKernelGGL(cma_history_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, gen);
@@ -525,7 +544,8 @@ int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *strea
         // bookkeeping from its percentiles, then the weighted squared excess on top (the second pass recomputes the same raw values)
         hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, a->fit, P, a->pen_order, state,
                            (double *)nullptr, gen);
-        hipLaunchKernelGGL(cma_penalty_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen);
+        hipLaunchKernelGGL(cma_penalty_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, (const double *)nullptr,
+                           (const double *)nullptr);
         if ((rc = sx_cmaes_eval_penalized(a->fun_id, a->arx, P, n, a->xm, a->xstd, a->pen_ws + n, a->fit,
                                           a->pen_ws + 2 * (int64_t)n, stream)))
             return rc;

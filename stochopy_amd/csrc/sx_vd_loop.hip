@@ -26,6 +26,7 @@ int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, 
 int cma_rank_launch(const double *fit, int64_t P, int64_t *order, sx_cma_state *state, double *besthist, int64_t gen,
                     void *stream);
 int cma_history_launch(const sx_cma_args &h, int64_t gen, void *stream);
+int cma_penalize_launch(const sx_cma_args &h, int64_t gen, const double *dvec, const double *vvec, void *stream);
 }  // namespace sx
 
 namespace {
@@ -354,7 +355,11 @@ __global__ __launch_bounds__(kVdThreads) void vd_update_kernel(const sx_vd_args 
         status = -8;
     if (status != SX_STATUS_NONE) {  // the caller's result: best candidate of THIS generation, un-standardised
         const double *row = a.arx + state->best_row * (int64_t)n;
-        for (int e = tid; e < n; e += kVdThreads) a.xbest[e] = row[e] * a.xstd[e] + a.xm[e];
+        for (int e = tid; e < n; e += kVdThreads) {
+            double x = row[e];
+            if (a.pen_ws != nullptr) x = fmin(fmax(x, -1.0), 1.0);  // Penalize: the clipped point is what the caller sees
+            a.xbest[e] = x * a.xstd[e] + a.xm[e];
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -395,13 +400,19 @@ extern "C" int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *strea
     if ((rc = sx_cmaes_normals(a->zinj, 1, n, P, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
     hipLaunchKernelGGL(vd_inject_kernel, dim3(1), dim3(kVdThreads), 0, st, *a);
     if ((rc = sx::vd_sample_launch(a->Z, P, n, a->dvec, a->vn, a->xmean, a->dy, a->ary, a->arx, state, stream))) return rc;
-    if ((rc = sx_eval(a->fun_id, a->arx, P, n, n, a->xm, a->xstd, a->fit, nullptr, nullptr, stream))) return rc;
+    sx_cma_args h = {};  // what the kernels shared with CMA-ES read
+    h.arx = a->arx, h.fit = a->fit, h.xm = a->xm, h.xstd = a->xstd, h.hist_x = a->hist_x, h.hist_f = a->hist_f;
+    h.state = a->state, h.n = n, h.P = P, h.hist_rows = a->hist_rows, h.xmean = a->xmean, h.xold = a->xold;
+    h.pen_ws = a->pen_ws, h.pen_order = a->pen_order, h.mueff = a->mueff, h.fun_id = a->fun_id;
+    if (a->pen_ws == nullptr) {
+        if ((rc = sx_eval(a->fun_id, a->arx, P, n, n, a->xm, a->xstd, a->fit, nullptr, nullptr, stream))) return rc;
+    } else {  // constraints="Penalize" (cmaes/_constraints.py:4-82, shared with CMA-ES): clipped objective, weights, excess
+        if ((rc = sx_cmaes_eval_penalized(a->fun_id, a->arx, P, n, a->xm, a->xstd, nullptr, a->fit, nullptr, stream))) return rc;
+        if ((rc = sx::cma_penalize_launch(h, gen, a->dvec, a->vvec, stream))) return rc;
+    }
     if ((rc = sx::cma_rank_launch(a->fit, P, a->order, state, a->besthist, gen, stream))) return rc;
     if (a->hist_x) {
         SX_REQUIRE(a->hist_f != nullptr && a->hist_rows >= 0 && a->hist_rows <= P, "sx_vdcma_generation: bad history arguments");
-        sx_cma_args h = {};
-        h.arx = a->arx, h.fit = a->fit, h.xm = a->xm, h.xstd = a->xstd, h.hist_x = a->hist_x, h.hist_f = a->hist_f;
-        h.state = a->state, h.n = n, h.hist_rows = a->hist_rows;
         if ((rc = sx::cma_history_launch(h, gen, stream))) return rc;
     }
     if ((rc = sx::vd_moments_launch(a->arx, a->ary, a->order, a->w, a->mu, n, a->dvec, a->vn, 0.0, state, a->mws, a->mout,

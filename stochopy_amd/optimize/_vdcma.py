@@ -61,11 +61,13 @@ def minimize(
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
     workers = _common.resolve_workers(workers)
-    if (rng == "philox" and isinstance(fun_id, int) and workers == 1 and constraints is None and callback is None
-            and len(lower) <= 4096):
-        # nothing the host has to see between generations: the whole loop (and the history) stays on the device
+    if (rng == "philox" and isinstance(fun_id, int) and workers == 1 and callback is None and len(lower) <= 4096
+            and (constraints is None or 20.0 + 3.0 * len(lower) / int(popsize) + 1.0 <= 256.0)):
+        # nothing the host has to see between generations: the whole loop (and the history) stays on the device --
+        # since round 3 including constraints="Penalize" (boundary-weight bookkeeping shared with CMA-ES: cma_penalty_kernel)
         return _VdDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
-                            float(xtol), float(ftol), seed, bool(return_all), float(verbosity)).result()
+                            float(xtol), float(ftol), seed, bool(return_all), float(verbosity),
+                            penalize=constraints == "Penalize").result()
     run = _VdRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, workers,
                  constraints == "Penalize")
@@ -93,7 +95,7 @@ class _VdDeviceRun:
     LOOK = 16
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
-                 verbosity=1.0, run=True):
+                 verbosity=1.0, run=True, penalize=False):
         """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
         with ``step`` from a state of their choosing."""
         import ctypes as C
@@ -118,6 +120,12 @@ class _VdDeviceRun:
                 dy=ctx.zeros((n,)), w=ctx.upload(w), mws=ctx.empty((((mu + 7) // 8) * 8 + 4 * 64 * n,)),
                 mout=ctx.empty((4, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
                 xbest=ctx.zeros((n,)), order=ctx.empty((P,), dtype=t.int64))
+            if penalize:  # cmaes/_constraints.py:4-82 on the device: weights 0, spread history [1.0], both phase flags as at the start
+                pw = np.zeros(2 * n + P + 256 + 4)
+                pw[2 * n + P] = 1.0
+                pw[2 * n + P + 256: 2 * n + P + 259] = (1.0, 0.0, 1.0)
+                keep["pen_ws"] = ctx.upload(pw)
+                keep["pen_order"] = ctx.empty((P,), dtype=t.int64)
             nout = int(np.ceil(verbosity * P)) if return_all else 0
             if return_all:  # device-side history slabs, read back once at the end
                 keep["hist_x"] = ctx.empty((maxiter, max(1, nout), n))

@@ -88,6 +88,36 @@ def test_vdcma_philox_vs_oracle(sa, constraints):
     assert np.allclose(got.x, ref.x, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("obj,n,P,lo,hi,maxiter,verbosity", [("rosenbrock", 30, 20, 0.5, 3.0, 50, 1.0), ("sphere", 12, 10, 1.0, 4.0, 80, 0.0),
+                                                             ("rastrigin", 200, 24, 0.2, 5.12, 30, 0.5)])
+def test_vdcma_penalize_in_the_device_resident_loop_vs_oracle(sa, obj, n, P, lo, hi, maxiter, verbosity, monkeypatch):
+    """constraints="Penalize" without a callback stays in the device-resident VD-CMA loop since round 3 (the boundary-weight
+    bookkeeping is CMA-ES's cma_penalty_kernel with the diagonal of D (I + v v^T) D): stopping generation, status, the
+    history of clipped points and penalised fitness, and the result against the oracle."""
+    from stochopy_amd.optimize import _vdcma
+
+    taken = []
+    orig = _vdcma._VdDeviceRun.__init__
+
+    def spy(self, *a, **k):
+        taken.append(k.get("penalize"))
+        orig(self, *a, **k)
+
+    monkeypatch.setattr(_vdcma._VdDeviceRun, "__init__", spy)
+    bounds = [[lo, hi]] * n
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 77, "sigma": 0.25, "constraints": "Penalize", "return_all": True,
+            "verbosity": verbosity, "ftol": -1.0, "xtol": 0.0}
+    ref = oracle.minimize(obj, bounds, method="vdcma", options=dict(opts), rng="philox")
+    got = sa.optimize.minimize(getattr(sa.factory, obj), bounds, method="vdcma", options=dict(opts, backend="hip", rng="philox"))
+    assert taken == [True]
+    assert (got.nit, got.nfev, got.status) == (ref.nit, ref.nfev, ref.status)
+    assert got.funall.shape == ref.funall.shape
+    assert np.allclose(got.funall, ref.funall, rtol=1e-6, atol=1e-300), np.abs(got.funall / ref.funall - 1).max()
+    assert np.allclose(got.xall, ref.xall, rtol=1e-5, atol=1e-6 * (hi - lo))
+    assert np.isclose(got.fun, ref.fun, rtol=1e-6) and np.allclose(got.x, ref.x, rtol=1e-5, atol=1e-6 * (hi - lo))
+    assert np.all(got.xall >= lo - 1e-15) and np.all(got.xall <= hi + 1e-15)
+
+
 def test_vdcma_large_dimension_runs(sa):
     """The O(n) model at a dimension where full CMA-ES would need a 4096 x 4096 eigendecomposition per generation."""
     n = 4096
