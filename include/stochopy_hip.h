@@ -564,6 +564,10 @@ typedef struct sx_vd_args {
 } sx_vd_args;
 
 int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *stream);
+/* two steps around one all-gather for candidates sharded over ranks, as sx_cmaes_generation_stage (stage 0 fills
+ * ary_loc / arx_loc (rows,n) and fit_loc (rows) for rows [row0, row0 + rows); the injected pair is global rows 0, 1) */
+int sx_vdcma_generation_stage(const sx_vd_args *a, int64_t gen, int stage, int64_t row0, int64_t rows, double *ary_loc,
+                              double *arx_loc, double *fit_loc, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Neighbourhood Algorithm: the resampling walk (csrc/sx_na.hip)

@@ -443,10 +443,10 @@ extern "C" int sx_vdcma_sample(const double *Z, int64_t P, int n, int64_t row0, 
 namespace sx {
 // the same with sigma / coefficient / injection flag read from the device state (sx_vdcma_generation)
 int vd_sample_launch(const double *Z, int64_t P, int n, const double *dvec, const double *vn, const double *xmean,
-                     const double *dy, double *ary, double *arx, const sx_cma_state *st, void *stream) {
+                     const double *dy, double *ary, double *arx, const sx_cma_state *st, void *stream, int64_t row0) {
     const int rows_per_block = 4;
     hipLaunchKernelGGL(vd_sample_kernel, dim3((unsigned)((P + rows_per_block - 1) / rows_per_block)),
-                       dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, (int64_t)0, dvec, vn, 0.0, xmean, 0.0,
+                       dim3(rows_per_block * kWave), 0, (hipStream_t)stream, Z, P, n, row0, dvec, vn, 0.0, xmean, 0.0,
                        dy, ary, arx, st);
     SX_LAUNCH_CHECK();
     return 0;

@@ -19,7 +19,7 @@ using namespace sx;
 
 namespace sx {
 int vd_sample_launch(const double *Z, int64_t P, int n, const double *dvec, const double *vn, const double *xmean,
-                     const double *dy, double *ary, double *arx, const sx_cma_state *st, void *stream);
+                     const double *dy, double *ary, double *arx, const sx_cma_state *st, void *stream, int64_t row0 = 0);
 int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
                       const double *dvec, const double *vn, double norm_v2, const sx_cma_state *state, double *ws,
                       double *out, void *stream);
@@ -382,7 +382,8 @@ __global__ __launch_bounds__(kVdThreads) void vd_update_kernel(const sx_vd_args 
 
 }  // namespace
 
-extern "C" int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *stream) {
+namespace {
+int check_vd_args(const sx_vd_args *a, int64_t gen) {
     SX_REQUIRE(a && a->Z && a->ary && a->arx && a->fit && a->xmean && a->xold && a->dx && a->dvec && a->vvec && a->vn &&
                    a->pc && a->zinj && a->dy && a->w && a->mws && a->mout && a->besthist && a->xm && a->xstd && a->xbest &&
                    a->order && a->state,
@@ -390,24 +391,62 @@ extern "C" int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *strea
     SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->n <= kVdPer * kVdThreads && a->mu >= 1 && a->mu <= a->P && gen >= 1 &&
                    gen <= a->maxiter,
                "sx_vdcma_generation: bad shape or generation number (n <= 4096)");
+    return 0;
+}
+
+// candidates [row0, row0 + rows) of generation `gen` (the injected pair +-dy is rows 0 and 1 of the generation): normals
+// keyed by the global row, the injection's own row and its dy (replicated), steps y, candidates x, objective (of the
+// clipped points with Penalize) -> ary_out, arx_out (rows, n), fit_out (rows); a->Z: scratch (rows, n)
+int vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t rows, double *ary_out, double *arx_out,
+                  double *fit_out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int n = a->n;
+    sx_cma_state *state = (sx_cma_state *)a->state;
+    int rc;
+    if ((rc = sx_cmaes_normals(a->Z, rows, n, row0, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
+    // the injection's own normal row: "row P" of the generation, one past the population (:245)
+    if ((rc = sx_cmaes_normals(a->zinj, 1, n, a->P, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
+    hipLaunchKernelGGL(vd_inject_kernel, dim3(1), dim3(kVdThreads), 0, st, *a);
+    if ((rc = sx::vd_sample_launch(a->Z, rows, n, a->dvec, a->vn, a->xmean, a->dy, ary_out, arx_out, state, stream, row0)))
+        return rc;
+    if (a->pen_ws == nullptr) return sx_eval(a->fun_id, arx_out, rows, n, n, a->xm, a->xstd, fit_out, nullptr, nullptr, stream);
+    return sx_cmaes_eval_penalized(a->fun_id, arx_out, rows, n, a->xm, a->xstd, nullptr, fit_out, nullptr, stream);
+}
+int vd_model_update(const sx_vd_args *a, int64_t gen, void *stream);
+}  // namespace
+
+extern "C" int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *stream) {
+    if (int rc = check_vd_args(a, gen)) return rc;
+    if (int rc = vd_candidates(a, gen, 0, a->P, a->ary, a->arx, a->fit, stream)) return rc;
+    return vd_model_update(a, gen, stream);
+}
+
+// The same generation in two steps for candidates sharded over ranks (as sx_cmaes_generation_stage): stage 0 = this rank's
+// candidates into ary_loc / arx_loc / fit_loc; the caller all-gathers them into a->ary / a->arx / a->fit; stage 1 = ranking,
+// moments, the O(n) model update and the stop rules, replicated on every rank.
+extern "C" int sx_vdcma_generation_stage(const sx_vd_args *a, int64_t gen, int stage, int64_t row0, int64_t rows,
+                                         double *ary_loc, double *arx_loc, double *fit_loc, void *stream) {
+    if (int rc = check_vd_args(a, gen)) return rc;
+    if (stage == 0) {
+        SX_REQUIRE(ary_loc && arx_loc && fit_loc && row0 >= 0 && rows >= 1 && row0 + rows <= a->P,
+                   "sx_vdcma_generation_stage: bad shard");
+        return vd_candidates(a, gen, row0, rows, ary_loc, arx_loc, fit_loc, stream);
+    }
+    return vd_model_update(a, gen, stream);
+}
+
+namespace {
+int vd_model_update(const sx_vd_args *a, int64_t gen, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int n = a->n;
     const int64_t P = a->P;
     sx_cma_state *state = (sx_cma_state *)a->state;
     int rc;
-    if ((rc = sx_cmaes_normals(a->Z, P, n, 0, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
-    // the injection's own normal row: "row P" of the generation, one past the population (:245)
-    if ((rc = sx_cmaes_normals(a->zinj, 1, n, P, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
-    hipLaunchKernelGGL(vd_inject_kernel, dim3(1), dim3(kVdThreads), 0, st, *a);
-    if ((rc = sx::vd_sample_launch(a->Z, P, n, a->dvec, a->vn, a->xmean, a->dy, a->ary, a->arx, state, stream))) return rc;
     sx_cma_args h = {};  // what the kernels shared with CMA-ES read
     h.arx = a->arx, h.fit = a->fit, h.xm = a->xm, h.xstd = a->xstd, h.hist_x = a->hist_x, h.hist_f = a->hist_f;
     h.state = a->state, h.n = n, h.P = P, h.hist_rows = a->hist_rows, h.xmean = a->xmean, h.xold = a->xold;
     h.pen_ws = a->pen_ws, h.pen_order = a->pen_order, h.mueff = a->mueff, h.fun_id = a->fun_id;
-    if (a->pen_ws == nullptr) {
-        if ((rc = sx_eval(a->fun_id, a->arx, P, n, n, a->xm, a->xstd, a->fit, nullptr, nullptr, stream))) return rc;
-    } else {  // constraints="Penalize" (cmaes/_constraints.py:4-82, shared with CMA-ES): clipped objective, weights, excess
-        if ((rc = sx_cmaes_eval_penalized(a->fun_id, a->arx, P, n, a->xm, a->xstd, nullptr, a->fit, nullptr, stream))) return rc;
+    if (a->pen_ws != nullptr) {  // constraints="Penalize" (cmaes/_constraints.py:4-82, shared with CMA-ES): weights, excess
         if ((rc = sx::cma_penalize_launch(h, gen, a->dvec, a->vvec, stream))) return rc;
     }
     if ((rc = sx::cma_rank_launch(a->fit, P, a->order, state, a->besthist, gen, stream))) return rc;
@@ -422,3 +461,4 @@ extern "C" int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *strea
     SX_LAUNCH_CHECK();
     return 0;
 }
+}  // namespace

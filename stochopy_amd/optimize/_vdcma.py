@@ -61,13 +61,14 @@ def minimize(
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
     workers = _common.resolve_workers(workers)
-    if (rng == "philox" and isinstance(fun_id, int) and workers == 1 and callback is None and len(lower) <= 4096
+    if (rng == "philox" and isinstance(fun_id, int) and callback is None and len(lower) <= 4096
             and (constraints is None or 20.0 + 3.0 * len(lower) / int(popsize) + 1.0 <= 256.0)):
         # nothing the host has to see between generations: the whole loop (and the history) stays on the device --
         # since round 3 including constraints="Penalize" (boundary-weight bookkeeping shared with CMA-ES: cma_penalty_kernel)
+        # and workers > 1 (own candidates, one gather of steps / candidates / fitness, the O(n) model update replicated)
         return _VdDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
                             float(xtol), float(ftol), seed, bool(return_all), float(verbosity),
-                            penalize=constraints == "Penalize").result()
+                            penalize=constraints == "Penalize", workers=workers).result()
     run = _VdRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, workers,
                  constraints == "Penalize")
@@ -95,7 +96,7 @@ class _VdDeviceRun:
     LOOK = 16
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
-                 verbosity=1.0, run=True, penalize=False):
+                 verbosity=1.0, run=True, penalize=False, workers=1):
         """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
         with ``step`` from a state of their choosing."""
         import ctypes as C
@@ -104,6 +105,12 @@ class _VdDeviceRun:
         ctx = self.ctx = _device.Context()
         t = _device.torch()
         ptr, n = _device.ptr, len(lower)
+        world, row0, Pl = None, 0, P
+        if workers != 1:
+            from ..parallel import require_world
+
+            world = require_world(workers)
+            row0, Pl = world.shard(P)  # popsize must divide evenly
         with t.cuda.stream(ctx.stream):
             init = _rng.make_init_stream("philox", seed)
             key0, key1 = _rng.philox_key(seed)
@@ -145,16 +152,27 @@ class _VdDeviceRun:
                 return
             look, since, t0 = 1, 0, time.perf_counter()
             state = st
+            if world is not None:
+                ary_loc, arx_loc, fit_loc = ctx.empty((Pl, n)), ctx.empty((Pl, n)), ctx.empty((Pl,))
             for gen in range(1, maxiter + 1):
-                _lib.check(ctx.L.sx_vdcma_generation(C.byref(a), gen, ctx.stream_ptr), "sx_vdcma_generation")
+                if world is None:
+                    _lib.check(ctx.L.sx_vdcma_generation(C.byref(a), gen, ctx.stream_ptr), "sx_vdcma_generation")
+                else:  # own candidates, one gather of steps / candidates / fitness, the model update replicated
+                    _lib.check(ctx.L.sx_vdcma_generation_stage(C.byref(a), gen, 0, row0, Pl, ptr(ary_loc), ptr(arx_loc),
+                                                               ptr(fit_loc), ctx.stream_ptr), "sx_vdcma_generation_stage")
+                    world.all_gather_rows(ary_loc, keep["ary"])
+                    world.all_gather_rows(arx_loc, keep["arx"])
+                    world.all_gather_rows(fit_loc, keep["fit"])
+                    _lib.check(ctx.L.sx_vdcma_generation_stage(C.byref(a), gen, 1, 0, 0, None, None, None, ctx.stream_ptr),
+                               "sx_vdcma_generation_stage")
                 since += 1
                 if since >= look or gen == maxiter:
                     state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
                     if state.done:
                         break
                     now = time.perf_counter()
-                    if now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
-                        look *= 2
+                    if world is None and now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
+                        look *= 2  # (sharded: every generation, so that all ranks stop enqueueing collectives together)
                     since, t0 = 0, now
             if not state.done:  # cannot happen: generation maxiter sets status -1
                 raise RuntimeError("VD-CMA device loop ended without a status")

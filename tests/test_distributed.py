@@ -373,11 +373,12 @@ def test_sharded_vdcma_matches_single_gpu(rng):
     resident = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method="vdcma",
                                     options=dict(opts, backend="hip"))
     assert (resident.nit, resident.status) == (one.nit, one.status) and np.isclose(resident.fun, one.fun, rtol=1e-6)
+    want = resident if rng == "philox" else one  # (round 3: the sharded Philox run stays on the device, as CMA-ES's)
     out = _spawn(gpu_minimize_worker, 2, cfg)
     for r in range(2):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
-        assert (fun, nit, nfev, status) == (one.fun, one.nit, one.nfev, one.status)
-        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), one.x)
+        assert (fun, nit, nfev, status) == (want.fun, want.nit, want.nfev, want.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), want.x)
 
 
 @pytest.mark.gpu
