@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 src = os.path.join(ROOT, "stochopy_amd", "csrc")
 out = "/tmp/libsx_seltrace.so"
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-DSX_SELTRACE",
-                "-shared", "-x", "hip"] + [os.path.join(src, f) for f in ("sx_pso.hip", "sx_core.hip", "sx_mt19937.cpp", "sx_xchg.hip", "sx_cmaes.hip", "sx_async.hip", "sx_unfused.hip", "sx_de.hip")] + ["-o", out], check=True)
+                "-shared", "-x", "hip"] + sorted(glob.glob(src + "/*.hip") + glob.glob(src + "/*.cpp")) + ["-o", out], check=True)
 from stochopy_amd import _lib
 _lib.LIB_PATH = out
 import torch
@@ -26,6 +26,6 @@ _cpso._PsoRun._restart_device = restart
 os.environ["SX_NO_GRAPH"] = "1"
 r = sa.optimize.minimize(sa.factory.ackley, [[-5.12, 5.12]] * 256, method="cpso",
                          options={"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "maxiter": 30, "return_all": True, "verbosity": 0.0, "updating": "deferred"})
-for s in stamps[5:12]:
+for s in stamps[3:25]:
     d = np.diff(s)
-    print("ticks(10ns) between stamps 0..7:", d.tolist())
+    print("ticks(10ns) between stamps 0..7 [state+radii | keys | minmax | hist | scan+digit | gather | rank]:", d.tolist())
