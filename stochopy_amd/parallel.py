@@ -94,7 +94,10 @@ class World:
             if idle is None:
                 time.sleep(0.35)
                 return
-            if idle or time.perf_counter() > deadline:
+            if idle:
+                return
+            if time.perf_counter() > deadline:  # the recorder never reported an empty list: fall back to the waiting rule
+                time.sleep(0.35)
                 return
             time.sleep(0.01)
 
