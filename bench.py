@@ -262,6 +262,7 @@ def main():
 
         # torch's NCCL flight recorder on: graph captures of the RCCL transport wait for the watchdog to RETIRE earlier
         # collectives by reading it (parallel.World.quiesce_for_capture) instead of sleeping
+        os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "256")  # (TORCH_NCCL_TRACE_BUFFER_SIZE before torch 2.8)
         os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "256")
         backend = os.environ.get("SX_BENCH_BACKEND", "nccl")
         if backend == "nccl":

@@ -167,7 +167,7 @@ def nccl_multi_gpu_worker(rank, world, port, cfg, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = "256"
+    os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = os.environ["TORCH_FR_BUFFER_SIZE"] = "256"
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     try:
@@ -225,7 +225,7 @@ def nccl_single_rank_worker(rank, world, port, cfg, out_dir):
     # (must be set before the group exists; with it graph captures wait on the flight recorder, without it they sleep:
     #  parallel.World.quiesce_for_capture -- the tests cover both)
     if cfg.get("flight_recorder"):
-        os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = "256"
+        os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = os.environ["TORCH_FR_BUFFER_SIZE"] = "256"
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     try:
