@@ -12,7 +12,8 @@
 //   A (16x4): lane l holds A[l & 15][l >> 4];  B (4x16): lane l holds B[l >> 4][l & 15];
 //   C/D: 4 doubles per lane, col = l & 15, row = (l >> 4) + 4 * reg.
 // Workgroup tiles 64x64 / 32x64 / 32x32 (chosen so the small CMA-ES shapes still give >= 256 workgroups),
-// four waves in a 2x2 grid, K chunk 32 staged through LDS with register prefetch of the next chunk.
+// four waves in a 2x2 grid, K chunk 32 staged through LDS, the next three chunks already on their way in registers.
+#include <type_traits>
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 
@@ -21,10 +22,12 @@ using namespace sx;
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const volatile double lds_cvd;  // a volatile read that stays a DS instruction
 
 constexpr int KC = 32;        // K chunk
-constexpr int LDA = KC + 2;   // A tile [BM][LDA]: row stride 34 doubles -> conflict-free ds_read_b64 of a column slab
+constexpr int LDA = KC + 2;   // k-major tiles [rows][LDA]: row stride 34 doubles -> conflict-free ds_read_b64 of a column slab
 constexpr int kGemmThreads = 256;
+constexpr int kGemmAhead = 3;  // operand chunks in flight per thread
 
 struct SampleOp {  // arx = xmean + sigma * (Z o D) * B^T
     const double *Z;      // (P,n)
@@ -62,14 +65,21 @@ __global__ __launch_bounds__(256) void cma_y_kernel(const double *__restrict__ a
 
 // MODE 0: M = P rows, N = n, K = n.   MODE 1: M = N = n, K = mu.
 // Workgroup tile BM x BN, four waves in a 2x2 grid, wave tile (BM/2) x (BN/2) of 16x16 MFMA tiles.
-// The global loads of chunk k+1 are issued into registers before the MFMAs of chunk k.
+// The global loads of chunks k+1 .. k+3 are in registers or in flight while the MFMAs of chunk k run.
 template <int MODE, int BM, int BN, class Op>
 __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
-    constexpr int LDB = BN + 16;  // B tile [KC][LDB]: the two k-groups of a 32-lane half land 32 banks apart
+    // LDS images follow the way the operands lie in memory, so staging is a contiguous copy for both of them:
+    //   MODE 0  Z and B are rows along k      -> As[BM][LDA], Bs[BN][LDA]        (fragment reads: row stride 34 doubles)
+    //   MODE 1  Y is rows along the tile axes -> As[KC][BM + 16], Bs[KC][BN + 16] (fragment reads: k stride = 16 mod 32 doubles)
+    // Both give conflict-free ds_read_b64 fragments (32-lane halves, 64 banks) and at most 2-way staging stores.
+    constexpr int LDM = BM + 16, LDN = BN + 16;
     constexpr int TM = BM / 32, TN = BN / 32;  // MFMA tiles per wave
     constexpr int NA = BM * KC / kGemmThreads, NB = BN * KC / kGemmThreads;  // staged elements per thread
-    __shared__ __attribute__((aligned(16))) double As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
+    constexpr int ASZ = MODE == 0 ? BM * LDA : KC * LDM, BSZ = MODE == 0 ? BN * LDA : KC * LDN;
+    // two LDS images where they fit the 64 KB of static LDS: chunk c+1 is staged while chunk c is multiplied, one barrier per chunk
+    constexpr int NBUF = 2 * (ASZ + BSZ) * 8 <= 65536 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) double As_[NBUF * ASZ];
+    __shared__ __attribute__((aligned(16))) double Bs_[NBUF * BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int64_t m0 = (int64_t)blockIdx.y * BM;
@@ -89,90 +99,190 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    double ra[NA], rb[NB];
-    // thread -> staged elements.  MODE 0: A row i = tid / (KC/NA), NA contiguous k; B row j = tid / (KC/NB), NB contiguous k.
-    //                             MODE 1: k = tid / 8 for both; NA contiguous i, NB contiguous j.
-    auto fetch = [&](int k0) {
-        if (MODE == 0) {
-            const SampleOp &o = (const SampleOp &)op;
-            {
-                const int i = tid / (KC / NA), kk = (tid % (KC / NA)) * NA;
-                const int64_t gi = m0 + i;
+    // kGemmAhead chunks of operands live in registers: a workgroup is one wave per SIMD and the small CMA-ES shapes put one or
+    // two workgroups on a CU, so the only thing that hides the ~1 us of a global load is having several chunks in flight.
+    // fetch() only LOADS (nothing that needs the value): every use -- the D and w factors, the zero fill of the ragged
+    // edge -- waits until stage(), three chunks later.  A workgroup whose tile and K range lie inside the operands (FULL)
+    // runs without a single guard: no exec-masked branches, so the compiler's s_waitcnt vmcnt(N) can leave the younger
+    // chunks in flight (with the guards in the way it waits for vmcnt(0) at every stage and the depth collapses to one).
+    double ra[kGemmAhead][NA], rb[kGemmAhead][NB];
+    double rs[kGemmAhead][2];  // MODE 0: D[k] of the thread's two k; MODE 1: w[k] of the thread's two k rows
+    const int nchunk = (K + KC - 1) / KC;
+    // thread -> staged elements: 16 consecutive lanes take the 16 pieces of 16 B that make up one 256-byte row of a chunk
+    // (MODE 0: 32 k of one candidate / eigenvector row; MODE 1: 32 columns of one Y row), so a wave's load is four whole
+    // 256-byte runs -- the address unit (TA) was the busiest block of this kernel when lanes gathered 16-byte pieces from
+    // eight rows each -- and its ds_write_b128 (served 8 consecutive lanes at a time) fills 8 consecutive 16-byte slots.
+    //   MODE 0  row = 16 q + tid/16 (q < rows/16),            k = 2 (tid%16) + {0,1}
+    //   MODE 1  k   = 16 q + tid/16 (q < 2),   col = 32 c + 2 (tid%16) + {0,1} (c < cols/32)
+    const int t16 = tid >> 4, p2 = 2 * (tid & 15);
+    auto run = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        auto fetch = [&](const int s, const int k0) {
+            if (MODE == 0) {
+                const SampleOp &o = (const SampleOp &)op;
+                int gk[2];
 #pragma unroll
-                for (int u = 0; u < NA; ++u) {
-                    const int gk = k0 + kk + u;
-                    ra[u] = (gi < M && gk < K) ? o.D[gk] * o.Z[gi * (int64_t)o.n + gk] : 0.0;  // D * z (:234)
+                for (int u = 0; u < 2; ++u) {
+                    gk[u] = FULL || k0 + p2 + u < K ? k0 + p2 + u : K - 1;
+                    rs[s][u] = o.D[gk[u]];
+                }
+#pragma unroll
+                for (int q = 0; q < NA / 2; ++q) {
+                    const int64_t gi = m0 + q * 16 + t16;
+                    const double *zr = o.Z + (FULL || gi < M ? gi : M - 1) * (int64_t)o.n;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) ra[s][q * 2 + u] = zr[gk[u]];
+                }
+#pragma unroll
+                for (int q = 0; q < NB / 2; ++q) {
+                    const int gj = n0 + q * 16 + t16;
+                    const double *br = o.Bm + (int64_t)(FULL || gj < N ? gj : N - 1) * o.n;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) rb[s][q * 2 + u] = br[gk[u]];
+                }
+            } else {
+                const RankMuOp &o = (const RankMuOp &)op;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int gk = FULL || k0 + q * 16 + t16 < K ? k0 + q * 16 + t16 : K - 1;
+                    const double *yr = o.Y + (int64_t)gk * o.n;
+                    rs[s][q] = o.w[gk];
+#pragma unroll
+                    for (int c = 0; c < BM / 32; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int64_t gi = m0 + c * 32 + p2 + u;
+                            ra[s][(q * (BM / 32) + c) * 2 + u] = yr[FULL || gi < M ? gi : M - 1];
+                        }
+#pragma unroll
+                    for (int c = 0; c < BN / 32; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int gj = n0 + c * 32 + p2 + u;
+                            rb[s][(q * (BN / 32) + c) * 2 + u] = yr[FULL || gj < N ? gj : N - 1];
+                        }
                 }
             }
-            {
-                const int j = tid / (KC / NB), kk = (tid % (KC / NB)) * NB;
-                const int gj = n0 + j;
+        };
+        auto stage = [&](const int s, const int k0, const int buf) {
+            double *As = As_ + buf * ASZ, *Bs = Bs_ + buf * BSZ;
+            if (MODE == 0) {
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int gk = k0 + kk + u;
-                    rb[u] = (gj < N && gk < K) ? o.Bm[(int64_t)gj * o.n + gk] : 0.0;
+                for (int q = 0; q < NA / 2; ++q) {
+                    const bool rin = FULL || m0 + q * 16 + t16 < M;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {  // D * z (:234)
+                        const double v = rs[s][u] * ra[s][q * 2 + u];
+                        As[(q * 16 + t16) * LDA + p2 + u] = (FULL || (rin && k0 + p2 + u < K)) ? v : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NB / 2; ++q) {
+                    const bool rin = FULL || n0 + q * 16 + t16 < N;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        Bs[(q * 16 + t16) * LDA + p2 + u] = (FULL || (rin && k0 + p2 + u < K)) ? rb[s][q * 2 + u] : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool kin = FULL || k0 + q * 16 + t16 < K;
+#pragma unroll
+                    for (int c = 0; c < BM / 32; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {  // artmp.T @ diag(w)
+                            const double v = ra[s][(q * (BM / 32) + c) * 2 + u] * rs[s][q];
+                            As[(q * 16 + t16) * LDM + c * 32 + p2 + u] = (FULL || (kin && m0 + c * 32 + p2 + u < M)) ? v : 0.0;
+                        }
+#pragma unroll
+                    for (int c = 0; c < BN / 32; ++c)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            Bs[(q * 16 + t16) * LDN + c * 32 + p2 + u] =
+                                (FULL || (kin && n0 + c * 32 + p2 + u < N)) ? rb[s][(q * (BN / 32) + c) * 2 + u] : 0.0;
                 }
             }
-        } else {
-            const RankMuOp &o = (const RankMuOp &)op;
-            const int kk = tid >> 3, gk = k0 + kk;
-            const bool kin = gk < K;
-            const double wk = kin ? o.w[gk] : 0.0;
-            const double *yr = o.Y + (int64_t)(kin ? gk : 0) * o.n;
+        };
+        auto multiply = [&](const int buf) {
+            const double *As = As_ + buf * ASZ, *Bs = Bs_ + buf * BSZ;
+            // All fragment reads of the chunk are issued before its first MFMA: a wave is one dependent chain per accumulator,
+            // so a read placed between two MFMAs puts the LDS latency on that chain 8 times per chunk.
+            // volatile: one ds_read_b64 per fragment (2 LDS cycles, conflict-free in both layouts); left alone the compiler
+            // pairs the reads of two k steps into ds_read2_b64, which the LDS serves at half that rate.
+            // (with 2x2 tiles per wave there are four chains to interleave and the registers are better spent elsewhere: G = 1)
+            constexpr int G = TM * TN == 1 ? KC / 4 : 1;  // k steps whose fragments are read together
+            double af[G][TM], bf[G][TN];
 #pragma unroll
-            for (int u = 0; u < NA; ++u) {
-                const int64_t gi = m0 + (tid & 7) * NA + u;
-                ra[u] = (kin && gi < M) ? yr[gi] * wk : 0.0;  // artmp.T @ diag(w)
-            }
+            for (int x0 = 0; x0 < KC / 4; x0 += G) {
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int gj = n0 + (tid & 7) * NB + u;
-                rb[u] = (kin && gj < N) ? yr[gj] : 0.0;
-            }
-        }
-    };
-    auto stage = [&]() {
-        if (MODE == 0) {
-            {
-                const int i = tid / (KC / NA), kk = (tid % (KC / NA)) * NA;
+            for (int x = 0; x < G; ++x) {
+                const int kq = 4 * (x0 + x) + (lane >> 4);
 #pragma unroll
-                for (int u = 0; u < NA; ++u) As[i * LDA + kk + u] = ra[u];
-            }
-            {
-                const int j = tid / (KC / NB), kk = (tid % (KC / NB)) * NB;
-#pragma unroll
-                for (int u = 0; u < NB; ++u) Bs[(kk + u) * LDB + j] = rb[u];
-            }
-        } else {
-            const int kk = tid >> 3;
-#pragma unroll
-            for (int u = 0; u < NA; ++u) As[((tid & 7) * NA + u) * LDA + kk] = ra[u];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) Bs[kk * LDB + (tid & 7) * NB + u] = rb[u];
-        }
-    };
-
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        stage();
-        __syncthreads();
-        if (k0 + KC < K) fetch(k0 + KC);  // in flight while the MFMAs below run
-#pragma unroll
-        for (int ks = 0; ks < KC; ks += 4) {
-            const int kq = ks + (lane >> 4);
-            double af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[(wm + i * 16 + (lane & 15)) * LDA + kq];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[kq * LDB + wn + j * 16 + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
+                    af[x][i] = *(lds_cvd *)(MODE == 0 ? &As[(wm + i * 16 + (lane & 15)) * LDA + kq]
+                                                      : &As[kq * LDM + wm + i * 16 + (lane & 15)]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    bf[x][j] = *(lds_cvd *)(MODE == 0 ? &Bs[(wn + j * 16 + (lane & 15)) * LDA + kq]
+                                                      : &Bs[kq * LDN + wn + j * 16 + (lane & 15)]);
+            }
+#pragma unroll
+            for (int x = 0; x < G; ++x)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[x][i], bf[x][j], acc[i][j], 0, 0, 0);
+            }
+        };
+        // chunk c lives in register set c % kGemmAhead; every loop below is unrolled so that the set is a compile-time index
+#pragma unroll
+        for (int s = 0; s < kGemmAhead; ++s)
+            if (s < nchunk) fetch(s, s * KC);
+        int c0 = 0;
+        if (NBUF == 1) {
+            auto step = [&](const int s, const int c, const bool more) {
+                stage(s, c * KC, 0);
+                __syncthreads();
+                if (more) fetch(s, (c + kGemmAhead) * KC);  // in flight for the next kGemmAhead chunks
+                multiply(0);
+                __syncthreads();
+            };
+            for (; c0 + 2 * kGemmAhead <= nchunk; c0 += kGemmAhead) {  // steady state: every step also fetches, no conditions
+#pragma unroll
+                for (int s = 0; s < kGemmAhead; ++s) step(s, c0 + s, true);
+            }
+#pragma unroll
+            for (int t = 0; t < 2 * kGemmAhead - 1; ++t) {  // the last kGemmAhead .. 2*kGemmAhead-1 chunks
+                const int c = c0 + t;
+                if (c < nchunk) step(t % kGemmAhead, c, c + kGemmAhead < nchunk);
+            }
+        } else {
+            auto step = [&](const int s, const int c, const bool next, const bool more) {
+                constexpr int A = kGemmAhead;
+                if (next) stage((s + 1) % A, (c + 1) * KC, (c + 1) & 1);  // the image the previous step multiplied from
+                if (more) fetch((s + 1) % A, (c + 1 + A) * KC);
+                multiply(c & 1);
+                __syncthreads();
+            };
+            stage(0, 0, 0);
+            if (kGemmAhead < nchunk) fetch(0, kGemmAhead * KC);
+            __syncthreads();
+            for (; c0 + 2 * kGemmAhead + 1 <= nchunk; c0 += kGemmAhead) {
+#pragma unroll
+                for (int s = 0; s < kGemmAhead; ++s) step(s, c0 + s, true, true);
+            }
+#pragma unroll
+            for (int t = 0; t < 2 * kGemmAhead; ++t) {
+                const int c = c0 + t;
+                if (c < nchunk) step(t % kGemmAhead, c, c + 1 < nchunk, c + 1 + kGemmAhead < nchunk);
+            }
         }
-        __syncthreads();
-    }
+    };
+    if (m0 + BM <= M && n0 + BN <= N && K % KC == 0)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
     // ---- epilogue: C/D element (row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile ----
 #pragma unroll
     for (int ti = 0; ti < TM; ++ti) {

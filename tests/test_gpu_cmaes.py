@@ -27,7 +27,9 @@ def ctx(sa):
     return _device.Context()
 
 
-@pytest.mark.parametrize("shape", [(10, 2), (7, 3), (64, 64), (65, 33), (100, 130), (1024, 512), (300, 257)])
+# the last four reach the 32x64 and 64x64 workgroup tiles (whole and ragged), which the CMA-ES shapes below n = 1024 never launch
+@pytest.mark.parametrize("shape", [(10, 2), (7, 3), (64, 64), (65, 33), (100, 130), (1024, 512), (300, 257), (1024, 1024), (1000, 1030),
+                                   (2048, 1024), (2050, 1030)])
 def test_sample_kernel_vs_numpy(sa, ctx, shape):
     from stochopy_amd import _device, _lib
 
@@ -49,7 +51,9 @@ def test_sample_kernel_vs_numpy(sa, ctx, shape):
     assert np.abs(got - ref).max() <= GEMM_RTOL * scale
 
 
-@pytest.mark.parametrize("shape", [(10, 2, 5), (12, 3, 6), (64, 64, 32), (200, 130, 77), (1024, 512, 512), (90, 257, 45)])
+# (64, 1472, 64) and (70, 1475, 67): the 64x64 tile of the covariance update (n >= 1408)
+@pytest.mark.parametrize("shape", [(10, 2, 5), (12, 3, 6), (64, 64, 32), (200, 130, 77), (1024, 512, 512), (90, 257, 45), (64, 1472, 64),
+                                   (70, 1475, 67)])
 @pytest.mark.parametrize("cond", [True, False])
 def test_rank_mu_and_recombine_vs_numpy(sa, ctx, shape, cond):
     from stochopy_amd import _device, _lib
