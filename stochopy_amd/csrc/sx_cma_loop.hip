@@ -28,6 +28,8 @@ int cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, 
 int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
                        const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
                        const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream);
+int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
+                 double tol, const int *skip, void *stream);  // sx_eigh.hip
 }  // namespace sx
 
 namespace {
@@ -41,46 +43,55 @@ static_assert(sizeof(sx_cma_state) == 128, "sx_cma_state is 128 bytes");
 __device__ __forceinline__ bool key_less(double a, double b) { return a < b || (b != b && a == a); }
 
 // order = argsort(fit) (ties: lower index first); best row / value and the history entry of the generation.
-// 64 elements per workgroup, 4 slices of the key range per element; the keys pass through LDS 4096 at a time.
+// A wavefront ranks four elements: the keys pass through LDS 4096 at a time, lane l looks at keys l, l + 64, ... and the
+// number of keys in front of an element is the population count of the wave's votes (one comparison per 64 keys and
+// element instead of 64; round 3: 25.6 -> a few us at P = 1024, where the old form kept 16 workgroups busy with 256
+// serial comparisons per thread).
 // besthist == NULL: ranking only (the raw fitness behind Penalize's percentiles): no best row, no history entry
+constexpr int kRankPerWave = 4;
 __global__ __launch_bounds__(256) void cma_rank_kernel(const double *__restrict__ fit, int64_t P,
                                                        int64_t *__restrict__ order, sx_cma_state *state,
                                                        double *__restrict__ besthist, int64_t gen) {
     constexpr int CH = 4096;
     __shared__ double keys[CH];
-    __shared__ int part[4][64];
     if (state->done) return;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + tx;
-    const double fi = i < P ? fit[i] : 0.0;
-    int cnt = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * kRankPerWave;
+    double fi[kRankPerWave];
+    int cnt[kRankPerWave];
+#pragma unroll
+    for (int u = 0; u < kRankPerWave; ++u) fi[u] = i0 + u < P ? fit[i0 + u] : 0.0, cnt[u] = 0;
     for (int64_t c0 = 0; c0 < P; c0 += CH) {
         const int len = (int)(P - c0 < CH ? P - c0 : CH);
         __syncthreads();
         for (int e = threadIdx.x; e < len; e += 256) keys[e] = fit[c0 + e];
         __syncthreads();
-        if (i < P) {
-            const int span = (len + 3) / 4, k0 = ty * span, k1 = k0 + span < len ? k0 + span : len;
-            const int64_t ii = i - c0;
-#pragma unroll 16
-            for (int k = k0; k < k1; ++k) {
-                const double fk = keys[k];
-                cnt += (key_less(fk, fi) || (!key_less(fi, fk) && k < ii)) ? 1 : 0;
+        for (int k0 = 0; k0 < len; k0 += 64) {  // uniform trip count: every lane adds every vote
+            const int k = k0 + lane;
+            const bool in = k < len;
+            const double fk = in ? keys[k] : 0.0;
+            const int64_t kk = c0 + k;
+#pragma unroll
+            for (int u = 0; u < kRankPerWave; ++u) {
+                const bool front = in && (key_less(fk, fi[u]) || (!key_less(fi[u], fk) && kk < i0 + u));
+                cnt[u] += (int)__popcll(__ballot(front));
             }
         }
     }
-    part[ty][tx] = cnt;
-    __syncthreads();
-    if (ty == 0 && i < P) {
-        const int64_t rank = (int64_t)part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
-        order[rank] = i;
-        if (rank == 0 && besthist != nullptr) {
-            state->best_row = i;
-            state->fbest = fi;
-            besthist[gen - 1] = fi;
+#pragma unroll
+    for (int u = 0; u < kRankPerWave; ++u) {
+        if (lane == u && i0 + u < P) {
+            const int64_t rank = cnt[u];
+            order[rank] = i0 + u;
+            if (rank == 0 && besthist != nullptr) {
+                state->best_row = i0 + u;
+                state->fbest = fi[u];
+                besthist[gen - 1] = fi[u];
+            }
         }
     }
 }
+constexpr unsigned rank_grid(int64_t P) { return (unsigned)((P + 4 * kRankPerWave - 1) / (4 * kRankPerWave)); }
 
 // part[q][e] = sum over k = q (mod 64) of w[k] * arx[order[k]][e]   (grid: ceil(n/64) x 16, 256 threads)
 __global__ __launch_bounds__(256) void cma_mean_partial_kernel(const double *__restrict__ arx,
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(kPathThreads) void cma_paths_kernel(const sx_cma_ar
 // result copy when one fires, and the publication of the new step size / generation counter.  One workgroup.
 __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_args a, int64_t gen, int did_eigh) {
     __shared__ double red14[kPathThreads / 64][14];
+    __shared__ double fin14[14];
     sx_cma_state *state = (sx_cma_state *)a.state;
     if (state->done) return;
     const int n = a.n, tid = threadIdx.x;
@@ -394,15 +406,22 @@ __global__ __launch_bounds__(kPathThreads) void cma_stop_kernel(const sx_cma_arg
         for (int q = 0; q < 14; ++q) red14[tid >> 6][q] = vs[q];
     }
     __syncthreads();
+    // the 16 waves' partials of quantity q are folded by 16 adjacent lanes (a workgroup-wide serial loop over
+    // 14 x 16 LDS words in every thread was most of this kernel's 31 us at n = 512)
+    static_assert(kPathThreads / 64 == 16, "sixteen partials per quantity");
+    if (tid < 14 * 16) {
+        const int q = tid >> 4;
+        double r = red14[tid & 15][q];
 #pragma unroll
-    for (int q = 0; q < 14; ++q) {
-        double r = red14[0][q];
-        for (int wv = 1; wv < kPathThreads / 64; ++wv) {
-            const double o = red14[wv][q];
+        for (int off = 8; off > 0; off >>= 1) {
+            const double o = __shfl_xor(r, off, 16);
             r = q < 7 ? r + o : (q < 11 ? fmax(r, o) : fmin(r, o));
         }
-        vs[q] = r;
+        if ((tid & 15) == 0) fin14[q] = r;
     }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 14; ++q) vs[q] = fin14[q];
     dx2 = vs[0], fail4 = vs[1], any5 = vs[2], any8 = vs[3], fail10 = vs[4], nan_sd = vs[5], nan_d = vs[6];
     dmax = vs[7], sdmax = vs[8], wmax = vs[9], jmax = vs[10], dmin = vs[11], wmin = vs[12], jmin = vs[13];
     int status = SX_STATUS_NONE;
@@ -454,7 +473,7 @@ namespace sx {
 // shared with the VD-CMA generation (sx_vd_loop.hip)
 int cma_rank_launch(const double *fit, int64_t P, int64_t *order, sx_cma_state *state, double *besthist, int64_t gen,
                     void *stream) {
-    hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, (hipStream_t)stream, fit, P, order,
+    hipLaunchKernelGGL(cma_rank_kernel, dim3(rank_grid(P)), dim3(256), 0, (hipStream_t)stream, fit, P, order,
                        state, besthist, gen);
     SX_LAUNCH_CHECK();
     return 0;
@@ -465,7 +484,7 @@ int cma_penalize_launch(const sx_cma_args &h, int64_t gen, const double *dvec, c
     hipStream_t st = (hipStream_t)stream;
     SX_REQUIRE(h.pen_ws && h.pen_order && 20.0 + 3.0 * h.n / (double)h.P + 1.0 <= (double)kPenHist,
                "Penalize on the device needs pen_order and a spread history of at most 256 entries");
-    hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((h.P + 63) / 64)), dim3(256), 0, st, (const double *)h.fit, h.P, h.pen_order,
+    hipLaunchKernelGGL(cma_rank_kernel, dim3(rank_grid(h.P)), dim3(256), 0, st, (const double *)h.fit, h.P, h.pen_order,
                        (sx_cma_state *)h.state, (double *)nullptr, gen);
     hipLaunchKernelGGL(cma_penalty_kernel, dim3(1), dim3(kPathThreads), 0, st, h, gen, dvec, vvec);
     if (int rc = sx_cmaes_eval_penalized(h.fun_id, h.arx, h.P, h.n, h.xm, h.xstd, h.pen_ws + h.n, h.fit,
@@ -542,7 +561,7 @@ int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *strea
     if (a->pen_ws != nullptr) {
         // Penalize (cmaes/_constraints.py:4-82): a->fit holds the objective of the clipped candidates; the boundary-weight
         // bookkeeping from its percentiles, then the weighted squared excess on top (the second pass recomputes the same raw values)
-        hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, a->fit, P, a->pen_order, state,
+        hipLaunchKernelGGL(cma_rank_kernel, dim3(rank_grid(P)), dim3(256), 0, st, a->fit, P, a->pen_order, state,
                            (double *)nullptr, gen);
         hipLaunchKernelGGL(cma_penalty_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, (const double *)nullptr,
                            (const double *)nullptr);
@@ -551,7 +570,7 @@ int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *strea
             return rc;
         hipLaunchKernelGGL(cma_add_penalty_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, *a);
     }
-    hipLaunchKernelGGL(cma_rank_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, a->fit, P, a->order, state,
+    hipLaunchKernelGGL(cma_rank_kernel, dim3(rank_grid(P)), dim3(256), 0, st, a->fit, P, a->order, state,
                        a->besthist, gen);
     if (a->hist_x) {
         SX_REQUIRE(a->hist_f != nullptr && a->hist_rows >= 0 && a->hist_rows <= P, "sx_cmaes_generation: bad history arguments");
@@ -573,8 +592,8 @@ int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *strea
         // tolerance: what LAPACK's own decomposition guarantees, a backward error of n * eps * |C|_F (never below the
         // solver's default 1e-14): at n = 512 that is 5.7e-14 -- about one decomposition in two stops a sweep earlier
         const double tol = std::max(1.0e-14, (double)n * 1.1102230246251565e-16);
-        if ((rc = sx_eigh(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes,
-                          a->eig_sweeps, tol, stream)))
+        if ((rc = sx::eigh_enqueue(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes,
+                                   a->eig_sweeps, tol, &state->done, stream)))
             return rc;
     }
     hipLaunchKernelGGL(cma_stop_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, do_eigh ? 1 : 0);

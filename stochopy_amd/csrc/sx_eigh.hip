@@ -541,25 +541,39 @@ __global__ __launch_bounds__(jacobi_threads<M2>()) void eigh_small_kernel(const 
 // ---------------------------------------------------------------------------------------------------
 // M0 = C (upper triangle mirrored) padded with zeros to npad; V0 = I, or the caller's starting basis padded with
 // the identity; both rotation buffers = I; ||C||_F^2 into info->norm2 (info zeroed by the host beforehand)
+// A grid-stride loop over a bounded grid: every workgroup ends with ONE atomic on info->norm2, and a thousand of
+// them on one address were most of this kernel's 15 us at n = 512 (~12 ns each, serialised).
+// skip != NULL and *skip != 0 (the CMA-ES loop's done flag): the run is closed at once and every later launch of it
+// is a no-op -- generations enqueued ahead of the host's look at the state cost launches, not decompositions.
+constexpr unsigned kPrepareMaxBlocks = 128;
 __global__ __launch_bounds__(256) void eigh_prepare_kernel(const double *__restrict__ C, int n, int npad,
                                                            const double *__restrict__ Vstart, double *__restrict__ M0,
                                                            double *__restrict__ V0, double *__restrict__ U,
-                                                           int64_t ucount, EighInfo *info) {
+                                                           int64_t ucount, EighInfo *info, const int *__restrict__ skip) {
     __shared__ double red[4];
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double v = 0.0;
-    if (e < (int64_t)npad * npad) {
-        const int i = (int)(e / npad), j = (int)(e % npad);
-        const bool in = i < n && j < n;
-        if (in) v = i <= j ? C[(int64_t)i * n + j] : C[(int64_t)j * n + i];
-        M0[e] = v;
-        V0[e] = (in && Vstart) ? Vstart[(int64_t)i * n + j] : (i == j ? 1.0 : 0.0);
+    if (skip != nullptr && *skip != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) info->done_seq = 1;  // (sweeps = 0, converged = 0: nothing was decomposed)
+        return;
     }
-    if (e < ucount) {
-        const int w = (int)(e % kUU);
-        U[e] = (w / kM2 == w % kM2) ? 1.0 : 0.0;
+    const unsigned np2 = (unsigned)npad * (unsigned)npad, un = (unsigned)npad;
+    const unsigned tot = np2 > (unsigned)ucount ? np2 : (unsigned)ucount;
+    double acc = 0.0;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < tot; e += gridDim.x * 256u) {
+        if (e < np2) {
+            const unsigned i = e / un, j = e - i * un;
+            const bool in = i < (unsigned)n && j < (unsigned)n;
+            double v = 0.0;
+            if (in) v = i <= j ? C[(int64_t)i * n + j] : C[(int64_t)j * n + i];
+            M0[e] = v;
+            V0[e] = (in && Vstart) ? Vstart[(int64_t)i * n + j] : (i == j ? 1.0 : 0.0);
+            acc += v * v;
+        }
+        if (e < (unsigned)ucount) {
+            const unsigned w = e % (unsigned)kUU;
+            U[e] = (w / kM2 == w % kM2) ? 1.0 : 0.0;
+        }
     }
-    const double s = block_sum<256>(v * v, red, threadIdx.x);
+    const double s = block_sum<256>(acc, red, threadIdx.x);
     if (threadIdx.x == 0 && s != 0.0) atomicAdd(&info->norm2, s);
 }
 
@@ -905,23 +919,29 @@ __global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double
 
 // per column j of V: |v_j|^2 and the sign of its largest-magnitude component (lowest row on ties);
 // lam[j] = M_jj / |v_j|^2, scl[j] = sign / |v_j|.  One workgroup per 16 columns, 16 row strips (rows of 128 bytes).
-__global__ __launch_bounds__(256) void eigh_colstats_kernel(const double *__restrict__ M0, const double *__restrict__ M1,
-                                                            const double *__restrict__ V0, const double *__restrict__ V1,
-                                                            int n, int npad, const EighInfo *info,
-                                                            double *__restrict__ lam, double *__restrict__ scl) {
-    __shared__ double s_n2[16][16], s_mx[16][16], s_sg[16][16];
-    __shared__ int s_ix[16][16];
+__global__ __launch_bounds__(1024) void eigh_colstats_kernel(const double *__restrict__ M0, const double *__restrict__ M1,
+                                                             const double *__restrict__ V0, const double *__restrict__ V1,
+                                                             int n, int npad, const EighInfo *info,
+                                                             double *__restrict__ lam, double *__restrict__ scl) {
+    constexpr int RS = 64;  // row strips (round 3: 16 strips of 32 serial loads each took 15 us at n = 512)
+    __shared__ double s_n2[RS][16], s_mx[RS][16], s_sg[RS][16];
+    __shared__ int s_ix[RS][16];
     const double *M = info->parity ? M1 : M0, *V = info->parity ? V1 : V0;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + tx;
     double n2 = 0.0, mx = -1.0, sg = 1.0;
     int ix = 0;
     if (j < n) {
-        for (int i = ty; i < n; i += 16) {
-            const double v = V[(int64_t)i * npad + j];
-            n2 += v * v;
-            const double a = fabs(v);
-            if (a > mx) mx = a, ix = i, sg = v < 0.0 ? -1.0 : 1.0;
+        for (int i0 = ty; i0 < n; i0 += 8 * RS) {  // eight loads in flight
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i0 + u * RS < n ? V[(int64_t)(i0 + u * RS) * npad + j] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                n2 += v[u] * v[u];
+                const double a = fabs(v[u]);
+                if (i0 + u * RS < n && a > mx) mx = a, ix = i0 + u * RS, sg = v[u] < 0.0 ? -1.0 : 1.0;
+            }
         }
     }
     s_n2[ty][tx] = n2, s_mx[ty][tx] = mx, s_sg[ty][tx] = sg, s_ix[ty][tx] = ix;
@@ -930,8 +950,8 @@ __global__ __launch_bounds__(256) void eigh_colstats_kernel(const double *__rest
         if (j < n) {
             double tot = 0.0, bm = -1.0, bs = 1.0;
             int bi = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
+#pragma unroll 8
+            for (int k = 0; k < RS; ++k) {
                 tot += s_n2[k][tx];
                 const double m = s_mx[k][tx];
                 if (m > bm || (m == bm && s_ix[k][tx] < bi)) bm = m, bi = s_ix[k][tx], bs = s_sg[k][tx];
@@ -946,32 +966,38 @@ __global__ __launch_bounds__(256) void eigh_colstats_kernel(const double *__rest
 }
 
 // ascending rank of every eigenvalue (ties: lower position first); inv[rank] = position, w[rank] = value.
-// The values pass through LDS 4096 at a time.
-__global__ __launch_bounds__(1024) void eigh_rank_kernel(const double *__restrict__ lam, int n, int *__restrict__ inv,
-                                                         double *__restrict__ w) {
+// A wavefront ranks four values: lane l looks at values l, l + 64, ... (through LDS, 4096 at a time) and the rank is
+// the population count of the wave's votes (round 3: one workgroup with n serial comparisons per thread took 16 us).
+constexpr int kEigRankPerWave = 4;
+__global__ __launch_bounds__(256) void eigh_rank_kernel(const double *__restrict__ lam, int n, int *__restrict__ inv,
+                                                        double *__restrict__ w) {
     constexpr int CH = 4096;
     __shared__ double keys[CH];
-    for (int j0 = 0; j0 < n; j0 += 1024) {
-        const int j = j0 + threadIdx.x;
-        const double lj = j < n ? lam[j] : 0.0;
-        int rank = 0;
-        for (int c0 = 0; c0 < n; c0 += CH) {
-            const int len = n - c0 < CH ? n - c0 : CH;
-            __syncthreads();
-            for (int e = threadIdx.x; e < len; e += 1024) keys[e] = lam[c0 + e];
-            __syncthreads();
-            if (j < n) {
-                const int jj = j - c0;  // position of this value inside the chunk (ties: lower position first)
-#pragma unroll 16
-                for (int k = 0; k < len; ++k) {
-                    const double lk = keys[k];
-                    rank += (lk < lj || (lk == lj && k < jj)) ? 1 : 0;
-                }
-            }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = ((int)blockIdx.x * 4 + wave) * kEigRankPerWave;
+    double lj[kEigRankPerWave];
+    int rank[kEigRankPerWave];
+#pragma unroll
+    for (int u = 0; u < kEigRankPerWave; ++u) lj[u] = j0 + u < n ? lam[j0 + u] : 0.0, rank[u] = 0;
+    for (int c0 = 0; c0 < n; c0 += CH) {
+        const int len = n - c0 < CH ? n - c0 : CH;
+        __syncthreads();
+        for (int e = threadIdx.x; e < len; e += 256) keys[e] = lam[c0 + e];
+        __syncthreads();
+        for (int k0 = 0; k0 < len; k0 += 64) {  // uniform trip count: every lane adds every vote
+            const int k = k0 + lane;
+            const bool in = k < len;
+            const double lk = in ? keys[k] : 0.0;
+#pragma unroll
+            for (int u = 0; u < kEigRankPerWave; ++u)
+                rank[u] += (int)__popcll(__ballot(in && (lk < lj[u] || (lk == lj[u] && c0 + k < j0 + u))));
         }
-        if (j < n) {
-            inv[rank] = j;
-            w[rank] = lj;
+    }
+#pragma unroll
+    for (int u = 0; u < kEigRankPerWave; ++u) {
+        if (lane == u && j0 + u < n) {
+            inv[rank[u]] = j0 + u;
+            w[rank[u]] = lj[u];
         }
     }
 }
@@ -1025,9 +1051,11 @@ extern "C" int64_t sx_eigh_workspace_bytes(int n) {
     return eigh_layout(nullptr, n).bytes;
 }
 
-extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
-                       int max_sweeps, double tol, void *stream) {
-    SX_REQUIRE(C && w && B && ws && n >= 1, "sx_eigh: bad arguments");
+namespace sx {
+// sx_eigh with a device-side skip flag (the CMA-ES loops' done word): see eigh_prepare_kernel
+int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
+                 int max_sweeps, double tol, const int *skip, void *stream) {
+    SX_REQUIRE(C && w && B && ws && n >= 1 && n <= 32768, "sx_eigh: bad arguments");
     const EighWs L = eigh_layout(ws, n);
     SX_REQUIRE(ws_bytes >= L.bytes, "sx_eigh: workspace too small (sx_eigh_workspace_bytes)");
     if (max_sweeps <= 0) max_sweeps = 24;
@@ -1046,9 +1074,10 @@ extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, doub
         SX_LAUNCH_CHECK();
     } else {
         const int64_t tot = std::max<int64_t>((int64_t)npad * npad, L.ucount);
+        const unsigned pgrid = (unsigned)std::min<int64_t>((tot + 255) / 256, kPrepareMaxBlocks);
         if (V0 == nullptr) {
-            hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, n, npad,
-                               (const double *)nullptr, L.M[0], L.V[0], L.U[0], L.ucount, L.info);
+            hipLaunchKernelGGL(eigh_prepare_kernel, dim3(pgrid), dim3(256), 0, st, C, n, npad,
+                               (const double *)nullptr, L.M[0], L.V[0], L.U[0], L.ucount, L.info, skip);
         } else {
             // Warm start from a nearly orthonormal basis (the previous generation's eigenvectors):
             //   V <- V0 (3 I - V0^T V0) / 2   one Newton-Schulz step: orthonormal to rounding, so that a basis handed
@@ -1057,8 +1086,8 @@ extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, doub
             // Four n^3 products on the matrix cores (~1 % of a cold decomposition); the sweeps then start from a
             // nearly diagonal M and the stopping rule ends them after the few that are needed.
             const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
-            hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, n, npad, V0,
-                               L.M[1], L.V[1], L.U[0], L.ucount, L.info);                       // M1 = C, V1 = V0
+            hipLaunchKernelGGL(eigh_prepare_kernel, dim3(pgrid), dim3(256), 0, st, C, n, npad, V0,
+                               L.M[1], L.V[1], L.U[0], L.ucount, L.info, skip);                 // M1 = C, V1 = V0
             hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[1], L.V[1], L.M[0], npad, -0.5, 1.5);
             hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.V[1], L.M[0], L.V[0], npad, 1.0, 0.0);
             hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.M[1], L.V[0], L.V[1], npad, 1.0, 0.0);
@@ -1083,13 +1112,20 @@ extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, doub
         hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, max_sweeps, cur, tol);
         SX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 15) / 16)), dim3(256), 0, st, L.M[0], L.M[1], L.V[0],
+    hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 15) / 16)), dim3(1024), 0, st, L.M[0], L.M[1], L.V[0],
                        L.V[1], n, npad, L.info, L.lam, L.scl);
-    hipLaunchKernelGGL(eigh_rank_kernel, dim3(1), dim3(1024), 0, st, L.lam, n, L.inv, w);
+    hipLaunchKernelGGL(eigh_rank_kernel, dim3((unsigned)((n + 4 * kEigRankPerWave - 1) / (4 * kEigRankPerWave))), dim3(256), 0, st,
+                       L.lam, n, L.inv, w);
     hipLaunchKernelGGL(eigh_write_kernel, dim3((unsigned)n), dim3(256), 0, st, L.V[0], L.V[1], n, npad, L.info, L.inv,
                        L.scl, B);
     SX_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace sx
+
+extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
+                       int max_sweeps, double tol, void *stream) {
+    return sx::eigh_enqueue(C, n, V0, w, B, ws, ws_bytes, max_sweeps, tol, nullptr, stream);
 }
 
 // sweeps carried out / converged flag of the last sx_eigh on this workspace (synchronises the stream)
