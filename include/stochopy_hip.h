@@ -517,11 +517,18 @@ int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, in
  * Asynchronous on `stream`; the host never waits: launches after convergence are no-ops.
  * sx_eigh_info (synchronises): sweeps carried out, whether the rule was met, off-diagonal mass / |C|_F left
  * behind by the last sweep.
+ * sx_eigh_set_refine(mode): the last sweep of a run may be replaced by the first-order refinement step
+ * V <- V (I + K + K K / 2), K_ij = M_ij / (M_jj - M_ii), once what the sweeps left is small against every gap
+ * (off(M) <= 1e-7 |C|_F and max |K_ij| <= 1e-3, both measured on the device; csrc/sx_eigh.hip kRefineOff).
+ * mode 1: always allowed; 0: never; -1 (initial): allowed inside the CMA-ES generation loops (sx_cmaes_generation*),
+ * not in sx_eigh itself; the environment variable SX_EIGH_REFINE = 0 / 1 sets the initial mode.  Returns the
+ * previous mode.  Process-wide, not thread-safe.
  * ------------------------------------------------------------------------- */
 int64_t sx_eigh_workspace_bytes(int n);
 int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
             double tol, void *stream);
 int sx_eigh_info(const void *ws, int *sweeps, int *converged, double *off_rel, void *stream);
+int sx_eigh_set_refine(int mode);
 
 /* VD-CMA: everything of the model update that is O(mu n), on the device.
  * replaces vdcma/_vdcma.py:289-295 (w . arx[arindex[:mu]]), :317 (w . ary[arindex[:mu]]) and :331-339 with :428-444 (the

@@ -172,6 +172,7 @@ PROTOTYPES = {
     "sx_eigh_workspace_bytes": (i64, [C.c_int]),
     "sx_eigh": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, vp]),
     "sx_eigh_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64), vp]),
+    "sx_eigh_set_refine": (C.c_int, [C.c_int]),
     "sx_mt_create": (vp, [C.c_uint32]),
     "sx_mt_destroy": (None, [vp]),
     "sx_mt_seed": (None, [vp, C.c_uint32]),

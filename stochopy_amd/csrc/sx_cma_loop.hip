@@ -29,7 +29,8 @@ int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, i
                        const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
                        const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream);
 int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
-                 double tol, const int *skip, void *stream);  // sx_eigh.hip
+                 double tol, const int *skip, int refine, void *stream);  // sx_eigh.hip
+int eigh_refine_in_loops();
 }  // namespace sx
 
 namespace {
@@ -593,7 +594,7 @@ int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *strea
         // solver's default 1e-14): at n = 512 that is 5.7e-14 -- about one decomposition in two stops a sweep earlier
         const double tol = std::max(1.0e-14, (double)n * 1.1102230246251565e-16);
         if ((rc = sx::eigh_enqueue(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes,
-                                   a->eig_sweeps, tol, &state->done, stream)))
+                                   a->eig_sweeps, tol, &state->done, sx::eigh_refine_in_loops(), stream)))
             return rc;
     }
     hipLaunchKernelGGL(cma_stop_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, do_eigh ? 1 : 0);

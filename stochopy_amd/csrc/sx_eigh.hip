@@ -78,7 +78,25 @@ struct EighInfo {  // first bytes of the workspace
     double acc[kEighMaxSweeps];   // squared off-diagonal mass met during each sweep
     double offm[kEighMaxSweeps];  // squared off-diagonal mass of M AFTER each sweep, measured exactly by the tile
                                   // workgroups that apply the sweep's last rotations
+    int32_t refine;     // 1: the run ended with the first-order refinement step still to be applied (see below)
+    int32_t pad_;
+    unsigned long long kmax2[kEighMaxSweeps];  // bits of max (M_ij / (M_jj - M_ii))^2 over the significant elements
+                                               // of M after each sweep (same launch as offm)
 };
+
+// The last sweep of a run meets a matrix whose off-diagonal part E is tiny against every gap of the diagonal D: its
+// rotations are the first-order solution of (D + E) -> diagonal, K_ij = E_ij / (d_j - d_i), which needs no sequential
+// sweep at all.  With `refine` on (the CMA-ES loops), a run whose matrix after sweep s has
+//     off(M) <= kRefineOff |C|_F,   max |K_ij| <= kRefineCap   and   max |K_ij| * off(M) / |C|_F <= kRefineProd
+// ends there, and V <- V (I + K + K^2 / 2) (orthogonal to O(K^3); two n^3 products on the matrix cores, ~35 us at
+// n = 512), d_i <- d_i - sum_j K_ij E_ij (the second-order term of the eigenvalues) stand in for sweep s + 1
+// (~320 us).  What the step leaves behind is ~0.5 max|K| off(M) (measured: tools/eigh_refine_check.py,
+// profiles/r3_eigh_refine.txt) -- hence the product rule, which keeps the residual at the 1e-12 |C|_F level and the
+// eigenvectors within ~1e-9 of LAPACK's, where two solvers differ anyway inside a cluster (eps / gap).
+// Elements below tol |C|_F / npad are left alone (together they stay below the tolerance) -- a multiple eigenvalue,
+// where d_j - d_i is rounding noise, thus never blocks the step, while a significant element over a tiny gap
+// (max |K| large) does, and the run goes on sweeping as before.
+constexpr double kRefineOff = 1.0e-7, kRefineCap = 1.0e-3, kRefineProd = 1.0e-12;
 
 // Stopping rule, evaluated from the off-diagonal mass a_s = sqrt(acc[s] / |C|_F^2) met DURING the sweeps so far:
 // the sweep s that just ended is the last one when a_s <= tol (nothing left), or when the iteration is in its
@@ -611,9 +629,9 @@ __device__ __forceinline__ v4d mma_atb(const double *A, int lda, int i0, const d
 // start.  One workgroup per 32x32 tile, four waves = its four 16x16 quadrants, K in chunks of 32 through LDS with
 // the next chunk's global loads in flight during the MFMAs.
 template <bool TA>
-__global__ __launch_bounds__(256) void eigh_gemm_kernel(const double *__restrict__ A, const double *__restrict__ B,
-                                                        double *__restrict__ Out, int npad, double alpha, double diag) {
-    __shared__ double As[kM2 * LDX], Bs[kM2 * LDU];
+__device__ __forceinline__ void eigh_gemm_body(const double *__restrict__ A, const double *__restrict__ B,
+                                               double *__restrict__ Out, int npad, double alpha, double diag,
+                                               const double *__restrict__ addend, double *As, double *Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.y * kM2, j0 = blockIdx.x * kM2;
     const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
@@ -650,8 +668,73 @@ __global__ __launch_bounds__(256) void eigh_gemm_kernel(const double *__restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gi = i0 + wi + lk + 4 * r, gj = j0 + wj + lr;
-        Out[(int64_t)gi * npad + gj] = alpha * acc[r] + (gi == gj ? diag : 0.0);
+        double v = alpha * acc[r] + (gi == gj ? diag : 0.0);
+        if (addend != nullptr) v += addend[(int64_t)gi * npad + gj];
+        Out[(int64_t)gi * npad + gj] = v;
     }
+}
+
+template <bool TA>
+__global__ __launch_bounds__(256) void eigh_gemm_kernel(const double *__restrict__ A, const double *__restrict__ B,
+                                                        double *__restrict__ Out, int npad, double alpha, double diag) {
+    __shared__ double As[kM2 * LDX], Bs[kM2 * LDU];
+    eigh_gemm_body<TA>(A, B, Out, npad, alpha, diag, nullptr, As, Bs);
+}
+
+// ---- the refinement step (see kRefineOff): three launches that do nothing unless the run ended with info->refine ----
+// With p = info->parity:  M[p], V[p] hold the result of the sweeps; M[p ^ 1], V[p ^ 1] are free.
+//   1. K  -> M[p ^ 1]:  K_ij = M_ij / (d_j - d_i) for the significant elements (upper triangle, mirrored with the sign)
+//   2. T = I + K + K K / 2 -> V[p ^ 1]
+//   3. V[p] T -> M[p ^ 1]   (the eigenvectors; eigh_colstats / eigh_write read them from there, the eigenvalues stay d)
+__global__ __launch_bounds__(256) void eigh_refine_k_kernel(const double *__restrict__ M0, const double *__restrict__ M1,
+                                                            double *K0, double *K1, int npad,
+                                                            const EighInfo *info, double tol) {
+    if (!info->refine) return;
+    const double *M = info->parity ? M1 : M0;
+    double *K = info->parity ? K0 : K1;
+    const double tolel2 = tol * tol * info->norm2 / ((double)npad * (double)npad);
+    const unsigned e = blockIdx.x * 256u + threadIdx.x, un = (unsigned)npad;
+    if (e >= un * un) return;
+    const unsigned i = e / un, j = e - i * un;
+    double k = 0.0;
+    if (i != j) {
+        const unsigned a = i < j ? i : j, b = i < j ? j : i;  // the upper-triangle element decides for both
+        const double m = M[(int64_t)a * npad + b];
+        const double g = M[(int64_t)b * npad + b] - M[(int64_t)a * npad + a];
+        if (m * m > tolel2) k = m / g;
+        if (!(fabs(k) <= 2.0 * kRefineCap)) k = 0.0;  // (cannot happen after the rule held; never divide by noise)
+        if (i > j) k = -k;
+    }
+    K[e] = k;
+}
+// d_i <- d_i - sum_j K_ij M_ij  (= d_i + sum_j M_ij^2 / (d_i - d_j)), one wavefront per row; runs after step 1
+__global__ __launch_bounds__(256) void eigh_refine_diag_kernel(double *M0, double *M1, int npad, const EighInfo *info) {
+    if (!info->refine) return;
+    double *M = info->parity ? M1 : M0;
+    const double *K = info->parity ? M0 : M1;
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= npad) return;
+    double acc = 0.0;
+    for (int j = lane; j < npad; j += 64)
+        if (j != i) acc = fma(K[(int64_t)i * npad + j], M[(int64_t)i * npad + j], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    // (the diagonal is only read by other rows' K -- already formed -- and by eigh_colstats afterwards)
+    if (lane == 0) M[(int64_t)i * npad + i] -= acc;
+}
+// step 2 (which = 0) and step 3 (which = 1)
+__global__ __launch_bounds__(256) void eigh_refine_gemm_kernel(double *__restrict__ M0, double *__restrict__ M1,
+                                                               double *__restrict__ V0, double *__restrict__ V1, int npad,
+                                                               const EighInfo *info, int which) {
+    __shared__ double As[kM2 * LDX], Bs[kM2 * LDU];
+    if (!info->refine) return;
+    const int p = info->parity;
+    double *Kb = p ? M0 : M1, *Tb = p ? V0 : V1;
+    const double *Vb = p ? V1 : V0;
+    if (which == 0)
+        eigh_gemm_body<false>(Kb, Kb, Tb, npad, 0.5, 1.0, Kb, As, Bs);
+    else
+        eigh_gemm_body<false>(Vb, Tb, Kb, npad, 1.0, 0.0, nullptr, As, Bs);
 }
 
 struct RoundLds {
@@ -677,6 +760,7 @@ struct RoundLds {
     alignas(16) double cs[4 * kBS];  // (c, s) of every pair of the current / next inner round, interleaved
     double red[17];
     double scale;                // power of two that brings |C|_F (hence every pivot entry) below 1
+    double tolel2;               // square of the size below which an off-diagonal element does not count (tol |C|_F / npad)
     int flag;
 };
 
@@ -690,7 +774,8 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
                                                          double *__restrict__ Mout, double *__restrict__ Vout, int npad,
                                                          int nb, const double *__restrict__ Uprev,
                                                          double *__restrict__ Ucur, EighInfo *info, int sweep, int rprev,
-                                                         int rcur, int parity_out, double tol, int flush, int seq) {
+                                                         int rcur, int parity_out, double tol, int flush, int seq,
+                                                         int refine) {
     __shared__ RoundLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int np = nb / 2;
@@ -699,10 +784,11 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
     // pair workgroups' own loads are in flight: those do not depend on it (a launch that turns out to be a no-op has
     // read a few valid tiles for nothing).
     int ended = 0;
-    double nrm2 = 0.0, left = 0.0, met1 = 0.0, met0 = 0.0;
+    double nrm2 = 0.0, left = 0.0, met1 = 0.0, met0 = 0.0, kmax2 = 0.0;
     if (tid == 0) {
         ended = info->done_seq, nrm2 = info->norm2;
         if (sweep > 0) left = info->offm[sweep - 1], met1 = info->acc[sweep - 1];
+        if (sweep > 0 && refine) kmax2 = __longlong_as_double((long long)info->kmax2[sweep - 1]);
         if (sweep > 1) met0 = info->acc[sweep - 2];
     }
     // pair workgroups: source tiles (pairs of rprev) 0: (PI,PI)  1: (PI,PJ)  2: (PJ,PJ) and the rotations of PI and PJ.
@@ -746,6 +832,17 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
                 info->done_seq = seq;
             }
         }
+        if (!flag && refine && rcur == 1 && sweep > 0 && !flush && left <= kRefineOff * kRefineOff * nrm2 &&
+            kmax2 <= kRefineCap * kRefineCap && kmax2 * left <= kRefineProd * kRefineProd * nrm2) {
+            // what is left is first order against every gap: the run ends here and the refinement step finishes it
+            flag = 2;
+            if (blockIdx.x == 0) {
+                info->sweeps = sweep, info->parity = parity_out ^ 1, info->converged = 1;
+                info->thr2 = thr2;
+                info->refine = 1;
+                info->done_seq = seq;
+            }
+        }
         if (!flag && rcur == 0 && sweep > 0 && !flush) {
             // second rule, from the mass met DURING the last two sweeps (eigh_last_sweep)
             const bool last = met1 <= thr2 || (met1 <= 1.0e-20 * nrm2 && (sweep == 1 || met1 * met1 <= thr2 * met0));
@@ -759,6 +856,7 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
             }
         }
         L.flag = flag;
+        L.tolel2 = tol * tol * nrm2 / ((double)npad * (double)npad);
         int ex = 0;
         const double nrm = sqrt(nrm2);
         if (nrm > 0.0 && nrm < __builtin_inf()) (void)frexp(nrm, &ex);
@@ -788,6 +886,19 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
         }
         __syncthreads();
         const int i0 = (wave >> 1) * 16, j0 = (wave & 1) * 16;  // waves 0..3: one 16x16 quadrant each
+        // the launch that measures what a sweep left also measures max |M_ij / (d_j - d_i)| (refinement rule); the
+        // diagonal is taken from the matrix BEFORE this round's rotations -- in this phase it moves by second-order amounts
+        const bool measure_k = refine && is_m && rcur == 0 && sweep > 0 && wave < 4;
+        double dgi[4] = {0.0, 0.0, 0.0, 0.0}, dgj = 0.0;
+        if (measure_k) {
+            const int gj = pair_index(j0 + lr, aq, bq);
+            dgj = Min[(int64_t)gj * npad + gj];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = pair_index(i0 + lk + 4 * r, ap, bp);
+                dgi[r] = Min[(int64_t)gi * npad + gi];
+            }
+        }
         v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
         if (wave < 4) acc = mma_ab(L.t.X, LDX, i0, L.t.UQ, LDU, j0, lane);
         if (is_m) {
@@ -798,7 +909,7 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
             __syncthreads();
             if (wave < 4) acc = mma_atb(L.t.UP, LDU, i0, L.t.Y, LDU, j0, lane);
         }
-        double m2 = 0.0;
+        double m2 = 0.0, k2 = 0.0;
         if (wave < 4) {
             const int gj = pair_index(j0 + lr, aq, bq);
 #pragma unroll
@@ -806,7 +917,13 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
                 const int i = i0 + lk + 4 * r;
                 const int gi = is_m ? pair_index(i, ap, bp) : P * kM2 + i;
                 dst[(int64_t)gi * npad + gj] = acc[r];
-                if (gi != gj) m2 = fma(acc[r], acc[r], m2);
+                if (gi != gj) {
+                    m2 = fma(acc[r], acc[r], m2);
+                    if (measure_k) {
+                        const double a2 = acc[r] * acc[r], g = dgj - dgi[r];
+                        if (a2 > L.tolel2) k2 = fmax(k2, a2 / (g * g));  // (a zero gap under a significant element: inf)
+                    }
+                }
             }
         }
         // this launch applies the LAST rotations of sweep `sweep - 1`: what it writes is the matrix after that sweep,
@@ -814,11 +931,18 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
         if (is_m && rcur == 0 && sweep > 0) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
-            if (lane == 0 && wave < 4) L.red[wave] = m2;
+            if (refine) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) k2 = fmax(k2, __shfl_xor(k2, off, kWave));
+            }
+            if (lane == 0 && wave < 4) L.red[wave] = m2, L.red[4 + wave] = k2;
             __syncthreads();
             if (tid == 0) {
                 const double t = (L.red[0] + L.red[1]) + (L.red[2] + L.red[3]);
                 if (t != 0.0) atomicAdd(&info->offm[sweep - 1], t);
+                const double km = fmax(fmax(L.red[4], L.red[5]), fmax(L.red[6], L.red[7]));
+                // (non-negative doubles order like their bit patterns; NaN -- 0/0 cannot occur, a2 > 0 -- would read as huge)
+                if (refine && km > 0.0) atomicMax(&info->kmax2[sweep - 1], (unsigned long long)__double_as_longlong(km));
             }
         }
         return;
@@ -927,6 +1051,7 @@ __global__ __launch_bounds__(1024) void eigh_colstats_kernel(const double *__res
     __shared__ double s_n2[RS][16], s_mx[RS][16], s_sg[RS][16];
     __shared__ int s_ix[RS][16];
     const double *M = info->parity ? M1 : M0, *V = info->parity ? V1 : V0;
+    if (info->refine) V = info->parity ? M0 : M1;  // the refinement step left the eigenvectors in the free M buffer
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + tx;
     double n2 = 0.0, mx = -1.0, sg = 1.0;
@@ -1003,11 +1128,13 @@ __global__ __launch_bounds__(256) void eigh_rank_kernel(const double *__restrict
 }
 
 // B[i][r] = V[i][inv[r]] * scl[inv[r]]   (eigenvectors in columns, row-major like numpy's)
-__global__ __launch_bounds__(256) void eigh_write_kernel(const double *__restrict__ V0, const double *__restrict__ V1,
+__global__ __launch_bounds__(256) void eigh_write_kernel(const double *__restrict__ M0, const double *__restrict__ M1,
+                                                         const double *__restrict__ V0, const double *__restrict__ V1,
                                                          int n, int npad, const EighInfo *info,
                                                          const int *__restrict__ inv, const double *__restrict__ scl,
                                                          double *__restrict__ B) {
     const double *V = info->parity ? V1 : V0;
+    if (info->refine) V = info->parity ? M0 : M1;
     const int i = blockIdx.x;
     for (int r = threadIdx.x; r < n; r += 256) {
         const int j = inv[r];
@@ -1029,8 +1156,8 @@ inline EighWs eigh_layout(void *ws, int n) {
     const int64_t np = eigh_npad(n);
     char *p = (char *)ws;
     EighWs w;
-    int64_t off = 1024;  // EighInfo
-    static_assert(sizeof(EighInfo) <= 1024, "info block");
+    int64_t off = 2048;  // EighInfo
+    static_assert(sizeof(EighInfo) <= 2048, "info block");
     w.info = (EighInfo *)p;
     for (int k = 0; k < 2; ++k) w.M[k] = (double *)(p + off), off += np * np * 8;
     for (int k = 0; k < 2; ++k) w.V[k] = (double *)(p + off), off += np * np * 8;
@@ -1052,9 +1179,27 @@ extern "C" int64_t sx_eigh_workspace_bytes(int n) {
 }
 
 namespace sx {
+// The refinement step: the CMA-ES loops take it unless told otherwise, sx_eigh itself only when asked
+// (sx_eigh_set_refine, or the environment variable SX_EIGH_REFINE = 0 / 1 read once).
+static int g_refine_mode = -1;  // -1: SX_EIGH_REFINE or the defaults; 0: never; 1: always
+static int refine_env() {
+    static const int v = [] {
+        const char *e = getenv("SX_EIGH_REFINE");
+        return e == nullptr ? -1 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1));
+    }();
+    return v;
+}
+int eigh_refine_default() {
+    const int m = g_refine_mode >= 0 ? g_refine_mode : refine_env();
+    return m == 1 ? 1 : 0;
+}
+int eigh_refine_in_loops() {
+    const int m = g_refine_mode >= 0 ? g_refine_mode : refine_env();
+    return m == 0 ? 0 : 1;
+}
 // sx_eigh with a device-side skip flag (the CMA-ES loops' done word): see eigh_prepare_kernel
 int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
-                 int max_sweeps, double tol, const int *skip, void *stream) {
+                 int max_sweeps, double tol, const int *skip, int refine, void *stream) {
     SX_REQUIRE(C && w && B && ws && n >= 1 && n <= 32768, "sx_eigh: bad arguments");
     const EighWs L = eigh_layout(ws, n);
     SX_REQUIRE(ws_bytes >= L.bytes, "sx_eigh: workspace too small (sx_eigh_workspace_bytes)");
@@ -1100,24 +1245,33 @@ int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B,
         for (int sw = 0; sw < max_sweeps; ++sw) {
             for (int r = 0; r < nb - 1; ++r) {
                 hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
-                                   L.V[cur ^ 1], npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, sw, rprev, r, cur ^ 1, tol, 0, ++seq);
+                                   L.V[cur ^ 1], npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, sw, rprev, r, cur ^ 1, tol, 0, ++seq, refine);
                 cur ^= 1, ucur ^= 1, rprev = r;
             }
         }
         // apply the last rotations, then close
         hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1], L.V[cur ^ 1],
-                           npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, max_sweeps, rprev, 0, cur ^ 1, tol, 1, ++seq);
+                           npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, max_sweeps, rprev, 0, cur ^ 1, tol, 1, ++seq, 0);
         cur ^= 1;
         SX_LAUNCH_CHECK();
         hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, max_sweeps, cur, tol);
         SX_LAUNCH_CHECK();
+        if (refine) {
+            const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
+            hipLaunchKernelGGL(eigh_refine_k_kernel, dim3((unsigned)(((int64_t)npad * npad + 255) / 256)), dim3(256), 0, st, L.M[0],
+                               L.M[1], L.M[0], L.M[1], npad, L.info, tol);
+            hipLaunchKernelGGL(eigh_refine_diag_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, st, L.M[0], L.M[1], npad, L.info);
+            hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 0);
+            hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 1);
+            SX_LAUNCH_CHECK();
+        }
     }
     hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 15) / 16)), dim3(1024), 0, st, L.M[0], L.M[1], L.V[0],
                        L.V[1], n, npad, L.info, L.lam, L.scl);
     hipLaunchKernelGGL(eigh_rank_kernel, dim3((unsigned)((n + 4 * kEigRankPerWave - 1) / (4 * kEigRankPerWave))), dim3(256), 0, st,
                        L.lam, n, L.inv, w);
-    hipLaunchKernelGGL(eigh_write_kernel, dim3((unsigned)n), dim3(256), 0, st, L.V[0], L.V[1], n, npad, L.info, L.inv,
-                       L.scl, B);
+    hipLaunchKernelGGL(eigh_write_kernel, dim3((unsigned)n), dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], n, npad, L.info,
+                       L.inv, L.scl, B);
     SX_LAUNCH_CHECK();
     return 0;
 }
@@ -1125,7 +1279,13 @@ int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B,
 
 extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
                        int max_sweeps, double tol, void *stream) {
-    return sx::eigh_enqueue(C, n, V0, w, B, ws, ws_bytes, max_sweeps, tol, nullptr, stream);
+    return sx::eigh_enqueue(C, n, V0, w, B, ws, ws_bytes, max_sweeps, tol, nullptr, sx::eigh_refine_default(), stream);
+}
+
+extern "C" int sx_eigh_set_refine(int mode) {
+    const int prev = sx::g_refine_mode;
+    sx::g_refine_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
 }
 
 // sweeps carried out / converged flag of the last sx_eigh on this workspace (synchronises the stream)

@@ -27,7 +27,7 @@ class Eigh:
         if self.bytes <= 0:
             raise ValueError(f"sx_eigh_workspace_bytes({n}) = {self.bytes}")
         self.ws = t.empty((self.bytes + 7) // 8, dtype=t.float64, device=ctx.device)
-        self.ws[:128].zero_()  # the run record: info() before the first decomposition reads zeros, not stale memory
+        self.ws[:256].zero_()  # the run record: info() before the first decomposition reads zeros, not stale memory
         self.w = ctx.empty((self.n,))
         self.B = ctx.empty((self.n, self.n))
 

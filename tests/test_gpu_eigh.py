@@ -70,7 +70,7 @@ def run(ctx, Cm, **kw):
     return w.cpu().numpy(), B.cpu().numpy(), sweeps, conv, off
 
 
-def check(Cm, w, B, sweeps, conv):
+def check(Cm, w, B, sweeps, conv, EIG_RTOL=EIG_RTOL, RESID_TOL=RESID_TOL, ORTH_TOL=ORTH_TOL):
     n = Cm.shape[0]
     Cs = np.triu(Cm) + np.triu(Cm, 1).T
     wr, Br = oe.eigh_canonical(Cs)
@@ -196,3 +196,38 @@ def test_eigh_c4_golden_matrices(ctx):
         w, B, sweeps, conv, off = run(ctx, Cm)
         wr, Br = check(Cm, w, B, sweeps, conv)
         assert np.allclose(w, wr, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("kind,n", [("cma", 100), ("cma", 130), ("spd", 200), ("indefinite", 256), ("cma", 257), ("spd", 384),
+                                    ("cma", 512), ("graded", 192), ("repeated", 192), ("diagonal", 96)])
+def test_eigh_with_the_refinement_step(ctx, kind, n):
+    """sx_eigh_set_refine(1): once what the sweeps left is first order against every gap (off <= 1e-7 |C|, max |K| <= 1e-3,
+    max |K| * off <= 1e-12 |C|; measured on the device) the last sweep is replaced by V <- V (I + K + K^2/2) and the
+    second-order term of the eigenvalues -- what the CMA-ES loops run with.  Never more sweeps than without it; the
+    residual stays at the 1e-12 |C| level (the rule's bound), orthogonality at rounding level; eigenvectors of separated
+    eigenvalues agree with LAPACK's; a multiple eigenvalue (`repeated`) does not trip the step up."""
+    from stochopy_amd import _lib
+
+    L = _lib.lib()
+    rs = np.random.RandomState(77 + n)
+    Cm = make(kind, n, rs)
+    w0, B0, sweeps0, conv0, _ = run(ctx, Cm)
+    prev = L.sx_eigh_set_refine(1)
+    try:
+        from stochopy_amd.linalg import Eigh
+
+        eig = Eigh(ctx, n)
+        w, B = eig(ctx.upload(Cm))
+        sweeps, conv, off = eig.info()
+        refined = int(eig.ws[124:125].cpu().numpy().view(np.int32)[0])  # EighInfo.refine
+        w, B = w.cpu().numpy(), B.cpu().numpy()
+    finally:
+        L.sx_eigh_set_refine(prev)
+    assert sweeps <= sweeps0 and (not refined or sweeps < sweeps0 or sweeps0 == 0)
+    wr, Br = check(Cm, w, B, sweeps, conv, EIG_RTOL=2e-12, RESID_TOL=2e-12, ORTH_TOL=1e-13)
+    if n > 64 and kind in ("cma", "spd", "indefinite"):
+        assert refined == 1  # generic spectra always reach the rule one sweep early
+    gap = np.minimum(np.diff(wr, prepend=-np.inf), np.diff(wr, append=np.inf)) / max(np.abs(wr).max(), 1e-300)
+    good = gap > 1e-6
+    if good.any():
+        assert np.abs(B[:, good] - Br[:, good]).max() <= 1e-8
