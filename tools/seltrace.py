@@ -4,8 +4,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "stochopy_amd", "csrc")
 out = "/tmp/libsx_seltrace.so"
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-DSX_SELTRACE",
-                "-shared", "-x", "hip"] + sorted(glob.glob(src + "/*.hip") + glob.glob(src + "/*.cpp")) + ["-o", out], check=True)
+pre = os.path.join(ROOT, "build_ab", "libsx_seltrace.so")  # prebuilt in the build container (travels with the snapshot)
+if os.path.exists(pre):
+    out = pre
+else:
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-DSX_SELTRACE",
+                    "-shared", "-x", "hip"] + sorted(glob.glob(src + "/*.hip") + glob.glob(src + "/*.cpp")) + ["-o", out], check=True)
 from stochopy_amd import _lib
 _lib.LIB_PATH = out
 import torch
@@ -25,7 +29,8 @@ def restart(self):
 _cpso._PsoRun._restart_device = restart
 os.environ["SX_NO_GRAPH"] = "1"
 r = sa.optimize.minimize(sa.factory.ackley, [[-5.12, 5.12]] * 256, method="cpso",
-                         options={"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "maxiter": 30, "return_all": True, "verbosity": 0.0, "updating": "deferred"})
-for s in stamps[3:25]:
+                         options={"popsize": 16384, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0, "maxiter": int(os.environ.get("SELTRACE_MAXITER", "30")), "return_all": True, "verbosity": 0.0, "updating": "deferred"})
+step = int(os.environ.get("SELTRACE_EVERY", "1"))
+for s in stamps[3::step][:40]:
     d = np.diff(s)
     print("ticks(10ns) between stamps 0..7 [state+radii | keys | minmax | hist | scan+digit | gather | rank]:", d.tolist())
