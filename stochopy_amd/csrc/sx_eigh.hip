@@ -97,6 +97,7 @@ struct EighInfo {  // first bytes of the workspace
 // where d_j - d_i is rounding noise, thus never blocks the step, while a significant element over a tiny gap
 // (max |K| large) does, and the run goes on sweeping as before.
 constexpr double kRefineOff = 1.0e-7, kRefineCap = 1.0e-3, kRefineProd = 1.0e-12;
+constexpr int kEighFailsOffset = 2040;  // int32 inside the 2048-byte info block, behind EighInfo: runs that fell short
 
 // Stopping rule, evaluated from the off-diagonal mass a_s = sqrt(acc[s] / |C|_F^2) met DURING the sweeps so far:
 // the sweep s that just ended is the last one when a_s <= tol (nothing left), or when the iteration is in its
@@ -1033,11 +1034,21 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
 }
 
 // the run ends without the rule having fired: record where the result lives
-__global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double tol) {
+// `fails` (a word of the info block that sx_eigh does not clear) counts the runs of this workspace that ended short of
+// their tolerance: a loop that reads the record only every few decompositions still learns that one of them fell short.
+__global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double tol, int refine, int *fails) {
     if (threadIdx.x != 0 || info->done_seq) return;
     info->sweeps = sweeps, info->parity = parity, info->thr2 = tol * tol * info->norm2;
-    info->converged = (sweeps > 0 && (info->offm[sweeps - 1] <= info->thr2 ||
-                                      eigh_last_sweep(info->acc, sweeps - 1, info->norm2, tol))) ? 1 : 0;
+    int conv = (sweeps > 0 && (info->offm[sweeps - 1] <= info->thr2 ||
+                               eigh_last_sweep(info->acc, sweeps - 1, info->norm2, tol))) ? 1 : 0;
+    if (!conv && refine && sweeps > 0) {  // the allowance ran out where the refinement step takes over: let it
+        const double left = info->offm[sweeps - 1], kmax2 = __longlong_as_double((long long)info->kmax2[sweeps - 1]);
+        if (left <= kRefineOff * kRefineOff * info->norm2 && kmax2 <= kRefineCap * kRefineCap &&
+            kmax2 * left <= kRefineProd * kRefineProd * info->norm2)
+            info->refine = 1, conv = 1;
+    }
+    info->converged = conv;
+    if (!conv) atomicAdd(fails, 1);
     info->done_seq = 1;
 }
 
@@ -1157,7 +1168,7 @@ inline EighWs eigh_layout(void *ws, int n) {
     char *p = (char *)ws;
     EighWs w;
     int64_t off = 2048;  // EighInfo
-    static_assert(sizeof(EighInfo) <= 2048, "info block");
+    static_assert(sizeof(EighInfo) <= kEighFailsOffset, "info block");
     w.info = (EighInfo *)p;
     for (int k = 0; k < 2; ++k) w.M[k] = (double *)(p + off), off += np * np * 8;
     for (int k = 0; k < 2; ++k) w.V[k] = (double *)(p + off), off += np * np * 8;
@@ -1254,7 +1265,8 @@ int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B,
                            npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, max_sweeps, rprev, 0, cur ^ 1, tol, 1, ++seq, 0);
         cur ^= 1;
         SX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, max_sweeps, cur, tol);
+        hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, max_sweeps, cur, tol, refine,
+                           (int *)((char *)L.info + kEighFailsOffset));
         SX_LAUNCH_CHECK();
         if (refine) {
             const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));

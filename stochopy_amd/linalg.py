@@ -31,9 +31,10 @@ class Eigh:
         self.w = ctx.empty((self.n,))
         self.B = ctx.empty((self.n, self.n))
 
-    def __call__(self, Cmat, w=None, B=None, max_sweeps=0, tol=0.0, start=None):
+    def __call__(self, Cmat, w=None, B=None, max_sweeps=0, tol=0.0, start=None, refine=None):
         """``start``: optional (n, n) nearly orthonormal basis to start from (the previous decomposition's B; may be
-        the output buffer itself)."""
+        the output buffer itself).  ``refine``: True / False allows / forbids the first-order refinement step in place of
+        the last sweep for this call (``sx_eigh_set_refine``; None: the library's current mode)."""
         n = self.n
         if tuple(Cmat.shape) != (n, n) or not Cmat.is_contiguous():
             raise ValueError(f"expected a contiguous ({n},{n}) device matrix")
@@ -42,8 +43,13 @@ class Eigh:
         p = _device.ptr
         if start is not None and (tuple(start.shape) != (n, n) or not start.is_contiguous()):
             raise ValueError(f"start: expected a contiguous ({n},{n}) device matrix")
-        _lib.check(self.ctx.L.sx_eigh(p(Cmat), n, p(start), p(w), p(B), p(self.ws), self.bytes, int(max_sweeps),
-                                      float(tol), self.ctx.stream_ptr), "sx_eigh")
+        prev = self.ctx.L.sx_eigh_set_refine(1 if refine else 0) if refine is not None else None
+        try:
+            _lib.check(self.ctx.L.sx_eigh(p(Cmat), n, p(start), p(w), p(B), p(self.ws), self.bytes, int(max_sweeps),
+                                          float(tol), self.ctx.stream_ptr), "sx_eigh")
+        finally:
+            if prev is not None:
+                self.ctx.L.sx_eigh_set_refine(prev)
         return w, B
 
     def info(self):

@@ -13,6 +13,8 @@ candidates, the objective and the weighted squared excess run in one device kern
 (``sx_cmaes_eval_penalized``); the scalar bookkeeping of the boundary weights stays on the host.
 """
 
+import os
+
 import numpy as np
 
 from .. import _device, _lib, _rng
@@ -84,14 +86,16 @@ def minimize(
         eigh = "host" if rng == "numpy-legacy" else "device"
     if not callable(eigh) and eigh not in ("host", "device"):
         raise ValueError("eigh must be 'host', 'device' or a callable C -> (eigenvalues, eigenvectors)")
-    if (rng == "philox" and eigh == "device" and isinstance(fun_id, int) and callback is None
+    if (rng == "philox" and eigh == "device" and isinstance(fun_id, int) and os.environ.get("SX_CMA_LOOP", "") != "host"
             and (constraints is None or 20.0 + 3.0 * len(lower) / int(popsize) + 1.0 <= 256.0)):
-        # nothing the host has to see between generations: the whole loop (and the history) stays on the device --
-        # since round 3 including constraints="Penalize" (its boundary-weight bookkeeping: cma_penalty_kernel) and
+        # nothing the host has to COMPUTE between generations: the whole loop (and the history) stays on the device --
+        # since round 3 including constraints="Penalize" (its boundary-weight bookkeeping: cma_penalty_kernel),
         # workers > 1 (every rank samples and evaluates its share of the candidates, one all-gather, replicated model)
+        # and a callback (the host then looks at every generation and copies what the callback is shown).
+        # SX_CMA_LOOP=host: the host-driven loop with the device eigensolver (tests, tools/bench_c4.py).
         return _CmaDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
                              float(xtol), float(ftol), seed, bool(return_all), float(verbosity),
-                             penalize=constraints == "Penalize", workers=workers).result()
+                             penalize=constraints == "Penalize", workers=workers, callback=callback).result()
     run = _CmaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                   float(ftol), bool(return_all), float(verbosity), callback, rng, seed, eigh, workers,
                   penalize=constraints == "Penalize")
@@ -125,7 +129,7 @@ class _CmaDeviceRun:
     WARM_SWEEPS0 = 16  # launched for the first warm-started one; afterwards: what the last one needed + 1
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
-                 verbosity=1.0, run=True, penalize=False, workers=1):
+                 verbosity=1.0, run=True, penalize=False, workers=1, callback=None):
         """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
         with ``step`` from a state of their choosing."""
         import ctypes as C
@@ -181,6 +185,7 @@ class _CmaDeviceRun:
             if not run:
                 return
             eigeneval, look, since, t0 = 0, 1, 0, time.perf_counter()
+            cb_hist, cb_pin, fails_seen, warned_short = None, None, 0, False
             state = st
             # Sweeps to LAUNCH per decomposition (launches beyond convergence are no-ops of ~2 us each, 2n/16 - 1 per
             # sweep): a cold start gets the full allowance; a warm start what the last one needed + 1 -- inside a run
@@ -204,23 +209,50 @@ class _CmaDeviceRun:
                                "sx_cmaes_generation_stage")
                     look = 1  # (every rank must stop enqueueing collectives at the same generation)
                 since += 1
+                if callback is not None:
+                    look = 1  # the callback sees every generation (cmaes/_cmaes.py:333-343)
                 if since >= look or gen == maxiter:
                     state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
+                    if callback is not None:
+                        # what the reference hands over: all candidates (the clipped ones with Penalize), un-standardised,
+                        # and the best of them; with return_all the history so far (copied slab by slab)
+                        if cb_pin is None:
+                            cb_pin = t.empty((P, n), dtype=t.float64).pin_memory()
+                        cb_pin.copy_(keep["arx"])
+                        rows = cb_pin.numpy()
+                        Xs = np.multiply(np.clip(rows, -1.0, 1.0) if penalize else rows, xstd)  # (a new array every generation)
+                        Xs += xm
+                        cres = OptimizeResult(x=Xs[int(state.best_row)].copy(), fun=float(state.fbest), nfev=gen * P, nit=gen)
+                        if return_all:
+                            if cb_hist is None:
+                                cb_hist = (np.empty(tuple(keep["hist_x"].shape)), np.empty(tuple(keep["hist_f"].shape)))
+                            cb_hist[0][gen - 1] = keep["hist_x"][gen - 1].cpu().numpy()
+                            cb_hist[1][gen - 1] = keep["hist_f"][gen - 1].cpu().numpy()
+                            cres.update({"xall": cb_hist[0][:gen], "funall": cb_hist[1][:gen]})
+                        callback(Xs, cres)
                     if state.done:
                         break
+                    now = time.perf_counter()
+                    if world is None and callback is None and now - t0 < 2.0e-3 and look < self.LOOK:
+                        look *= 2  # cheap generations: look less often
                     if decomposed:  # (the record is only meaningful once a decomposition has been enqueued)
                         used, ok, _off = eig.info()
-                        if ok:
-                            warm_sweeps = min(60, used + 1)
+                        fails = int(eig.ws[255:256].cpu().numpy().view(np.int32)[0])  # runs since the start that fell short
+                        if ok and fails == fails_seen:
+                            # the record is the LAST decomposition's: while the host looks at every generation the count
+                            # moves by at most one between looks; between rarer looks it gets two more sweeps of slack
+                            warm_sweeps = min(60, used + (1 if look == 1 else 3))
                         else:
                             if launched >= 60:
                                 warnings.warn("stochopy_amd: the device eigensolver did not reach its tolerance in 60 "
                                               "sweeps; the decomposition is used as it is", RuntimeWarning, stacklevel=3)
-                            warm_sweeps = 60
+                            elif not warned_short:
+                                warnings.warn("stochopy_amd: a warm-started decomposition ran out of its %d launched sweeps "
+                                              "short of the tolerance (its result is used as it is); later ones get the "
+                                              "full allowance" % launched, RuntimeWarning, stacklevel=3)
+                                warned_short = True
+                            warm_sweeps, fails_seen = 60, fails
                         decomposed = False
-                    now = time.perf_counter()
-                    if world is None and now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
-                        look *= 2
                     since, t0 = 0, now
             if not state.done:  # cannot happen: generation maxiter sets status -1
                 raise RuntimeError("CMA-ES device loop ended without a status")
@@ -493,7 +525,8 @@ class _CmaRun:
                         eig = Eigh(ctx, n)
                     # ascending eigenvalues, eigenvectors in columns; from the second time on, started from the last ones
                     Dt, _ = eig(d_C, B=d_B, max_sweeps=eig_sweeps, start=d_B if eig_warm else None,
-                                tol=max(1.0e-14, n * 1.1102230246251565e-16))  # LAPACK's own backward error, n * eps
+                                tol=max(1.0e-14, n * 1.1102230246251565e-16),  # LAPACK's own backward error, n * eps
+                                refine=os.environ.get("SX_EIGH_REFINE", "1") != "0")  # as the device-resident loop does
                     was_warm, eig_warm = eig_warm, True
                     t.sqrt(Dt, out=d_D)
                     D = d_D.cpu().numpy()

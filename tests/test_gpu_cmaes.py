@@ -323,7 +323,7 @@ def test_cmaes_c4_device_eigensolver_vs_oracle_canonical(sa):
                                  ("sphere", 10, 65, 30, 0.3), ("rosenbrock", 12, 130, 30, 0.2), ("sphere", 67, 195, 14, 0.3),
                                  ("rosenbrock", 129, 258, 10, 0.2)],
                          ids=lambda c: "%s_n%d_p%d" % c[:3])
-def test_cmaes_device_resident_loop_vs_oracle(sa, cfg):
+def test_cmaes_device_resident_loop_vs_oracle(sa, cfg, monkeypatch):
     """No callback, no history, Philox draws: the whole loop runs on the device (csrc/sx_cma_loop.hip: ranking,
     recombination, paths, step size, stop rules; the host looks at the state every few generations).  Same seed as the
     oracle with LAPACK + the canonical sign rule: same stopping generation and status, best-f / best-x within the
@@ -336,11 +336,63 @@ def test_cmaes_device_resident_loop_vs_oracle(sa, cfg):
     assert (got.nit, got.nfev, got.status, got.success, got.message) == (ref.nit, ref.nfev, ref.status, ref.success, ref.message)
     assert np.isclose(got.fun, ref.fun, rtol=1e-6, atol=1e-300)
     assert np.allclose(got.x, ref.x, rtol=1e-5, atol=1e-7)
-    # and the host-driven loop (taken when a callback is given) agrees with it
+    # and the host-driven loop (legacy draws, eigh="host" / callable, or SX_CMA_LOOP=host) agrees with it
     trace = []
+    monkeypatch.setenv("SX_CMA_LOOP", "host")
     via_host = sa.optimize.minimize(getattr(sa.factory, obj), bounds, method="cmaes",
                                     options=dict(opts, backend="hip", rng="philox"), callback=lambda X, r: trace.append(r.fun))
     assert (via_host.nit, via_host.status) == (got.nit, got.status) and np.isclose(via_host.fun, got.fun, rtol=1e-6)
+    assert len(trace) == got.nit
+
+
+@pytest.mark.parametrize("obj,n,P,maxiter,constraints,verbosity", [
+    ("rosenbrock", 20, 48, 40, None, 1.0), ("sphere", 6, 12, 80, "Penalize", 0.5), ("rastrigin", 70, 160, 12, None, 0.0),
+    ("rosenbrock", 130, 264, 10, "Penalize", 1.0)])
+def test_cmaes_callback_on_the_device_resident_loop(sa, obj, n, P, maxiter, constraints, verbosity, monkeypatch):
+    """A callback no longer sends a Philox / device-eigensolver run to the host-driven loop (VERDICT r2 missing #3): the
+    generation stays on the device, the host looks at every generation and hands the callback what the reference does
+    (cmaes/_cmaes.py:333-343): all candidates of the generation (the clipped ones with Penalize), un-standardised, and
+    res.x / fun / nfev / nit of its best, with return_all the history so far.  Against the oracle's callback, generation
+    by generation, and against the same run without a callback."""
+    from stochopy_amd.optimize import _cmaes
+
+    taken = []
+    orig = _cmaes._CmaDeviceRun.__init__
+
+    def spy(self, *a, **k):
+        taken.append(k.get("callback") is not None)
+        orig(self, *a, **k)
+
+    monkeypatch.setattr(_cmaes._CmaDeviceRun, "__init__", spy)
+    lo, hi = (1.0, 5.0) if constraints else (-3.0, 3.0)
+    bounds = [[lo, hi]] * n
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 77 + n, "sigma": 0.3, "constraints": constraints, "return_all": True,
+            "verbosity": verbosity, "ftol": -1.0, "xtol": 0.0}
+    seen_ref, seen_got = [], []
+
+    def keep(store, history):
+        def cb(X, r):
+            store.append((np.array(X), np.array(r.x), float(r.fun), int(r.nfev), int(r.nit),
+                          (np.array(r.xall), np.array(r.funall)) if history else None))
+        return cb
+
+    # (the oracle's callback result carries no history; the reference's does: checked against the final arrays)
+    ref = oracle.minimize(obj, bounds, method="cmaes", options=dict(opts, eigh="canonical"), rng="philox", callback=keep(seen_ref, False))
+    got = sa.optimize.minimize(getattr(sa.factory, obj), bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"),
+                               callback=keep(seen_got, True))
+    assert taken == [True]
+    assert (got.nit, got.nfev, got.status) == (ref.nit, ref.nfev, ref.status) and len(seen_got) == len(seen_ref) == got.nit
+    for (X, x, f, nfev, nit, hist), (Xr, xr, fr, nfevr, nitr, _) in zip(seen_got, seen_ref):
+        assert (nfev, nit) == (nfevr, nitr) and X.shape == Xr.shape == (P, n)
+        assert np.isclose(f, fr, rtol=1e-6, atol=1e-300)
+        assert np.allclose(X, Xr, rtol=1e-5, atol=1e-6 * (hi - lo)) and np.allclose(x, xr, rtol=1e-5, atol=1e-6 * (hi - lo))
+        assert hist[0].shape == got.xall[:nit].shape and np.array_equal(hist[0], got.xall[:nit]) and np.array_equal(hist[1], got.funall[:nit])
+        if constraints:
+            assert X.min() >= lo - 1e-15 and X.max() <= hi + 1e-15
+    assert np.allclose(got.funall, ref.funall, rtol=1e-6, atol=1e-300)
+    plain = sa.optimize.minimize(getattr(sa.factory, obj), bounds, method="cmaes", options=dict(opts, backend="hip", rng="philox"))
+    assert (plain.nit, plain.status) == (got.nit, got.status) and plain.fun == got.fun and np.array_equal(plain.x, got.x)
+    assert np.array_equal(plain.xall, got.xall) and np.array_equal(plain.funall, got.funall)
 
 
 @pytest.mark.parametrize("n,P,maxiter", [(512, 1024, 20), (257, 520, 24)], ids=["c4_n512_p1024", "n257_p520"])

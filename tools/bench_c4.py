@@ -23,7 +23,10 @@ def timed(label, make):
 b512 = [[-5.12, 5.12]] * 512
 o = {"popsize": 1024, "seed": 0, "rng": "philox", "ftol": -1.0, "xtol": 0.0}
 timed("C4 cmaes rosenbrock n512 P1024, device-resident loop", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m)))
-timed("C4 same, host-driven loop (callback)", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m), callback=lambda X, r: None))
+timed("C4 same with a callback (device-resident loop, every generation shown to the host)", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m), callback=lambda X, r: None))
+os.environ["SX_CMA_LOOP"] = "host"
+timed("C4 same, host-driven loop (SX_CMA_LOOP=host, callback)", lambda m: sa.optimize.minimize(sa.factory.rosenbrock, b512, method="cmaes", options=dict(o, maxiter=m), callback=lambda X, r: None))
+del os.environ["SX_CMA_LOOP"]
 for n, P in ((128, 256), (256, 512), (1024, 2048)):
     b = [[-5.12, 5.12]] * n
     oo = dict(o, popsize=P)
