@@ -14,6 +14,8 @@ B and D).  SURVEY.md section 8f rank 3: the covariance model is D (I + v v^T) D,
 ``workers > 1``: candidates sharded by rows like CMA-ES (one all-gather of y, x and the fitness per generation).
 """
 
+import os
+
 import numpy as np
 
 from .. import _device, _lib, _rng
@@ -61,14 +63,16 @@ def minimize(
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
     workers = _common.resolve_workers(workers)
-    if (rng == "philox" and isinstance(fun_id, int) and callback is None and len(lower) <= 4096
+    if (rng == "philox" and isinstance(fun_id, int) and len(lower) <= 4096 and os.environ.get("SX_CMA_LOOP", "") != "host"
             and (constraints is None or 20.0 + 3.0 * len(lower) / int(popsize) + 1.0 <= 256.0)):
         # nothing the host has to see between generations: the whole loop (and the history) stays on the device --
         # since round 3 including constraints="Penalize" (boundary-weight bookkeeping shared with CMA-ES: cma_penalty_kernel)
-        # and workers > 1 (own candidates, one gather of steps / candidates / fitness, the O(n) model update replicated)
+        # and workers > 1 (own candidates, one gather of steps / candidates / fitness, the O(n) model update replicated);
+        # a callback is served from this loop too (the host then looks at every generation).  SX_CMA_LOOP=host: the
+        # host-driven loop (tests)
         return _VdDeviceRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc),
                             float(xtol), float(ftol), seed, bool(return_all), float(verbosity),
-                            penalize=constraints == "Penalize", workers=workers).result()
+                            penalize=constraints == "Penalize", workers=workers, callback=callback).result()
     run = _VdRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(sigma), float(muperc), float(xtol),
                  float(ftol), bool(return_all), float(verbosity), callback, rng, seed, workers,
                  constraints == "Penalize")
@@ -96,7 +100,7 @@ class _VdDeviceRun:
     LOOK = 16
 
     def __init__(self, fun_id, lower, upper, x0, maxiter, P, sigma, muperc, xtol, ftol, seed, return_all=False,
-                 verbosity=1.0, run=True, penalize=False, workers=1):
+                 verbosity=1.0, run=True, penalize=False, workers=1, callback=None):
         """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
         with ``step`` from a state of their choosing."""
         import ctypes as C
@@ -151,6 +155,7 @@ class _VdDeviceRun:
             if not run:
                 return
             look, since, t0 = 1, 0, time.perf_counter()
+            cb_pin = cb_hist = None
             state = st
             if world is not None:
                 ary_loc, arx_loc, fit_loc = ctx.empty((Pl, n)), ctx.empty((Pl, n)), ctx.empty((Pl,))
@@ -168,10 +173,27 @@ class _VdDeviceRun:
                 since += 1
                 if since >= look or gen == maxiter:
                     state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
+                    if callback is not None:
+                        # what the reference hands over (vdcma/_vdcma.py:413-423): all candidates (the clipped ones with
+                        # Penalize), un-standardised, and the best of them; with return_all the history so far
+                        if cb_pin is None:
+                            cb_pin = t.empty((P, n), dtype=t.float64).pin_memory()
+                        cb_pin.copy_(keep["arx"])
+                        rows = cb_pin.numpy()
+                        Xs = np.multiply(np.clip(rows, -1.0, 1.0) if penalize else rows, xstd)  # (a new array every generation)
+                        Xs += xm
+                        cres = OptimizeResult(x=Xs[int(state.best_row)].copy(), fun=float(state.fbest), nfev=gen * P, nit=gen)
+                        if return_all:
+                            if cb_hist is None:
+                                cb_hist = (np.empty(tuple(keep["hist_x"].shape)), np.empty(tuple(keep["hist_f"].shape)))
+                            cb_hist[0][gen - 1] = keep["hist_x"][gen - 1].cpu().numpy()
+                            cb_hist[1][gen - 1] = keep["hist_f"][gen - 1].cpu().numpy()
+                            cres.update({"xall": cb_hist[0][:gen], "funall": cb_hist[1][:gen]})
+                        callback(Xs, cres)
                     if state.done:
                         break
                     now = time.perf_counter()
-                    if world is None and now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
+                    if world is None and callback is None and now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
                         look *= 2  # (sharded: every generation, so that all ranks stop enqueueing collectives together)
                     since, t0 = 0, now
             if not state.done:  # cannot happen: generation maxiter sets status -1

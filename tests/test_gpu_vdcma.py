@@ -189,7 +189,7 @@ def test_device_loop_generation_by_generation_from_the_oracles_state(sa, objecti
                                                          ("rastrigin", 130, 24, 60, {"return_all": True}),
                                                          ("rosenbrock", 700, 64, 40, {"return_all": True, "verbosity": 0.0}),
                                                          ("sphere", 2000, 16, 25, {})])
-def test_vdcma_device_loop_matches_oracle(sa, objective, n, P, maxiter, extra):
+def test_vdcma_device_loop_matches_oracle(sa, objective, n, P, maxiter, extra, monkeypatch):
     """Whole runs through the device-resident loop (Philox draws, no callback) against the oracle: same stopping
     generation and status, best-f / result / histories within the north-star tolerance (1e-6 rel)."""
     opts = dict(maxiter=maxiter, popsize=P, sigma=0.3, seed=7, **extra)
@@ -204,11 +204,23 @@ def test_vdcma_device_loop_matches_oracle(sa, objective, n, P, maxiter, extra):
         assert got.xall.shape == ref["xall"].shape
         assert np.allclose(got.funall, ref["funall"], rtol=1e-6, atol=1e-300)
         assert np.allclose(got.xall, ref["xall"], rtol=1e-5, atol=1e-6)
-    # and the host-driven loop (callback) gives the same run
+    # a callback is served from the same loop (round 3): every generation's candidates and best, as the oracle's callback sees them
+    seen_ref, seen_got = [], []
+    oracle.minimize(objective, bounds, method="vdcma", options=dict(opts), rng="philox",
+                    callback=lambda X, r: seen_ref.append((np.array(X), np.array(r.x), float(r.fun), int(r.nfev), int(r.nit))))
+    cb = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="vdcma", options=dict(opts, backend="hip", rng="philox"),
+                              callback=lambda X, r: seen_got.append((np.array(X), np.array(r.x), float(r.fun), int(r.nfev), int(r.nit))))
+    assert (cb.nit, cb.status) == (got.nit, got.status) and cb.fun == got.fun and np.array_equal(cb.x, got.x)
+    assert len(seen_got) == len(seen_ref) == got.nit
+    for (X, x, f, nfev, nit), (Xr, xr, fr, nfevr, nitr) in zip(seen_got, seen_ref):
+        assert (nfev, nit) == (nfevr, nitr) and X.shape == Xr.shape == (P, n)
+        assert np.isclose(f, fr, rtol=1e-6, atol=1e-300) and np.allclose(X, Xr, rtol=1e-5, atol=1e-6) and np.allclose(x, xr, rtol=1e-5, atol=1e-6)
+    # and the host-driven loop (SX_CMA_LOOP=host; legacy draws take it too) gives the same run
+    monkeypatch.setenv("SX_CMA_LOOP", "host")
     trace = []
-    cb = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="vdcma",
+    hl = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="vdcma",
                               options=dict(opts, backend="hip", rng="philox"), callback=lambda X, r: trace.append(r.fun))
-    assert (cb.nit, cb.status) == (got.nit, got.status) and np.isclose(cb.fun, got.fun, rtol=1e-6, atol=1e-300)
+    assert (hl.nit, hl.status) == (got.nit, got.status) and np.isclose(hl.fun, got.fun, rtol=1e-6, atol=1e-300)
 
 
 def test_vdcma_device_loop_small_shapes_and_short_runs(sa):
