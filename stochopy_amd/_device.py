@@ -4,12 +4,15 @@ PyTorch is used for memory, streams and torch.distributed only; all compute is
 in the HIP library.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
 from . import _lib
 
 _torch = None
+_TLS = threading.local()
+_ARENA, _ARENA_OFF, _ARENA_BYTES = None, 0, 1 << 20  # pinned staging for upload_async
 
 
 def torch():
@@ -47,8 +50,17 @@ class Context:
         t = torch()
         self.device = require_device(device)
         self.L = _lib.lib()
-        with t.cuda.device(self.device):
-            self.stream = t.cuda.Stream(device=self.device)
+        # ONE engine stream per device and host thread, kept for the life of the process: torch's caching allocator
+        # keeps its free blocks per stream, so a fresh stream per run meant fresh hipMallocs for every population buffer
+        # (~0.35 ms of the 0.8 ms a whole minimize() call at the metric shape spent before its first generation)
+        key = (self.device.index if self.device.index is not None else t.cuda.current_device())
+        streams = getattr(_TLS, "streams", None)
+        if streams is None:
+            streams = _TLS.streams = {}
+        if key not in streams:
+            with t.cuda.device(self.device):
+                streams[key] = t.cuda.Stream(device=self.device)
+        self.stream = streams[key]
 
     @property
     def stream_ptr(self):
@@ -67,6 +79,29 @@ class Context:
         a = np.array(array, order="C", copy=True)  # also normalises negative / zero strides
         x = t.from_numpy(a).to(self.device, non_blocking=False)
         return x if dtype is None else x.to(dtype)
+
+    def upload_async(self, array):
+        """Small host array -> device WITHOUT the blocking pageable copy of ``upload`` (~0.2 ms each through
+        ``Tensor.to``): the bytes go through a process-wide pinned arena and an asynchronous copy on the CURRENT torch
+        stream -- callers run inside ``torch.cuda.stream(ctx.stream)``, so kernels enqueued afterwards see the data."""
+        global _ARENA, _ARENA_OFF
+        t = torch()
+        a = np.ascontiguousarray(array)
+        nbytes = a.nbytes
+        if nbytes == 0 or nbytes > _ARENA_BYTES // 4:
+            return self.upload(a)
+        if _ARENA is None:
+            _ARENA = t.empty(_ARENA_BYTES, dtype=t.uint8).pin_memory()
+        off = (_ARENA_OFF + 63) & ~63
+        if off + nbytes > _ARENA_BYTES:  # wrap: every copy that read the arena so far must have landed
+            t.cuda.synchronize()
+            off = 0
+        _ARENA_OFF = off + nbytes
+        stage = _ARENA[off:off + nbytes]
+        stage.numpy()[:] = a.reshape(-1).view(np.uint8)
+        dev = t.empty(a.shape, dtype=t.from_numpy(a.reshape(-1)[:0]).dtype, device=self.device)  # (ascontiguousarray: ndim >= 1)
+        dev.reshape(-1).view(t.uint8).copy_(stage, non_blocking=True)
+        return dev
 
     def sync(self):
         self.stream.synchronize()
