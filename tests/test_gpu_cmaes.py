@@ -131,7 +131,8 @@ def test_cmaes_matches_reference_golden(sa, case):
             ref["nit"], ref["nfev"], ref["status"], ref["success"], ref["message"])
         assert np.isclose(res.fun, unhex(ref["fun"]), rtol=1e-6, atol=0)
     else:
-        # generation 1 (B = I) is exact; afterwards only the distribution is determined
+        # NOT a parity check, a property test: generation 1 (B = I) is exact; afterwards only the distribution is determined
+        # (same-seed parity for these two cases: test_cmaes_golden_with_the_references_eigenpairs_replayed below)
         assert np.isclose(trace[0], want[0], rtol=1e-12)
         assert res.status == ref["status"]
         assert res.fun <= max(10.0 * unhex(ref["fun"]), case["options"].get("ftol", 1e-8))
