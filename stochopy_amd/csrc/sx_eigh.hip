@@ -637,34 +637,69 @@ __device__ __forceinline__ void eigh_gemm_body(const double *__restrict__ A, con
     const int i0 = blockIdx.y * kM2, j0 = blockIdx.x * kM2;
     const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
     const int lr = lane & 15, lk = lane >> 4;
-    double ra[4], rb[4];
-    auto fetch = [&](int k0) {
+    // kAhead chunks of both operands live in registers: one workgroup (four waves) per CU has nothing else to hide the
+    // ~1 us of a global load behind (round 3: one chunk ahead = 13.5 us per n = 512 product, of which 3.6 us MFMA)
+    constexpr int kAhead = 4;
+    double ra[kAhead][4], rb[kAhead][4];
+    auto fetch = [&](int k0, double (&a4)[4], double (&b4)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u, r = e / kM2, c = e % kM2;
             // As[i][k]: TA reads A[k0 + r][i0 + c] (r = k, c = i: coalesced along i), else A[i0 + r][k0 + c]
-            ra[u] = TA ? A[(int64_t)(k0 + r) * npad + i0 + c] : A[(int64_t)(i0 + r) * npad + k0 + c];
-            rb[u] = B[(int64_t)(k0 + r) * npad + j0 + c];
+            a4[u] = TA ? A[(int64_t)(k0 + r) * npad + i0 + c] : A[(int64_t)(i0 + r) * npad + k0 + c];
+            b4[u] = B[(int64_t)(k0 + r) * npad + j0 + c];
         }
     };
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    fetch(0);
-    for (int k0 = 0; k0 < npad; k0 += kM2) {
+    const int nchunk = npad / kM2;
+    // two LDS images: chunk c + 1 is staged while chunk c is multiplied, ONE barrier per chunk (a wave reaches the barrier of
+    // chunk c + 1 only with chunk c's fragments in its registers, so image c & 1 is free again when chunk c + 2 is staged)
+    int img = 0;
+    auto stage_and_multiply = [&](double (&a4)[4], double (&b4)[4], auto &&refill) {
+        double *Ai = As + img * (kM2 * LDX), *Bi = Bs + img * (kM2 * LDU);
+        img ^= 1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u, r = e / kM2, c = e % kM2;
             if (TA)
-                As[c * LDX + r] = ra[u];
+                Ai[c * LDX + r] = a4[u];
             else
-                As[r * LDX + c] = ra[u];
-            Bs[r * LDU + c] = rb[u];
+                Ai[r * LDX + c] = a4[u];
+            Bi[r * LDU + c] = b4[u];
         }
         __syncthreads();
-        if (k0 + kM2 < npad) fetch(k0 + kM2);
+        refill();
+        double av[kM2 / 4], bv[kM2 / 4];  // all sixteen fragment reads in flight before the first MFMA
 #pragma unroll
-        for (int kk = 0; kk < kM2; kk += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(wi + lr) * LDX + kk + lk], Bs[(kk + lk) * LDU + wj + lr], acc, 0, 0, 0);
-        __syncthreads();
+        for (int k = 0; k < kM2 / 4; ++k) av[k] = Ai[(wi + lr) * LDX + 4 * k + lk], bv[k] = Bi[(4 * k + lk) * LDU + wj + lr];
+#pragma unroll
+        for (int k = 0; k < kM2 / 4; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
+    };
+    if (nchunk % kAhead == 0) {
+        // whole groups (npad a multiple of 128: n = 512, 1024 ...): not a single guard between the loads and their use, so
+        // the compiler's s_waitcnt vmcnt(N) leaves the three younger chunks in flight (with uniform guards in the way it
+        // falls back to vmcnt(0) at the joins and the depth collapses: the lesson of the CMA-ES GEMM kernels)
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s) fetch(s * kM2, ra[s], rb[s]);
+        for (int c0 = 0; c0 < nchunk - kAhead; c0 += kAhead) {
+#pragma unroll
+            for (int s = 0; s < kAhead; ++s)
+                stage_and_multiply(ra[s], rb[s], [&] { fetch((c0 + s + kAhead) * kM2, ra[s], rb[s]); });
+        }
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s) stage_and_multiply(ra[s], rb[s], [] {});
+    } else {
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s)
+            if (s < nchunk) fetch(s * kM2, ra[s], rb[s]);
+        for (int c0 = 0; c0 < nchunk; c0 += kAhead) {
+#pragma unroll
+            for (int s = 0; s < kAhead; ++s) {  // (static register indices: slot s holds chunk c0 + s)
+                const int ck = c0 + s;
+                if (ck < nchunk)
+                    stage_and_multiply(ra[s], rb[s], [&] { if (ck + kAhead < nchunk) fetch((ck + kAhead) * kM2, ra[s], rb[s]); });
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -678,7 +713,7 @@ __device__ __forceinline__ void eigh_gemm_body(const double *__restrict__ A, con
 template <bool TA>
 __global__ __launch_bounds__(256) void eigh_gemm_kernel(const double *__restrict__ A, const double *__restrict__ B,
                                                         double *__restrict__ Out, int npad, double alpha, double diag) {
-    __shared__ double As[kM2 * LDX], Bs[kM2 * LDU];
+    __shared__ double As[2 * kM2 * LDX], Bs[2 * kM2 * LDU];
     eigh_gemm_body<TA>(A, B, Out, npad, alpha, diag, nullptr, As, Bs);
 }
 
@@ -727,7 +762,7 @@ __global__ __launch_bounds__(256) void eigh_refine_diag_kernel(double *M0, doubl
 __global__ __launch_bounds__(256) void eigh_refine_gemm_kernel(double *__restrict__ M0, double *__restrict__ M1,
                                                                double *__restrict__ V0, double *__restrict__ V1, int npad,
                                                                const EighInfo *info, int which) {
-    __shared__ double As[kM2 * LDX], Bs[kM2 * LDU];
+    __shared__ double As[2 * kM2 * LDX], Bs[2 * kM2 * LDU];
     if (!info->refine) return;
     const int p = info->parity;
     double *Kb = p ? M0 : M1, *Tb = p ? V0 : V1;
