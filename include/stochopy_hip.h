@@ -510,7 +510,7 @@ int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, in
  * largest magnitude (lowest row on ties) is positive.  V0: NULL, or DEVICE (n,n) nearly orthonormal starting basis
  * (e.g. the eigenvectors of the previous, slightly different matrix; may alias B): it is re-orthonormalised (one
  * Newton-Schulz step) and the iteration starts from V0^T C V0 -- same result to rounding, fewer sweeps; ignored for
- * n <= 64 (one-workgroup path).  ws: DEVICE scratch of
+ * n <= 32 (one-workgroup path).  ws: DEVICE scratch of
  * sx_eigh_workspace_bytes(n) bytes; it starts with the run record read by sx_eigh_info.  max_sweeps <= 0: 24;
  * tol <= 0: 1e-14 (a sweep is the last one when the off-diagonal mass it leaves behind -- measured on the device
  * while its last rotations are applied -- is <= tol*|C|_F).

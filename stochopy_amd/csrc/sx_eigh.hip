@@ -1188,6 +1188,10 @@ __global__ __launch_bounds__(256) void eigh_write_kernel(const double *__restric
     }
 }
 
+// n <= 32: one workgroup does the whole decomposition; above, the block method (round 3: also for 33 <= n <= 64 -- four blocks,
+// three rounds per sweep, warm start and refinement step included: 507 us per decomposition at n = 64 in the one-workgroup
+// form, whose 1 024 updating threads move S AND W through LDS every inner round)
+constexpr int kSmallPathMax = 32;
 inline int eigh_npad(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 64 ? 64 : ((n + kM2 - 1) / kM2) * kM2)); }
 
 struct EighWs {
@@ -1255,7 +1259,7 @@ int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B,
     hipStream_t st = (hipStream_t)stream;
     const int npad = eigh_npad(n);
     SX_HIP(hipMemsetAsync(L.info, 0, sizeof(EighInfo), st));
-    if (n <= 64) {
+    if (n <= kSmallPathMax) {
         if (npad == 16)
             hipLaunchKernelGGL((eigh_small_kernel<16>), dim3(1), dim3(jacobi_threads<16>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
         else if (npad == 32)
