@@ -13,11 +13,11 @@ def wall(method, n, P, extra, m):
     torch.cuda.synchronize(); return time.perf_counter() - t0
 
 CASES = [("de", 128, 4096, {"updating": "deferred"}), ("de", 128, 4096, {"updating": "immediate"}), ("pso", 256, 16384, {"updating": "deferred"}),
-         ("cpso", 256, 16384, {"updating": "deferred"}), ("cmaes", 64, 128, {}), ("cmaes", 512, 1024, {}), ("vdcma", 512, 64, {}),
+         ("cpso", 256, 16384, {"updating": "deferred"}), ("cmaes", 10, 20, {}), ("cmaes", 20, 40, {}), ("cmaes", 32, 64, {}), ("cmaes", 64, 128, {}), ("cmaes", 512, 1024, {}), ("vdcma", 512, 64, {}),
          ("na", 8, 64, {})]
 for method, n, P, extra in CASES:
     for _ in range(3): wall(method, n, P, extra, 3)
     t2 = min(wall(method, n, P, extra, 2) for _ in range(7))
-    t12 = min(wall(method, n, P, extra, 12) for _ in range(7))
-    per = (t12 - t2) / 10
+    t12 = min(wall(method, n, P, extra, 42) for _ in range(7))
+    per = (t12 - t2) / 40
     print("%-6s n=%4d P=%6d %-26s 2 generations: %7.3f ms   (per generation %8.2f us -> fixed part ~%6.3f ms)" % (method, n, P, extra, t2 * 1e3, per * 1e6, (t2 - 2 * per) * 1e3), flush=True)
