@@ -12,6 +12,7 @@ from . import _lib
 
 _torch = None
 _TLS = threading.local()
+_ARENA_LOCK = threading.Lock()
 _ARENA, _ARENA_OFF, _ARENA_BYTES = None, 0, 1 << 20  # pinned staging for upload_async
 
 
@@ -90,15 +91,16 @@ class Context:
         nbytes = a.nbytes
         if nbytes == 0 or nbytes > _ARENA_BYTES // 4:
             return self.upload(a)
-        if _ARENA is None:
-            _ARENA = t.empty(_ARENA_BYTES, dtype=t.uint8).pin_memory()
-        off = (_ARENA_OFF + 63) & ~63
-        if off + nbytes > _ARENA_BYTES:  # wrap: every copy that read the arena so far must have landed
-            t.cuda.synchronize()
-            off = 0
-        _ARENA_OFF = off + nbytes
-        stage = _ARENA[off:off + nbytes]
-        stage.numpy()[:] = a.reshape(-1).view(np.uint8)
+        with _ARENA_LOCK:  # (host threads share the arena: the slice is claimed and filled under the lock)
+            if _ARENA is None:
+                _ARENA = t.empty(_ARENA_BYTES, dtype=t.uint8).pin_memory()
+            off = (_ARENA_OFF + 63) & ~63
+            if off + nbytes > _ARENA_BYTES:  # wrap: every copy that read the arena so far must have landed
+                t.cuda.synchronize()
+                off = 0
+            _ARENA_OFF = off + nbytes
+            stage = _ARENA[off:off + nbytes]
+            stage.numpy()[:] = a.reshape(-1).view(np.uint8)
         dev = t.empty(a.shape, dtype=t.from_numpy(a.reshape(-1)[:0]).dtype, device=self.device)  # (ascontiguousarray: ndim >= 1)
         dev.reshape(-1).view(t.uint8).copy_(stage, non_blocking=True)
         return dev

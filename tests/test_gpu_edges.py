@@ -191,3 +191,45 @@ def test_result_surface(sa):
     assert np.allclose(r.x, [0.99997096, 0.99993643]) and np.isclose(r.fun, 3.862267664744548e-09, rtol=1e-6)
     assert sorted(r.keys()) == ["fun", "message", "nfev", "nit", "status", "success", "x"]
     assert r.message == "best solution value is lower than ftol"
+
+
+def test_concurrent_calls_from_two_host_threads(sa):
+    """SURVEY.md section 8 row b6 (threading / streams): every host thread gets its own engine stream (kept for the life of
+    the process, so that torch's caching allocator can hand a run the previous run's buffers back) -- two threads calling
+    minimize() at the same time, repeatedly and with different methods, get the results of the same calls made one
+    after the other."""
+    import threading
+
+    jobs = {
+        "de": (sa.factory.rosenbrock, [[-5.12, 5.12]] * 40, "de",
+               {"maxiter": 60, "popsize": 256, "seed": 3, "rng": "philox", "updating": "deferred", "backend": "hip"}),
+        "pso": (sa.factory.ackley, [[-5.12, 5.12]] * 64, "pso",
+                {"maxiter": 50, "popsize": 512, "seed": 4, "rng": "philox", "updating": "deferred", "backend": "hip"}),
+        "cmaes": (sa.factory.rosenbrock, [[-3.0, 3.0]] * 12, "cmaes",
+                  {"maxiter": 40, "popsize": 24, "seed": 5, "rng": "philox", "backend": "hip"}),
+    }
+
+    def run(tag):
+        fun, bounds, method, opts = jobs[tag]
+        return sa.optimize.minimize(fun, bounds, method=method, options=dict(opts))
+
+    serial = {tag: run(tag) for tag in jobs}
+    for pair in (("de", "pso"), ("cmaes", "de"), ("pso", "cmaes")):
+        out, errs = {}, []
+
+        def work(tag):
+            try:
+                for _ in range(3):
+                    out[tag] = run(tag)
+            except Exception as exc:  # noqa: BLE001 -- reported below
+                errs.append((tag, exc))
+
+        threads = [threading.Thread(target=work, args=(tag,)) for tag in pair]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errs, errs
+        for tag in pair:
+            assert (out[tag].nit, out[tag].status) == (serial[tag].nit, serial[tag].status)
+            assert out[tag].fun == serial[tag].fun and np.array_equal(out[tag].x, serial[tag].x)
