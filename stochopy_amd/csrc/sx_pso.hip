@@ -480,11 +480,98 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
         }
     }
     SEL_TP(2);
+    // 0. (round 3) A histogram over ALL keys is bound by the LDS atomic rate -- 16 384 atomics at about one per cycle are
+    //    the 6.5-8.8 us the step took at BASELINE config 3b, whatever the digits look like (tools/seltrace.py).  So the
+    //    keys are first cut down to a WINDOW around the target: 128 of them (the first key of the first 128 threads) are
+    //    ranked among themselves (eight threads per sample, 16 comparisons each); the target's rank nw, scaled to the
+    //    sample, +- kWinHalf sample ranks (+- 2.5 sigma of the sampling error at the median) gives two keys lo <= hi; one
+    //    pass over the register-held keys counts those above hi and packs those inside [lo, hi] into LDS (one returning
+    //    atomic per WAVE).  If the target lies inside -- nw - above in [1, window size], the window fits -- the selection
+    //    goes on over the window (a few thousand keys) exactly as it would over the whole swarm; otherwise over the whole
+    //    swarm, as before.  Exact either way: the k-th largest of all keys is the (k - above)-th largest of the window.
+    constexpr int kSample = 128, kWinHalf = 14, kWinCap = 4096;
+    __shared__ unsigned long long s_sample[kSample], s_win[kWinCap], s_lohi[2];
+    __shared__ unsigned s_nwin, s_abv[kSelThreads / kWave];
+    bool use_regs = in_regs;      // where the keys of the steps below come from: registers, the window, or memory
+    int64_t Peff = Ptot;          // how many there are
+    unsigned remaining0 = (unsigned)nw;
+    const bool try_window = in_regs && Ptot >= 2 * kWinCap;
+    if (try_window) {
+        if (tid < kSample) s_sample[tid] = key[0];  // (Ptot >= 16384: the first 256 keys exist)
+        if (tid == 0) s_nwin = 0u, s_lohi[0] = 0ull, s_lohi[1] = ~0ull;
+        __syncthreads();
+        {   // descending rank of sample (tid >> 3): lanes 8s .. 8s+7 take an eighth of the comparisons each
+            const unsigned long long mine = s_sample[tid >> 3];
+            unsigned g = 0u, e = 0u;
+            const int q0 = (tid & 7) * (kSample / 8);
+#pragma unroll
+            for (int c = q0; c < q0 + kSample / 8; ++c) {
+                const unsigned long long o = s_sample[c];
+                g += o > mine;
+                e += o == mine;
+            }
+            g += __shfl_xor(g, 1, kWave), e += __shfl_xor(e, 1, kWave);
+            g += __shfl_xor(g, 2, kWave), e += __shfl_xor(e, 2, kWave);
+            g += __shfl_xor(g, 4, kWave), e += __shfl_xor(e, 4, kWave);
+            // target rank nw of Ptot  ->  sample rank r (1-based, descending); the window's ends are the samples at ranks
+            // r - kWinHalf (hi) and r + kWinHalf (lo), or the extremes of the key range beyond the sample's ends
+            const int r = (int)(((int64_t)nw * kSample + Ptot - 1) / Ptot);
+            const int rhi = r - kWinHalf, rlo = r + kWinHalf;
+            if ((tid & 7) == 0) {
+                if (rhi >= 1 && (int)g < rhi && rhi <= (int)(g + e)) s_lohi[1] = mine;
+                if (rlo <= kSample && (int)g < rlo && rlo <= (int)(g + e)) s_lohi[0] = mine;
+            }
+        }
+        __syncthreads();
+        const unsigned long long lo = s_lohi[0], hi = s_lohi[1];
+        unsigned above = 0u, inmask = 0u;  // (bit k: key k lies inside the window -- one comparison pass, the packing walks the bits)
+#pragma unroll
+        for (int k = 0; k < kSelPerThread; ++k) {
+            const int64_t i = (int64_t)k * kSelThreads + tid;
+            const bool valid = (int64_t)k * kSelThreads < Ptot && i < Ptot;
+            above += valid && key[k] > hi;
+            inmask |= (valid && key[k] >= lo && key[k] <= hi) ? (1u << k) : 0u;
+        }
+        const unsigned mine_in = (unsigned)__popc(inmask);
+        // exclusive prefix of mine_in over the wave + the wave's base in the window (one returning LDS atomic per wave)
+        unsigned incl = mine_in;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        unsigned wbase = 0u;
+        const unsigned wtot = __shfl(incl, kWave - 1, kWave);
+        if (lane == kWave - 1) wbase = atomicAdd(&s_nwin, wtot);
+        wbase = __shfl(wbase, kWave - 1, kWave);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) above += __shfl_xor(above, off, kWave);
+        if (lane == 0) s_abv[wv] = above;
+        unsigned pos = wbase + incl - mine_in;
+#pragma unroll
+        for (int k = 0; k < kSelPerThread; ++k) {
+            if ((inmask >> k) & 1u) {
+                if (pos < (unsigned)kWinCap) s_win[pos] = key[k];
+                ++pos;
+            }
+        }
+        __syncthreads();
+        unsigned abv = 0u;
+#pragma unroll
+        for (int k = 0; k < kSelThreads / kWave; ++k) abv += s_abv[k];
+        const unsigned nwin = s_nwin;
+        if (nwin <= (unsigned)kWinCap && (unsigned)nw > abv && (unsigned)nw - abv <= nwin) {
+            use_regs = false;
+            Peff = (int64_t)nwin;
+            remaining0 = (unsigned)nw - abv;
+        }
+    }
+    const bool from_window = try_window && !use_regs;
     // 1. the keys' common leading bits carry no information (sign, exponent and the first mantissa bits are the
     //    same all over a converged swarm): find the highest bit in which any two keys differ
     __shared__ unsigned long long s_min[kSelThreads / kWave], s_max[kSelThreads / kWave];
     unsigned long long kmin = ~0ull, kmax = 0ull;
-    if (in_regs) {
+    if (use_regs) {
 #pragma unroll
         for (int k = 0; k < kSelPerThread; ++k) {
             const int64_t i = (int64_t)k * kSelThreads + tid;
@@ -494,10 +581,18 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
             }
         }
     } else {
-        for (int64_t i = tid; i < Ptot; i += kSelThreads) {
-            const unsigned long long kk = sort_key(fit_at(i));
-            kmin = kk < kmin ? kk : kmin;
-            kmax = kk > kmax ? kk : kmax;
+        if (from_window) {
+            for (int i = tid; i < (int)Peff; i += kSelThreads) {
+                const unsigned long long kk = s_win[i];
+                kmin = kk < kmin ? kk : kmin;
+                kmax = kk > kmax ? kk : kmax;
+            }
+        } else {
+            for (int64_t i = tid; i < Peff; i += kSelThreads) {
+                const unsigned long long kk = sort_key(fit_at(i));
+                kmin = kk < kmin ? kk : kmin;
+                kmax = kk > kmax ? kk : kmax;
+            }
         }
     }
 #pragma unroll
@@ -530,14 +625,14 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
     __shared__ unsigned long long cand[kSelThreads];
     int top = 63 - __clzll((long long)(kmin ^ kmax));  // keys agree above this bit
     unsigned long long prefix = top == 63 ? 0ull : (kmax >> (top + 1)) << (top + 1);
-    unsigned remaining = (unsigned)nw;
+    unsigned remaining = remaining0;
     for (;;) {
         const int shift = top >= 9 ? top - 9 : 0, width = top - shift + 1;
         const unsigned dmask = (1u << width) - 1u;
         const unsigned long long himask = top == 63 ? 0ull : (~0ull << (top + 1));
         bins[tid] = 0u;
         __syncthreads();
-        if (in_regs) {
+        if (use_regs) {
 #pragma unroll
             for (int k = 0; k < kSelPerThread; ++k) {
                 const int64_t i = (int64_t)k * kSelThreads + tid;
@@ -546,17 +641,24 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
                              lane);
             }
         } else {
-            for (int64_t i0 = tid; i0 < Ptot; i0 += (int64_t)kSelThreads * 8) {
+            // (uniform trip count: hist_add votes across the wave; a slot costs ~30 instructions of voting whether it
+            //  holds a key or not -- 16 waves on 4 SIMDs, that, not the atomics, is the step's time -- so only the slots a
+            //  few-thousand-key window fills are walked)
+            for (int64_t i0 = tid - lane; i0 < Peff; i0 += (int64_t)kSelThreads * 8) {
                 unsigned long long kk[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t i = i0 + (int64_t)u * kSelThreads;
-                    kk[u] = i < Ptot ? sort_key(fit_at(i)) : 0ull;
+                    const int64_t i = i0 + lane + (int64_t)u * kSelThreads;
+                    if (from_window)
+                        kk[u] = i < Peff ? s_win[i] : 0ull;
+                    else
+                        kk[u] = i < Peff ? sort_key(fit_at(i)) : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t i = i0 + (int64_t)u * kSelThreads;
-                    hist_add(bins, (i < Ptot && (kk[u] & himask) == prefix) ? (int)((unsigned)(kk[u] >> shift) & dmask) : -1, lane);
+                    const int64_t i = i0 + lane + (int64_t)u * kSelThreads;
+                    if (i0 + (int64_t)u * kSelThreads >= Peff) break;  // (uniform over the wave: no slot of it holds a key)
+                    hist_add(bins, (i < Peff && (kk[u] & himask) == prefix) ? (int)((unsigned)(kk[u] >> shift) & dmask) : -1, lane);
                 }
             }
         }
@@ -592,7 +694,7 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
             const unsigned long long lomask = ~0ull << shift;
             if (tid == 0) s_ncand = 0u;
             __syncthreads();
-            if (in_regs) {
+            if (use_regs) {
 #pragma unroll
                 for (int k = 0; k < kSelPerThread; ++k) {
                     const int64_t i = (int64_t)k * kSelThreads + tid;
@@ -600,9 +702,16 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
                         cand[atomicAdd(&s_ncand, 1u)] = key[k];
                 }
             } else {
-                for (int64_t i = tid; i < Ptot; i += kSelThreads) {
-                    const unsigned long long kk = sort_key(fit_at(i));
-                    if ((kk & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = kk;
+                if (from_window) {
+                    for (int i = tid; i < (int)Peff; i += kSelThreads) {
+                        const unsigned long long kk = s_win[i];
+                        if ((kk & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = kk;
+                    }
+                } else {
+                    for (int64_t i = tid; i < Peff; i += kSelThreads) {
+                        const unsigned long long kk = sort_key(fit_at(i));
+                        if ((kk & lomask) == prefix) cand[atomicAdd(&s_ncand, 1u)] = kk;
+                    }
                 }
             }
             __syncthreads();

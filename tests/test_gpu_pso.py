@@ -202,3 +202,64 @@ def test_pso_chained_kernel_equals_two_kernel_path_and_oracle(sa, objective, n, 
             assert np.isclose(got.fun, ref.fun, rtol=1e-6)
     if ftol > 0:
         assert got.status in (0, 1) and got.nit < maxiter
+
+
+def _sort_key_np(f):
+    b = np.asarray(f, dtype=np.float64).view(np.uint64)
+    return np.where(b >> np.uint64(63), ~b, b | np.uint64(0x8000000000000000))
+
+
+@pytest.mark.parametrize("P", [8192, 12000, 16384])
+@pytest.mark.parametrize("kind", ["spread", "converged", "outliers", "ties", "two_values", "reseeded"])
+def test_restart_selection_kernel_vs_numpy(sa, P, kind):
+    """sx_pso_restart_select at the swarm sizes where it first cuts the keys down to a sample-guided window (round 3:
+    256 samples ranked, the target's sample rank +- 24, keys above counted, keys inside packed into LDS) before the radix
+    descent: nw and the threshold key against numpy for fitness sets that stress the window -- spread values, a converged
+    swarm (common leading bits), a few huge outliers, many exact ties (the window overflows / the target sits in a tie),
+    two distinct values only, and freshly re-seeded particles at 1e30 -- across generation numbers that move nw from
+    P - 1 down to 1."""
+    import ctypes as C
+
+    from stochopy_amd import _device, _lib
+
+    ctx = _device.Context()
+    L, t, p = ctx.L, _device.torch(), _device.ptr
+    rs = np.random.RandomState(P + len(kind))
+    n, maxiter, delta, gamma = 8, 1000, 1.0e-2, 1.0
+    if kind == "spread":
+        fit = rs.uniform(0.0, 100.0, P)
+    elif kind == "converged":
+        fit = 3.7 + 1.0e-9 * rs.rand(P)
+    elif kind == "outliers":
+        fit = 1.0e-3 * rs.rand(P)
+        fit[rs.choice(P, 7, replace=False)] = 10.0 ** rs.uniform(3, 200, 7)
+    elif kind == "ties":
+        fit = np.round(rs.rand(P) * 20.0) / 20.0
+    elif kind == "two_values":
+        fit = np.where(rs.rand(P) < 0.3, 1.0, 2.0)
+    else:
+        fit = 0.5 + 1.0e-6 * rs.rand(P)
+        fit[rs.choice(P, P // 3, replace=False)] = 1.0e30
+    with t.cuda.stream(ctx.stream):
+        g = ctx.L.sx_num_partials(P, n)
+        d = {k: ctx.zeros((P, n)) for k in ("X", "V", "pbest")}
+        d_fit = ctx.upload(fit)
+        d_gbest, d_pf, d_pi = ctx.zeros((n,)), ctx.zeros((g,)), ctx.zeros((g,), dtype=t.int64)
+        d_partr = ctx.upload(np.full(g, 1.0e-6))  # radius far below delta: a restart is due
+        out = ctx.zeros((3,), dtype=t.int64)
+        for it in (40, 300, 480, 520, 560, 640, 760, 900):
+            st = _lib.SxState(it=it, gbidx=0, gfit=0.0, dx=0.0, status=_lib.SX_STATUS_NONE, done=0)
+            d_state = ctx.upload(np.frombuffer(bytes(st), dtype=np.int64).copy())
+            a = _lib.SxPsoArgs()
+            a.X, a.V, a.pbest, a.pbestfit, a.gbest = (x.data_ptr() for x in (d["X"], d["V"], d["pbest"], d_fit, d_gbest))
+            a.state, a.part_f, a.part_i = d_state.data_ptr(), d_pf.data_ptr(), d_pi.data_ptr()
+            a.P, a.ld, a.row0, a.n, a.fun_id, a.rng, a.maxiter = P, n, 0, n, 0, _lib.SX_RNG_PHILOX, maxiter
+            _lib.check(L.sx_pso_restart_select(C.byref(a), p(d_partr), delta, gamma, p(out), ctx.stream_ptr),
+                       "sx_pso_restart_select")
+            ctx.sync()
+            got = out.cpu().numpy().view(np.uint64)
+            nw = int((P - 1.0) / (1.0 + np.exp(1.0 / 0.09 * (it / maxiter - gamma + 0.5))))
+            assert int(got[0]) == max(nw, 0), (it, got[0], nw)
+            if nw > 0:
+                want = np.sort(_sort_key_np(fit))[::-1][nw - 1]
+                assert got[1] == want, (kind, P, it, nw, hex(int(got[1])), hex(int(want)))
