@@ -272,7 +272,7 @@ def run_pso(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=
     if callback is not None:
         callback(X, Result(x=gbest, fun=gfit, nfev=P, nit=1))
     it = 1
-    restarts = []
+    restarts, restart_rows = [], []
     while True:
         it += 1
         r1, r2 = stream.pso_generation(it, P, n)
@@ -308,8 +308,10 @@ def run_pso(fobj, lower, upper, x0, stream, callback=None, maxiter=100, popsize=
                     pbest[rows] = X[rows]
                     pbestfit[rows] = 1.0e30
                     restarts.append((it, nw))
+                    restart_rows.append(np.sort(rows))
     res = _final(gbest, gfit, status, it * P, it, hist)
     res["_restarts"] = restarts
+    res["_restart_rows"] = restart_rows  # which rows each restart re-seeded (sorted): pinned by tests/golden/configs_long
     return res
 
 

@@ -55,7 +55,8 @@ extern "C" int sx_de_generation(const sx_de_args *a, int finalize, void *stream)
     PlanArg plan;
     if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan, 0, 0, (int64_t)g.blocks,
+    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, (const sx_state *)nullptr,
+                       (const double *)nullptr, (const int64_t *)nullptr, (int64_t)g.blocks, *a, plan, 0, 0,
                        sx_xchg_args{});
     SX_LAUNCH_CHECK();
     if (finalize) {
@@ -83,7 +84,8 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
     int zero = 0;
     int64_t npart = g.blocks;
     sx_xchg_args nox = {};
-    void *kargs[] = {&args, &plan, &zero, &zero, &npart, &nox};
+    const void *none = nullptr;
+    void *kargs[] = {&none, &none, &none, &npart, &args, &plan, &zero, &zero, &nox};
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
         hipKernelNodeParams kp = {};
@@ -137,8 +139,10 @@ static int chain_launch(const sx_de_args *a, const sx_xchg_args *x, int parity, 
     de_kernel_t kern = (de_kernel_t)(x ? de_p2p_kernel(a->fun_id, a->n, a->P, a->strategy, a->constraints)
                                        : de_chain_kernel(a->fun_id, a->n, a->P, a->strategy, a->constraints));
     const unsigned blocks = finalize_only ? 1u : g.blocks + (x ? 1u : 0u);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream, *a, plan, parity,
-                       finalize_only ? 1 : 0, (int64_t)g.blocks, x ? *x : sx_xchg_args{});
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), g.lds, (hipStream_t)stream,
+                       (const sx_state *)(a->state + parity), (const double *)(a->part_f + (int64_t)parity * g.blocks),
+                       (const int64_t *)(a->part_i + (int64_t)parity * g.blocks), (int64_t)g.blocks, *a, plan, parity,
+                       finalize_only ? 1 : 0, x ? *x : sx_xchg_args{});
     SX_LAUNCH_CHECK();
     return 0;
 }
@@ -159,7 +163,10 @@ static int chain_graph_create(const sx_de_args *a, const sx_xchg_args *x, int ng
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
         int parity = (start_parity + i) & 1;
-        void *kargs[] = {&args, &plan, &parity, &mode, &npart, &xa};
+        const sx_state *sin_pre = a->state + parity;  // preloadable leading arguments (sx_de_kernel.hpp)
+        const double *pf_pre = a->part_f + (int64_t)parity * npart;
+        const int64_t *pi_pre = a->part_i + (int64_t)parity * npart;
+        void *kargs[] = {&sin_pre, &pf_pre, &pi_pre, &npart, &args, &plan, &parity, &mode, &xa};
         hipKernelNodeParams kp = {};
         kp.func = x ? de_p2p_kernel(a->fun_id, a->n, a->P, a->strategy, a->constraints)
                     : de_chain_kernel(a->fun_id, a->n, a->P, a->strategy, a->constraints);

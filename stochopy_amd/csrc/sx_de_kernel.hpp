@@ -203,11 +203,18 @@ constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its l
 // fetch and the mutant's formula are otherwise uniform branches inside the row's dependent chain: 9.03 -> 8.52 us per
 // generation at the headline shape), and no repair code; -1 = strategy and constraints read from the arguments.
 template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
-__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_de_args a,
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_state *const sin_pre,
+                                                                                 const double *const pf_pre,
+                                                                                 const int64_t *const pi_pre,
+                                                                                 const int64_t npart,
+                                                                                 const sx_de_args a,
                                                                                  const PlanArg plan,
                                                                                  const int chain_p, const int mode,
-                                                                                 const int64_t npart,
                                                                                  const sx_xchg_args x) {
+    // sin_pre / pf_pre / pi_pre (single-GPU chained kernel): a.state + chain_p and the record set part[chain_p], worked out
+    // on the host and passed, with the number of records, as the FIRST arguments so that they can arrive preloaded in SGPRs
+    // (-amdgpu-kernarg-preload-count, sx_de_chain.hip): the first trip to memory after the kernel boundary -- state word
+    // and records -- then does not wait for a load of the kernel-argument segment (a by-value struct is never preloaded)
     constexpr bool CHAIN = XM >= 1;  // finalise the predecessor's generation in the prologue
     constexpr bool P2P = XM == 2;    // ... over all ranks, through the peer exchange buffers
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
 
     // ---- A. which generation?  (CHAIN) every wave fetches the predecessor's records right away (their
     //      addresses do not depend on the state word) and keeps them in registers until stage C
-    const sx_state *sin = CHAIN ? a.state + chain_p : a.state;
+    const sx_state *sin = (CHAIN && !P2P) ? sin_pre : CHAIN ? a.state + chain_p : a.state;
     constexpr int kRecPerLane = 8;  // npart <= 512 in chained mode
     double pfv[kRecPerLane];
     // whole-wave rows keep the record rows as 32 bits (rows < 2^31, check_args): 8 registers less is what
@@ -235,8 +242,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     constexpr rec_t kNoRec = LPR == kWave ? (rec_t)INT32_MAX : (rec_t)INT64_MAX;
     rec_t piv[kRecPerLane];
     if (CHAIN && !P2P) {
-        const double *pf = a.part_f + (int64_t)chain_p * npart;
-        const int64_t *pi = a.part_i + (int64_t)chain_p * npart;
+        const double *pf = pf_pre;
+        const int64_t *pi = pi_pre;
         const int per = (int)((npart + kWave - 1) / kWave);  // contiguous slice per lane: first-minimum rule
         const int64_t k0 = (int64_t)id.lane * per;
 #pragma unroll
@@ -552,9 +559,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const bool better = fc < fold;  // _common.py:127 strict <
     if (FULL || id.active) {
         double *__restrict__ xo = nxt + id.row * ld;
-        if constexpr (NFIX != 0) {  // both rows are in registers already: no load behind the objective
+        if constexpr (NFIX != 0) {  // both rows are in registers already: no load behind the objective; streaming stores
 #pragma unroll
-            for (int t = 0; t < kStep; ++t) xo[l + t * LPR] = better ? keep[t] : B0.x[t];
+            for (int t = 0; t < kStep; ++t) st_stream(xo + l + t * LPR, better ? keep[t] : B0.x[t]);
         } else {
             const double *__restrict__ src = better ? U : xi;  // LDS or global: generic loads
             for (int e0 = l; e0 < n; e0 += kStep * LPR) {
@@ -576,8 +583,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     SX_TP(5);
 }
 
-typedef void (*de_kernel_t)(const sx_de_args, const PlanArg, const int, const int, const int64_t,
-                            const sx_xchg_args);
+typedef void (*de_kernel_t)(const sx_state *, const double *, const int64_t *, const int64_t, const sx_de_args,
+                            const PlanArg, const int, const int, const sx_xchg_args);
 
 template <int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
 de_kernel_t pick_kernel_lpr(int fun_id) {

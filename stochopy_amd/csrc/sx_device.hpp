@@ -647,6 +647,15 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 
 // (min f, its index) over the wave when LOWER LANES HOLD LOWER INDICES: the first lane that holds the
 // minimum wins = np.argmin's first-minimum rule.  Result in every lane.
+// One-batch DE rows (the metric shape): the 4 MB a generation writes are next read after the kernel boundary, and as
+// streaming (nt) stores they do not sit dirty in the XCDs' L2s until the end-of-kernel write-back: 7.45 -> 6.95 us per
+// generation (profiles/r4_de_m_store_flavours.txt: sc1 / sc0 sc1 write-through -1 %, uncached buffers +2.6 %, nt LOADS
+// of the own / donor rows +1 % / +8 %).  NOT for long rows or PSO: n=1024 P=16384 90 -> 96 us, C3a / C3b unchanged.
+template <class T>
+__device__ __forceinline__ void st_stream(T *p, T v) {
+    __builtin_nontemporal_store(v, p);
+}
+
 __device__ __forceinline__ void wave_argmin_ordered(double &f, int64_t &i) {
     const double m = wave_min_f64(f);
     const unsigned long long mask = __ballot(f == m);

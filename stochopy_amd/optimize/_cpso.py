@@ -490,8 +490,8 @@ class _PsoRun:
         if self.rng == "numpy-legacy":
             self.stream.sync_back()
         ctx.sync()
-        if self.px is not None:
-            self.world.barrier()  # no rank frees its exchange buffer while a peer may still write into it
+        # (peer exchange: the one meeting point of all ranks -- success flag included -- is `all_agree` in the caller's
+        #  `finally`; a barrier here would pair with a failing rank's all_gather there: mismatched collectives)
         self._res = res
 
     # ---- chained mode (one kernel per generation) ----

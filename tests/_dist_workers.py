@@ -176,6 +176,37 @@ def nccl_multi_gpu_worker(rank, world, port, cfg, out_dir):
         dist.destroy_process_group()
 
 
+def gpu_late_failure_worker(rank, world, port, cfg, out_dir):
+    """Peer exchange, callback on every rank; rank 1's callback raises at the LAST generation, i.e. after its peers' final
+    kernels are queued: every rank must come out of minimize() with an exception (rank 1 its own, the others "a peer
+    rank failed"), nobody may be left in a collective the failing rank never enters."""
+    dist = _init(rank, world, port)
+    try:
+        import torch
+
+        torch.cuda.set_device(0)
+        import stochopy_amd as sa
+
+        n, opts = cfg["n"], dict(cfg["options"], backend="hip", workers=world, rng="philox")
+        last = opts["maxiter"]
+
+        def cb(X, r):
+            if rank == 1 and int(r.nit) >= last:
+                raise ValueError("callback failed on purpose")
+
+        try:
+            sa.optimize.minimize(getattr(sa.factory, cfg["objective"]), [[-5.12, 5.12]] * n, method=cfg["method"],
+                                 options=opts, callback=cb)
+            msg = "no error"
+        except Exception as e:  # noqa: BLE001
+            msg = f"{type(e).__name__}: {e}"
+        with open(os.path.join(out_dir, f"err_{rank}.txt"), "w") as f:
+            f.write(msg)
+        dist.barrier()  # both ranks are out of minimize() and their process group still works
+    finally:
+        dist.destroy_process_group()
+
+
 def gpu_p2p_straggler_worker(rank, world, port, cfg, out_dir):
     """Rank 1 sets the exchange up and then never launches a generation; rank 0 must time out and raise."""
     import time

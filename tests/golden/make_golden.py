@@ -310,6 +310,80 @@ def configs():
 
 
 # --------------------------------------------------------------------------- #
+# 4b. BASELINE configs at FULL size over longer runs (round 4): best-f of every generation, the final x, a projection
+#     of the WHOLE population every few generations (P numbers per look: X @ w with a fixed seeded w -- a flipped `<`
+#     anywhere in the population moves one of them by O(search range)), and for CPSO the competitive restart's
+#     bookkeeping (cpso/_cpso.py:405-426): for every generation in which it fires, nw and the rows it re-seeds.
+# --------------------------------------------------------------------------- #
+def configs_long():
+    cpso_mod = sys.modules["stochopy.optimize.cpso._cpso"]  # (the package re-exports `minimize` under the module's name)
+
+    out = dict(STAMP)
+    cases = []
+    arrays = {}
+
+    def add(tag, fun_name, n, method, options, every):
+        fun = getattr(stochopy.factory, fun_name)
+        bounds = [[-5.12, 5.12]] * n
+        w = np.random.RandomState(20240929).standard_normal(n)
+        trace, looks, proj, rows8 = [], [], [], {}
+        restarts = []
+        gen = [0]
+
+        def cb(X, res):
+            gen[0] += 1
+            trace.append(float(res.fun))
+            if gen[0] == 1 or gen[0] % every == 0 or gen[0] == options["maxiter"]:
+                looks.append(gen[0])
+                proj.append(np.asarray(X, dtype=np.float64) @ w)
+                rows8[str(gen[0])] = [hx(r[:8]) for r in X[:4]]
+
+        orig = cpso_mod.restart
+
+        def spy(it, X, V, pbest, gbest, pbestfit, *a):
+            before = pbestfit.copy()
+            ret = orig(it, X, V, pbest, gbest, pbestfit, *a)
+            rows = np.flatnonzero((ret[3] == 1.0e30) & (before != 1.0e30))
+            if len(rows):
+                restarts.append((int(it), rows.astype(np.int32)))
+            return ret
+
+        cpso_mod.restart = spy
+        try:
+            res = minimize(fun, bounds, method=method, options=dict(options), callback=cb)
+        finally:
+            cpso_mod.restart = orig
+        entry = {
+            "tag": tag, "objective": fun_name, "ndim": n, "bounds": [bounds[0], "...repeated ndim times"],
+            "method": method, "options": dict(options), "x0": None,
+            "result": {"x": hx(res.x), "fun": hx(res.fun), "nit": int(res.nit), "nfev": int(res.nfev),
+                       "status": int(res.status), "success": bool(res.success), "message": res.message},
+            "fun_trace": hx(np.array(trace)),
+            "looks": looks,                      # generations (1-based callback count) whose population is projected
+            "pop_rows": rows8,                   # first 8 elements of the first 4 rows at those generations
+            "restarts": [[it, int(len(r))] for it, r in restarts],
+        }
+        arrays[tag + "__w"] = w
+        arrays[tag + "__proj"] = np.array(proj)
+        for it, r in restarts:
+            arrays[tag + "__restart_%d" % it] = np.sort(r)
+        cases.append(entry)
+        print(" ", tag, "fun", float(res.fun), "nit", res.nit, "status", res.status, "restarts", entry["restarts"][:6], flush=True)
+
+    add("C2L_de_rastrigin_n128_p4096", "rastrigin", 128, "de",
+        {"maxiter": 40, "popsize": 4096, "seed": 0, "updating": "deferred"}, 5)
+    add("C3aL_pso_ackley_n256_p16384", "ackley", 256, "pso",
+        {"maxiter": 30, "popsize": 16384, "seed": 0, "updating": "deferred"}, 5)
+    add("C3bL_cpso_ackley_n256_p16384", "ackley", 256, "cpso",
+        {"maxiter": 30, "popsize": 16384, "seed": 0, "updating": "deferred"}, 5)
+    add("C4L_cmaes_rosen_n512_p1024", "rosenbrock", 512, "cmaes", {"maxiter": 16, "popsize": 1024, "seed": 0}, 1)
+    out["cases"] = cases
+    dump("configs_long.json", out)
+    np.savez_compressed(os.path.join(HERE, "configs_long.npz"), **arrays)
+    print("wrote configs_long.npz", os.path.getsize(os.path.join(HERE, "configs_long.npz")))
+
+
+# --------------------------------------------------------------------------- #
 # 5. CMA-ES with constraints="Penalize" (stochopy/optimize/cmaes/_constraints.py:4-82): the reference's own
 #    test rows (tests/test_optimize.py:9-20) and boxes in which the penalty is actually at work
 # --------------------------------------------------------------------------- #
@@ -502,3 +576,5 @@ if __name__ == "__main__":
         suite()
     if "configs" in which:
         configs()
+    if "configs_long" in which:
+        configs_long()

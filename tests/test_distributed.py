@@ -211,6 +211,22 @@ def test_p2p_exchange_timeout_is_reported():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("method", ["de", "pso"])
+def test_late_failure_on_one_rank_raises_on_every_rank(method):
+    """One rank's callback raises at the last generation (its peers have already finished their loop): all ranks leave
+    minimize() with an exception and meet again afterwards -- the success path and the failure path issue the SAME
+    collective (one all_gather of the success flags), no barrier that a failing rank would skip."""
+    from _dist_workers import gpu_late_failure_worker
+
+    cfg = {"n": 12, "objective": "rosenbrock", "method": method,
+           "options": {"maxiter": 12, "popsize": 64, "seed": 3, "ftol": -1.0, "xtol": 0.0, "exchange": "p2p"}}
+    out = _spawn(gpu_late_failure_worker, 2, cfg)
+    assert "callback failed on purpose" in open(os.path.join(out, "err_1.txt")).read()
+    assert "peer rank failed" in open(os.path.join(out, "err_0.txt")).read()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange", ["rccl", "p2p"])
 def test_sharded_pso_on_gpu_is_exact(exchange):
     """PSO state is row-local and the Philox counters use global rows: 2 shards == the unsharded run, with the

@@ -138,6 +138,15 @@ def test_cmaes_matches_reference_golden(sa, case):
         assert res.fun <= max(10.0 * unhex(ref["fun"]), case["options"].get("ftol", 1e-8))
 
 
+def test_cmaes_c4_long_run_follows_the_reference(sa):
+    """BASELINE config 4 (n=512, P=1024; mu + 1 >= n: the eigenbasis is determined) over 16 generations against the
+    reference's vectors: best-f of every generation, the final x, and ALL candidates of every generation (projection)."""
+    from conftest import check_long_case
+
+    case = {c["tag"]: c for c in load_golden("configs_long.json")["cases"]}["C4L_cmaes_rosen_n512_p1024"]
+    check_long_case(sa, case)
+
+
 @pytest.mark.parametrize("case", CMA_CASES, ids=lambda c: c["tag"])
 def test_cmaes_golden_with_the_references_eigenpairs_replayed(sa, case):
     """Same-seed parity for EVERY CMA-ES golden, the two with a repeated eigenvalue (mu + 1 < n) included: the oracle

@@ -74,6 +74,16 @@ def test_de_matches_reference_golden(sa, case):
         ref["nit"], ref["nfev"], ref["status"], ref["success"], ref["message"])
 
 
+def test_de_c2_long_run_follows_the_reference(sa):
+    """BASELINE config 2 (Rastrigin -- device cos) over 40 generations at full size: best-f of every generation, the final
+    x and the whole population (projection every 5 generations) against the reference's (a flipped
+    `<` deep in the population must not pass)."""
+    from conftest import check_long_case
+
+    case = {c["tag"]: c for c in load_golden("configs_long.json")["cases"]}["C2L_de_rastrigin_n128_p4096"]
+    check_long_case(sa, case)
+
+
 @pytest.mark.parametrize("tag", ["de_rand1bin", "de_rand2bin", "de_best1bin", "de_best2bin", "de_rand1bin_random"])
 def test_de_reference_suite_xrefs(sa, tag):
     """The reference's own xrefs (tests/test_optimize.py:51-86, deferred rows) incl. return_all."""

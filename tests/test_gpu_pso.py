@@ -51,6 +51,29 @@ def test_pso_matches_reference_golden(sa, case):
         ref["nit"], ref["nfev"], ref["status"], ref["success"], ref["message"])
 
 
+@pytest.mark.parametrize("tag", ["C3aL_pso_ackley_n256_p16384", "C3bL_cpso_ackley_n256_p16384"])
+def test_pso_c3_long_run_follows_the_reference(sa, tag, monkeypatch):
+    """BASELINE configs 3a / 3b (Ackley -- device cos / exp / sqrt) over 30 generations at full size: best-f of every
+    generation, the final x, the whole swarm (projection every 5 generations), and for CPSO the competitive restart's
+    bookkeeping -- in which generations it fires, nw, and exactly WHICH rows it re-seeds (cpso/_cpso.py:405-426; the
+    reference restarts ~16 000 of the 16 384 particles per generation here) -- against the reference's."""
+    from conftest import check_long_case
+    from stochopy_amd.optimize import _cpso
+
+    case = {c["tag"]: c for c in load_golden("configs_long.json")["cases"]}[tag]
+    fired = {}
+    orig = _cpso._CpsoRun._restart_host_order
+
+    def spy(self, it):
+        orig(self, it)
+        rows = np.flatnonzero(self.pbestfit.cpu().numpy() == 1.0e30)
+        if rows.size:
+            fired[int(it)] = rows.astype(np.int32)
+
+    monkeypatch.setattr(_cpso._CpsoRun, "_restart_host_order", spy)
+    check_long_case(sa, case, restart_rows=fired)
+
+
 def test_cpso_population_history_bit_exact(sa):
     arrays = np.load(os.path.join(GOLDEN, "configs_pops.npz"))
     tag = "cpso_Shrink_rosenbrock_n16_p256"

@@ -85,6 +85,49 @@ def test_reference_suite_xrefs(case):
         assert np.all(res.xall + 1.0e-15 >= -5.12) and np.all(res.xall - 1.0e-15 <= 5.12)  # helpers.py:23-25
 
 
+LONG = load_golden("configs_long.json")["cases"]
+
+
+def long_arrays():
+    return np.load(os.path.join(GOLDEN, "configs_long.npz"))
+
+
+@pytest.mark.parametrize("case", LONG, ids=lambda c: c["tag"])
+def test_long_configs_bit_exact(case):
+    """BASELINE configs 2 / 3a / 3b / 4 at full size over 40 / 30 / 30 / 16 generations (round 4): best-f of every
+    generation, the final x, a projection of the WHOLE population every few generations, and for CPSO the restart's
+    bookkeeping (cpso/_cpso.py:405-426: in which generations it fires, nw, and exactly which rows it re-seeds)."""
+    arrays = long_arrays()
+    tag = case["tag"]
+    w = arrays[tag + "__w"]
+    looks, proj, rows8, count = set(case["looks"]), [], {}, [0]
+    trace = []
+
+    def cb(X, r):
+        count[0] += 1
+        trace.append(float(r.fun))
+        if count[0] in looks:
+            proj.append(np.asarray(X) @ w)
+            rows8[str(count[0])] = X[:4, :8].copy()
+
+    res = oracle.minimize(case["objective"], case_bounds(case), method=case["method"], options=dict(case["options"]),
+                          callback=cb)
+    restarts = list(zip([it for it, _ in res.get("_restarts", [])], res.get("_restart_rows", [])))
+    ref = case["result"]
+    assert np.array_equal(unhex(case["fun_trace"]), np.array(trace))
+    assert (res.nit, res.nfev, res.status, res.success, res.message) == (
+        ref["nit"], ref["nfev"], ref["status"], ref["success"], ref["message"])
+    assert float(res.fun).hex() == ref["fun"] and np.array_equal(unhex(ref["x"]), res.x)
+    # (X @ w is a BLAS product: its rounding, ~1e-14 here, depends on the library's blocking; a population that differs in
+    #  ONE decision differs by O(search range) in that row's entry)
+    assert np.allclose(arrays[tag + "__proj"], np.array(proj), rtol=0, atol=1e-9)
+    for g, rows in case["pop_rows"].items():
+        assert np.array_equal(unhex(rows), rows8[g])
+    assert [[it, len(r)] for it, r in restarts] == case["restarts"]
+    for it, r in restarts:
+        assert np.array_equal(arrays[tag + "__restart_%d" % it], r)
+
+
 PENALIZE = load_golden("cmaes_penalize.json")["cases"]
 
 
