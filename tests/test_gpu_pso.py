@@ -62,7 +62,7 @@ def test_pso_c3_long_run_follows_the_reference(sa, tag, monkeypatch):
 
     case = {c["tag"]: c for c in load_golden("configs_long.json")["cases"]}[tag]
     fired = {}
-    orig = _cpso._CpsoRun._restart_host_order
+    orig = _cpso._PsoRun._restart_host_order
 
     def spy(self, it):
         orig(self, it)
@@ -70,7 +70,7 @@ def test_pso_c3_long_run_follows_the_reference(sa, tag, monkeypatch):
         if rows.size:
             fired[int(it)] = rows.astype(np.int32)
 
-    monkeypatch.setattr(_cpso._CpsoRun, "_restart_host_order", spy)
+    monkeypatch.setattr(_cpso._PsoRun, "_restart_host_order", spy)
     check_long_case(sa, case, restart_rows=fired)
 
 
