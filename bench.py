@@ -131,7 +131,7 @@ def other_configs():
 
     def per_gen(method, fun, n, opts, short, long_, reps=3):
         bounds = [[-5.12, 5.12]] * n
-        o = dict(opts, seed=0, rng="philox", ftol=-1.0, xtol=0.0, backend="hip")
+        o = dict(dict(seed=0, rng="philox", ftol=-1.0, xtol=0.0, backend="hip"), **opts)
 
         def wall(m):
             torch.cuda.synchronize()
@@ -153,6 +153,24 @@ def other_configs():
     t = per_gen("de", sa.factory.rastrigin, 128, {"popsize": 4096, "updating": "deferred", "strategy": "best1bin"}, 200, 2200)
     out["C2_de_rastrigin_n128_p4096"] = {"evals_per_s": 4096 / t, "us_per_generation": t * 1e6, "bound": "hbm",
                                         "frac": 4112 * 4096 / t / (HBM_PEAK_GBS * 1e9)}
+    # BASELINE config 5 on ONE GPU (round 4): its 8-GPU shard (16 384 rows: the denominator-free per-GPU figure of a weak-
+    # scaling read) and the whole population (131 072 rows = 2 x 1 GiB of row buffers: the N=1 point of the strong-
+    # scaling curve the driver's N = 1, 2, 4, 8 runs draw through `c5`)
+    de5 = {"updating": "deferred", "strategy": "best1bin"}
+    t = per_gen("de", sa.factory.rosenbrock, 1024, dict(de5, popsize=16384), 100, 600)
+    out["C5_shard_de_n1024_p16384"] = {"evals_per_s": 16384 / t, "us_per_generation": t * 1e6, "bound": "hbm",
+                                      "frac": 32784 * 16384 / t / (HBM_PEAK_GBS * 1e9)}
+    t = per_gen("de", sa.factory.rosenbrock, 1024, dict(de5, popsize=131072), 20, 120, reps=2)
+    out["C5_full_de_n1024_p131072_1gpu"] = {"evals_per_s": 131072 / t, "us_per_generation": t * 1e6, "bound": "hbm",
+                                           "frac": 32784 * 131072 / t / (HBM_PEAK_GBS * 1e9)}
+    # the metric shape with the reference's own random stream (rng="numpy-legacy": seed-for-seed the reference's run,
+    # tests/golden/configs.json M_de_rosen_n128_p4096): host-bound by the replay of numpy's MT19937 donor permutations
+    t = per_gen("de", sa.factory.rosenbrock, 128, {"popsize": 4096, "updating": "deferred", "strategy": "best1bin",
+                                                   "rng": "numpy-legacy"}, 5, 25, reps=2)
+    out["M_numpy_legacy_de_rosenbrock_n128_p4096"] = {
+        "evals_per_s": 4096 / t, "ms_per_generation": t * 1e3, "bound": "host",
+        "note": "parity mode: same seed => the reference's trajectory bit for bit; per generation the host replays 23 M words of "
+                "numpy's legacy MT19937 stream (de/_de.py:304-311, P permutations of P-1 indices) -- csrc/sx_mt19937.cpp"}
     c3 = {"popsize": 16384, "updating": "deferred"}
     t = per_gen("pso", sa.factory.ackley, 256, c3, 200, 1200)
     out["C3a_pso_ackley_n256_p16384"] = {"evals_per_s": 16384 / t, "us_per_generation": t * 1e6, "bound": "hbm",

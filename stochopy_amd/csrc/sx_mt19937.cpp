@@ -16,8 +16,16 @@
 // tests/golden/rng_stream.json.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define SX_HAVE_X86 1
+#define SX_AVX512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512dq,avx512vpopcntdq,bmi2,popcnt,lzcnt,bmi")))
+#else
+#define SX_HAVE_X86 0
+#endif
 
 #include "../../include/stochopy_hip.h"
 
@@ -54,7 +62,65 @@ inline void mt_temper_block(sx_mt *g) {  // one vectorisable pass instead of 624
     g->out_valid = 1;
 }
 
+#if SX_HAVE_X86
+// The wide forms below produce the SAME words (they are the same recurrence, 16 lanes at a time); SX_MT_SCALAR=1 keeps the
+// scalar forms (tests compare the two).
+inline bool have_avx512() {
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
+                           __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq") &&
+                           __builtin_cpu_supports("avx512vpopcntdq") && __builtin_cpu_supports("bmi2") &&
+                           std::getenv("SX_MT_SCALAR") == nullptr;
+    return ok;
+}
+
+SX_AVX512 inline __m512i twist16(const uint32_t *mt, int k, int src) {
+    const __m512i UP = _mm512_set1_epi32((int)0x80000000u), A = _mm512_set1_epi32((int)0x9908b0dfu),
+                  one = _mm512_set1_epi32(1);
+    const __m512i a = _mm512_loadu_si512(mt + k), b = _mm512_loadu_si512(mt + k + 1), c = _mm512_loadu_si512(mt + src);
+    const __m512i y = _mm512_ternarylogic_epi32(UP, a, b, 0xCA);  // (a & UP) | (b & ~UP)
+    const __m512i r = _mm512_xor_si512(c, _mm512_srli_epi32(y, 1));
+    return _mm512_mask_xor_epi32(r, _mm512_test_epi32_mask(y, one), r, A);
+}
+
+SX_AVX512 void mt_twist_avx512(sx_mt *g) {
+    uint32_t *mt = g->mt;
+    const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    int k = 0;
+    // words 0..226 read words k+1 (old) and k+397 (old): 14 whole vectors, then 3 words
+    for (; k + 16 <= 624 - 397; k += 16) _mm512_storeu_si512(mt + k, twist16(mt, k, k + 397));
+    for (; k < 624 - 397; ++k) {
+        const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
+        mt[k] = mt[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    // words 227..622 read k+1 (old: k+16 <= 623) and k-227 (new: 227 words behind, further than a vector)
+    for (; k + 16 <= 623; k += 16) _mm512_storeu_si512(mt + k, twist16(mt, k, k - 227));
+    for (; k < 623; ++k) {
+        const uint32_t y = (mt[k] & UP) | (mt[k + 1] & LO);
+        mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    const uint32_t y = (mt[623] & UP) | (mt[0] & LO);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    g->pos = 0;
+    const __m512i B = _mm512_set1_epi32((int)0x9d2c5680u), Cc = _mm512_set1_epi32((int)0xefc60000u);
+    for (int q = 0; q < 624; q += 16) {  // 39 vectors exactly
+        __m512i v = _mm512_loadu_si512(mt + q);
+        v = _mm512_xor_si512(v, _mm512_srli_epi32(v, 11));
+        v = _mm512_ternarylogic_epi32(v, _mm512_slli_epi32(v, 7), B, 0x78);   // v ^ (t & B)
+        v = _mm512_ternarylogic_epi32(v, _mm512_slli_epi32(v, 15), Cc, 0x78);
+        v = _mm512_xor_si512(v, _mm512_srli_epi32(v, 18));
+        _mm512_storeu_si512(g->out + q, v);
+    }
+    g->out_valid = 1;
+}
+#endif
+
 inline void mt_twist(sx_mt *g) {
+#if SX_HAVE_X86
+    if (have_avx512()) {
+        mt_twist_avx512(g);
+        return;
+    }
+#endif
     uint32_t *mt = g->mt;
     const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
     int k = 0;
@@ -249,8 +315,152 @@ extern "C" void sx_mt_latin_hypercube(sx_mt *g, int64_t P, int n, const double *
     }
 }
 
+#if SX_HAVE_X86
+// The donor permutations without the permutations (round 4).  The reference shuffles arange(P-1) for every individual and
+// keeps entries 0..k-1 (de/_de.py:304-311): 16.8 million Fisher-Yates steps per generation at P = 4096, one dependent
+// load-swap-store each.  Two observations: (1) the SWAP TARGETS j_i (i = m-1 .. 1) depend only on the word stream -- masked
+// rejection, a compare per word, 64 words at a time: word L is accepted iff v_L <= i - (#accepted words before L), which
+// only the few words within 63 of the bound have to be asked one by one; (2) what ends up
+// at position t is found by walking the swaps BACKWARDS from the last one (i = 1) to the first (i = m-1): q = t; at step i:
+// q == i -> q = j_i, else q == j_i -> q = i; the array starts as the identity, so the entry is the final q.  q changes
+// ~ln(m) times, so the walk is a vector search for the next step that touches it.  Same words consumed, same donors
+// (tests/test_host_cpu.py compares with the scalar replay), no array of P-1 entries is ever shuffled.
+SX_AVX512 void de_donors_avx512(sx_mt *g, int64_t P, int k, int32_t *donors) {
+    const int m = (int)(P - 1);
+    std::vector<uint32_t> store((size_t)m + 64, 0xffffffffu);
+    uint32_t *J = store.data() + 16;  // J[s] = j of step s (i = m-1-s); 16 words of padding in front for the walk
+    const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    for (int64_t ind = 0; ind < P; ++ind) {
+        // ---- (1) the swap targets
+        int s = 0, i = m - 1;
+        while (i >= 1) {
+            uint32_t mask = (uint32_t)i;
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            const int lo = (int)(mask >> 1) + 1;  // smallest i with this mask
+            if (i < 256) {
+                while (i >= lo) {  // no data-dependent branch: a rejected word is overwritten by the next one
+                    const uint32_t v = next32(g) & mask;
+                    const int take = v <= (uint32_t)i;
+                    J[s] = v;
+                    s += take;
+                    i -= take;
+                }
+                continue;
+            }
+            const __m512i vmask = _mm512_set1_epi32((int)mask);
+            // 64 words per trip.  With i0 = i at the start of the trip, word L (a = accepted words before it, a <= L <= 63)
+            // is accepted iff v_L <= i0 - a: certainly if v_L <= i0 - 63, certainly not if v_L > i0, whatever happened
+            // before it -- eight compares that do not wait for anything but i0.  The few words in between (64 * 63 / mask of
+            // a trip's words on average) are settled one by one from the accept mask so far.  (i >= 256 here; below that
+            // most words are such words and the plain loop above is as good.)
+            const int W = 64;
+            while (i >= lo) {
+                if (g->pos == 624) mt_twist(g);
+                else if (!g->out_valid) mt_temper_block(g);
+                const int avail = 624 - g->pos, cnt = avail < W ? avail : W;
+                const uint32_t *w = g->out + g->pos;
+                const __m512i hi_t = _mm512_set1_epi32(i), lo_t = _mm512_set1_epi32(i - (W - 1));
+                __m512i v[4];
+                uint64_t opt = 0, def = 0;
+                const int nv = (cnt + 15) >> 4;
+                if (cnt == 64) {  // the common trip: no lane masks, straight-line
+                    v[0] = _mm512_and_si512(_mm512_loadu_si512(w), vmask);
+                    v[1] = _mm512_and_si512(_mm512_loadu_si512(w + 16), vmask);
+                    v[2] = _mm512_and_si512(_mm512_loadu_si512(w + 32), vmask);
+                    v[3] = _mm512_and_si512(_mm512_loadu_si512(w + 48), vmask);
+                    opt = (uint64_t)_mm512_cmple_epu32_mask(v[0], hi_t) | ((uint64_t)_mm512_cmple_epu32_mask(v[1], hi_t) << 16) |
+                          ((uint64_t)_mm512_cmple_epu32_mask(v[2], hi_t) << 32) | ((uint64_t)_mm512_cmple_epu32_mask(v[3], hi_t) << 48);
+                    def = (uint64_t)_mm512_cmple_epu32_mask(v[0], lo_t) | ((uint64_t)_mm512_cmple_epu32_mask(v[1], lo_t) << 16) |
+                          ((uint64_t)_mm512_cmple_epu32_mask(v[2], lo_t) << 32) | ((uint64_t)_mm512_cmple_epu32_mask(v[3], lo_t) << 48);
+                } else {
+                    for (int u = 0; u < nv; ++u) {
+                        const int left = cnt - 16 * u;
+                        const __mmask16 lanes = left >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << left) - 1u);
+                        v[u] = _mm512_and_si512(_mm512_maskz_loadu_epi32(lanes, w + 16 * u), vmask);
+                        opt |= (uint64_t)_mm512_mask_cmple_epu32_mask(lanes, v[u], hi_t) << (16 * u);
+                        def |= (uint64_t)_mm512_mask_cmple_epu32_mask(lanes, v[u], lo_t) << (16 * u);
+                    }
+                }
+                uint64_t acc = def;
+                for (uint64_t amb = opt & ~def; amb; amb &= amb - 1) {  // (no branch on the answer: it is a coin toss)
+                    const int L = __builtin_ctzll(amb);
+                    const int before = __builtin_popcountll(acc & ((1ull << L) - 1ull));
+                    acc |= (uint64_t)((w[L] & mask) <= (uint32_t)(i - before)) << L;
+                }
+                const int na = __builtin_popcountll(acc);
+                int used = cnt;
+                if (na >= i - lo + 1) {
+                    // the run (this mask) ends inside these words, at its (i - lo + 1)-th accepted one: what lies behind
+                    // that word belongs to the next mask and is looked at again
+                    const uint64_t last = _pdep_u64(1ull << (i - lo), acc);  // the (i - lo + 1)-th set bit of acc
+                    used = __builtin_ctzll(last) + 1;
+                    acc &= last | (last - 1);
+                }
+                const int taken = __builtin_popcountll(acc);
+                // (compress to a register, then a plain store: the memory form of vpcompressd is slow on Zen)
+                if (cnt == 64) {
+                    const __mmask16 m0 = (__mmask16)acc, m1 = (__mmask16)(acc >> 16), m2 = (__mmask16)(acc >> 32),
+                                    m3 = (__mmask16)(acc >> 48);
+                    const int s1 = s + __builtin_popcount((unsigned)m0), s2 = s1 + __builtin_popcount((unsigned)m1),
+                              s3 = s2 + __builtin_popcount((unsigned)m2);
+                    _mm512_storeu_si512(J + s, _mm512_maskz_compress_epi32(m0, v[0]));
+                    _mm512_storeu_si512(J + s1, _mm512_maskz_compress_epi32(m1, v[1]));
+                    _mm512_storeu_si512(J + s2, _mm512_maskz_compress_epi32(m2, v[2]));
+                    _mm512_storeu_si512(J + s3, _mm512_maskz_compress_epi32(m3, v[3]));
+                    s += taken;
+                } else {
+                    for (int u = 0; u < nv; ++u) {
+                        const __mmask16 m16 = (__mmask16)(acc >> (16 * u));
+                        _mm512_storeu_si512(J + s, _mm512_maskz_compress_epi32(m16, v[u]));
+                        s += __builtin_popcount((unsigned)m16);
+                    }
+                }
+                i -= taken;
+                g->pos += used;
+            }
+        }
+        // ---- (2) walk the swaps backwards (s = m-2 .. 0, i.e. i = 1 .. m-1) for positions 0..k-1
+        uint32_t q[8];
+        for (int t = 0; t < k; ++t) q[t] = (uint32_t)t;
+        for (int hi = m - 2; hi >= 0; hi -= 16) {
+            const int base = hi - 15;  // lanes b = 0..15 <-> s = base + b (padding in front: J == ~0, lanes masked)
+            const __mmask16 lanes = base >= 0 ? (__mmask16)0xffff : (__mmask16)(0xffffu << (-base));
+            const __m512i Jv = _mm512_loadu_si512(J + base);
+            const __m512i Iv = _mm512_sub_epi32(_mm512_set1_epi32(m - 1 - base), iota);
+            for (int t = 0; t < k; ++t) {
+                __m512i qv = _mm512_set1_epi32((int)q[t]);
+                unsigned h = (unsigned)(_mm512_mask_cmpeq_epi32_mask(lanes, Jv, qv) | _mm512_mask_cmpeq_epi32_mask(lanes, Iv, qv));
+                while (h) {
+                    const int b = 31 - __builtin_clz(h);  // the earliest of these steps in walking order: the largest s
+                    const int ss = base + b;
+                    const uint32_t ii = (uint32_t)(m - 1 - ss);
+                    q[t] = q[t] == ii ? J[ss] : ii;
+                    qv = _mm512_set1_epi32((int)q[t]);
+                    h = (unsigned)(_mm512_mask_cmpeq_epi32_mask(lanes, Jv, qv) | _mm512_mask_cmpeq_epi32_mask(lanes, Iv, qv)) &
+                        ((1u << b) - 1u);
+                }
+            }
+        }
+        for (int t = 0; t < k; ++t) {
+            const int32_t v = (int32_t)q[t];
+            donors[(int64_t)t * P + ind] = v + (v >= ind ? 1 : 0);
+        }
+    }
+}
+#endif
+
 extern "C" void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors) {
     // individual i: permutation of arange(P) without i; entry t becomes donor t (de/_de.py:304-311)
+#if SX_HAVE_X86
+    if (have_avx512() && P >= 256 && P <= 0x40000000 && k <= 8) {
+        de_donors_avx512(g, P, k, donors);
+        return;
+    }
+#endif
     std::vector<int32_t> a((size_t)(P - 1));
     for (int64_t i = 0; i < P; ++i) {
         for (int64_t v = 0; v < P - 1; ++v) a[v] = (int32_t)v;

@@ -127,6 +127,44 @@ def test_rng_matches_numpy_live(lib, seed):
     assert np.array_equal(s.randn((3,)), rs.randn(3))
 
 
+@pytest.mark.parametrize("P,k,seed,skip", [(256, 2, 1, 0), (300, 5, 2, 7), (1000, 3, 3, 1), (2048, 2, 5, 11), (4096, 2, 0, 5),
+                                           (4097, 4, 9, 3), (257, 3, 4, 623)])
+@pytest.mark.parametrize("scalar", [False, True])
+def test_large_population_donors_match_numpy(lib, P, k, seed, skip, scalar):
+    """de/_de.py:304-311 at population sizes that take the wide form of the donor draws (csrc/sx_mt19937.cpp: masked
+    rejection 64 words at a time, the permutation's first k entries by walking the swaps backwards -- no array is
+    shuffled): the same donors as numpy's legacy permutation() of every individual's index list, and the stream left at
+    the same word (the draws behind it agree).  Both forms (SX_MT_SCALAR=1: the plain replay) in a fresh process each,
+    the CPU check is made once per process."""
+    import subprocess
+    import sys
+
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+from stochopy_amd import _rng
+s = _rng.LegacyHostStream({seed})
+rs = np.random.RandomState({seed})
+if {skip}:
+    assert np.array_equal(s.random({skip}), rs.rand({skip}))
+got = s.de_donors({P}, {k})
+ref = np.empty(({k}, {P}), dtype=np.int32)
+idx = np.arange({P})
+for i in range({P}):
+    ref[:, i] = rs.permutation(np.delete(idx, i))[:{k}]
+assert np.array_equal(got, ref), "donors differ"
+assert np.array_equal(s.randint(1000, 8), rs.randint(1000, size=8)), "stream position differs"
+assert np.array_equal(s.random((3, 5)), rs.rand(3, 5))
+print("ok")
+"""
+    env = dict(os.environ)
+    env.pop("SX_MT_SCALAR", None)
+    if scalar:
+        env["SX_MT_SCALAR"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("P,k,n,bounded", [(9, 3, 1, False), (37, 5, 13, True), (130, 2, 64, True), (40, 4, 5, False)])
 def test_async_de_draws_match_numpy(lib, P, k, n, bounded):
     """updating="immediate": per individual donor permutation, randint(ndim), Random's uniform(lower, upper, n)
