@@ -160,6 +160,77 @@ __global__ __launch_bounds__(THREADS) void one_generation(double *A, double *B, 
     double *dst = (g & 1) ? A : B;
     (void)generation<LAUNCH>(src, dst, rec, g, err, 1ll << 40, nullptr);
 }
+
+// the per-launch skeleton with the two changes the product kernel could still take: OWN = the row's own elements requested
+// before the generation number has arrived (the buffer parity is known from the launch's position in the graph), NT =
+// streaming row stores
+template <bool OWN, bool NT>
+__global__ __launch_bounds__(THREADS) void one_generation_v(double *A, double *B, uint64_t *rec, const int *gen_p, int k,
+                                                            int *err) {
+    __shared__ int s_best;
+    __shared__ double s_val[ROWS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & (LPR - 1), sub = lane / LPR;
+    const int wg = blockIdx.x, r = wave * 2 + sub, i = wg * ROWS + r;
+    const int par = k & 1;  // graphs have an even number of generations and start at an even generation
+    const double *src = par ? B : A;
+    double *dst = par ? A : B;
+    double xi[4];
+    if (OWN) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xi[q] = src[(size_t)i * N + q * LPR + l];
+    }
+    const uint64_t *rin = rec + (size_t)par * WG;
+    uint64_t w[4] = {0, 0, 0, 0};
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = rin[lane * 4 + u];
+    }
+    const int g = *gen_p + k;
+    if (wave == 0) {
+        uint64_t best = ~0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t key = ((w[u] & 0xffffffffull) << 32) | (uint64_t)(lane * 4 + u);
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t o = __shfl_xor(best, off, 64);
+            best = o < best ? o : best;
+        }
+        if (lane == 0) s_best = (int)(best & 0xffffffffull) * ROWS;
+    }
+    __syncthreads();
+    const int brow = s_best;
+    const unsigned h = (unsigned)i * 2654435761u + (unsigned)g * 40503u;
+    const int d0 = (h >> 4) % P, d1 = (h >> 16) % P;
+    double x[4], s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = q * LPR + l;
+        if (!OWN) xi[q] = src[(size_t)i * N + e];
+        const double a = src[(size_t)d0 * N + e], b = src[(size_t)d1 * N + e], gb = src[(size_t)brow * N + e];
+        const double u = ((h >> q) & 1) ? 0.25 * (gb + xi[q]) + 0.5 * (a - b) : xi[q];
+        x[q] = u;
+        s += u * u;
+    }
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (NT)
+            __builtin_nontemporal_store(x[q], dst + (size_t)i * N + q * LPR + l);
+        else
+            dst[(size_t)i * N + q * LPR + l] = x[q];
+    }
+    if (l == 0) s_val[r] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float m = (float)s_val[0];
+        for (int kk = 1; kk < ROWS; ++kk) m = fminf(m, (float)s_val[kk]);
+        rec[(size_t)(par ^ 1) * WG + wg] = ((uint64_t)(uint32_t)(g + 1) << 32) | (uint64_t)__float_as_uint(m);
+    }
+}
 __global__ void bump(int *gen_p, int by) { *gen_p += by; }
 
 static double checksum(const double *d, std::vector<double> &h) {
@@ -232,6 +303,43 @@ int main() {
                 printf("%-78s %6.2f us per generation   checksum %.17g\n",
                        "one launch per generation (graph of 50 + 1 counter kernel, replayed)", ms * 1e3 / gens,
                        checksum((gens & 1) ? B : A, h));
+        }
+    }
+    // ---- the per-launch form with streaming stores / the own row requested early
+    struct { const char *name; const void *fn; } lv[] = {
+        {"one launch per generation, streaming (nt) row stores", (const void *)one_generation_v<false, true>},
+        {"one launch per generation, own row requested before the generation number", (const void *)one_generation_v<true, false>},
+        {"one launch per generation, both", (const void *)one_generation_v<true, true>},
+    };
+    for (auto &c : lv) {
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        CK(hipGraphCreate(&graph, 0));
+        hipGraphNode_t prev = nullptr;
+        const int chunk = 50;
+        for (int k = 0; k <= chunk; ++k) {
+            hipKernelNodeParams kp = {};
+            int kk = k, by = chunk;
+            void *a1[] = {&A, &B, &rec, &gen_p, &kk, &err};
+            void *a2[] = {&gen_p, &by};
+            kp.func = k < chunk ? (void *)c.fn : (void *)bump;
+            kp.gridDim = dim3(k < chunk ? WG : 1);
+            kp.blockDim = dim3(k < chunk ? THREADS : 1);
+            kp.kernelParams = k < chunk ? a1 : a2;
+            hipGraphNode_t node;
+            CK(hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+            prev = node;
+        }
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int rep = 0; rep < 2; ++rep) {
+            reset();
+            CK(hipEventRecord(e0, s));
+            for (int k = 0; k < gens / chunk; ++k) CK(hipGraphLaunch(exec, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("%-78s %6.2f us per generation   checksum %.17g\n", c.name, ms * 1e3 / gens, checksum((gens & 1) ? B : A, h));
         }
     }
     // ---- persistent forms
