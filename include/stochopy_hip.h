@@ -527,6 +527,10 @@ int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, in
 int64_t sx_eigh_workspace_bytes(int n);
 int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
             double tol, void *stream);
+/* sx_eigh with the refinement step allowed (refine > 0) / forbidden (0) for THIS call only (< 0: the process-wide mode):
+ * what a multi-threaded host uses instead of flipping sx_eigh_set_refine around a call. */
+int sx_eigh_refined(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
+                    int max_sweeps, double tol, int refine, void *stream);
 int sx_eigh_info(const void *ws, int *sweeps, int *converged, double *off_rel, void *stream);
 int sx_eigh_set_refine(int mode);
 

@@ -12,8 +12,7 @@ from . import _lib
 
 _torch = None
 _TLS = threading.local()
-_ARENA_LOCK = threading.Lock()
-_ARENA, _ARENA_OFF, _ARENA_BYTES = None, 0, 1 << 20  # pinned staging for upload_async
+_ARENA_BYTES = 1 << 20  # pinned staging for upload_async: one arena per host thread and device (_TLS.arenas)
 
 
 def torch():
@@ -83,24 +82,33 @@ class Context:
 
     def upload_async(self, array):
         """Small host array -> device WITHOUT the blocking pageable copy of ``upload`` (~0.2 ms each through
-        ``Tensor.to``): the bytes go through a process-wide pinned arena and an asynchronous copy on the CURRENT torch
-        stream -- callers run inside ``torch.cuda.stream(ctx.stream)``, so kernels enqueued afterwards see the data."""
-        global _ARENA, _ARENA_OFF
+        ``Tensor.to``): the bytes go through a pinned arena (per host thread and device) and an asynchronous copy on the
+        CURRENT torch stream -- callers run inside ``torch.cuda.stream(ctx.stream)``, so kernels enqueued afterwards see it."""
         t = torch()
         a = np.ascontiguousarray(array)
         nbytes = a.nbytes
         if nbytes == 0 or nbytes > _ARENA_BYTES // 4:
             return self.upload(a)
-        with _ARENA_LOCK:  # (host threads share the arena: the slice is claimed and filled under the lock)
-            if _ARENA is None:
-                _ARENA = t.empty(_ARENA_BYTES, dtype=t.uint8).pin_memory()
-            off = (_ARENA_OFF + 63) & ~63
-            if off + nbytes > _ARENA_BYTES:  # wrap: every copy that read the arena so far must have landed
-                t.cuda.synchronize()
-                off = 0
-            _ARENA_OFF = off + nbytes
-            stage = _ARENA[off:off + nbytes]
-            stage.numpy()[:] = a.reshape(-1).view(np.uint8)
+        # The arena belongs to THIS host thread and THIS device (ADVICE r3): a slice is claimed, filled and its copy
+        # enqueued by one thread, so no other thread's copy can still be waiting to be enqueued when the arena wraps, and
+        # the device-wide synchronize at the wrap covers every stream a copy of this arena may have gone to.
+        arenas = getattr(_TLS, "arenas", None)
+        if arenas is None:
+            arenas = _TLS.arenas = {}
+        key = self.device.index if self.device.index is not None else t.cuda.current_device()
+        if key not in arenas:
+            arenas[key] = [t.empty(_ARENA_BYTES, dtype=t.uint8).pin_memory(), 0]
+        arena = arenas[key]
+        off = (arena[1] + 63) & ~63
+        if off + nbytes > _ARENA_BYTES:  # wrap: every copy that read the arena so far must have landed
+            if t.cuda.is_current_stream_capturing():
+                raise RuntimeError("upload_async: the staging arena wrapped during a stream capture (a synchronisation "
+                                   "is not allowed there); upload before capturing")
+            t.cuda.synchronize(self.device)
+            off = 0
+        arena[1] = off + nbytes
+        stage = arena[0][off:off + nbytes]
+        stage.numpy()[:] = a.reshape(-1).view(np.uint8)
         dev = t.empty(a.shape, dtype=t.from_numpy(a.reshape(-1)[:0]).dtype, device=self.device)  # (ascontiguousarray: ndim >= 1)
         dev.reshape(-1).view(t.uint8).copy_(stage, non_blocking=True)
         return dev

@@ -171,6 +171,7 @@ PROTOTYPES = {
     "sx_vdcma_generation_stage": (C.c_int, [C.POINTER(SxVdArgs), i64, C.c_int, i64, i64, vp, vp, vp, vp]),
     "sx_eigh_workspace_bytes": (i64, [C.c_int]),
     "sx_eigh": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, vp]),
+    "sx_eigh_refined": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, C.c_int, vp]),
     "sx_eigh_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64), vp]),
     "sx_eigh_set_refine": (C.c_int, [C.c_int]),
     "sx_mt_create": (vp, [C.c_uint32]),

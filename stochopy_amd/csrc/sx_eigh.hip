@@ -1333,6 +1333,14 @@ extern "C" int sx_eigh(const double *C, int n, const double *V0, double *w, doub
     return sx::eigh_enqueue(C, n, V0, w, B, ws, ws_bytes, max_sweeps, tol, nullptr, sx::eigh_refine_default(), stream);
 }
 
+// the same with the refinement step decided by the CALLER for this call (refine > 0: allowed, 0: not, < 0: the library's mode):
+// nothing process-wide is touched, so concurrent callers (other host threads, the generation loops) are not affected
+extern "C" int sx_eigh_refined(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
+                               int max_sweeps, double tol, int refine, void *stream) {
+    return sx::eigh_enqueue(C, n, V0, w, B, ws, ws_bytes, max_sweeps, tol, nullptr,
+                            refine < 0 ? sx::eigh_refine_default() : (refine ? 1 : 0), stream);
+}
+
 extern "C" int sx_eigh_set_refine(int mode) {
     const int prev = sx::g_refine_mode;
     sx::g_refine_mode = mode < 0 ? -1 : (mode ? 1 : 0);

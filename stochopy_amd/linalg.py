@@ -27,14 +27,17 @@ class Eigh:
         if self.bytes <= 0:
             raise ValueError(f"sx_eigh_workspace_bytes({n}) = {self.bytes}")
         self.ws = t.empty((self.bytes + 7) // 8, dtype=t.float64, device=ctx.device)
-        self.ws[:256].zero_()  # the run record: info() before the first decomposition reads zeros, not stale memory
+        with t.cuda.stream(ctx.stream):  # (the stream sx_eigh writes the record on: a memset on torch's current stream --
+            self.ws[:256].zero_()        #  the default one for callers outside the engine's -- could land on a running call)
+        # the run record: info() before the first decomposition reads zeros, not stale memory
         self.w = ctx.empty((self.n,))
         self.B = ctx.empty((self.n, self.n))
 
     def __call__(self, Cmat, w=None, B=None, max_sweeps=0, tol=0.0, start=None, refine=None):
         """``start``: optional (n, n) nearly orthonormal basis to start from (the previous decomposition's B; may be
         the output buffer itself).  ``refine``: True / False allows / forbids the first-order refinement step in place of
-        the last sweep for this call (``sx_eigh_set_refine``; None: the library's current mode)."""
+        the last sweep for THIS call (``sx_eigh_refined``: nothing process-wide is touched, so other host threads' runs keep
+        their mode); None: the library's current mode (``sx_eigh_set_refine`` / ``SX_EIGH_REFINE``)."""
         n = self.n
         if tuple(Cmat.shape) != (n, n) or not Cmat.is_contiguous():
             raise ValueError(f"expected a contiguous ({n},{n}) device matrix")
@@ -43,13 +46,9 @@ class Eigh:
         p = _device.ptr
         if start is not None and (tuple(start.shape) != (n, n) or not start.is_contiguous()):
             raise ValueError(f"start: expected a contiguous ({n},{n}) device matrix")
-        prev = self.ctx.L.sx_eigh_set_refine(1 if refine else 0) if refine is not None else None
-        try:
-            _lib.check(self.ctx.L.sx_eigh(p(Cmat), n, p(start), p(w), p(B), p(self.ws), self.bytes, int(max_sweeps),
-                                          float(tol), self.ctx.stream_ptr), "sx_eigh")
-        finally:
-            if prev is not None:
-                self.ctx.L.sx_eigh_set_refine(prev)
+        _lib.check(self.ctx.L.sx_eigh_refined(p(Cmat), n, p(start), p(w), p(B), p(self.ws), self.bytes, int(max_sweeps),
+                                              float(tol), -1 if refine is None else int(bool(refine)), self.ctx.stream_ptr),
+                   "sx_eigh")
         return w, B
 
     def info(self):

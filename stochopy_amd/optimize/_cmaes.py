@@ -133,7 +133,6 @@ class _CmaDeviceRun:
         """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
         with ``step`` from a state of their choosing."""
         import ctypes as C
-        import time
         import warnings
 
         ctx = self.ctx = _device.Context()
@@ -184,7 +183,13 @@ class _CmaDeviceRun:
             self.eig_every = eig_every = P / (c1 + cmu) / n / 10.0  # :301
             if not run:
                 return
-            eigeneval, look, since, t0 = 0, 1, 0, time.perf_counter()
+            # How often the host looks is a matter of speed only (generations after the stop are no-ops) -- except that the
+            # sweep allowance below follows what the host has SEEN.  Both are therefore functions of the problem, not of
+            # the clock or of the number of ranks: look_cap generations between looks (about 2 ms of them),
+            # reached by doubling, and the same allowance rule whether this run looks that rarely or (callback, workers > 1)
+            # at every generation.
+            look_cap = 1 if n > 256 else min(self.LOOK, max(1, 512 // max(n, 32)))
+            eigeneval, look, since = 0, 1, 0
             cb_hist, cb_pin, fails_seen, warned_short = None, None, 0, False
             state = st
             # Sweeps to LAUNCH per decomposition (launches beyond convergence are no-ops of ~2 us each, 2n/16 - 1 per
@@ -232,8 +237,7 @@ class _CmaDeviceRun:
                         callback(Xs, cres)
                     if state.done:
                         break
-                    now = time.perf_counter()
-                    if world is None and callback is None and now - t0 < 2.0e-3 and look < self.LOOK:
+                    if world is None and callback is None and look < look_cap:
                         look *= 2  # cheap generations: look less often
                     if decomposed:  # (the record is only meaningful once a decomposition has been enqueued)
                         used, ok, _off = eig.info()
@@ -241,7 +245,7 @@ class _CmaDeviceRun:
                         if ok and fails == fails_seen:
                             # the record is the LAST decomposition's: while the host looks at every generation the count
                             # moves by at most one between looks; between rarer looks it gets two more sweeps of slack
-                            warm_sweeps = min(60, used + (1 if look == 1 else 3))
+                            warm_sweeps = min(60, used + (1 if look_cap == 1 else 3))
                         else:
                             if launched >= 60:
                                 warnings.warn("stochopy_amd: the device eigensolver did not reach its tolerance in 60 "
@@ -253,7 +257,7 @@ class _CmaDeviceRun:
                                 warned_short = True
                             warm_sweeps, fails_seen = 60, fails
                         decomposed = False
-                    since, t0 = 0, now
+                    since = 0
             if not state.done:  # cannot happen: generation maxiter sets status -1
                 raise RuntimeError("CMA-ES device loop ended without a status")
             nit = int(state.stop_it)
