@@ -141,31 +141,35 @@ int make_plan_arg(int fun_id, int n, PlanArg *out) {
 // ---------------------------------------------------------------------------
 // Batched evaluation kernel: one wavefront per individual.
 // ---------------------------------------------------------------------------
-template <int FUN, int LPR>
+// FULL: n is a whole number of 4-step batches and P a whole number of workgroups (no bounds test survives);
+// NFIX: FULL with n == 4 * LPR exactly (64 / 128 / 256): the row length, and with it numpy's summation plan, is a
+// compile-time constant (row_reduce_fixed / row_reduce_static, as in the one-batch DE / PSO kernels); 0 otherwise.
+template <int FUN, int LPR, bool FULL = false, int NFIX = 0>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
-    const double *__restrict__ X, int64_t P, int n, int64_t ldx, const double *__restrict__ xm,
+    const double *__restrict__ X, int64_t P, int n_arg, int64_t ldx, const double *__restrict__ xm,
     const double *__restrict__ xstd, double *__restrict__ f, const PlanArg plan, double *__restrict__ part_f,
     int64_t *__restrict__ part_i, const int clip, const double *__restrict__ pen_v, double *__restrict__ pen_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
+    const int n = NFIX ? NFIX : n_arg;
     const RowIds<LPR> id(P);
     double *U = lds + id.slot * lds_row_stride(n);
     const double *xr = X + id.rowc * ldx;
     const bool affine = xm != nullptr;
     double pacc = 0.0;
-    constexpr int kBatch = 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
+    constexpr int kBatch = NFIX ? 4 : 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
     for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
         double xv[kBatch];
 #pragma unroll
         for (int t = 0; t < kBatch; ++t) {
             const int e = e0 + t * LPR;
-            xv[t] = e < n ? xr[e] : 0.0;
+            xv[t] = (FULL || e < n) ? xr[e] : 0.0;
         }
 #pragma unroll
         for (int t = 0; t < kBatch; ++t) {
             const int e = e0 + t * LPR;
-            if (e >= n) continue;
+            if (!FULL && e >= n) continue;
             double v = xv[t];
             if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
                 const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
         pacc = row_sum<LPR>(pacc);
         if (id.active && id.l == 0) pen_out[id.row] = pacc;
     }
-    const double val = row_objective<FUN, LPR>(U, n, plan, id.l);
-    if (id.active && id.l == 0) f[id.row] = val;
+    const double val = row_objective<FUN, LPR, FULL, NFIX>(U, n, plan, id.l);
+    if ((FULL || id.active) && id.l == 0) f[id.row] = val;
     if (part_f != nullptr) block_partial<LPR>(val, id, sf, si, part_f, part_i);
 }
 
@@ -190,8 +194,26 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
                        const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s, int clip = 0,
                        const double *pen_v = nullptr, double *pen_out = nullptr) {
     const Geometry g = row_geometry(P, n);
-    SX_DISPATCH_LPR(n, hipLaunchKernelGGL((eval_kernel<FUN, LPR>), dim3(g.blocks), dim3(g.threads), g.lds, s, X, P, n,
-                                          ldx, xm, xstd, f, plan, part_f, part_i, clip, pen_v, pen_out))
+    // whole batches and whole workgroups: the guard-free form; one batch per row on top: the compile-time plan
+    // (plain evaluation only -- the clip / penalty variants keep the general kernel, to keep the build small)
+    const int lpr = lanes_per_row(n);
+    const bool full = clip == 0 && n % (8 * lpr) == 0 && P % rows_per_block(n) == 0;
+    const bool fix = clip == 0 && n == 4 * lpr && P % rows_per_block(n) == 0;
+#define SX_EVAL_GO(...)                                                                                              \
+    hipLaunchKernelGGL((eval_kernel<FUN, __VA_ARGS__>), dim3(g.blocks), dim3(g.threads), g.lds, s, X, P, n, ldx, xm, xstd, f, \
+                       plan, part_f, part_i, clip, pen_v, pen_out)
+    if (fix) {
+        switch (lpr) {
+            case 16: SX_EVAL_GO(16, true, 64); break;
+            case 32: SX_EVAL_GO(32, true, 128); break;
+            default: SX_EVAL_GO(64, true, 256); break;
+        }
+    } else if (full) {
+        SX_DISPATCH_LPR(n, SX_EVAL_GO(LPR, true, 0))
+    } else {
+        SX_DISPATCH_LPR(n, SX_EVAL_GO(LPR, false, 0))
+    }
+#undef SX_EVAL_GO
     SX_LAUNCH_CHECK();
     return 0;
 }

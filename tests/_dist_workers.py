@@ -187,6 +187,7 @@ def gpu_late_failure_worker(rank, world, port, cfg, out_dir):
         torch.cuda.set_device(0)
         import stochopy_amd as sa
 
+        os.environ.update(cfg.get("env", {}))
         n, opts = cfg["n"], dict(cfg["options"], backend="hip", workers=world, rng="philox")
         last = opts["maxiter"]
 

@@ -219,8 +219,10 @@ def test_late_failure_on_one_rank_raises_on_every_rank(method):
     collective (one all_gather of the success flags), no barrier that a failing rank would skip."""
     from _dist_workers import gpu_late_failure_worker
 
-    cfg = {"n": 12, "objective": "rosenbrock", "method": method,
-           "options": {"maxiter": 12, "popsize": 64, "seed": 3, "ftol": -1.0, "xtol": 0.0, "exchange": "p2p"}}
+    opts = {"maxiter": 12, "popsize": 64, "seed": 3, "ftol": -1.0, "xtol": 0.0}
+    if method == "de":
+        opts["exchange"] = "p2p"  # (PSO takes the transport from the environment)
+    cfg = {"n": 12, "objective": "rosenbrock", "method": method, "options": opts, "env": {"SX_EXCHANGE": "p2p"}}
     out = _spawn(gpu_late_failure_worker, 2, cfg)
     assert "callback failed on purpose" in open(os.path.join(out, "err_1.txt")).read()
     assert "peer rank failed" in open(os.path.join(out, "err_0.txt")).read()
