@@ -241,7 +241,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     using rec_t = typename std::conditional<LPR == kWave, int32_t, int64_t>::type;
     constexpr rec_t kNoRec = LPR == kWave ? (rec_t)INT32_MAX : (rec_t)INT64_MAX;
     rec_t piv[kRecPerLane];
-    if (CHAIN && !P2P) {
+#ifndef SX_CHAIN_REC_WAVE0
+#define SX_CHAIN_REC_WAVE0 0  // A/B: 1 = wavefront 0 alone reads the records and shares the result through LDS
+#endif
+    if (CHAIN && !P2P && (!SX_CHAIN_REC_WAVE0 || id.wave == 0)) {
         const double *pf = pf_pre;
         const int64_t *pi = pi_pre;
         const int per = (int)((npart + kWave - 1) / kWave);  // contiguous slice per lane: first-minimum rule
@@ -418,24 +421,32 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
         // the first record that holds it -- lanes own contiguous slices, so that is the first matching record of the
         // first matching lane.  (A lexicographic compare-and-select chain over the 8 records is ~60 dependent
         // instructions in front of the best row's address.)
+        double bf = 0.0;
+        int64_t bi = 0;
+        if (!SX_CHAIN_REC_WAVE0 || id.wave == 0) {
         double lm[kRecPerLane / 2];
 #pragma unroll
         for (int u = 0; u < kRecPerLane / 2; ++u) lm[u] = fmin(pfv[2 * u], pfv[2 * u + 1]);
         const double lmin = fmin(fmin(lm[0], lm[1]), fmin(lm[2], lm[3]));
-        const double bf = wave_min_f64(lmin);
+        bf = wave_min_f64(lmin);
         rec_t br = piv[0];  // (all NaN: record 0, as a sequential scan would)
 #pragma unroll
         for (int u = kRecPerLane - 1; u >= 0; --u)
             if (pfv[u] == bf) br = piv[u];
         const unsigned long long hit = __ballot(lmin == bf);
         const int src = hit ? (int)__ffsll((long long)hit) - 1 : 0;
-        int64_t bi;
         if (LPR == kWave) {
             bi = (int64_t)__builtin_amdgcn_readlane((int)br, src);
         } else {
             const int lo = __builtin_amdgcn_readlane((int)((int64_t)br & 0xffffffffll), src);
             const int hi = __builtin_amdgcn_readlane((int)((int64_t)br >> 32), src);
             bi = ((int64_t)hi << 32) | (int64_t)(unsigned)lo;
+        }
+        }
+        if (SX_CHAIN_REC_WAVE0) {
+            if (id.wave == 0 && id.lane == 0) s_gf = bf, s_gi = bi;
+            __syncthreads();
+            bf = s_gf, bi = s_gi;
         }
         int status = SX_STATUS_NONE;
         if (it >= 2) {  // the reference does not test the initial population (de/_de.py:212-218)
