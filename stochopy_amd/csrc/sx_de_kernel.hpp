@@ -242,7 +242,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     constexpr rec_t kNoRec = LPR == kWave ? (rec_t)INT32_MAX : (rec_t)INT64_MAX;
     rec_t piv[kRecPerLane];
 #ifndef SX_CHAIN_REC_WAVE0
-#define SX_CHAIN_REC_WAVE0 0  // A/B: 1 = wavefront 0 alone reads the records and shares the result through LDS
+#define SX_CHAIN_REC_WAVE0 1  // wavefront 0 alone reads the records and shares the result through LDS (round 4: all eight
+                              // wavefronts reading them was 8 MB of L2 reads per generation at the metric shape: 6.83 -> 6.58 us); 0: A/B
 #endif
     if (CHAIN && !P2P && (!SX_CHAIN_REC_WAVE0 || id.wave == 0)) {
         const double *pf = pf_pre;

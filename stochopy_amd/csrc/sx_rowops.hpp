@@ -62,6 +62,98 @@ __device__ __forceinline__ double row_sum(double v) {
     return v;
 }
 
+// One-batch rows of 64 / 128 elements (one leaf of numpy's recursion: <= 128 terms), round 4: the objective WITHOUT the
+// term arrays.  numpy's sum is eight accumulators r_j = a[j] + a[8+j] + a[16+j] + ... (strictly left to right), the tree
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail terms one by one (loops_utils.h.src pairwise_sum).  Lane
+// L = SEG*j + g of the row (SEG = LPR/8 lanes per accumulator) reads the four elements 8(4g+i)+j, i = 0..3, of the staged
+// vector, forms their terms in registers and adds them -- in order -- onto the running sum that arrives from lane L-1
+// (same quad: one DPP move): accumulator j's chain walks through SEG adjacent lanes and ends in lane SEG*j + SEG-1.
+// Same additions in the same order as row_reduce_static / row_reduce_fixed (same bits), but per row 2 LDS reads per term
+// instead of two staged term arrays written and read back by every 8-lane group (the objective was 0.7 us of the 6.9 us
+// generation at the metric shape).
+template <int FUN, int LPR, int NFIX>
+__device__ __forceinline__ double row_objective_chain(const double *U, int l) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    constexpr int M = O::NEXT ? NFIX - 1 : NFIX;  // terms
+    constexpr int SEG = LPR / kGroup;             // lanes per accumulator chain: 2 (n = 64) or 4 (n = 128)
+    static_assert(NFIX == 4 * LPR && (SEG == 2 || SEG == 4) && M <= 128, "one leaf, four elements per lane");
+    constexpr int NB = M / kGroup, TAIL = M % kGroup;  // blocks that go into the accumulators; tail terms
+    static_assert(TAIL == 0 || NB == 4 * SEG - 1, "the tail is the last block");
+    constexpr int kHop = SEG == 4 ? 0x90 : 0xA0;  // quad_perm [0,0,1,2] / [0,0,2,2]: lane L takes lane L-1's value
+    const int j = l / SEG, g = l % SEG;
+    double a[4], b[4];
+    {
+        double x[4], xn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = kGroup * (4 * g + i) + j;
+            x[i] = U[e];
+            xn[i] = O::NEXT ? U[e + 1] : 0.0;  // (U[NFIX .. NFIX+7] is padding: the term of element NFIX-1 is never used)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) O::term(x[i], xn[i], kGroup * (4 * g + i) + j, a[i], b[i]);
+    }
+    // the chain: segment s continues from what segment s-1 hands over.  Every lane runs every segment's code; only the
+    // lanes whose turn it is (g == s) hold meaningful values, and only those are passed on.
+    double ra = a[0], rb = b[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        if (i < NB) {
+            ra = ra + a[i];
+            if (TWO) rb = combine<BMUL>(rb, b[i]);
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < SEG; ++s) {
+        ra = dpp_f64<kHop>(ra);
+        if (TWO) rb = dpp_f64<kHop>(rb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (4 * s + i < NB) {
+                ra = ra + a[i];
+                if (TWO) rb = combine<BMUL>(rb, b[i]);
+            }
+        }
+    }
+    // r_j sits in lane SEG*j + SEG-1; the tree over j (each + / * commutes exactly)
+    constexpr int kShl1 = 0x100 + SEG, kShl2 = 0x100 + 2 * SEG;  // row_shl: lane L takes lane L+SEG / L+2 SEG
+    ra = combine<false>(ra, dpp_f64<kShl1>(ra));
+    ra = combine<false>(ra, dpp_f64<kShl2>(ra));
+    if (TWO) {
+        rb = combine<BMUL>(rb, dpp_f64<kShl1>(rb));
+        rb = combine<BMUL>(rb, dpp_f64<kShl2>(rb));
+    }
+    double sa, sb = BMUL ? 1.0 : 0.0;
+    if constexpr (SEG == 2) {  // a row is one 16-lane DPP row: the last level is a DPP move too
+        ra = combine<false>(ra, dpp_f64<0x108>(ra));
+        if (TWO) rb = combine<BMUL>(rb, dpp_f64<0x108>(rb));
+        sa = row_lane_value<LPR>(ra, SEG - 1, l);
+        if (TWO) sb = row_lane_value<LPR>(rb, SEG - 1, l);
+    } else {  // two DPP rows: (r0..r3) in lane 3, (r4..r7) in lane 19
+        sa = row_lane_value<LPR>(ra, SEG - 1, l) + row_lane_value<LPR>(ra, 4 * SEG + SEG - 1, l);
+        if (TWO) sb = combine<BMUL>(row_lane_value<LPR>(rb, SEG - 1, l), row_lane_value<LPR>(rb, 4 * SEG + SEG - 1, l));
+    }
+    if constexpr (TAIL > 0) {
+        // the tail terms a[M-7 .. M-1] are added one by one to the total: every lane forms them itself from TAIL + 1
+        // broadcast reads of the staged vector (independent of the chains above, so they hide behind them) instead of
+        // fetching them from the lanes that own those elements (4 cross-lane moves per term and stream)
+        double tx[TAIL + 1];
+#pragma unroll
+        for (int t = 0; t <= TAIL; ++t) tx[t] = U[kGroup * NB + t];
+#pragma unroll
+        for (int t = 0; t < TAIL; ++t) {
+            double ta, tb;
+            O::term(tx[t], tx[t + 1], kGroup * NB + t, ta, tb);
+            sa = sa + ta;
+            if (TWO) sb = combine<BMUL>(sb, tb);
+        }
+    }
+    sa = 0.0 + sa;  // add.reduce starts from the identity
+    sb = !TWO ? (BMUL ? 1.0 : 0.0) : (BMUL ? sb : 0.0 + sb);
+    return O::finish(sa, sb, NFIX);
+}
+
 // Objective of the row staged in LDS at U[0..n): terms by the row's LPR lanes -> A/B (behind U),
 // then the numpy-order row sums (lanes l >= 8 repeat the chains of lanes l & 7: LDS broadcasts, same bits).
 // Every lane of the row returns the value.  Each row works on its own LDS slice (no workgroup barrier).
@@ -71,6 +163,10 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     using O = Obj<FUN>;
     const int m = O::NEXT ? n - 1 : n;
     lds_wave_fence();  // U complete (written and read by this wave only)
+#ifndef SX_OBJ_CHAIN
+#define SX_OBJ_CHAIN 1  // A/B switch: 0 = the staged-terms form for one-batch rows too
+#endif
+    if constexpr (SX_OBJ_CHAIN && NFIX != 0 && NFIX <= 128 && LPR < kWave) return row_objective_chain<FUN, LPR, NFIX>(U, l);
     if (LPR == kWave && fused_terms(n)) {  // terms are formed inside the reduction, nothing else is staged
         double sa, sb;
         row_reduce_leaves_fused<FUN, LPR>(U, U + n + 8, leaf_cap(n), m, plan, l, sa, sb);
