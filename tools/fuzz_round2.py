@@ -62,7 +62,15 @@ def one_eigh():
     e1 = np.abs(w - wr).max() / max(np.abs(wr).max(), 1e-300)
     e2 = np.linalg.norm(Cs / nC - (B * (w / nC)) @ B.T)
     e3 = np.abs(B.T @ B - np.eye(n)).max()
-    ok = conv and e1 <= 1e-12 and e2 <= 1e-13 * max(1.0, np.sqrt(n) / 4) and e3 <= 1e-13
+    # Limits.  Full sweeps: residual 1e-13 sqrt(n)/4 |C|, orthogonality 1e-13.  With the refinement step allowed
+    # (SX_EIGH_REFINE=1: what the CMA-ES loops run with) the rule that admits the step bounds what it leaves behind by
+    # ~0.5 max|K| off <= 5e-13 |C| (csrc/sx_eigh.hip kRefineProd): residual 2e-12 |C| (the limit
+    # tests/test_gpu_eigh.py::test_eigh_with_the_refinement_step states); orthogonality 1e-12: the step's two products on a
+    # graded spectrum (condition up to 1e10, 15+ sweeps before it) were seen at 3e-13 ... 5e-13 twice in 3 211 runs
+    # (profiles/r4_c4_parity_margin.txt), everything else below 2e-13.
+    refine = os.environ.get("SX_EIGH_REFINE") == "1"
+    res_lim = 2e-12 if refine else 1e-13 * max(1.0, np.sqrt(n) / 4)
+    ok = conv and e1 <= (2e-12 if refine else 1e-12) and e2 <= res_lim and e3 <= (1e-12 if refine else 1e-13)
     return ok, f"n={n} {kind} warm={start is not None} sweeps={sweeps} conv={conv} eig={e1:.1e} resid={e2:.1e} orth={e3:.1e}"
 
 
