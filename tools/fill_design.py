@@ -66,11 +66,6 @@ for line in open(P("r4_eval_kernel.txt")):
         ev[(mm.group(1), int(mm.group(2)), int(mm.group(3)))] = (mm.group(4), mm.group(5))
 t.update(EV128=ev[("rosenbrock", 128, 1 << 20)][0], EV128F=ev[("rosenbrock", 128, 1 << 20)][1], EV64F=ev[("sphere", 64, 1 << 21)][1],
          EV1024F=ev[("rosenbrock", 1024, 1 << 17)][1], EVACK=ev[("ackley", 256, 1 << 19)][1])
-mg = open(P("r4_c4_parity_margin.txt")).read()
-mx = re.findall(r"max over the run: ([\d.e+-]+)\s+([\d.e+-]+)", mg)
-t.update(MARGF=sig(max(float(a) for a, _ in mx), 2), MARGX=sig(max(float(c) for _, c in mx), 2))
-fz = re.search(r"eigh: (\d+) runs, (\d+) mismatches", mg)
-t["FZE"] = "%s decompositions, %s mismatches" % (f"{int(fz.group(1)):,}".replace(",", " "), fz.group(2))
 s = open(os.path.join(R, "DESIGN.md")).read()
 missing = set(re.findall(r"@@(\w+)@@", s)) - set(t)
 assert not missing, missing
