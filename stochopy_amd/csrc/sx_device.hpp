@@ -163,6 +163,39 @@ __device__ __forceinline__ double philox_u53(int e, int lpr, uint32_t row, uint3
 // ---------------------------------------------------------------------------
 constexpr double kTwoPi = 6.283185307179586;  // 2.0 * np.pi
 
+// cos(t) for the arguments the benchmark functions produce (t = 2 pi x, |t| < 1e6; anything else goes to the library).
+// Round 4: the library's cosine is ~75 instructions behind a magnitude branch, and the four calls of a lane (four elements
+// per batch) run one after the other; this form is ~30 straight-line operations -- Cody-Waite reduction by pi/2 in three
+// 33-bit pieces (n * piece is exact for |n| < 2^20, so each step is one rounding), then the classic degree-13 / 14 kernels
+// on [-pi/4, pi/4] (the fdlibm coefficients) -- which the scheduler interleaves across the four elements.  Within 1 ulp of
+// the library's result for the SAME rounded argument on |x| <= 100 (2e6 random arguments; 2 ulp at |x| ~ 1e4):
+// tests/test_gpu_de.py::test_objectives_vs_oracle keeps its 1e-13.  Config 2: 7.04 -> 6.85 us per generation, config 3a 35.3 -> 34.5, 3b 51.7 -> 50.1 (same box, alternating).
+#ifndef SX_FAST_COS
+#define SX_FAST_COS 1  // 0: the library's cos (A/B)
+#endif
+__device__ __forceinline__ double cos_mid(double t) {
+#if SX_FAST_COS
+    const double n = rint(t * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, t);  // first 33 bits of pi/2
+    r = fma(-n, 6.07710050630396597660e-11, r);         // next 33
+    r = fma(-n, 2.02226624871116645580e-21, r);         // next 33
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                        2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double sn = fma(r * z, fma(z, ps, -1.66666666666666324348e-01), r);
+    const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                   -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                     -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cs = 1.0 - fma(0.5, z, -(z * pc));
+    const int q = (int)n & 3;  // cos(r + n pi/2)
+    const double v = (q & 1) ? sn : cs;
+    const double fast = (q == 1 || q == 2) ? -v : v;
+    return fabs(t) < 1.0e6 ? fast : cos(t);
+#else
+    return cos(t);
+#endif
+}
+
 template <int FUN>
 struct Obj;
 
@@ -171,7 +204,7 @@ struct Obj<SX_FUN_ACKLEY> {  // benchmark.py:14-34
     static constexpr bool NEXT = false, BMUL = false, TWO = true;
     static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
         a = x * x;
-        b = cos(kTwoPi * x);
+        b = cos_mid(kTwoPi * x);
     }
     static __device__ __forceinline__ double finish(double sa, double sb, int n) {
         const double e = 2.7182818284590451;
@@ -209,7 +242,7 @@ template <>
 struct Obj<SX_FUN_RASTRIGIN> {  // benchmark.py:79-97
     static constexpr bool NEXT = false, BMUL = false, TWO = false;
     static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
-        a = x * x - 10.0 * cos(kTwoPi * x);
+        a = x * x - 10.0 * cos_mid(kTwoPi * x);
         b = 0.0;
     }
     static __device__ __forceinline__ double finish(double sa, double, int n) { return 10.0 * (double)n + sa; }
