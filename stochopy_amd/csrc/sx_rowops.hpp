@@ -75,24 +75,29 @@ template <int FUN, int LPR, int NFIX>
 __device__ __forceinline__ double row_objective_chain(const double *U, int l) {
     using O = Obj<FUN>;
     constexpr bool TWO = O::TWO, BMUL = O::BMUL;
-    constexpr int M = O::NEXT ? NFIX - 1 : NFIX;  // terms
-    constexpr int SEG = LPR / kGroup;             // lanes per accumulator chain: 2 (n = 64) or 4 (n = 128)
-    static_assert(NFIX == 4 * LPR && (SEG == 2 || SEG == 4) && M <= 128, "one leaf, four elements per lane");
+    // n = 256 with one term per element: numpy splits 256 = 128 + 128, two such leaves -- the row's two 32-lane halves
+    constexpr int NLEAF = NFIX > 128 ? 2 : 1;
+    constexpr int M = (O::NEXT ? NFIX - 1 : NFIX) / NLEAF;  // terms per leaf
+    constexpr int SEG = LPR / kGroup / NLEAF;               // lanes per accumulator chain: 2 (n = 64) or 4 (n = 128, 256)
+    static_assert(NFIX == 4 * LPR && (SEG == 2 || SEG == 4) && M <= 128 && (NLEAF == 1 || !O::NEXT),
+                  "one leaf (or two full ones), four elements per lane");
     constexpr int NB = M / kGroup, TAIL = M % kGroup;  // blocks that go into the accumulators; tail terms
     static_assert(TAIL == 0 || NB == 4 * SEG - 1, "the tail is the last block");
     constexpr int kHop = SEG == 4 ? 0x90 : 0xA0;  // quad_perm [0,0,1,2] / [0,0,2,2]: lane L takes lane L-1's value
-    const int j = l / SEG, g = l % SEG;
+    constexpr int LPL = LPR / NLEAF;               // lanes per leaf
+    const int leaf0 = NLEAF == 2 ? (l / LPL) * (NFIX / 2) : 0;  // first element of this lane's leaf
+    const int j = (l % LPL) / SEG, g = l % SEG;
     double a[4], b[4];
     {
         double x[4], xn[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = kGroup * (4 * g + i) + j;
+            const int e = leaf0 + kGroup * (4 * g + i) + j;
             x[i] = U[e];
             xn[i] = O::NEXT ? U[e + 1] : 0.0;  // (U[NFIX .. NFIX+7] is padding: the term of element NFIX-1 is never used)
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) O::term(x[i], xn[i], kGroup * (4 * g + i) + j, a[i], b[i]);
+        for (int i = 0; i < 4; ++i) O::term(x[i], xn[i], leaf0 + kGroup * (4 * g + i) + j, a[i], b[i]);
     }
     // the chain: segment s continues from what segment s-1 hands over.  Every lane runs every segment's code; only the
     // lanes whose turn it is (g == s) hold meaningful values, and only those are passed on.
@@ -130,9 +135,15 @@ __device__ __forceinline__ double row_objective_chain(const double *U, int l) {
         if (TWO) rb = combine<BMUL>(rb, dpp_f64<0x108>(rb));
         sa = row_lane_value<LPR>(ra, SEG - 1, l);
         if (TWO) sb = row_lane_value<LPR>(rb, SEG - 1, l);
-    } else {  // two DPP rows: (r0..r3) in lane 3, (r4..r7) in lane 19
+    } else if constexpr (NLEAF == 1) {  // two DPP rows: (r0..r3) in lane 3, (r4..r7) in lane 19
         sa = row_lane_value<LPR>(ra, SEG - 1, l) + row_lane_value<LPR>(ra, 4 * SEG + SEG - 1, l);
         if (TWO) sb = combine<BMUL>(row_lane_value<LPR>(rb, SEG - 1, l), row_lane_value<LPR>(rb, 4 * SEG + SEG - 1, l));
+    } else {  // two leaves: leaf 0 ends in lanes 3 / 19, leaf 1 in lanes 35 / 51; numpy adds leaf 0 + leaf 1
+        sa = (row_lane_value<LPR>(ra, 3, l) + row_lane_value<LPR>(ra, 19, l)) +
+             (row_lane_value<LPR>(ra, 35, l) + row_lane_value<LPR>(ra, 51, l));
+        if (TWO)
+            sb = combine<BMUL>(combine<BMUL>(row_lane_value<LPR>(rb, 3, l), row_lane_value<LPR>(rb, 19, l)),
+                               combine<BMUL>(row_lane_value<LPR>(rb, 35, l), row_lane_value<LPR>(rb, 51, l)));
     }
     if constexpr (TAIL > 0) {
         // the tail terms a[M-7 .. M-1] are added one by one to the total: every lane forms them itself from TAIL + 1
@@ -166,7 +177,11 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
 #ifndef SX_OBJ_CHAIN
 #define SX_OBJ_CHAIN 1  // A/B switch: 0 = the staged-terms form for one-batch rows too
 #endif
-    if constexpr (SX_OBJ_CHAIN && NFIX != 0 && NFIX <= 128 && LPR < kWave) return row_objective_chain<FUN, LPR, NFIX>(U, l);
+#ifndef SX_OBJ_CHAIN256
+#define SX_OBJ_CHAIN256 1  // A/B: 0 = rows of 256 elements stage their terms
+#endif
+    if constexpr (SX_OBJ_CHAIN && NFIX != 0 && (NFIX <= 128 || (SX_OBJ_CHAIN256 && NFIX == 256 && !O::NEXT)))
+        return row_objective_chain<FUN, LPR, NFIX>(U, l);
     if (LPR == kWave && fused_terms(n)) {  // terms are formed inside the reduction, nothing else is staged
         double sa, sb;
         row_reduce_leaves_fused<FUN, LPR>(U, U + n + 8, leaf_cap(n), m, plan, l, sa, sb);
