@@ -165,6 +165,19 @@ __device__ __forceinline__ double row_objective_chain(const double *U, int l) {
     return O::finish(sa, sb, NFIX);
 }
 
+// rows whose objective needs nothing but the staged vector itself (row_objective_chain): kernels that stage for nobody else
+// (sx_eval) can then give a row n + 8 doubles of LDS instead of lds_row_stride(n) and fit twice the workgroups on a CU
+#ifndef SX_OBJ_CHAIN
+#define SX_OBJ_CHAIN 1  // A/B switch: 0 = the staged-terms form for one-batch rows too
+#endif
+#ifndef SX_OBJ_CHAIN256
+#define SX_OBJ_CHAIN256 1  // A/B: 0 = rows of 256 elements stage their terms
+#endif
+template <int FUN, int NFIX>
+constexpr bool chain_only() {
+    return SX_OBJ_CHAIN && NFIX != 0 && (NFIX <= 128 || (SX_OBJ_CHAIN256 && NFIX == 256 && !Obj<FUN>::NEXT));
+}
+
 // Objective of the row staged in LDS at U[0..n): terms by the row's LPR lanes -> A/B (behind U),
 // then the numpy-order row sums (lanes l >= 8 repeat the chains of lanes l & 7: LDS broadcasts, same bits).
 // Every lane of the row returns the value.  Each row works on its own LDS slice (no workgroup barrier).
@@ -174,13 +187,7 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     using O = Obj<FUN>;
     const int m = O::NEXT ? n - 1 : n;
     lds_wave_fence();  // U complete (written and read by this wave only)
-#ifndef SX_OBJ_CHAIN
-#define SX_OBJ_CHAIN 1  // A/B switch: 0 = the staged-terms form for one-batch rows too
-#endif
-#ifndef SX_OBJ_CHAIN256
-#define SX_OBJ_CHAIN256 1  // A/B: 0 = rows of 256 elements stage their terms
-#endif
-    if constexpr (SX_OBJ_CHAIN && NFIX != 0 && (NFIX <= 128 || (SX_OBJ_CHAIN256 && NFIX == 256 && !O::NEXT)))
+    if constexpr (chain_only<FUN, NFIX>())
         return row_objective_chain<FUN, LPR, NFIX>(U, l);
     if (LPR == kWave && fused_terms(n)) {  // terms are formed inside the reduction, nothing else is staged
         double sa, sb;
