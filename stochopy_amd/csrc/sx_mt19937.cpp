@@ -325,11 +325,39 @@ extern "C" void sx_mt_latin_hypercube(sx_mt *g, int64_t P, int n, const double *
 // q == i -> q = j_i, else q == j_i -> q = i; the array starts as the identity, so the entry is the final q.  q changes
 // ~ln(m) times, so the walk is a vector search for the next step that touches it.  Same words consumed, same donors
 // (tests/test_host_cpu.py compares with the scalar replay), no array of P-1 entries is ever shuffled.
+// JT: the swap targets as 16-bit entries while they fit (P <= 65535: the walk then looks at 32 steps per compare), else 32-bit
+template <class JT>
+SX_AVX512 inline void store_targets(JT *dst, __m512i packed) {
+    if constexpr (sizeof(JT) == 2)
+        _mm256_storeu_si256((__m256i *)dst, _mm512_cvtepi32_epi16(packed));
+    else
+        _mm512_storeu_si512(dst, packed);
+}
+
+// steps of this block of the walk that touch position qq: J == qq (qq is swapped away) or i == qq (qq is the step's own index);
+// lane b holds step base + b, whose index is i0 - b
+template <class JT>
+SX_AVX512 inline uint64_t walk_hits(__m512i Jv, int i0, uint32_t qq, uint64_t lanes, __m512i iota, __m512i iota16) {
+    if constexpr (sizeof(JT) == 2) {
+        const __m512i qv = _mm512_set1_epi16((short)qq);
+        const __m512i Iv = _mm512_sub_epi16(_mm512_set1_epi16((short)i0), iota16);
+        return ((uint64_t)_mm512_cmpeq_epi16_mask(Jv, qv) | (uint64_t)_mm512_cmpeq_epi16_mask(Iv, qv)) & lanes;
+    } else {
+        const __m512i qv = _mm512_set1_epi32((int)qq);
+        const __m512i Iv = _mm512_sub_epi32(_mm512_set1_epi32(i0), iota);
+        return ((uint64_t)_mm512_cmpeq_epi32_mask(Jv, qv) | (uint64_t)_mm512_cmpeq_epi32_mask(Iv, qv)) & lanes;
+    }
+}
+
+template <class JT>
 SX_AVX512 void de_donors_avx512(sx_mt *g, int64_t P, int k, int32_t *donors) {
     const int m = (int)(P - 1);
-    std::vector<uint32_t> store((size_t)m + 64, 0xffffffffu);
-    uint32_t *J = store.data() + 16;  // J[s] = j of step s (i = m-1-s); 16 words of padding in front for the walk
+    constexpr int NL = 64 / (int)sizeof(JT);  // steps per compare in the walk
+    std::vector<JT> store((size_t)m + 128, (JT)~(JT)0);
+    JT *J = store.data() + 32;  // J[s] = j of step s (i = m-1-s); padding (all ones: no valid index) in front for the walk
     const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const __m512i iota16 = _mm512_set_epi16(31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8,
+                                            7, 6, 5, 4, 3, 2, 1, 0);
     for (int64_t ind = 0; ind < P; ++ind) {
         // ---- (1) the swap targets
         int s = 0, i = m - 1;
@@ -345,7 +373,7 @@ SX_AVX512 void de_donors_avx512(sx_mt *g, int64_t P, int k, int32_t *donors) {
                 while (i >= lo) {  // no data-dependent branch: a rejected word is overwritten by the next one
                     const uint32_t v = next32(g) & mask;
                     const int take = v <= (uint32_t)i;
-                    J[s] = v;
+                    J[s] = (JT)v;
                     s += take;
                     i -= take;
                 }
@@ -374,8 +402,12 @@ SX_AVX512 void de_donors_avx512(sx_mt *g, int64_t P, int k, int32_t *donors) {
                     v[3] = _mm512_and_si512(_mm512_loadu_si512(w + 48), vmask);
                     opt = (uint64_t)_mm512_cmple_epu32_mask(v[0], hi_t) | ((uint64_t)_mm512_cmple_epu32_mask(v[1], hi_t) << 16) |
                           ((uint64_t)_mm512_cmple_epu32_mask(v[2], hi_t) << 32) | ((uint64_t)_mm512_cmple_epu32_mask(v[3], hi_t) << 48);
-                    def = (uint64_t)_mm512_cmple_epu32_mask(v[0], lo_t) | ((uint64_t)_mm512_cmple_epu32_mask(v[1], lo_t) << 16) |
-                          ((uint64_t)_mm512_cmple_epu32_mask(v[2], lo_t) << 32) | ((uint64_t)_mm512_cmple_epu32_mask(v[3], lo_t) << 48);
+                    // (word L of vector u has at most 16 u + 15 accepted words before it: a tighter bound per vector, fewer
+                    //  words left to settle one by one)
+                    def = (uint64_t)_mm512_cmple_epu32_mask(v[0], _mm512_set1_epi32(i - 15)) |
+                          ((uint64_t)_mm512_cmple_epu32_mask(v[1], _mm512_set1_epi32(i - 31)) << 16) |
+                          ((uint64_t)_mm512_cmple_epu32_mask(v[2], _mm512_set1_epi32(i - 47)) << 32) |
+                          ((uint64_t)_mm512_cmple_epu32_mask(v[3], lo_t) << 48);
                 } else {
                     for (int u = 0; u < nv; ++u) {
                         const int left = cnt - 16 * u;
@@ -407,15 +439,15 @@ SX_AVX512 void de_donors_avx512(sx_mt *g, int64_t P, int k, int32_t *donors) {
                                     m3 = (__mmask16)(acc >> 48);
                     const int s1 = s + __builtin_popcount((unsigned)m0), s2 = s1 + __builtin_popcount((unsigned)m1),
                               s3 = s2 + __builtin_popcount((unsigned)m2);
-                    _mm512_storeu_si512(J + s, _mm512_maskz_compress_epi32(m0, v[0]));
-                    _mm512_storeu_si512(J + s1, _mm512_maskz_compress_epi32(m1, v[1]));
-                    _mm512_storeu_si512(J + s2, _mm512_maskz_compress_epi32(m2, v[2]));
-                    _mm512_storeu_si512(J + s3, _mm512_maskz_compress_epi32(m3, v[3]));
+                    store_targets(J + s, _mm512_maskz_compress_epi32(m0, v[0]));
+                    store_targets(J + s1, _mm512_maskz_compress_epi32(m1, v[1]));
+                    store_targets(J + s2, _mm512_maskz_compress_epi32(m2, v[2]));
+                    store_targets(J + s3, _mm512_maskz_compress_epi32(m3, v[3]));
                     s += taken;
                 } else {
                     for (int u = 0; u < nv; ++u) {
                         const __mmask16 m16 = (__mmask16)(acc >> (16 * u));
-                        _mm512_storeu_si512(J + s, _mm512_maskz_compress_epi32(m16, v[u]));
+                        store_targets(J + s, _mm512_maskz_compress_epi32(m16, v[u]));
                         s += __builtin_popcount((unsigned)m16);
                     }
                 }
@@ -426,22 +458,19 @@ SX_AVX512 void de_donors_avx512(sx_mt *g, int64_t P, int k, int32_t *donors) {
         // ---- (2) walk the swaps backwards (s = m-2 .. 0, i.e. i = 1 .. m-1) for positions 0..k-1
         uint32_t q[8];
         for (int t = 0; t < k; ++t) q[t] = (uint32_t)t;
-        for (int hi = m - 2; hi >= 0; hi -= 16) {
-            const int base = hi - 15;  // lanes b = 0..15 <-> s = base + b (padding in front: J == ~0, lanes masked)
-            const __mmask16 lanes = base >= 0 ? (__mmask16)0xffff : (__mmask16)(0xffffu << (-base));
+        for (int hi = m - 2; hi >= 0; hi -= NL) {
+            const int base = hi - (NL - 1);  // lanes b = 0..NL-1 <-> s = base + b (padding in front: all ones, lanes masked)
+            const uint64_t all = NL == 32 ? 0xffffffffull : 0xffffull;
+            const uint64_t lanes = base >= 0 ? all : (all << (-base)) & all;
             const __m512i Jv = _mm512_loadu_si512(J + base);
-            const __m512i Iv = _mm512_sub_epi32(_mm512_set1_epi32(m - 1 - base), iota);
             for (int t = 0; t < k; ++t) {
-                __m512i qv = _mm512_set1_epi32((int)q[t]);
-                unsigned h = (unsigned)(_mm512_mask_cmpeq_epi32_mask(lanes, Jv, qv) | _mm512_mask_cmpeq_epi32_mask(lanes, Iv, qv));
+                uint64_t h = walk_hits<JT>(Jv, m - 1 - base, q[t], lanes, iota, iota16);
                 while (h) {
-                    const int b = 31 - __builtin_clz(h);  // the earliest of these steps in walking order: the largest s
+                    const int b = 63 - __builtin_clzll(h);  // the earliest of these steps in walking order: the largest s
                     const int ss = base + b;
                     const uint32_t ii = (uint32_t)(m - 1 - ss);
-                    q[t] = q[t] == ii ? J[ss] : ii;
-                    qv = _mm512_set1_epi32((int)q[t]);
-                    h = (unsigned)(_mm512_mask_cmpeq_epi32_mask(lanes, Jv, qv) | _mm512_mask_cmpeq_epi32_mask(lanes, Iv, qv)) &
-                        ((1u << b) - 1u);
+                    q[t] = q[t] == ii ? (uint32_t)J[ss] : ii;
+                    h = walk_hits<JT>(Jv, m - 1 - base, q[t], lanes, iota, iota16) & ((1ull << b) - 1ull);
                 }
             }
         }
@@ -457,7 +486,10 @@ extern "C" void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors) {
     // individual i: permutation of arange(P) without i; entry t becomes donor t (de/_de.py:304-311)
 #if SX_HAVE_X86
     if (have_avx512() && P >= 256 && P <= 0x40000000 && k <= 8) {
-        de_donors_avx512(g, P, k, donors);
+        if (P <= 65535)
+            de_donors_avx512<uint16_t>(g, P, k, donors);
+        else
+            de_donors_avx512<uint32_t>(g, P, k, donors);
         return;
     }
 #endif
