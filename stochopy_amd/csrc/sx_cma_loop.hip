@@ -27,7 +27,8 @@ int cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, 
                       const double *Z, double *arx, int64_t P, int n, void *stream);
 int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
                        const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
-                       const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream);
+                       const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream, double *split_ws = nullptr,
+                       int *mirrored = nullptr);
 int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
                  double tol, const int *skip, int refine, void *stream);  // sx_eigh.hip
 int eigh_refine_in_loops();
@@ -539,8 +540,8 @@ extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eig
 }
 
 // The same generation in two steps, for candidates sharded over ranks (workers > 1: what the reference's parallel backends
-// shard, _common.py:58-72): stage 0 = this rank's candidates [row0, row0 + rows) into arx_loc / fit_loc (a->Z: scratch of at
-// least rows x n); the caller all-gathers them into a->arx / a->fit; stage 1 = everything else, replicated on every rank
+// shard, _common.py:58-72): stage 0 = this rank's candidates [row0, row0 + rows) into arx_loc / fit_loc (a->Z: the (P, n) buffer of the struct; stage 0 uses
+// rows x n of it, the model update all of it as scratch); the caller all-gathers them into a->arx / a->fit; stage 1 = everything else, replicated on every rank
 // (ranking, recombination, paths, covariance, decomposition, stop rules -- and Penalize's bookkeeping + penalty pass).
 extern "C" int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, int stage, int64_t row0,
                                          int64_t rows, double *arx_loc, double *fit_loc, void *stream) {
@@ -584,11 +585,15 @@ int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *strea
     hipLaunchKernelGGL(cma_b_y_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)n * sizeof(double), st, *a);
     hipLaunchKernelGGL(cma_paths_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen);
     SX_LAUNCH_CHECK();
+    // the normals (P x n) are dead by now: where they hold two n x n half-sums, the covariance update takes its
+    // upper-triangle / split-K form (csrc/sx_cmaes.hip), which leaves C symmetric
+    int mirrored = 0;
+    double *split_ws = P >= 2 * (int64_t)n ? a->Z : nullptr;
     if ((rc = sx::cma_rank_mu_launch(a->arx, a->order, a->w, a->mu, a->xold, 0.0, &state->sigma, a->pc, a->c1, a->cmu, 0.0,
-                                     &state->tmp_coef, a->C, a->Y, n, stream)))
+                                     &state->tmp_coef, a->C, a->Y, n, stream, split_ws, &mirrored)))
         return rc;
     if (do_eigh) {
-        if ((rc = sx_symmetrize_upper(a->C, n, stream))) return rc;
+        if (!mirrored && (rc = sx_symmetrize_upper(a->C, n, stream))) return rc;
         // do_eigh == 2: start from the previous eigenvectors (B is both the starting basis and the output)
         // tolerance: what LAPACK's own decomposition guarantees, a backward error of n * eps * |C|_F (never below the
         // solver's default 1e-14): at n = 512 that is 5.7e-14 -- about one decomposition in two stops a sweep earlier

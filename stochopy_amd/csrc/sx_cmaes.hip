@@ -13,6 +13,7 @@
 //   C/D: 4 doubles per lane, col = l & 15, row = (l >> 4) + 4 * reg.
 // Workgroup tiles 64x64 / 32x64 / 32x32 (chosen so the small CMA-ES shapes still give >= 256 workgroups),
 // four waves in a 2x2 grid, K chunk 32 staged through LDS, the next three chunks already on their way in registers.
+#include <cstdlib>
 #include <type_traits>
 #include "sx_device.hpp"
 #include "sx_host.hpp"
@@ -49,6 +50,13 @@ struct RankMuOp {  // C = (1-c1-cmu)*C + cmu * Y^T diag(w) Y + c1 * pc pc^T + tm
     double decay, cmu, c1, tmpc;
     const double *tmpc_p;  // when set: tmp coefficient on the device (0 when `cond` held, else c1*cc*(2-cc))
     int mu, n;
+    // round 4: only the upper triangle is ever read back (cmaes/_cmaes.py:303 mirrors triu(C); :290-295 is elementwise), so
+    // only the tiles on and above the diagonal are formed -- `tri` tile rows -- and the chip is filled by splitting K in two
+    // instead: blockIdx.z = which half of the mu terms, raw products to part[z] (n x n each), cma_cov_finish_kernel adds the
+    // halves in a fixed order, applies the update and mirrors.  part == NULL: the full matrix, updated in place (as before).
+    double *part;
+    int tri;     // tiles per side when the grid enumerates the upper triangle (blockIdx.x = tile number), else 0
+    int ksplit;  // 1 or 2
 };
 
 // Y[k][:] = (arx[idx[k]][:] - xold) / sigma   (cmaes/_cmaes.py:290), once per generation
@@ -82,16 +90,28 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
     __shared__ __attribute__((aligned(16))) double Bs_[NBUF * BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    int64_t m0 = (int64_t)blockIdx.y * BM;
+    int n0 = blockIdx.x * BN;
     int64_t M;
     int N, K;
+    int kbase = 0;  // MODE 1 with split K: this workgroup's first term
     if (MODE == 0) {
         const SampleOp &o = (const SampleOp &)op;
         M = o.P, N = o.n, K = o.n;
     } else {
         const RankMuOp &o = (const RankMuOp &)op;
         M = o.n, N = o.n, K = o.mu;
+        if (o.tri > 0) {  // tile number -> (row block bi <= column block bj), row by row of the upper triangle
+            int t = (int)blockIdx.x, bi = 0, len = o.tri;
+            while (t >= len) t -= len, ++bi, --len;  // (uniform, at most `tri` steps)
+            m0 = (int64_t)bi * BM;
+            n0 = (bi + t) * BN;
+        }
+        if (o.ksplit > 1) {  // halves of whole K chunks
+            const int chunks = (K + KC - 1) / KC, first = (int)blockIdx.z * (chunks / 2) * KC;
+            const int last = blockIdx.z == 0 ? (chunks / 2) * KC : K;
+            kbase = first, K = last - first;
+        }
     }
     v4d acc[TM][TN];
 #pragma unroll
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
                 const RankMuOp &o = (const RankMuOp &)op;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int gk = FULL || k0 + q * 16 + t16 < K ? k0 + q * 16 + t16 : K - 1;
+                    const int gk = kbase + (FULL || k0 + q * 16 + t16 < K ? k0 + q * 16 + t16 : K - 1);
                     const double *yr = o.Y + (int64_t)gk * o.n;
                     rs[s][q] = o.w[gk];
 #pragma unroll
@@ -300,6 +320,10 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
                     o.arx[gi * (int64_t)o.n + gj] = o.xmean[gj] + sg * g;  // xmean + sigma * dot(B, D*z)
                 } else {
                     const RankMuOp &o = (const RankMuOp &)op;
+                    if (o.part != nullptr) {  // raw products of this half of K; cma_cov_finish_kernel does the rest
+                        o.part[((int64_t)blockIdx.z * o.n + gi) * (int64_t)o.n + gj] = g;
+                        continue;
+                    }
                     const double tmpc = o.tmpc_p ? *o.tmpc_p : o.tmpc;
                     double *cp = o.C + gi * (int64_t)o.n + gj;
                     const double cold = *cp;
@@ -386,6 +410,25 @@ __global__ __launch_bounds__(256) void symmetrize_upper_kernel(double *__restric
     if (i > j) C[t] = C[(int64_t)j * n + i];
 }
 
+// the covariance update from the two half-sums of cma_gemm_kernel<1> (RankMuOp.part), upper triangle, mirrored:
+// C_ij = C_ij (1-c1-cmu) + cmu (G0_ij + G1_ij) + c1 pc_i pc_j + tmp C_ij(old)  -- the operations of :291-295 in their order
+__global__ __launch_bounds__(256) void cma_cov_finish_kernel(const RankMuOp o, int nparts) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = o.n;
+    if (t >= (int64_t)n * n) return;
+    const int i = (int)(t / n), j = (int)(t % n);
+    if (i > j) return;
+    const double g = nparts > 1 ? o.part[t] + o.part[(int64_t)n * n + t] : o.part[t];
+    const double tmpc = o.tmpc_p ? *o.tmpc_p : o.tmpc;
+    const double cold = o.C[t];
+    double c = cold * o.decay;
+    c = c + o.cmu * g;
+    c = c + o.c1 * (o.pc[i] * o.pc[j]);
+    c = c + tmpc * cold;
+    o.C[t] = c;
+    if (i != j) o.C[(int64_t)j * n + i] = c;
+}
+
 }  // namespace
 
 // tile choice: enough workgroups to cover the 256 CUs on the (small) CMA-ES shapes
@@ -394,7 +437,8 @@ int cma_sample_launch(const double *xmean, double sigma, const double *sigma_p, 
                       const double *Z, double *arx, int64_t P, int n, void *stream);
 int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
                        const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
-                       const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream);
+                       const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream, double *split_ws = nullptr,
+                       int *mirrored = nullptr);
 }  // namespace sx
 
 extern "C" int sx_cmaes_sample(const double *xmean, double sigma, const double *B, const double *D, const double *Z,
@@ -427,16 +471,39 @@ extern "C" int sx_cmaes_rank_mu(const double *arx, const int64_t *idx, const dou
     return sx::cma_rank_mu_launch(arx, idx, w, mu, xold, sigma, nullptr, pc, c1, cmu, tmp_coef, nullptr, C, ws_y, n, stream);
 }
 
+// split_ws: optional DEVICE scratch of 2 n^2 doubles -> the upper-triangle / split-K form (the result is then symmetric:
+// *mirrored = 1); without it the whole matrix is updated in place by the contraction kernel itself.
 int sx::cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, int mu, const double *xold, double sigma,
                            const double *sigma_p, const double *pc, double c1, double cmu, double tmp_coef,
-                           const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream) {
+                           const double *tmp_coef_p, double *C, double *ws_y, int n, void *stream, double *split_ws,
+                           int *mirrored) {
+    if (mirrored) *mirrored = 0;
     SX_REQUIRE(arx && idx && w && xold && pc && C && ws_y && mu >= 1 && n >= 1, "sx_cmaes_rank_mu: bad arguments");
     const int64_t total = (int64_t)mu * n;
     hipLaunchKernelGGL(cma_y_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, arx, idx,
                        xold, sigma, sigma_p, mu, n, ws_y);
     SX_LAUNCH_CHECK();
-    RankMuOp op{ws_y, w, pc, C, 1.0 - c1 - cmu, cmu, c1, tmp_coef, tmp_coef_p, mu, n};
+    RankMuOp op{ws_y, w, pc, C, 1.0 - c1 - cmu, cmu, c1, tmp_coef, tmp_coef_p, mu, n, nullptr, 0, 1};
     const int64_t big = ((int64_t)(n + 63) / 64) * ((n + 63) / 64);
+    static const bool tri_ok = !(getenv("SX_CMA_TRI") && getenv("SX_CMA_TRI")[0] == '0');  // (A/B switch)
+    if (split_ws != nullptr && tri_ok && n >= 128 && mu >= 4 * KC) {
+        op.part = split_ws, op.ksplit = 2;
+        if (big >= 1024) {  // (twice the full form's bound: the triangle has half the tiles, the split doubles them again)
+            op.tri = (n + 63) / 64;
+            hipLaunchKernelGGL((cma_gemm_kernel<1, 64, 64, RankMuOp>), dim3((unsigned)(op.tri * (op.tri + 1) / 2), 1, 2),
+                               dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+        } else {
+            op.tri = (n + 31) / 32;
+            hipLaunchKernelGGL((cma_gemm_kernel<1, 32, 32, RankMuOp>), dim3((unsigned)(op.tri * (op.tri + 1) / 2), 1, 2),
+                               dim3(kGemmThreads), 0, (hipStream_t)stream, op);
+        }
+        SX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cma_cov_finish_kernel, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, op, 2);
+        SX_LAUNCH_CHECK();
+        if (mirrored) *mirrored = 1;
+        return 0;
+    }
     if (big >= 512) {
         dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
         hipLaunchKernelGGL((cma_gemm_kernel<1, 64, 64, RankMuOp>), grid, dim3(kGemmThreads), 0, (hipStream_t)stream, op);
