@@ -1,7 +1,8 @@
 """does the throughput mode's 32-bit uniforms (PSO r1, r2; DE crossover decisions -- the reference
 draws 53-bit doubles) change what the optimisers DO?  Final best-f over many seeds, rng="philox" against
 rng="numpy-legacy" (the reference's own stream), same shapes, deferred updating; two-sample Kolmogorov-Smirnov and
-Mann-Whitney tests plus a legacy-vs-legacy split as the noise floor.  usage: rng_deviation.py [seeds]"""
+Mann-Whitney tests plus a legacy-vs-legacy split as the noise floor.  usage: rng_deviation.py [seeds]
+RNG_DEV_FULL=1: the BASELINE shapes themselves (round 4; the numpy-legacy arm runs at ~10 ms per generation there)."""
 import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,6 +17,15 @@ CASES = [
     ("pso ackley n16 P128 200 gens (C3a-like)", "pso", "ackley", 16, {"popsize": 128, "maxiter": 200}),
     ("cpso ackley n16 P128 200 gens (C3b-like)", "cpso", "ackley", 16, {"popsize": 128, "maxiter": 200}),
 ]
+
+
+if os.environ.get("RNG_DEV_FULL") == "1":
+    CASES = [
+        ("de best1bin rastrigin n128 P4096 60 gens (C2)", "de", "rastrigin", 128, {"popsize": 4096, "maxiter": 60, "strategy": "best1bin"}),
+        ("de best1bin rosenbrock n128 P4096 60 gens (M)", "de", "rosenbrock", 128, {"popsize": 4096, "maxiter": 60, "strategy": "best1bin"}),
+        ("pso ackley n256 P16384 30 gens (C3a)", "pso", "ackley", 256, {"popsize": 16384, "maxiter": 30}),
+        ("cpso ackley n256 P16384 30 gens (C3b)", "cpso", "ackley", 256, {"popsize": 16384, "maxiter": 30}),
+    ]
 
 
 def finals(method, obj, n, opts, rng, seeds):
