@@ -5,6 +5,7 @@
 //   stochopy/factory/benchmark.py:14-156              the seven objectives
 //   stochopy/optimize/_common.py:34-90                population wrapper fun(X) -> f
 //   stochopy/optimize/_common.py:131-158              argmin + termination ladder
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -134,6 +135,20 @@ int make_plan_arg(int fun_id, int n, PlanArg *out) {
             ++nm;
         }
     }
+    // work slots: consecutive leaves of <= 8 blocks each share one (sx_device.hpp, PlanArg)
+    int ns = 0;
+    for (int t = 0; t < buf[0];) {
+        const int b0 = t > 0 ? out->end[t - 1] : 0, b1 = out->end[t];
+        const bool pair = t + 1 < buf[0] && b1 - b0 <= 8 && out->end[t + 1] - b1 <= 8;
+        out->sfirst[ns++] = t;
+        t += pair ? 2 : 1;
+    }
+    if ((ns + 7) / 8 == (buf[0] + 7) / 8) {  // no pass saved (eight groups per pass): one leaf per slot, the plain form
+        ns = buf[0];
+        for (int t = 0; t < ns; ++t) out->sfirst[t] = t;
+    }
+    out->nslot = ns;
+    out->sfirst[ns] = buf[0];
     return 0;
 }
 }  // namespace sx
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const double *xr = X + id.rowc * ldx;
     const bool affine = xm != nullptr;
     double pacc = 0.0;
-    constexpr int kBatch = NFIX ? 4 : 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
+    constexpr int kBatch = (NFIX && NFIX <= 256) ? 4 : 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
     for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
         double xv[kBatch];
 #pragma unroll
@@ -200,10 +215,22 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
     const bool full = clip == 0 && n % (8 * lpr) == 0 && P % rows_per_block(n) == 0;
     const bool fix = clip == 0 && n == 4 * lpr && P % rows_per_block(n) == 0;
     size_t lds = g.lds;
+    // (objectives with a cosine per term keep the run-time plan: eight inlined cosines side by side need more registers than
+    //  a wavefront slot has, and their arithmetic, not the plan, is their time)
+    constexpr bool kLight = light_objective<FUN>();
 #define SX_EVAL_GO(...)                                                                                              \
     hipLaunchKernelGGL((eval_kernel<FUN, __VA_ARGS__>), dim3(g.blocks), dim3(g.threads), lds, s, X, P, n, ldx, xm, xstd, f, \
                        plan, part_f, part_i, clip, pen_v, pen_out)
-    if (fix) {
+    if (kLight && clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0) {
+        // long rows of a compile-time length: numpy's plan as constants (row_reduce_long).  Rosenbrock n = 1024: 0.54 -> 0.84
+        // of the HBM peak, n = 512: 0.44 -> 0.76, n = 2048: 0.43 -> 0.70 (profiles/r4_eval_long_rows.txt; a resident,
+        // software-pipelined form of the same kernel stayed at 0.72 and was dropped)
+        switch (n) {
+            case 512: SX_EVAL_GO(64, true, kLight ? 512 : 0); break;
+            case 1024: SX_EVAL_GO(64, true, kLight ? 1024 : 0); break;
+            default: SX_EVAL_GO(64, true, kLight ? 2048 : 0); break;
+        }
+    } else if (fix) {
         // the register-chain objective reads the staged vector only: n + 8 doubles per row, not the term arrays' 3n + ...
         switch (lpr) {
             case 16: if (chain_only<FUN, 64>()) lds = (size_t)rows_per_block(n) * (64 + 8) * sizeof(double); SX_EVAL_GO(16, true, 64); break;

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/stochopy_hip.h"
 
 namespace sx {
@@ -65,6 +67,11 @@ struct PlanArg {
     int32_t merges[kMaxLeaf];  // stack merges after leaf t
     int32_t mleft[kMaxLeaf];   // merge m adds slot mright[m] into slot mleft[m] (slots = leaf indices;
     int32_t mright[kMaxLeaf];  //  the recursion's combines in order; the total ends in slot 0)
+    // work slots of the whole-wave reduction (row_reduce_leaves_fused): a slot is what one 8-lane group carries in one
+    // pass of 16 steps -- one leaf, or two consecutive leaves of <= 8 blocks each (numpy cuts a trailing piece of
+    // 129..143 terms in two such halves: m = 1023 has 9 leaves, the last two of 8 blocks -- 8 slots, one pass, not two)
+    int32_t nslot;
+    int32_t sfirst[kMaxLeaf + 1];  // first leaf of slot s; sfirst[nslot] = nleaf
 };
 
 // ---------------------------------------------------------------------------
@@ -566,46 +573,49 @@ __device__ __forceinline__ void row_reduce_leaves(const double *A, const double 
 // adds term e reads U[e] (and U[e+1]) from LDS and forms the term itself -- every lane still handles m/64
 // terms, but no term array is written or staged, so a row needs n+8 doubles of LDS instead of 3n+8 (3x the
 // rows per CU at n = 1024).  Same operations on the same values: same bits as the staged form.
-template <int FUN, int LPR>
-__device__ __forceinline__ void row_reduce_leaves_fused(const double *U, double *L, int lcap, int m, const PlanArg &p,
-                                                        int l, double &sa, double &sb) {
+// PAIRED: some slot of the plan holds two leaves (PlanArg::nslot < nleaf -- only when that saves a pass); otherwise slot s
+// is leaf s and nothing of the pairing survives in the code.
+template <int FUN, int LPR, bool PAIRED>
+__device__ __forceinline__ void row_reduce_leaves_fused_impl(const double *U, double *L, int lcap, int m, const PlanArg &p,
+                                                             int l, double &sa, double &sb) {
     using O = Obj<FUN>;
     constexpr bool TWO = O::TWO, BMUL = O::BMUL;
     constexpr int NG = LPR / kGroup;
     const int j = l & (kGroup - 1), grp = l >> 3;
     const double identB = BMUL ? 1.0 : 0.0;
     const int t0 = p.mb * kGroup;
-    for (int leaf0 = 0; leaf0 < p.nleaf; leaf0 += NG) {
-        int b0 = 0, b1 = 0;
+    for (int slot0 = 0; slot0 < p.nslot; slot0 += NG) {
+        // this group's slot: leaves lfA (blocks [a0, a1)) and, when it holds two, lfA + 1 (blocks [a1, c1))
+        int lfA = 0, nl = 0, a0 = 0, a1 = 0, c1 = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int lf = leaf0 + g;
-            const int e1 = lf < p.nleaf ? (int)p.end[lf] : 0;
-            const int e0 = (lf > 0 && lf <= p.nleaf) ? (int)p.end[lf - 1] : 0;
-            if (grp == g) {
-                b0 = e0;
-                b1 = e1;
-            }
+            const int sl = slot0 + g;
+            const bool on = sl < p.nslot;
+            const int f = !on ? 0 : (PAIRED ? (int)p.sfirst[sl] : sl), f2 = !on ? 0 : (PAIRED ? (int)p.sfirst[sl + 1] : sl + 1);
+            const int e0 = (on && f > 0) ? (int)p.end[f - 1] : 0;
+            const int e1 = on ? (int)p.end[f] : 0;
+            const int e2 = (on && f2 - f == 2) ? (int)p.end[f + 1] : e1;
+            if (grp == g) lfA = f, nl = f2 - f, a0 = e0, a1 = e1, c1 = e2;
         }
-        const int leaf = leaf0 + grp;
-        const int cnt = b1 - b0;  // 0 for groups beyond the last leaf
+        const bool two = PAIRED && nl == 2;
+        const int cntA = a1 - a0;  // 0 for groups beyond the last slot
         double chA = 0.0, chB = identB;
-#pragma unroll
-        for (int h = 0; h < kLeafBlocks; h += 8) {
+        // steps 0..7: the first (or only) leaf
+        {
             double x[8], xn[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const bool in = h + t < cnt;
-                const int e = (b0 + h + t) * kGroup + j;
+                const bool in = t < cntA;
+                const int e = (a0 + t) * kGroup + j;
                 x[t] = in ? U[e] : 0.0;
                 xn[t] = (O::NEXT && in) ? U[e + 1] : 0.0;
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                if (h + t < cnt) {
+                if (t < cntA) {
                     double a, b;
-                    O::term(x[t], xn[t], (b0 + h + t) * kGroup + j, a, b);
-                    if (h + t == 0) {
+                    O::term(x[t], xn[t], (a0 + t) * kGroup + j, a, b);
+                    if (t == 0) {
                         chA = a;
                         chB = b;
                     } else {
@@ -615,6 +625,41 @@ __device__ __forceinline__ void row_reduce_leaves_fused(const double *U, double 
                 }
             }
         }
+        if (two) {  // the first leaf of a pair (<= 8 blocks) is complete: its tree, its sum; the chains start again
+            const double curA = group_tree<false>(chA);
+            const double curB = TWO ? group_tree<BMUL>(chB) : identB;
+            if (j == 0) {
+                L[lfA] = curA;
+                if (TWO) L[lcap + lfA] = curB;
+            }
+        }
+        // steps 8..15: the rest of the only leaf, or the second leaf of the pair from its first block
+        const int base2 = two ? a1 - 8 : a0, lim2 = two ? 8 + (c1 - a1) : cntA;
+        {
+            double x[8], xn[8];
+#pragma unroll
+            for (int t = 8; t < kLeafBlocks; ++t) {
+                const bool in = t < lim2;
+                const int e = (base2 + t) * kGroup + j;
+                x[t - 8] = in ? U[e] : 0.0;
+                xn[t - 8] = (O::NEXT && in) ? U[e + 1] : 0.0;
+            }
+#pragma unroll
+            for (int t = 8; t < kLeafBlocks; ++t) {
+                if (t < lim2) {
+                    double a, b;
+                    O::term(x[t - 8], xn[t - 8], (base2 + t) * kGroup + j, a, b);
+                    if (t == 8 && two) {
+                        chA = a;
+                        chB = b;
+                    } else {
+                        chA = chA + a;
+                        if (TWO) chB = combine<BMUL>(chB, b);
+                    }
+                }
+            }
+        }
+        const int leaf = lfA + (two ? 1 : 0);
         double curA = group_tree<false>(chA);
         double curB = TWO ? group_tree<BMUL>(chB) : identB;
         if (leaf == p.nleaf - 1) {
@@ -625,7 +670,7 @@ __device__ __forceinline__ void row_reduce_leaves_fused(const double *U, double 
                 if (TWO) curB = combine<BMUL>(curB, b);
             }
         }
-        if (cnt > 0 && j == 0) {
+        if (nl > 0 && j == 0) {
             L[leaf] = curA;
             if (TWO) L[lcap + leaf] = curB;
         }
@@ -648,6 +693,204 @@ __device__ __forceinline__ void row_reduce_leaves_fused(const double *U, double 
     sa = 0.0 + row_lane_value<LPR>(vA, 0, l);
     const double rb = TWO ? row_lane_value<LPR>(vB, 0, l) : identB;
     sb = (TWO && !BMUL) ? 0.0 + rb : rb;
+}
+template <int FUN, int LPR>
+__device__ __forceinline__ void row_reduce_leaves_fused(const double *U, double *L, int lcap, int m, const PlanArg &p,
+                                                        int l, double &sa, double &sb) {
+    if (p.nslot != p.nleaf)  // (uniform)
+        row_reduce_leaves_fused_impl<FUN, LPR, true>(U, L, lcap, m, p, l, sa, sb);
+    else
+        row_reduce_leaves_fused_impl<FUN, LPR, false>(U, L, lcap, m, p, l, sa, sb);
+}
+
+// ---------------------------------------------------------------------------
+// Whole-wave rows whose number of terms M is known when the kernel is compiled (sx_eval's streaming form: n = 512 / 1024 /
+// 2048): numpy's plan as constants.  The run-time form above spends more instructions on the plan (scalar loads of the
+// leaf table, selects per group, a branch per step, leaf sums through LDS, a merge loop over lane values) than on the
+// terms; here a pass is straight-line code: one base address per lane, 16 steps whose LDS offsets are immediates and whose
+// bound checks survive only where some leaf of the pass is shorter than the step, leaf sums picked up with v_readlane as
+// uniform values, the tail terms formed by seven lanes at once and added in order, the merges as a fixed sequence of
+// additions.  Same operations on the same values in the same order: same bits.
+// ---------------------------------------------------------------------------
+template <int M>
+struct LongPlan {
+    static constexpr int kCap = M / 64 + 2;
+    int nleaf = 0, nmerge = 0, nslot = 0;
+    int end[kCap] = {};                      // end block (exclusive) of leaf t
+    int mleft[kCap] = {}, mright[kCap] = {}; // the recursion's combines in order: leaf-slot mleft += leaf-slot mright
+    int sfirst[kCap + 1] = {};               // first leaf of work slot s (a slot: one leaf, or two of <= 8 blocks each)
+};
+template <int M>
+constexpr int long_plan_rec(LongPlan<M> &p, int lo, int n) {  // loops_utils.h.src pairwise sum; returns the slot of the sum
+    if (n <= 128) {
+        const int t = p.nleaf++;
+        p.end[t] = (lo + n) / kGroup;
+        return t;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const int a = long_plan_rec(p, lo, n2);
+    const int b = long_plan_rec(p, lo + n2, n - n2);
+    p.mleft[p.nmerge] = a, p.mright[p.nmerge] = b;
+    ++p.nmerge;
+    return a;
+}
+template <int M>
+constexpr LongPlan<M> make_long_plan() {
+    LongPlan<M> p{};
+    (void)long_plan_rec(p, 0, M);
+    for (int t = 0; t < p.nleaf;) {
+        const int b0 = t > 0 ? p.end[t - 1] : 0, b1 = p.end[t];
+        const bool pair = t + 1 < p.nleaf && b1 - b0 <= 8 && p.end[t + 1] - b1 <= 8;
+        p.sfirst[p.nslot++] = t;
+        t += pair ? 2 : 1;
+    }
+    if ((p.nslot + 7) / 8 == (p.nleaf + 7) / 8) {  // pairing saves no pass: one leaf per slot
+        p.nslot = p.nleaf;
+        for (int t = 0; t < p.nleaf; ++t) p.sfirst[t] = t;
+    }
+    p.sfirst[p.nslot] = p.nleaf;
+    return p;
+}
+template <int M>
+struct LongPlanOf {
+    static constexpr LongPlan<M> value = make_long_plan<M>();
+};
+// slot s of the plan: blocks [e0, e1) and, for a pair, [e1, e2)
+template <int M>
+constexpr int lp_e0(int s) {
+    const int f = LongPlanOf<M>::value.sfirst[s];
+    return f > 0 ? LongPlanOf<M>::value.end[f - 1] : 0;
+}
+template <int M>
+constexpr int lp_e1(int s) { return LongPlanOf<M>::value.end[LongPlanOf<M>::value.sfirst[s]]; }
+template <int M>
+constexpr bool lp_two(int s) { return LongPlanOf<M>::value.sfirst[s + 1] - LongPlanOf<M>::value.sfirst[s] == 2; }
+template <int M>
+constexpr int lp_e2(int s) { return lp_two<M>(s) ? LongPlanOf<M>::value.end[LongPlanOf<M>::value.sfirst[s] + 1] : lp_e1<M>(s); }
+// is step t of pass `pass` inside its leaf for EVERY slot of the pass (then it needs no bound check)?
+template <int M>
+constexpr bool lp_step_always(int pass, int t) {
+    for (int g = 0; g < 8; ++g) {
+        const int s = pass * 8 + g;
+        if (s >= LongPlanOf<M>::value.nslot) break;
+        const int cA = lp_e1<M>(s) - lp_e0<M>(s), cB = lp_e2<M>(s) - lp_e1<M>(s);
+        const bool in = lp_two<M>(s) ? (t < 8 ? t < cA : t - 8 < cB) : t < cA;
+        if (!in) return false;
+    }
+    return true;
+}
+template <int M>
+constexpr bool lp_pass_has_pair(int pass) {
+    for (int g = 0; g < 8; ++g)
+        if (pass * 8 + g < LongPlanOf<M>::value.nslot && lp_two<M>(pass * 8 + g)) return true;
+    return false;
+}
+
+template <int N, class F>
+__device__ __forceinline__ void sfor(F &&f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+    if constexpr (N > 0) {
+        sfor<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int FUN, int M>
+__device__ __forceinline__ void row_reduce_long(const double *U, int l, double &sa, double &sb) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    using PL = LongPlanOf<M>;
+    constexpr int NLEAF = PL::value.nleaf, NSLOT = PL::value.nslot, NPASS = (NSLOT + 7) / 8;
+    constexpr int TAIL = M % kGroup, T0 = (M / kGroup) * kGroup;
+    const int j = l & (kGroup - 1), grp = l >> 3;
+    const double identB = BMUL ? 1.0 : 0.0;
+    double leafA[NLEAF], leafB[NLEAF];  // leaf sums, uniform over the wave (compile-time indices only: registers)
+    // the tail terms (after the last leaf's tree), one per lane j < TAIL, requested before the passes
+    double tailA = 0.0, tailB = identB;
+    if constexpr (TAIL > 0) {
+        const int e = T0 + (j < TAIL ? j : 0);
+        O::term(U[e], O::NEXT ? U[e + 1] : 0.0, e, tailA, tailB);
+    }
+    sfor<NPASS>([&](auto pass_) {
+        constexpr int PASS = decltype(pass_)::value;
+        constexpr bool HASPAIR = lp_pass_has_pair<M>(PASS);
+        // this lane's slot: first block of the first half (steps 0..7), "first block - 8" of the second half, the limits
+        int a0 = 0, b0 = 0, lim1 = 16, lim2 = 16;
+        bool two = false;
+        sfor<8>([&](auto g_) {
+            constexpr int G = decltype(g_)::value, S = PASS * 8 + G;
+            if constexpr (S < NSLOT) {
+                constexpr int E0 = lp_e0<M>(S), E1 = lp_e1<M>(S), E2 = lp_e2<M>(S);
+                constexpr bool TW = lp_two<M>(S);
+                if (grp == G) a0 = E0, b0 = TW ? E1 - 8 : E0, lim1 = E1 - E0, lim2 = TW ? 8 + (E2 - E1) : E1 - E0, two = TW;
+            }
+        });  // (groups beyond the last slot walk over slot 0's blocks; nothing of theirs is kept)
+        const double *Ua = U + a0 * kGroup + j, *Ub = U + b0 * kGroup + j;
+        double chA = 0.0, chB = identB, firstA = 0.0, firstB = identB;
+        sfor<2>([&](auto h_) {
+            constexpr int H = decltype(h_)::value;
+            double x[8], xn[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double *q = (H ? Ub : Ua) + (8 * H + t) * kGroup;
+                x[t] = q[0];
+                xn[t] = O::NEXT ? q[1] : 0.0;
+            }
+            if constexpr (H == 1 && HASPAIR) {  // the first leaf of a pair is complete: its tree; the chains start again
+                firstA = group_tree<false>(chA);
+                firstB = TWO ? group_tree<BMUL>(chB) : identB;
+            }
+            sfor<8>([&](auto t_) {
+                constexpr int T = 8 * H + decltype(t_)::value;
+                double a, b;
+                O::term(x[T - 8 * H], xn[T - 8 * H], ((H ? b0 : a0) + T) * kGroup + j, a, b);
+                if constexpr (T == 0) {
+                    chA = a, chB = b;
+                } else {
+                    double nA = chA + a, nB = TWO ? combine<BMUL>(chB, b) : identB;
+                    if constexpr (T == 8 && HASPAIR) nA = two ? a : nA, nB = two ? b : nB;
+                    if constexpr (lp_step_always<M>(PASS, T)) {
+                        chA = nA, chB = nB;
+                    } else {
+                        const bool in = T < (H ? lim2 : lim1);
+                        chA = in ? nA : chA, chB = in ? nB : chB;
+                    }
+                }
+            });
+        });
+        const double curA = group_tree<false>(chA);
+        const double curB = TWO ? group_tree<BMUL>(chB) : identB;
+        sfor<8>([&](auto g_) {
+            constexpr int G = decltype(g_)::value, S = PASS * 8 + G;
+            if constexpr (S < NSLOT) {
+                constexpr int F = PL::value.sfirst[S];
+                if constexpr (lp_two<M>(S)) {
+                    leafA[F] = readlane_f64(firstA, 8 * G);
+                    leafB[F] = TWO ? readlane_f64(firstB, 8 * G) : identB;
+                    leafA[F + 1] = readlane_f64(curA, 8 * G);
+                    leafB[F + 1] = TWO ? readlane_f64(curB, 8 * G) : identB;
+                } else {
+                    leafA[F] = readlane_f64(curA, 8 * G);
+                    leafB[F] = TWO ? readlane_f64(curB, 8 * G) : identB;
+                }
+            }
+        });
+    });
+    if constexpr (TAIL > 0) {
+        sfor<TAIL>([&](auto k_) {
+            constexpr int K = decltype(k_)::value;
+            leafA[NLEAF - 1] = leafA[NLEAF - 1] + readlane_f64(tailA, K);
+            if (TWO) leafB[NLEAF - 1] = combine<BMUL>(leafB[NLEAF - 1], readlane_f64(tailB, K));
+        });
+    }
+    sfor<PL::value.nmerge>([&](auto m_) {
+        constexpr int MM = decltype(m_)::value;
+        constexpr int LEFT = PL::value.mleft[MM], RIGHT = PL::value.mright[MM];
+        leafA[LEFT] = leafA[LEFT] + leafA[RIGHT];
+        if (TWO) leafB[LEFT] = combine<BMUL>(leafB[LEFT], leafB[RIGHT]);
+    });
+    sa = 0.0 + leafA[0];
+    sb = (TWO && !BMUL) ? 0.0 + leafB[0] : leafB[0];
 }
 
 // lexicographic (value, index) minimum = np.argmin's first-minimum rule

@@ -173,6 +173,15 @@ __device__ __forceinline__ double row_objective_chain(const double *U, int l) {
 #ifndef SX_OBJ_CHAIN256
 #define SX_OBJ_CHAIN256 1  // A/B: 0 = rows of 256 elements stage their terms
 #endif
+// objectives whose terms are a few multiplications (no cosine): for these the summation plan, not the arithmetic, is the
+// row's time, and long rows of the usual lengths get the plan as constants (row_reduce_long)
+template <int FUN>
+constexpr bool light_objective() {
+    return FUN == SX_FUN_ROSENBROCK || FUN == SX_FUN_SPHERE || FUN == SX_FUN_QUARTIC || FUN == SX_FUN_STYBLINSKI_TANG;
+}
+#ifndef SX_LONG_STATIC
+#define SX_LONG_STATIC 1  // (0: long rows inside the generation kernels keep the run-time plan -- A/B builds)
+#endif
 template <int FUN, int NFIX>
 constexpr bool chain_only() {
     return SX_OBJ_CHAIN && NFIX != 0 && (NFIX <= 128 || (SX_OBJ_CHAIN256 && NFIX == 256 && !Obj<FUN>::NEXT));
@@ -189,6 +198,26 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     lds_wave_fence();  // U complete (written and read by this wave only)
     if constexpr (chain_only<FUN, NFIX>())
         return row_objective_chain<FUN, LPR, NFIX>(U, l);
+    if constexpr (NFIX > 256) {  // a long row of compile-time length: numpy's plan as constants (row_reduce_long)
+        static_assert(LPR == kWave, "whole-wave rows");
+        double sa, sb;
+        row_reduce_long<FUN, (O::NEXT ? NFIX - 1 : NFIX)>(U, l, sa, sb);
+        return O::finish(sa, sb, NFIX);
+    }
+    if constexpr (SX_LONG_STATIC && NFIX == 0 && LPR == kWave && light_objective<FUN>()) {
+        // long rows of the usual lengths inside the generation kernels (BASELINE config 5: n = 1024): the same constants, picked by
+        // a uniform branch on the run-time length
+        if (n == 1024 || n == 512 || n == 2048) {
+            double sa, sb;
+            if (n == 1024)
+                row_reduce_long<FUN, (O::NEXT ? 1023 : 1024)>(U, l, sa, sb);
+            else if (n == 512)
+                row_reduce_long<FUN, (O::NEXT ? 511 : 512)>(U, l, sa, sb);
+            else
+                row_reduce_long<FUN, (O::NEXT ? 2047 : 2048)>(U, l, sa, sb);
+            return O::finish(sa, sb, n);
+        }
+    }
     if (LPR == kWave && fused_terms(n)) {  // terms are formed inside the reduction, nothing else is staged
         double sa, sb;
         row_reduce_leaves_fused<FUN, LPR>(U, U + n + 8, leaf_cap(n), m, plan, l, sa, sb);

@@ -40,7 +40,8 @@ def test_bench_line_has_the_contract_fields():
     assert set(cf) == {"C2_de_rastrigin_n128_p4096", "C3a_pso_ackley_n256_p16384", "C3b_cpso_ackley_n256_p16384",
                        "C4_cmaes_rosenbrock_n512_p1024", "C5_shard_de_n1024_p16384", "C5_full_de_n1024_p131072_1gpu",
                        "M_numpy_legacy_de_rosenbrock_n128_p4096"}, cf
-    assert all(v["evals_per_s"] > 1e5 and 0.0 < v.get("frac", 0.5) < 1.0 for v in cf.values()), cf
+    bad = {k: v for k, v in cf.items() if not (v["evals_per_s"] > 1e5 and 0.0 < v.get("frac", 0.5) < 1.0)}
+    assert not bad, bad
     # config 5 on one GPU: its 8-GPU shard and the whole population (the N = 1 point of the strong-scaling curve)
     assert cf["C5_shard_de_n1024_p16384"]["frac"] > 0.5 and cf["C5_full_de_n1024_p131072_1gpu"]["frac"] > 0.5
     # the mode that is seed-for-seed the reference's run: >= 10x the CPU port of the same loop (VERDICT r3 missing #2; measured

@@ -34,6 +34,37 @@ def test_objectives_vs_oracle(sa, name, n):
         assert np.allclose(got, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
 
 
+@pytest.mark.parametrize("n", [512, 1024, 2048])
+@pytest.mark.parametrize("name", sorted(OBJECTIVES))
+def test_objectives_long_rows_compile_time_plan(sa, name, n):
+    """Whole batches of rows of 512 / 1024 / 2048 elements take the summation plan as compile-time constants
+    (row_reduce_long: sx_eval directly, the generation kernels by a branch on the length): same bits as the oracle, with
+    and without CMA-ES's affine map (cmaes/_cmaes.py:171)."""
+    import torch
+    from stochopy_amd import _device, _lib
+
+    P = 16384 + 8 * 37
+    rs = np.random.RandomState(n + 11)
+    X = rs.uniform(-5.12, 5.12, (P, n))
+    got = getattr(sa.factory, name)(X)
+    ref = OBJECTIVES[name](X)
+    if name in EXACT:
+        assert np.array_equal(got, ref)
+    else:
+        assert np.allclose(got, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
+    ctx = _device.Context()
+    xm, xstd = rs.uniform(-1, 1, n), rs.uniform(0.5, 2.0, n)
+    Xd = torch.as_tensor(X, device=ctx.device)
+    f = _device.evaluate(ctx, _lib.FUN_IDS[name], Xd, n, xm=torch.as_tensor(xm, device=ctx.device),
+                         xstd=torch.as_tensor(xstd, device=ctx.device))
+    ctx.sync()
+    ref = OBJECTIVES[name](X * xstd + xm)
+    if name in EXACT:
+        assert np.array_equal(f.cpu().numpy(), ref)
+    else:
+        assert np.allclose(f.cpu().numpy(), ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
+
+
 def test_objective_known_answers(sa):
     """reference tests/test_factory.py:7-23"""
     refs = load_golden("factory_kat.json")["test_factory_refs"]

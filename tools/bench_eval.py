@@ -6,7 +6,9 @@ from stochopy_amd import _device, _lib
 
 ctx = _device.Context()
 for name, n, P in (("rosenbrock", 128, 4096), ("rosenbrock", 128, 1 << 20), ("rastrigin", 128, 1 << 20),
-                   ("rosenbrock", 1024, 1 << 17), ("ackley", 256, 1 << 19), ("sphere", 64, 1 << 21)):
+                   ("rosenbrock", 1024, 1 << 17), ("ackley", 256, 1 << 19), ("sphere", 64, 1 << 21),
+                   ("rosenbrock", 512, 1 << 18), ("rosenbrock", 2048, 1 << 16), ("ackley", 1024, 1 << 17),
+                   ("rastrigin", 1024, 1 << 17), ("sphere", 1024, 1 << 17), ("rosenbrock", 1024, 1 << 13)):
     X = torch.rand((P, n), dtype=torch.float64, device=ctx.device) * 10.24 - 5.12
     f = ctx.empty((P,))
     fid = _lib.FUN_IDS[name]
