@@ -204,6 +204,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     if (part_f != nullptr) block_partial<LPR>(val, id, sf, si, part_f, part_i);
 }
 
+#ifndef SX_EVAL_HEAVY_STATIC
+#define SX_EVAL_HEAVY_STATIC 1  // (0: objectives with a cosine per term keep the run-time plan on long rows)
+#endif
 template <int FUN>
 static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
                        const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s, int clip = 0,
@@ -221,14 +224,14 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
 #define SX_EVAL_GO(...)                                                                                              \
     hipLaunchKernelGGL((eval_kernel<FUN, __VA_ARGS__>), dim3(g.blocks), dim3(g.threads), lds, s, X, P, n, ldx, xm, xstd, f, \
                        plan, part_f, part_i, clip, pen_v, pen_out)
-    if (kLight && clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0) {
+    if ((kLight || SX_EVAL_HEAVY_STATIC) && clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0) {
         // long rows of a compile-time length: numpy's plan as constants (row_reduce_long).  Rosenbrock n = 1024: 0.54 -> 0.84
         // of the HBM peak, n = 512: 0.44 -> 0.76, n = 2048: 0.43 -> 0.70 (profiles/r4_eval_long_rows.txt; a resident,
         // software-pipelined form of the same kernel stayed at 0.72 and was dropped)
         switch (n) {
-            case 512: SX_EVAL_GO(64, true, kLight ? 512 : 0); break;
-            case 1024: SX_EVAL_GO(64, true, kLight ? 1024 : 0); break;
-            default: SX_EVAL_GO(64, true, kLight ? 2048 : 0); break;
+            case 512: SX_EVAL_GO(64, true, 512); break;
+            case 1024: SX_EVAL_GO(64, true, 1024); break;
+            default: SX_EVAL_GO(64, true, 2048); break;
         }
     } else if (fix) {
         // the register-chain objective reads the staged vector only: n + 8 doubles per row, not the term arrays' 3n + ...

@@ -795,7 +795,7 @@ __device__ __forceinline__ void sfor(F &&f) {  // f(integral_constant<int, 0>) .
     }
 }
 
-template <int FUN, int M>
+template <int FUN, int M, int BATCH = 8>
 __device__ __forceinline__ void row_reduce_long(const double *U, int l, double &sa, double &sb) {
     using O = Obj<FUN>;
     constexpr bool TWO = O::TWO, BMUL = O::BMUL;
@@ -827,23 +827,25 @@ __device__ __forceinline__ void row_reduce_long(const double *U, int l, double &
         });  // (groups beyond the last slot walk over slot 0's blocks; nothing of theirs is kept)
         const double *Ua = U + a0 * kGroup + j, *Ub = U + b0 * kGroup + j;
         double chA = 0.0, chB = identB, firstA = 0.0, firstB = identB;
-        sfor<2>([&](auto h_) {
-            constexpr int H = decltype(h_)::value;
-            double x[8], xn[8];
+        static_assert(BATCH == 8 || BATCH == 4, "steps whose LDS reads are in flight together");
+        sfor<kLeafBlocks / BATCH>([&](auto q_) {
+            constexpr int Q = decltype(q_)::value, H = Q * BATCH >= 8 ? 1 : 0;  // H: second half (the pair's second leaf)
+            double x[BATCH], xn[BATCH];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const double *q = (H ? Ub : Ua) + (8 * H + t) * kGroup;
+            for (int t = 0; t < BATCH; ++t) {
+                const double *q = (H ? Ub : Ua) + (BATCH * Q + t) * kGroup;
                 x[t] = q[0];
                 xn[t] = O::NEXT ? q[1] : 0.0;
             }
-            if constexpr (H == 1 && HASPAIR) {  // the first leaf of a pair is complete: its tree; the chains start again
+            if constexpr (Q * BATCH == 8 && HASPAIR) {  // the first leaf of a pair is complete: its tree; the chains start again
                 firstA = group_tree<false>(chA);
                 firstB = TWO ? group_tree<BMUL>(chB) : identB;
             }
-            sfor<8>([&](auto t_) {
-                constexpr int T = 8 * H + decltype(t_)::value;
+            if constexpr (BATCH < 8) __builtin_amdgcn_sched_barrier(0);  // (keeps the batches' cosines from being interleaved: registers)
+            sfor<BATCH>([&](auto t_) {
+                constexpr int T = BATCH * Q + decltype(t_)::value;
                 double a, b;
-                O::term(x[T - 8 * H], xn[T - 8 * H], ((H ? b0 : a0) + T) * kGroup + j, a, b);
+                O::term(x[T - BATCH * Q], xn[T - BATCH * Q], ((H ? b0 : a0) + T) * kGroup + j, a, b);
                 if constexpr (T == 0) {
                     chA = a, chB = b;
                 } else {

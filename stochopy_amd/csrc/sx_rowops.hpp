@@ -201,7 +201,7 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     if constexpr (NFIX > 256) {  // a long row of compile-time length: numpy's plan as constants (row_reduce_long)
         static_assert(LPR == kWave, "whole-wave rows");
         double sa, sb;
-        row_reduce_long<FUN, (O::NEXT ? NFIX - 1 : NFIX)>(U, l, sa, sb);
+        row_reduce_long<FUN, (O::NEXT ? NFIX - 1 : NFIX), (light_objective<FUN>() ? 8 : 4)>(U, l, sa, sb);
         return O::finish(sa, sb, NFIX);
     }
     if constexpr (SX_LONG_STATIC && NFIX == 0 && LPR == kWave && light_objective<FUN>()) {
