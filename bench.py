@@ -140,13 +140,12 @@ def other_configs():
             torch.cuda.synchronize()
             return time.perf_counter() - t0, r.nit
 
+        # two run lengths, the fastest run of each (a disturbance only ever ADDS time: the minimum of the per-repetition
+        # DIFFERENCES would reward a slow short run), and their difference per generation
         wall(short)
-        best = None
-        for _ in range(reps):
-            (t1, n1), (t2, n2) = wall(short), wall(long_)
-            v = (t2 - t1) / (n2 - n1)
-            best = v if best is None or v < best else best
-        return best
+        runs = [(wall(short), wall(long_)) for _ in range(reps)]
+        (t1, n1), (t2, n2) = min(r[0] for r in runs), min(r[1] for r in runs)
+        return (t2 - t1) / (n2 - n1)
 
     out = {}
     mfma_f64 = 78.6e12  # dense fp64 MFMA peak used by SURVEY.md section 8d

@@ -215,6 +215,7 @@ extern "C" int sx_graph_destroy(sx_graph *g) {
     if (!g) return 0;
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->scratch) (void)hipFree(g->scratch);
     delete g;
     return 0;
 }

@@ -923,6 +923,21 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// What the best / termination kernel of a CPSO graph can say about the swarm radius R = max_i ||X_i - g_new|| from the
+// generation kernel's r = max_i ||X_i - g_old|| and the step of the best d = ||g_new - g_old|| (its dx):
+//   d == 0 (the best did not move: g_new IS g_old, bit for bit)  ->  R = r exactly, same operations as pso_radius_kernel;
+//   otherwise |R - r| <= d (triangle inequality), so r - d above / r + d below the threshold delta * sqrt(4n) by a relative
+//   margin of 1e-6 (rounding is 1e-13) decides `radius < delta` without the radius; else the radius pass runs.
+// rdec[0] = one of these, rdec[1] = bits of r.
+constexpr unsigned long long kRadiusExactNeeded = 0ull, kRadiusKnown = 1ull, kRadiusAbove = 2ull, kRadiusBelow = 3ull;
+__device__ __forceinline__ unsigned long long radius_decision(double r, double d, double delta, int n) {
+    if (d == 0.0) return kRadiusKnown;
+    const double thr = delta * sqrt(4.0 * (double)n);
+    if (r - d > thr * (1.0 + 1.0e-6)) return kRadiusAbove;
+    if (r + d < thr * (1.0 - 1.0e-6)) return kRadiusBelow;
+    return kRadiusExactNeeded;
+}
+
 // (min f, its index) over the wave when LOWER LANES HOLD LOWER INDICES: the first lane that holds the
 // minimum wins = np.argmin's first-minimum rule.  Result in every lane.
 // One-batch DE rows (the metric shape): the 4 MB a generation writes are next read after the kernel boundary, and as

@@ -22,6 +22,7 @@ inline int hip_fail(hipError_t e, const char *what, const char *file, int line) 
 struct sx_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    void *scratch = nullptr;  // device memory the graph's nodes own (freed with the graph)
 };
 
 #define SX_HIP(call)                                                          \

@@ -11,6 +11,8 @@
 //   stochopy/factory/benchmark.py             objective, fused
 //
 // One wavefront per particle; X, V, pbest, pbestfit are row-local and updated in place.
+#include <cstdlib>
+
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 #include "sx_rowops.hpp"
@@ -49,6 +51,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                                                                                 const int chain_p, const int mode,
                                                                                 const int64_t npart) {
     static_assert(!CHAIN || (PLAIN && FULL), "the chained form exists for the whole-batch constraints=None kernel");
+    // RAD (CPSO inside a graph; best_rows then points at npart doubles, see sx_pso_graph_create): the workgroup also leaves
+    // max_i ||X_i(new) - gbest(OLD)||_2 over its rows -- the swarm radius against the best the kernel was started with, in
+    // pso_radius_kernel's own order of operations.  cpso_post_kernel turns that into the restart decision (radius_decision)
+    // and the radius pass over X is skipped.
+    constexpr bool RAD = FULL && !PLAIN && !CHAIN;
+    double racc = 0.0;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sf[kMaxRowsPerBlock];
     __shared__ int64_t si[kMaxRowsPerBlock];
@@ -221,6 +229,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                     if (xc > hi) beta = fmin(beta, (hi - x[t]) / vn);
                 } else {  // cpso/_constraints.py:4-10: X + V
                     const double xn = x[t] + vn;
+                    if (RAD) {
+                        const double d = xn - g[t];
+                        racc += d * d;
+                    }
                     U[e] = xn;
                     if (id.active) {
                         vr[e] = vn;
@@ -237,6 +249,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
         for (int e = l; e < n; e += LPR) {
             const double vn = Vn[e] * beta;  // V *= beta[:, None]
             const double xn = xr[e] + vn;
+            if (RAD) {
+                const double d = xn - gb[e];
+                racc += d * d;
+            }
             U[e] = xn;
             if (id.active) {
                 vr[e] = vn;
@@ -258,7 +274,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
         }
     }
     if constexpr (!CHAIN) {
+        __shared__ double sr[kMaxRowsPerBlock];
+        const bool rad = RAD && best_rows != nullptr;  // (uniform) exactly pso_radius_kernel's reduction, behind the records' barrier
+        if (rad) {
+            racc = sqrt(row_sum<LPR>(racc));
+            if (id.l == 0) sr[id.slot] = id.active ? racc : 0.0;
+        }
         block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
+        if (rad && threadIdx.x < kWave) {
+            const int rows_in_block = (int)(blockDim.x >> 6) * RowIds<LPR>::RPW;
+            const double m = wave_max_f64((int)threadIdx.x < rows_in_block ? sr[threadIdx.x] : 0.0);
+            if (threadIdx.x == 0) best_rows[blockIdx.x] = m;
+        }
     } else {
         // the workgroup's record AND, when its best row changed, the row itself (see the head of the kernel)
         if (id.l == 0) {
@@ -402,63 +429,24 @@ __device__ __forceinline__ void hist_add(unsigned *bins, int dig, int lane) {
 constexpr int kSelThreads = 1024;
 constexpr int kSelPerThread = 16;  // keys held in registers up to 16384 particles (larger swarms re-read them each step)
 
-// One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
-// and the nw-th largest pbestfit is found by a radix descent over keys held in registers, starting at the first bit in
-// which the keys differ at all (see below).
-// out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
-// The swarm is `nseg` segments (one per rank; 1 on a single GPU) of `seg_len` fitness values followed by
-// `seg_npart` partial radii, `seg_stride` doubles apart: fit = base, part_r = base + seg_len.
-__global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const sx_pso_args a,
-                                                                         const double *__restrict__ fit,
-                                                                         const double *__restrict__ part_r,
-                                                                         int nseg, int64_t seg_len, int64_t seg_npart,
-                                                                         int64_t seg_stride, double delta, double gamma,
-                                                                         unsigned long long *__restrict__ out) {
-    const int64_t Ptot = (int64_t)nseg * seg_len, npart = (int64_t)nseg * seg_npart;
-    // element i of the (segmented) fitness / radius arrays; 32-bit arithmetic (Ptot < 2^31), nothing for one segment
-    const unsigned useg = (unsigned)seg_len, unp = (unsigned)seg_npart;
+#ifdef SX_SELTRACE
+#define SEL_TP(k) do { if (threadIdx.x == 0) ((unsigned long long *)a.candfit)[k] = wall_clock64(); } while (0)
+#else
+#define SEL_TP(k) do {} while (0)
+#endif
+
+// The nw-th largest pbestfit key of the (segmented) swarm -> out[1]; every thread of the 1024-thread workgroup takes part.
+// (The second half of pso_restart_select_kernel; cpso_post_kernel runs it behind its own restart decision.)
+__device__ __forceinline__ void restart_threshold(const sx_pso_args &a, const double *__restrict__ fit, const int nseg,
+                                                  const int64_t seg_len, const int64_t seg_stride, const int64_t Ptot,
+                                                  const int64_t nw, unsigned long long *__restrict__ out) {
+    const unsigned useg = (unsigned)seg_len;
     auto fit_at = [&](int64_t i) -> double {
         if (nseg == 1) return fit[i];
         const unsigned sg = (unsigned)i / useg;
         return fit[(int64_t)sg * seg_stride + ((unsigned)i - sg * useg)];
     };
-    __shared__ double smax[kSelThreads / kWave];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifdef SX_SELTRACE
-#define SEL_TP(k) do { if (tid == 0) ((unsigned long long *)a.candfit)[k] = wall_clock64(); } while (0)
-#else
-#define SEL_TP(k) do {} while (0)
-#endif
-    SEL_TP(0);
-    const int done = a.state->done;
-    const int64_t it = a.state->it;  // (fetched together, and looked at behind the radii: every dependent load is a trip to L2)
-    double m = 0.0;
-    for (int64_t k = tid; k < npart; k += kSelThreads) {
-        const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
-        m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
-    }
-    if (done) {
-        if (tid == 0) out[0] = 0;
-        return;
-    }
-    m = wave_max_f64(m);
-    if (lane == 0) smax[wv] = m;
-    __syncthreads();
-    m = smax[0];
-#pragma unroll
-    for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
-    const double radius = m / sqrt(4.0 * (double)a.n);
-    int64_t nw = 0;
-    if (radius < delta) {
-        const double inorm = (double)it / (double)a.maxiter;
-        nw = (int64_t)(((double)Ptot - 1.0) / (1.0 + exp(1.0 / 0.09 * (inorm - gamma + 0.5))));
-    }
-    if (tid == 0) {
-        out[0] = (unsigned long long)(nw > 0 ? nw : 0);
-        out[2] = (unsigned long long)__double_as_longlong(radius);
-    }
-    SEL_TP(1);
-    if (nw <= 0) return;  // uniform
     // up to 32768 particles the keys stay in registers for the 8 passes; larger swarms re-read them (L2)
     const bool in_regs = Ptot <= (int64_t)kSelThreads * kSelPerThread;
     unsigned long long key[kSelPerThread];
@@ -734,6 +722,203 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
     }
 }
 
+// One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
+// and the nw-th largest pbestfit is found by a radix descent over keys held in registers, starting at the first bit in
+// which the keys differ at all (see below).
+// out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
+// The swarm is `nseg` segments (one per rank; 1 on a single GPU) of `seg_len` fitness values followed by
+// `seg_npart` partial radii, `seg_stride` doubles apart: fit = base, part_r = base + seg_len.
+__global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const sx_pso_args a,
+                                                                         const double *__restrict__ fit,
+                                                                         const double *__restrict__ part_r,
+                                                                         int nseg, int64_t seg_len, int64_t seg_npart,
+                                                                         int64_t seg_stride, double delta, double gamma,
+                                                                         unsigned long long *__restrict__ out) {
+    const int64_t Ptot = (int64_t)nseg * seg_len, npart = (int64_t)nseg * seg_npart;
+    // element k of the (segmented) radius array; 32-bit arithmetic, nothing for one segment
+    const unsigned unp = (unsigned)seg_npart;
+    __shared__ double smax[kSelThreads / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    SEL_TP(0);
+    const int done = a.state->done;
+    const int64_t it = a.state->it;  // (fetched together, and looked at behind the radii: every dependent load is a trip to L2)
+    double m = 0.0;
+    for (int64_t k = tid; k < npart; k += kSelThreads) {
+        const unsigned sg = nseg == 1 ? 0u : (unsigned)k / unp;
+        m = fmax(m, part_r[(int64_t)sg * seg_stride + ((unsigned)k - sg * unp)]);
+    }
+    if (done) {
+        if (tid == 0) out[0] = 0;
+        return;
+    }
+    m = wave_max_f64(m);
+    if (lane == 0) smax[wv] = m;
+    __syncthreads();
+    m = smax[0];
+#pragma unroll
+    for (int k = 1; k < kSelThreads / kWave; ++k) m = fmax(m, smax[k]);
+    const double radius = m / sqrt(4.0 * (double)a.n);
+    int64_t nw = 0;
+    if (radius < delta) {
+        const double inorm = (double)it / (double)a.maxiter;
+        nw = (int64_t)(((double)Ptot - 1.0) / (1.0 + exp(1.0 / 0.09 * (inorm - gamma + 0.5))));
+    }
+    if (tid == 0) {
+        out[0] = (unsigned long long)(nw > 0 ? nw : 0);
+        out[2] = (unsigned long long)__double_as_longlong(radius);
+    }
+    SEL_TP(1);
+    if (nw <= 0) return;  // uniform
+    restart_threshold(a, fit, nseg, seg_len, seg_stride, Ptot, nw, out);
+}
+
+// ---------------------------------------------------------------------------
+// CPSO inside a graph, whole-batch rows (n = 4 * LPR): ONE kernel behind the generation kernel -- best / termination
+// (select_finalize_kernel's arithmetic on the in-place swarm), the restart question, and the selection when a restart is due.
+// The generation kernel leaves r = max_i ||X_i - g_old||_2 per workgroup (its RAD by-product, in pso_radius_kernel's order of
+// operations); with the step of the best d = ||g_new - g_old|| (= dx) radius_decision (sx_device.hpp) settles `radius < delta`
+// in all but a handful of generations (C3b, 1 199 generations: best unchanged 288, above 583, below 324, undecided 4:
+// tools/cpso_radius_decisions.py); the undecided ones get the radius from this workgroup's own pass over X.  Before: four
+// dependent launches per generation (generation, best / termination, radius pass over X, selection).
+// ---------------------------------------------------------------------------
+constexpr int kPostDxThreads = 256;  // the step of the best is summed exactly as select_finalize_kernel (256 threads) does
+template <int LPR>
+__global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_args a, const double *__restrict__ part_f,
+                                                                const int64_t *__restrict__ part_i,
+                                                                const double *__restrict__ part_rold, const int64_t npart,
+                                                                const double xtol, const double delta, const double gamma,
+                                                                unsigned long long *__restrict__ out, const int force_exact) {
+    constexpr int NW = kSelThreads / kWave, n = 4 * LPR;
+    __shared__ double sf[NW];
+    __shared__ int64_t si[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the records and the radii (npart <= 4 per thread at BASELINE config 3), requested before the state word is looked at
+    double bf = __builtin_huge_val(), rold = 0.0;
+    int64_t bi = INT64_MAX;
+    for (int64_t k0 = tid; k0 < npart; k0 += 4 * kSelThreads) {
+        double f[4], r[4];
+        int64_t i[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t k = k0 + (int64_t)u * kSelThreads, kc = k < npart ? k : npart - 1;
+            f[u] = part_f[kc], i[u] = part_i[kc], r[u] = part_rold[kc];
+            if (k >= npart) f[u] = __builtin_huge_val(), i[u] = INT64_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            argmin_combine(bf, bi, f[u], i[u]);
+            rold = fmax(rold, r[u]);
+        }
+    }
+    const int done0 = a.state->done;
+    const int64_t it = a.state->it + 1;  // the generation being finalised
+    if (done0) {
+        if (tid == 0) out[0] = 0;
+        return;
+    }
+    wave_argmin_all(bf, bi);
+    rold = wave_max_f64(rold);
+    if (lane == 0) sf[wv] = bf, si[wv] = bi;
+    __syncthreads();
+    bf = sf[0], bi = si[0];
+    for (int k = 1; k < NW; ++k) argmin_combine(bf, bi, sf[k], si[k]);
+    __syncthreads();
+    if (lane == 0) sf[wv] = rold;
+    __syncthreads();
+    double r = sf[0];
+    for (int k = 1; k < NW; ++k) r = fmax(r, sf[k]);
+    __syncthreads();
+    // dx = ||g_old - pbest[best]||_2, thread t < 256 the elements t, t + 256, ... (n <= 256: one each), then the wave, then the waves
+    const double *__restrict__ src = a.pbest + bi * a.ld;
+    double gv = 0.0, sv = 0.0, acc = 0.0;
+    const bool mine = tid < kPostDxThreads && tid < n;
+    if (mine) gv = a.gbest[tid], sv = src[tid];
+    if (mine) {
+        const double d = gv - sv;
+        acc += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if (lane == 0) sf[wv] = acc;
+    __syncthreads();
+    double ss = 0.0;
+    for (int k = 0; k < kPostDxThreads / kWave; ++k) ss += sf[k];
+    const double dx = sqrt(ss);
+    if (mine) a.gbest[tid] = sv;
+    int status = SX_STATUS_NONE;
+    if (dx <= xtol && bf <= a.ftol)
+        status = 0;
+    else if (bf <= a.ftol)
+        status = 1;
+    else if (it >= a.maxiter)
+        status = -1;
+    if (tid == 0) {
+        sx_state *st = a.state;
+        st->it = it;
+        st->gbidx = bi;
+        st->gfit = bf;
+        st->dx = dx;
+        st->status = status;
+        st->done = status != SX_STATUS_NONE;
+    }
+    if (status != SX_STATUS_NONE) {  // (what the selection does when it finds the run over)
+        if (tid == 0) out[0] = 0;
+        return;
+    }
+    // ---- the restart question, cpso/_cpso.py:405-412 ----
+    // (force_exact: SX_CPSO_FORCE_EXACT=1 at graph creation -- every generation takes the rare branch; tests)
+    const unsigned long long dec = force_exact ? kRadiusExactNeeded : radius_decision(r, dx, delta, n);
+    double m = r;
+    if (dec == kRadiusExactNeeded) {
+        // rare: this workgroup's own pass over X against the new best (= pbest[best], what gbest holds from now on), row by
+        // row as pso_radius_kernel does it -- 8 rows per wavefront in flight
+        constexpr int RPW = kWave / LPR;
+        const int l = lane & (LPR - 1), sub = lane / LPR;
+        double gn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gn[t] = src[l + t * LPR];
+        double mx = 0.0;
+        constexpr int kRows = 8;
+        for (int64_t row0 = (int64_t)wv * RPW + sub; row0 < a.P; row0 += (int64_t)NW * RPW * kRows) {
+            double xv[kRows][4];
+#pragma unroll
+            for (int q = 0; q < kRows; ++q) {
+                const int64_t row = row0 + (int64_t)q * NW * RPW, rc = row < a.P ? row : a.P - 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xv[q][t] = a.X[rc * a.ld + l + t * LPR];
+            }
+#pragma unroll
+            for (int q = 0; q < kRows; ++q) {
+                double ac = 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double d = xv[q][t] - gn[t];
+                    ac += d * d;
+                }
+                ac = sqrt(row_sum<LPR>(ac));
+                if (row0 + (int64_t)q * NW * RPW < a.P) mx = fmax(mx, ac);
+            }
+        }
+        mx = wave_max_f64(mx);
+        if (lane == 0) sf[wv] = mx;
+        __syncthreads();
+        m = sf[0];
+        for (int k = 1; k < NW; ++k) m = fmax(m, sf[k]);
+    }
+    const double radius = m / sqrt(4.0 * (double)n);  // (kRadiusAbove / kRadiusBelow: of r, within d of the swarm's)
+    int64_t nw = 0;
+    if (dec == kRadiusBelow || (dec != kRadiusAbove && radius < delta)) {
+        const double inorm = (double)it / (double)a.maxiter;
+        nw = (int64_t)(((double)a.P - 1.0) / (1.0 + exp(1.0 / 0.09 * (inorm - gamma + 0.5))));
+    }
+    if (tid == 0) {
+        out[0] = (unsigned long long)(nw > 0 ? nw : 0);
+        out[2] = (unsigned long long)__double_as_longlong(radius);
+    }
+    if (nw <= 0) return;  // uniform
+    restart_threshold(a, a.pbestfit, 1, a.P, a.P, a.P, nw, out);
+}
+
 // rows whose pbestfit is among the nw worst: V = 0, X = uniform(lower, upper), pbest = X, pbestfit = 1e30 (:420-424)
 // host_rows != NULL (numpy-legacy): row ids in the reference's descending-fitness order + their new positions
 __global__ __launch_bounds__(256) void pso_restart_apply_kernel(
@@ -860,9 +1045,17 @@ int add_kernel_node(hipGraph_t graph, hipGraphNode_t *prev, void *func, dim3 gri
     return 0;
 }
 
+bool fused_radius_off() {  // (read when a graph is created, so that one process can build both forms)
+    const char *e = getenv("SX_CPSO_FUSED_RADIUS");
+    return e != nullptr && e[0] == '0';
+}
 template <int LPR>
 void *radius_kernel_ptr() {
     return (void *)pso_radius_kernel<LPR>;
+}
+template <int LPR>
+void *post_kernel_ptr() {
+    return (void *)cpso_post_kernel<LPR>;
 }
 }  // namespace
 
@@ -884,6 +1077,17 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     const Geometry g = geometry(a->P, a->n);
     sx_graph *gr = new sx_graph();
     SX_HIP(hipGraphCreate(&gr->graph, 0));
+    // CPSO with whole-batch rows: two launches per generation (generation kernel with its radius by-product, cpso_post_kernel)
+    // instead of four -- C3b 51.7 -> 46.9 us per generation (profiles/r4_cpso_fused_radius.txt).  The graph owns the scratch (npart partial radii).
+    // SX_CPSO_FUSED_RADIUS=0: best / termination, the radius pass over X and the selection as launches of their own.
+    const bool fused_radius = part_r != nullptr && a->n == 4 * lanes_per_row(a->n) && a->n <= kPostDxThreads &&
+                              !fused_radius_off();
+    double *part_rold = nullptr;
+    if (fused_radius) {
+        SX_HIP(hipMalloc(&gr->scratch, (size_t)g.blocks * sizeof(double)));
+        SX_HIP(hipMemset(gr->scratch, 0, (size_t)g.blocks * sizeof(double)));
+        part_rold = (double *)gr->scratch;
+    }
     sx_pso_args args = *a;
     args.pending_restart = nullptr;
     // generations 2..ngen of the graph carry out the previous generation's restart themselves (sx_pso_args.pending_restart);
@@ -893,8 +1097,8 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     double *no_rows_buf = nullptr;
     int izero = 0;
     int64_t lzero = 0;
-    void *gen_args[] = {&args, &plan, &no_rows_buf, &izero, &izero, &lzero};
-    void *gen_args_inline[] = {&args_inline, &plan, &no_rows_buf, &izero, &izero, &lzero};
+    void *gen_args[] = {&args, &plan, fused_radius ? &part_rold : &no_rows_buf, &izero, &izero, &lzero};
+    void *gen_args_inline[] = {&args_inline, &plan, fused_radius ? &part_rold : &no_rows_buf, &izero, &izero, &lzero};
     // restart kernels' arguments
     const double *fit = a->pbestfit;
     const double *pr = part_r;
@@ -903,6 +1107,13 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     unsigned long long *sel = (unsigned long long *)sel3;
     void *rad_args[] = {&args, &part_r};
     void *sel_args[] = {&args, &fit, &pr, &one, &P, &npart, &P, &delta, &gamma, &sel};
+    const double *cpart_f = a->part_f, *cpart_rold = part_rold;
+    const int64_t *cpart_i = a->part_i;
+    double xtol = a->xtol;
+    int force_exact = getenv("SX_CPSO_FORCE_EXACT") != nullptr ? 1 : 0;
+    void *post_args[] = {&args, &cpart_f, &cpart_i, &cpart_rold, &npart, &xtol, &delta, &gamma, &sel, &force_exact};
+    void *post_fn = nullptr;
+    SX_DISPATCH_LPR(a->n, post_fn = post_kernel_ptr<LPR>())
     const int64_t *no_rows = nullptr;
     const double *no_x = nullptr;
     int64_t zero = 0;
@@ -913,19 +1124,25 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
         const bool inl = part_r != nullptr && i > 0;  // CPSO: generations 2.. carry out the restart decided before them
+        // (the first generation of a fused-radius graph takes the general kernel too: the plain one leaves no radius)
         if (int rc = add_kernel_node(gr->graph, &prev,
-                                     (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n, a->constraints == 0 && !inl),
+                                     (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n,
+                                                                        a->constraints == 0 && !inl && !fused_radius),
                                      dim3(g.blocks), dim3(g.threads), (unsigned)g.lds, inl ? gen_args_inline : gen_args))
             return rc;
-        if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n,
-                                       a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
+        if (fused_radius) {
+            if (int rc = add_kernel_node(gr->graph, &prev, post_fn, dim3(1), dim3(kSelThreads), 0, post_args)) return rc;
+        } else if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld,
+                                              a->n, a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
             return rc;
         if (part_r != nullptr) {
-            if (int rc = add_kernel_node(gr->graph, &prev, radius_fn, dim3(g.blocks), dim3(g.threads), 0, rad_args))
-                return rc;
-            if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_select_kernel, dim3(1), dim3(kSelThreads),
-                                         0, sel_args))
-                return rc;
+            if (!fused_radius) {
+                if (int rc = add_kernel_node(gr->graph, &prev, radius_fn, dim3(g.blocks), dim3(g.threads), 0, rad_args))
+                    return rc;
+                if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_select_kernel, dim3(1),
+                                             dim3(kSelThreads), 0, sel_args))
+                    return rc;
+            }
             const int rpb = 4;
             if (i == ngen - 1)
                 if (int rc = add_kernel_node(gr->graph, &prev, (void *)pso_restart_apply_kernel,

@@ -187,6 +187,38 @@ def test_cpso_graph_path_equals_stepping_and_oracle(sa, objective, n, P, maxiter
         assert ref.fun == graph.fun and np.array_equal(ref.x, graph.x) and ref.nit == graph.nit
 
 
+@pytest.mark.parametrize("objective,n,P,maxiter,shrink", [("sphere", 64, 1000, 150, None), ("rosenbrock", 128, 512, 120, "Shrink"),
+                                                          ("sphere", 256, 700, 130, None), ("ackley", 256, 4096, 80, None),
+                                                          ("sphere", 256, 130, 170, "Shrink")])
+def test_cpso_graph_two_launches_per_generation_all_three_forms_agree(sa, objective, n, P, maxiter, shrink, monkeypatch):
+    """Whole-batch rows (n = 64 / 128 / 256) inside a graph: the generation kernel leaves the radius against the OLD best and
+    cpso_post_kernel (best / termination + restart decision + selection) follows -- two launches per generation.  The run
+    is, bit for bit, (a) the four-launch graph (SX_CPSO_FUSED_RADIUS=0: best / termination, radius pass over X, selection),
+    (b) the same graph with every generation forced through the rare branch (SX_CPSO_FORCE_EXACT=1: the post kernel's own
+    pass over X, which the bound needs in ~0.3 % of generations) and (c) the generation-by-generation run; restarts fire
+    (counted by the oracle for the +,-,* objectives, which must agree as well)."""
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 5 + n, "updating": "deferred", "backend": "hip", "rng": "philox",
+            "constraints": shrink}
+    bounds = [[-5.12, 5.12]] * n
+    fun = getattr(sa.factory, objective)
+    fused = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
+    monkeypatch.setenv("SX_CPSO_FORCE_EXACT", "1")
+    forced = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
+    monkeypatch.delenv("SX_CPSO_FORCE_EXACT")
+    monkeypatch.setenv("SX_CPSO_FUSED_RADIUS", "0")
+    four = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
+    monkeypatch.delenv("SX_CPSO_FUSED_RADIUS")
+    step = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts, return_all=True))
+    for other in (forced, four, step):
+        assert fused.fun == other.fun and np.array_equal(fused.x, other.x)
+        assert (fused.nit, fused.status) == (other.nit, other.status)
+    if objective != "ackley":
+        ref = oracle.minimize(objective, bounds, method="cpso", rng="philox",
+                              options={k: v for k, v in opts.items() if k not in ("backend", "rng")})
+        assert len(ref["_restarts"]) > 3, len(ref["_restarts"])
+        assert ref.fun == fused.fun and np.array_equal(ref.x, fused.x) and ref.nit == fused.nit
+
+
 @pytest.mark.parametrize("objective,n,P,maxiter,ftol", [
     ("sphere", 64, 40, 70, -1.0), ("rosenbrock", 128, 33, 45, -1.0), ("sphere", 256, 70, 301, -1.0),
     ("ackley", 256, 2048, 90, -1.0), ("sphere", 64, 512, 4000, 1e-3), ("sphere", 128, 300, 4000, 30.0),
