@@ -498,6 +498,15 @@ int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *st
  * penalty pass), replicated on every rank.  stage 0 with all rows + stage 1 == sx_cmaes_generation. */
 int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, int stage, int64_t row0, int64_t rows,
                               double *arx_loc, double *fit_loc, void *stream);
+/* The generation with its decomposition (cmaes/_cmaes.py:301-309; do_eigh != 0) enqueued in pieces, one GPU: phase 0 =
+ * candidates + model update up to and including the decomposition's start and its rounds [0, r1); the caller reads the
+ * eigensolver's run record (the head of a->eigh_ws: int32 done_seq, sweeps, parity, converged; sx_eigh_info) and either adds
+ * rounds (phase 1: [r0, r1)) or lets phase 2 (r1 = rounds enqueued so far) finish the decomposition and apply the stop rules.
+ * Same kernels in the same order as sx_cmaes_generation, minus the no-op launches behind the run's end (a sweep's worth per
+ * decomposition when the allowance has to be guessed in advance).  sx_eigh_rounds_per_sweep(n): rounds of one sweep of the
+ * block method; 0 for the one-workgroup solver of small n, which cannot be enqueued in pieces. */
+int sx_eigh_rounds_per_sweep(int n);
+int sx_cmaes_generation_phased(const sx_cma_args *a, int64_t gen, int do_eigh, int phase, int r0, int r1, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Symmetric eigendecomposition on the device (csrc/sx_eigh.hip): parallel two-sided block Jacobi, the

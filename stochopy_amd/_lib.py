@@ -167,6 +167,8 @@ PROTOTYPES = {
     "sx_vdcma_moments": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, f64, vp, vp, vp]),
     "sx_cmaes_generation": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, vp]),
     "sx_cmaes_generation_stage": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, C.c_int, i64, i64, vp, vp, vp]),
+    "sx_cmaes_generation_phased": (C.c_int, [C.POINTER(SxCmaArgs), i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "sx_eigh_rounds_per_sweep": (C.c_int, [C.c_int]),
     "sx_vdcma_generation": (C.c_int, [C.POINTER(SxVdArgs), i64, vp]),
     "sx_vdcma_generation_stage": (C.c_int, [C.POINTER(SxVdArgs), i64, C.c_int, i64, i64, vp, vp, vp, vp]),
     "sx_eigh_workspace_bytes": (i64, [C.c_int]),

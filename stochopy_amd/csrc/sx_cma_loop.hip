@@ -32,6 +32,9 @@ int cma_rank_mu_launch(const double *arx, const int64_t *idx, const double *w, i
 int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
                  double tol, const int *skip, int refine, void *stream);  // sx_eigh.hip
 int eigh_refine_in_loops();
+int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, double tol,
+                        const int *skip, int refine, void *stream, int phases, int r0, int r1);  // sx_eigh.hip
+int eigh_rounds_per_sweep(int n);
 }  // namespace sx
 
 namespace {
@@ -530,13 +533,29 @@ int cma_candidates(const sx_cma_args *a, int64_t gen, int64_t row0, int64_t rows
     if (a->pen_ws == nullptr) return sx_eval(a->fun_id, arx_out, rows, n, n, a->xm, a->xstd, fit_out, nullptr, nullptr, stream);
     return sx_cmaes_eval_penalized(a->fun_id, arx_out, rows, n, a->xm, a->xstd, nullptr, fit_out, nullptr, stream);
 }
-int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream);
+int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream, int phase = -1, int r0 = 0, int r1 = 0);
 }  // namespace
 
 extern "C" int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
     if (int rc = check_cma_args(a, gen)) return rc;
     if (int rc = cma_candidates(a, gen, 0, a->P, a->Z, a->arx, a->fit, stream)) return rc;
     return cma_model_update(a, gen, do_eigh, stream);
+}
+
+// The generation with its decomposition enqueued in pieces (one GPU; do_eigh != 0): phase 0 = candidates + model update up to
+// and including the decomposition's start and its rounds [0, r1); the caller then reads the eigensolver's run record
+// (sx_eigh_info / the head of eigh_ws) and either adds rounds (phase 1: [r0, r1)) or lets phase 2 finish the decomposition and
+// apply the stop rules.  Same kernels in the same order as sx_cmaes_generation minus the launches behind the run's end.
+// sx_eigh_rounds_per_sweep(n): rounds of one sweep (0: the one-workgroup solver of small n, which cannot be enqueued in pieces).
+extern "C" int sx_eigh_rounds_per_sweep(int n) { return sx::eigh_rounds_per_sweep(n); }
+extern "C" int sx_cmaes_generation_phased(const sx_cma_args *a, int64_t gen, int do_eigh, int phase, int r0, int r1,
+                                          void *stream) {
+    if (int rc = check_cma_args(a, gen)) return rc;
+    SX_REQUIRE(do_eigh != 0 && phase >= 0 && phase <= 2 && r0 >= 0 && r1 >= r0 && sx::eigh_rounds_per_sweep(a->n) > 0,
+               "sx_cmaes_generation_phased: bad arguments");
+    if (phase == 0)
+        if (int rc = cma_candidates(a, gen, 0, a->P, a->Z, a->arx, a->fit, stream)) return rc;
+    return cma_model_update(a, gen, do_eigh, stream, phase, r0, r1);
 }
 
 // The same generation in two steps, for candidates sharded over ranks (workers > 1: what the reference's parallel backends
@@ -554,12 +573,29 @@ extern "C" int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int 
 }
 
 namespace {
-int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream) {
+// phase -1: the whole model update.  A decomposition enqueued in pieces (sx_cmaes_generation_phased; the host looks at the
+// eigensolver's run record between them instead of paying for a sweep of no-op launches "in case"): 0 = everything up to and
+// including the rounds [0, r1) of the decomposition, 1 = the rounds [r0, r1), 2 = the decomposition's finish + the stop rules.
+int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream, int phase, int r0, int r1) {
     hipStream_t st = (hipStream_t)stream;
     const int n = a->n;
     const int64_t P = a->P;
     sx_cma_state *state = (sx_cma_state *)a->state;
     int rc;
+    // tolerance of the decomposition: what LAPACK's own guarantees, a backward error of n * eps * |C|_F (never below the
+    // solver's default 1e-14): at n = 512 that is 5.7e-14 -- about one decomposition in two stops a sweep earlier
+    const double tol = std::max(1.0e-14, (double)n * 1.1102230246251565e-16);
+    if (phase >= 1) {
+        SX_REQUIRE(do_eigh != 0, "sx_cmaes_generation_phased: phases 1 and 2 belong to a decomposition");
+        if ((rc = sx::eigh_enqueue_phased(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes, tol,
+                                          &state->done, sx::eigh_refine_in_loops(), stream, phase == 1 ? 2 : 4, r0, r1)))
+            return rc;
+        if (phase == 2) {
+            hipLaunchKernelGGL(cma_stop_kernel, dim3(1), dim3(kPathThreads), 0, st, *a, gen, 1);
+            SX_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     if (a->pen_ws != nullptr) {
         // Penalize (cmaes/_constraints.py:4-82): a->fit holds the objective of the clipped candidates; the boundary-weight
         // bookkeeping from its percentiles, then the weighted squared excess on top (the second pass recomputes the same raw values)
@@ -595,9 +631,10 @@ int cma_model_update(const sx_cma_args *a, int64_t gen, int do_eigh, void *strea
     if (do_eigh) {
         if (!mirrored && (rc = sx_symmetrize_upper(a->C, n, stream))) return rc;
         // do_eigh == 2: start from the previous eigenvectors (B is both the starting basis and the output)
-        // tolerance: what LAPACK's own decomposition guarantees, a backward error of n * eps * |C|_F (never below the
-        // solver's default 1e-14): at n = 512 that is 5.7e-14 -- about one decomposition in two stops a sweep earlier
-        const double tol = std::max(1.0e-14, (double)n * 1.1102230246251565e-16);
+        if (phase == 0) {
+            return sx::eigh_enqueue_phased(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes, tol,
+                                           &state->done, sx::eigh_refine_in_loops(), stream, 1 | 2, 0, r1);
+        }
         if ((rc = sx::eigh_enqueue(a->C, n, do_eigh == 2 ? a->B : nullptr, a->eigw, a->B, a->eigh_ws, a->eigh_ws_bytes,
                                    a->eig_sweeps, tol, &state->done, sx::eigh_refine_in_loops(), stream)))
             return rc;

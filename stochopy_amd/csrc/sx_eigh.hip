@@ -1247,84 +1247,107 @@ int eigh_refine_in_loops() {
     const int m = g_refine_mode >= 0 ? g_refine_mode : refine_env();
     return m == 0 ? 0 : 1;
 }
-// sx_eigh with a device-side skip flag (the CMA-ES loops' done word): see eigh_prepare_kernel
-int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
-                 int max_sweeps, double tol, const int *skip, int refine, void *stream) {
+// sx_eigh with a device-side skip flag (the CMA-ES loops' done word): see eigh_prepare_kernel.
+// phases (bits): 1 = begin (run record, M = V0^T C V0 or C, V = V0 or I), 2 = the rounds [r0, r1) of the tournament (round r
+// belongs to sweep r / (nb - 1); which buffers it reads, whose rotations it applies and its launch number all follow from
+// r alone, so a caller may enqueue the rounds in pieces and look at the run record in between), 4 = finish (the last
+// rotations, the record's closing, the refinement step, eigenvalues / order / signs into w and B).
+int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, double tol,
+                        const int *skip, int refine, void *stream, int phases, int r0, int r1) {
     SX_REQUIRE(C && w && B && ws && n >= 1 && n <= 32768, "sx_eigh: bad arguments");
     const EighWs L = eigh_layout(ws, n);
     SX_REQUIRE(ws_bytes >= L.bytes, "sx_eigh: workspace too small (sx_eigh_workspace_bytes)");
-    if (max_sweeps <= 0) max_sweeps = 24;
-    if (max_sweeps > kEighMaxSweeps) max_sweeps = kEighMaxSweeps;
     if (!(tol > 0.0)) tol = 1.0e-14;
     hipStream_t st = (hipStream_t)stream;
     const int npad = eigh_npad(n);
-    SX_HIP(hipMemsetAsync(L.info, 0, sizeof(EighInfo), st));
+    const int nb = npad / kBS, np = nb / 2, rps = nb - 1;
+    SX_REQUIRE(r0 >= 0 && r1 >= r0 && r1 <= kEighMaxSweeps * (n <= kSmallPathMax ? 1 : rps), "sx_eigh: bad round range");
+    if (phases & 1) SX_HIP(hipMemsetAsync(L.info, 0, sizeof(EighInfo), st));
     if (n <= kSmallPathMax) {
-        if (npad == 16)
-            hipLaunchKernelGGL((eigh_small_kernel<16>), dim3(1), dim3(jacobi_threads<16>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
-        else if (npad == 32)
-            hipLaunchKernelGGL((eigh_small_kernel<32>), dim3(1), dim3(jacobi_threads<32>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
-        else
-            hipLaunchKernelGGL((eigh_small_kernel<64>), dim3(1), dim3(jacobi_threads<64>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
-        SX_LAUNCH_CHECK();
-    } else {
-        const int64_t tot = std::max<int64_t>((int64_t)npad * npad, L.ucount);
-        const unsigned pgrid = (unsigned)std::min<int64_t>((tot + 255) / 256, kPrepareMaxBlocks);
-        if (V0 == nullptr) {
-            hipLaunchKernelGGL(eigh_prepare_kernel, dim3(pgrid), dim3(256), 0, st, C, n, npad,
-                               (const double *)nullptr, L.M[0], L.V[0], L.U[0], L.ucount, L.info, skip);
-        } else {
-            // Warm start from a nearly orthonormal basis (the previous generation's eigenvectors):
-            //   V <- V0 (3 I - V0^T V0) / 2   one Newton-Schulz step: orthonormal to rounding, so that a basis handed
-            //                                 from decomposition to decomposition cannot drift
-            //   M <- V^T (C V)
-            // Four n^3 products on the matrix cores (~1 % of a cold decomposition); the sweeps then start from a
-            // nearly diagonal M and the stopping rule ends them after the few that are needed.
-            const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
-            hipLaunchKernelGGL(eigh_prepare_kernel, dim3(pgrid), dim3(256), 0, st, C, n, npad, V0,
-                               L.M[1], L.V[1], L.U[0], L.ucount, L.info, skip);                 // M1 = C, V1 = V0
-            hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[1], L.V[1], L.M[0], npad, -0.5, 1.5);
-            hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.V[1], L.M[0], L.V[0], npad, 1.0, 0.0);
-            hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.M[1], L.V[0], L.V[1], npad, 1.0, 0.0);
-            hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[0], L.V[1], L.M[0], npad, 1.0, 0.0);
-        }
-        SX_LAUNCH_CHECK();
-        const int nb = npad / kBS, np = nb / 2;
-        const unsigned grid = (unsigned)(np + np * np + (npad / kM2) * np);
-        int cur = 0, ucur = 0, rprev = 0, seq = 0;  // the very first "previous rotations" are identities under any pairing
-        for (int sw = 0; sw < max_sweeps; ++sw) {
-            for (int r = 0; r < nb - 1; ++r) {
-                hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
-                                   L.V[cur ^ 1], npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, sw, rprev, r, cur ^ 1, tol, 0, ++seq, refine);
-                cur ^= 1, ucur ^= 1, rprev = r;
-            }
-        }
-        // apply the last rotations, then close
-        hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1], L.V[cur ^ 1],
-                           npad, nb, L.U[ucur ^ 1], L.U[ucur], L.info, max_sweeps, rprev, 0, cur ^ 1, tol, 1, ++seq, 0);
-        cur ^= 1;
-        SX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, max_sweeps, cur, tol, refine,
-                           (int *)((char *)L.info + kEighFailsOffset));
-        SX_LAUNCH_CHECK();
-        if (refine) {
-            const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
-            hipLaunchKernelGGL(eigh_refine_k_kernel, dim3((unsigned)(((int64_t)npad * npad + 255) / 256)), dim3(256), 0, st, L.M[0],
-                               L.M[1], L.M[0], L.M[1], npad, L.info, tol);
-            hipLaunchKernelGGL(eigh_refine_diag_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, st, L.M[0], L.M[1], npad, L.info);
-            hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 0);
-            hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 1);
+        if (phases & 1) {
+            const int max_sweeps = std::max(1, std::min(kEighMaxSweeps, r1));  // (one workgroup: r1 counts sweeps here)
+            if (npad == 16)
+                hipLaunchKernelGGL((eigh_small_kernel<16>), dim3(1), dim3(jacobi_threads<16>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
+            else if (npad == 32)
+                hipLaunchKernelGGL((eigh_small_kernel<32>), dim3(1), dim3(jacobi_threads<32>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
+            else
+                hipLaunchKernelGGL((eigh_small_kernel<64>), dim3(1), dim3(jacobi_threads<64>()), 0, st, C, n, L.M[0], L.V[0], L.info, max_sweeps, tol);
             SX_LAUNCH_CHECK();
         }
+    } else {
+        if (phases & 1) {
+            const int64_t tot = std::max<int64_t>((int64_t)npad * npad, L.ucount);
+            const unsigned pgrid = (unsigned)std::min<int64_t>((tot + 255) / 256, kPrepareMaxBlocks);
+            if (V0 == nullptr) {
+                hipLaunchKernelGGL(eigh_prepare_kernel, dim3(pgrid), dim3(256), 0, st, C, n, npad,
+                                   (const double *)nullptr, L.M[0], L.V[0], L.U[0], L.ucount, L.info, skip);
+            } else {
+                // Warm start from a nearly orthonormal basis (the previous generation's eigenvectors):
+                //   V <- V0 (3 I - V0^T V0) / 2   one Newton-Schulz step: orthonormal to rounding, so that a basis handed
+                //                                 from decomposition to decomposition cannot drift
+                //   M <- V^T (C V)
+                // Four n^3 products on the matrix cores (~1 % of a cold decomposition); the sweeps then start from a
+                // nearly diagonal M and the stopping rule ends them after the few that are needed.
+                const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
+                hipLaunchKernelGGL(eigh_prepare_kernel, dim3(pgrid), dim3(256), 0, st, C, n, npad, V0,
+                                   L.M[1], L.V[1], L.U[0], L.ucount, L.info, skip);                 // M1 = C, V1 = V0
+                hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[1], L.V[1], L.M[0], npad, -0.5, 1.5);
+                hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.V[1], L.M[0], L.V[0], npad, 1.0, 0.0);
+                hipLaunchKernelGGL((eigh_gemm_kernel<false>), gg, dim3(256), 0, st, L.M[1], L.V[0], L.V[1], npad, 1.0, 0.0);
+                hipLaunchKernelGGL((eigh_gemm_kernel<true>), gg, dim3(256), 0, st, L.V[0], L.V[1], L.M[0], npad, 1.0, 0.0);
+            }
+            SX_LAUNCH_CHECK();
+        }
+        const unsigned grid = (unsigned)(np + np * np + (npad / kM2) * np);
+        if (phases & 2) {
+            // launch k (0-based) reads the buffer pair k & 1, applies the rotations of round (k - 1) % rps (identities for
+            // k = 0 under any pairing) and works out those of round k % rps; its launch number is k + 1
+            for (int k = r0; k < r1; ++k) {
+                const int cur = k & 1, rprev = k == 0 ? 0 : (k - 1) % rps;
+                hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
+                                   L.V[cur ^ 1], npad, nb, L.U[cur ^ 1], L.U[cur], L.info, k / rps, rprev, k % rps, cur ^ 1, tol, 0,
+                                   k + 1, refine);
+            }
+            SX_LAUNCH_CHECK();
+        }
+        if (phases & 4) {
+            // apply the last rotations, then close (r1 rounds have been enqueued; a run that ended earlier ignores both)
+            const int cur = r1 & 1, rprev = r1 == 0 ? 0 : (r1 - 1) % rps, sweeps = r1 / rps;
+            hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
+                               L.V[cur ^ 1], npad, nb, L.U[cur ^ 1], L.U[cur], L.info, sweeps, rprev, 0, cur ^ 1, tol, 1, r1 + 1, 0);
+            SX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, sweeps, cur ^ 1, tol, refine,
+                               (int *)((char *)L.info + kEighFailsOffset));
+            SX_LAUNCH_CHECK();
+            if (refine) {
+                const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
+                hipLaunchKernelGGL(eigh_refine_k_kernel, dim3((unsigned)(((int64_t)npad * npad + 255) / 256)), dim3(256), 0, st, L.M[0],
+                                   L.M[1], L.M[0], L.M[1], npad, L.info, tol);
+                hipLaunchKernelGGL(eigh_refine_diag_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, st, L.M[0], L.M[1], npad, L.info);
+                hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 0);
+                hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 1);
+                SX_LAUNCH_CHECK();
+            }
+        }
     }
-    hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 15) / 16)), dim3(1024), 0, st, L.M[0], L.M[1], L.V[0],
-                       L.V[1], n, npad, L.info, L.lam, L.scl);
-    hipLaunchKernelGGL(eigh_rank_kernel, dim3((unsigned)((n + 4 * kEigRankPerWave - 1) / (4 * kEigRankPerWave))), dim3(256), 0, st,
-                       L.lam, n, L.inv, w);
-    hipLaunchKernelGGL(eigh_write_kernel, dim3((unsigned)n), dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], n, npad, L.info,
-                       L.inv, L.scl, B);
-    SX_LAUNCH_CHECK();
+    if (phases & 4) {
+        hipLaunchKernelGGL(eigh_colstats_kernel, dim3((unsigned)((npad + 15) / 16)), dim3(1024), 0, st, L.M[0], L.M[1], L.V[0],
+                           L.V[1], n, npad, L.info, L.lam, L.scl);
+        hipLaunchKernelGGL(eigh_rank_kernel, dim3((unsigned)((n + 4 * kEigRankPerWave - 1) / (4 * kEigRankPerWave))), dim3(256), 0, st,
+                           L.lam, n, L.inv, w);
+        hipLaunchKernelGGL(eigh_write_kernel, dim3((unsigned)n), dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], n, npad, L.info,
+                           L.inv, L.scl, B);
+        SX_LAUNCH_CHECK();
+    }
     return 0;
+}
+int eigh_rounds_per_sweep(int n) { return n <= kSmallPathMax ? 0 : eigh_npad(n) / kBS - 1; }
+int eigh_enqueue(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes,
+                 int max_sweeps, double tol, const int *skip, int refine, void *stream) {
+    if (max_sweeps <= 0) max_sweeps = 24;
+    if (max_sweeps > kEighMaxSweeps) max_sweeps = kEighMaxSweeps;
+    const int rps = std::max(1, eigh_rounds_per_sweep(n));
+    return eigh_enqueue_phased(C, n, V0, w, B, ws, ws_bytes, tol, skip, refine, stream, 7, 0, max_sweeps * rps);
 }
 }  // namespace sx
 

@@ -191,11 +191,22 @@ class _CmaDeviceRun:
             look_cap = 1 if n > 256 else min(self.LOOK, max(1, 512 // max(n, 32)))
             eigeneval, look, since = 0, 1, 0
             cb_hist, cb_pin, fails_seen, warned_short = None, None, 0, False
+            pin_state = pin_eig = None
             state = st
             # Sweeps to LAUNCH per decomposition (launches beyond convergence are no-ops of ~2 us each, 2n/16 - 1 per
             # sweep): a cold start gets the full allowance; a warm start what the last one needed + 1 -- inside a run
             # the count moves by at most one between decompositions (tools/eigh_c4_sweeps.py).
             warm_sweeps, launched, decomposed = self.WARM_SWEEPS0, 0, False
+            # Large n, one GPU, no callback (the host looks at every generation anyway, look_cap == 1): the decomposition is
+            # enqueued in PIECES (sx_cmaes_generation_phased) -- the rounds the last one needed, one look at the solver's run
+            # record, then either its finish or another sweep -- instead of a whole sweep of no-op launches "in case" (~30 of
+            # 3.5 us per decomposition at n = 512).  That one look per generation also returns the state record the previous
+            # generation's stop rules wrote, so the host still waits once per generation (the stop is seen one generation
+            # late: what was enqueued in between does nothing).
+            rps = int(L.sx_eigh_rounds_per_sweep(n))
+            phased = (world is None and callback is None and look_cap == 1 and rps > 0
+                      and os.environ.get("SX_CMA_PHASED", "1") != "0")
+            warm_rounds = None  # rounds the last phased decomposition needed
             for gen in range(1, maxiter + 1):
                 due = gen * P - eigeneval > eig_every
                 if due:  # 1: first decomposition; 2: start from the previous eigenvectors (C changes by O(c1 + cmu))
@@ -203,6 +214,37 @@ class _CmaDeviceRun:
                     eigeneval = gen * P
                     a.eig_sweeps = launched = self.COLD_SWEEPS if due == 1 else warm_sweeps
                     decomposed = True
+                if phased and due:
+                    if pin_state is None:
+                        pin_state = t.empty_like(d_state, device="cpu").pin_memory()
+                        pin_eig = t.empty((256,), dtype=t.float64).pin_memory()
+                    cap = 60 * rps
+                    r1 = min(cap, warm_rounds if (due == 2 and warm_rounds) else 8 * rps + 2)
+                    _lib.check(L.sx_cmaes_generation_phased(C.byref(a), gen, int(due), 0, 0, r1, ctx.stream_ptr),
+                               "sx_cmaes_generation_phased")
+                    while True:
+                        pin_state.copy_(d_state, non_blocking=True)
+                        pin_eig.copy_(eig.ws[:256], non_blocking=True)
+                        ctx.sync()
+                        state = _lib.SxCmaState.from_buffer_copy(pin_state.numpy().tobytes())  # (of generation gen - 1)
+                        rec = pin_eig.numpy().view(np.int32)  # EighInfo: done_seq, sweeps, parity, converged, ...
+                        if state.done or rec[0] != 0 or r1 >= cap:
+                            break
+                        r0, r1 = r1, min(cap, r1 + rps)
+                        _lib.check(L.sx_cmaes_generation_phased(C.byref(a), gen, int(due), 1, r0, r1, ctx.stream_ptr),
+                                   "sx_cmaes_generation_phased")
+                    if state.done:
+                        break
+                    _lib.check(L.sx_cmaes_generation_phased(C.byref(a), gen, int(due), 2, 0, r1, ctx.stream_ptr),
+                               "sx_cmaes_generation_phased")
+                    if rec[0] != 0:  # ended within what was enqueued: it carried out rec[1] sweeps and the two rounds that tell
+                        warm_rounds = int(rec[1]) * rps + 2
+                    else:
+                        warnings.warn("stochopy_amd: the device eigensolver did not reach its tolerance in 60 sweeps; the "
+                                      "decomposition is used as it is", RuntimeWarning, stacklevel=3)
+                        warm_rounds = None
+                    decomposed, since = False, 0
+                    continue
                 if world is None:
                     _lib.check(L.sx_cmaes_generation(C.byref(a), gen, int(due), ctx.stream_ptr), "sx_cmaes_generation")
                 else:  # own candidates, one gather of candidates and fitness, the model update replicated on every rank
@@ -217,7 +259,17 @@ class _CmaDeviceRun:
                 if callback is not None:
                     look = 1  # the callback sees every generation (cmaes/_cmaes.py:333-343)
                 if since >= look or gen == maxiter:
-                    state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
+                    # ONE trip to the device per look: the state record and (when a decomposition was enqueued since the
+                    # last look) the head of the eigensolver's workspace -- its run record and the count of runs that fell
+                    # short -- through pinned memory behind a single synchronisation (three blocking copies before)
+                    if pin_state is None:
+                        pin_state = t.empty_like(d_state, device="cpu").pin_memory()
+                        pin_eig = t.empty((256,), dtype=t.float64).pin_memory()
+                    pin_state.copy_(d_state, non_blocking=True)
+                    if decomposed:
+                        pin_eig.copy_(eig.ws[:256], non_blocking=True)
+                    ctx.sync()
+                    state = _lib.SxCmaState.from_buffer_copy(pin_state.numpy().tobytes())
                     if callback is not None:
                         # what the reference hands over: all candidates (the clipped ones with Penalize), un-standardised,
                         # and the best of them; with return_all the history so far (copied slab by slab)
@@ -240,8 +292,9 @@ class _CmaDeviceRun:
                     if world is None and callback is None and look < look_cap:
                         look *= 2  # cheap generations: look less often
                     if decomposed:  # (the record is only meaningful once a decomposition has been enqueued)
-                        used, ok, _off = eig.info()
-                        fails = int(eig.ws[255:256].cpu().numpy().view(np.int32)[0])  # runs since the start that fell short
+                        rec = pin_eig.numpy().view(np.int32)  # csrc/sx_eigh.hip EighInfo: done_seq, sweeps, parity, converged, ...
+                        used, ok = int(rec[1]), bool(rec[3])
+                        fails = int(rec[510])  # (byte 2040) runs since the start that fell short
                         if ok and fails == fails_seen:
                             # the record is the LAST decomposition's: while the host looks at every generation the count
                             # moves by at most one between looks; between rarer looks it gets two more sweeps of slack
@@ -258,6 +311,8 @@ class _CmaDeviceRun:
                             warm_sweeps, fails_seen = 60, fails
                         decomposed = False
                     since = 0
+            if not state.done:  # (the phased loop sees a generation's record one look late)
+                state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
             if not state.done:  # cannot happen: generation maxiter sets status -1
                 raise RuntimeError("CMA-ES device loop ended without a status")
             nit = int(state.stop_it)

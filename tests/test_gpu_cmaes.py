@@ -428,6 +428,42 @@ def test_cmaes_device_resident_loop_block_eigensolver_vs_oracle(sa, n, P, maxite
     assert np.abs(got.x - ref.x).max() <= 1e-6 * 10.24, np.abs(got.x - ref.x).max()
 
 
+@pytest.mark.parametrize("objective,n,P,maxiter,ftol", [("rosenbrock", 300, 320, 40, -1.0), ("sphere", 512, 600, 30, -1.0),
+                                                        ("sphere", 260, 64, 400, 1.0)])
+def test_cmaes_decomposition_enqueued_in_pieces_is_the_same_run(sa, objective, n, P, maxiter, ftol, monkeypatch):
+    """n > 256 on one GPU without a callback: every decomposition is enqueued in pieces (sx_cmaes_generation_phased: the
+    rounds the last one needed, one look at the solver's run record, its finish or another sweep) and the state record is
+    seen one generation late.  Same kernels on the same data minus the no-op launches: the run is, bit for bit, the one
+    with whole decompositions enqueued ahead (SX_CMA_PHASED=0) -- incl. a stop by ftol in the middle of the run (the
+    generation enqueued behind the stop does nothing) and the device-side history."""
+    from stochopy_amd import _lib
+
+    opts = {"maxiter": maxiter, "popsize": P, "seed": 2, "sigma": 0.1, "ftol": ftol, "xtol": 0.0, "return_all": True,
+            "verbosity": 0.0, "backend": "hip", "rng": "philox"}
+    bounds = [[-5.12, 5.12]] * n
+    calls = []
+    L = _lib.lib()
+    orig = L.sx_cmaes_generation_phased
+
+    class Spy:
+        def __call__(self, *a):
+            calls.append(int(a[3]))
+            return orig(*a)
+
+    monkeypatch.setattr(L, "sx_cmaes_generation_phased", Spy())
+    pieces = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="cmaes", options=dict(opts))
+    assert calls.count(0) >= pieces.nit - 1 and calls.count(2) >= pieces.nit - 1, (len(calls), pieces.nit)
+    n_calls = len(calls)
+    monkeypatch.setenv("SX_CMA_PHASED", "0")
+    whole = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="cmaes", options=dict(opts))
+    assert len(calls) == n_calls
+    assert (pieces.nit, pieces.nfev, pieces.status) == (whole.nit, whole.nfev, whole.status)
+    assert pieces.fun == whole.fun and np.array_equal(pieces.x, whole.x)
+    assert np.array_equal(pieces.xall, whole.xall) and np.array_equal(pieces.funall, whole.funall)
+    if ftol > 0:
+        assert pieces.status == 1 and pieces.nit < maxiter
+
+
 @pytest.mark.parametrize("verbosity", [1.0, 0.4, 0.0])
 def test_cmaes_device_resident_loop_history(sa, verbosity):
     """return_all without a callback stays on the device (history slabs written by a kernel, read back once): same
