@@ -418,7 +418,7 @@ def main():
             try:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc.sh), with the
                 rec = json.load(open(pmc))  # commit they were measured at: not measured inside this run
                 traffic = rec.get(args.workload, {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc passes (tools/r3_profiles.sh) at commit %s" % rec.get(
+                traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc passes (tools/r4_profiles.sh) at commit %s" % rec.get(
                     "_commit", "unrecorded")
             except Exception:
                 traffic = None
