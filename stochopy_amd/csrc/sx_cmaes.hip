@@ -15,6 +15,9 @@
 // four waves in a 2x2 grid, K chunk 32 staged through LDS, the next three chunks already on their way in registers.
 #include <cstdlib>
 #include <type_traits>
+#ifndef SX_GEMM_XCD_SWIZZLE
+#define SX_GEMM_XCD_SWIZZLE 1  // (0: blockIdx.x = column tile, blockIdx.y = row tile as launched -- A/B builds)
+#endif
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 
@@ -92,6 +95,16 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     int64_t m0 = (int64_t)blockIdx.y * BM;
     int n0 = blockIdx.x * BN;
+#if SX_GEMM_XCD_SWIZZLE
+    if (MODE == 0) {
+        // Workgroups go to the 8 XCDs round-robin by their linear number.  Numbered with the COLUMN tile fastest an XCD meets
+        // every candidate row (all of Z: 4 MB at C4, the size of its L2) and two column tiles of B D; numbered with the ROW tile
+        // fastest it meets an eighth of Z (0.5 MB) and all of B D (2 MB), which its L2 holds.
+        const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
+        m0 = (int64_t)(id % gridDim.y) * BM;
+        n0 = (int)(id / gridDim.y) * BN;
+    }
+#endif
     int64_t M;
     int N, K;
     int kbase = 0;  // MODE 1 with split K: this workgroup's first term
