@@ -99,7 +99,8 @@ __global__ __launch_bounds__(kGemmThreads) void cma_gemm_kernel(const Op op) {
     if (MODE == 0) {
         // Workgroups go to the 8 XCDs round-robin by their linear number.  Numbered with the COLUMN tile fastest an XCD meets
         // every candidate row (all of Z: 4 MB at C4, the size of its L2) and two column tiles of B D; numbered with the ROW tile
-        // fastest it meets an eighth of Z (0.5 MB) and all of B D (2 MB), which its L2 holds.
+        // fastest it meets an eighth of Z (0.5 MB) and all of B D (2 MB), which its L2 holds.  (Isolated launches 17.05 -> 16.55 us, in
+        // situ no difference: profiles/r4_gemm_xcd_numbering.txt.)
         const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
         m0 = (int64_t)(id % gridDim.y) * BM;
         n0 = (int)(id / gridDim.y) * BN;
