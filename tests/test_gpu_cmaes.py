@@ -429,7 +429,8 @@ def test_cmaes_device_resident_loop_block_eigensolver_vs_oracle(sa, n, P, maxite
 
 
 @pytest.mark.parametrize("objective,n,P,maxiter,ftol", [("rosenbrock", 300, 320, 40, -1.0), ("sphere", 512, 600, 30, -1.0),
-                                                        ("sphere", 260, 64, 400, 1.0)])
+                                                        ("sphere", 260, 64, 400, 1.0), ("sphere", 300, 64, 1, -1.0),
+                                                        ("sphere", 300, 16, 25, -1.0), ("sphere", 300, 64, 30, 2500.0)])
 def test_cmaes_decomposition_enqueued_in_pieces_is_the_same_run(sa, objective, n, P, maxiter, ftol, monkeypatch):
     """n > 256 on one GPU without a callback: every decomposition is enqueued in pieces (sx_cmaes_generation_phased: the
     rounds the last one needed, one look at the solver's run record, its finish or another sweep) and the state record is
@@ -452,7 +453,7 @@ def test_cmaes_decomposition_enqueued_in_pieces_is_the_same_run(sa, objective, n
 
     monkeypatch.setattr(L, "sx_cmaes_generation_phased", Spy())
     pieces = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="cmaes", options=dict(opts))
-    assert calls.count(0) >= pieces.nit - 1 and calls.count(2) >= pieces.nit - 1, (len(calls), pieces.nit)
+    assert calls.count(0) >= max(1, pieces.nit - 1) and calls.count(2) >= pieces.nit - 1, (len(calls), pieces.nit)
     n_calls = len(calls)
     monkeypatch.setenv("SX_CMA_PHASED", "0")
     whole = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="cmaes", options=dict(opts))
