@@ -172,7 +172,7 @@ __global__ __launch_bounds__(sweep_waves(FUN) * kWave) void de_async_kernel(cons
             U[e] = cand;
             }
         }
-        return row_objective<FUN, LPR, false, NFIX>(U, n, plan, l);
+        return row_objective<FUN, LPR, false, NFIX, 0>(U, n, plan, l);
     };
 
     for (int64_t i0 = 0; i0 < P; i0 += B) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(sweep_waves(FUN) * kWave) void pso_async_kernel(con
                 U[e] = xr[e] + vn;
             }
         }
-        return row_objective<FUN, LPR, false, NFIX>(U, n, plan, l);
+        return row_objective<FUN, LPR, false, NFIX, 0>(U, n, plan, l);
     };
 
     for (int64_t i0 = 0; i0 < P; i0 += B) {

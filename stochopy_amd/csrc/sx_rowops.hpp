@@ -191,7 +191,9 @@ constexpr bool chain_only() {
 // then the numpy-order row sums (lanes l >= 8 repeat the chains of lanes l & 7: LDS broadcasts, same bits).
 // Every lane of the row returns the value.  Each row works on its own LDS slice (no workgroup barrier).
 // NFIX: the row length when it is a compile-time constant (the PSO kernel's whole-batch rows), else 0
-template <int FUN, int LPR, bool FULL = false, int NFIX = 0>
+// LONGSTATIC = 0: no branch to the compile-time plans of n = 512 / 1024 / 2048 (the one-workgroup kernels of
+// updating="immediate", 1 024 threads at the 128-VGPR cap, would spill for them)
+template <int FUN, int LPR, bool FULL = false, int NFIX = 0, int LONGSTATIC = SX_LONG_STATIC>
 __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg &plan, int l) {
     using O = Obj<FUN>;
     const int m = O::NEXT ? n - 1 : n;
@@ -204,7 +206,7 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
         row_reduce_long<FUN, (O::NEXT ? NFIX - 1 : NFIX), (light_objective<FUN>() ? 8 : 4)>(U, l, sa, sb);
         return O::finish(sa, sb, NFIX);
     }
-    if constexpr (SX_LONG_STATIC && NFIX == 0 && LPR == kWave && light_objective<FUN>()) {
+    if constexpr (LONGSTATIC != 0 && NFIX == 0 && LPR == kWave && light_objective<FUN>()) {
         // long rows of the usual lengths inside the generation kernels (BASELINE config 5: n = 1024): the same constants, picked by
         // a uniform branch on the run-time length
         if (n == 1024 || n == 512 || n == 2048) {

@@ -453,7 +453,8 @@ def test_cmaes_decomposition_enqueued_in_pieces_is_the_same_run(sa, objective, n
 
     monkeypatch.setattr(L, "sx_cmaes_generation_phased", Spy())
     pieces = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="cmaes", options=dict(opts))
-    assert calls.count(0) >= max(1, pieces.nit - 1) and calls.count(2) >= pieces.nit - 1, (len(calls), pieces.nit)
+    # (every due decomposition: one start, one finish -- the last start may belong to a generation behind the stop)
+    assert calls.count(0) >= 1 and 0 <= calls.count(0) - calls.count(2) <= 1, (calls.count(0), calls.count(2), pieces.nit)
     n_calls = len(calls)
     monkeypatch.setenv("SX_CMA_PHASED", "0")
     whole = sa.optimize.minimize(getattr(sa.factory, objective), bounds, method="cmaes", options=dict(opts))
