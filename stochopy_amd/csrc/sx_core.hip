@@ -373,9 +373,9 @@ extern "C" int sx_argmin(const double *f, int64_t P, double *ws_f, int64_t *ws_i
 // Best-of-generation + termination (stochopy/optimize/_common.py:131-158)
 // ---------------------------------------------------------------------------
 // best of the per-workgroup records, 8 records per thread and trip so their loads overlap
-__device__ __forceinline__ void scan_records(const double *__restrict__ part_f, const int64_t *__restrict__ part_i,
-                                             int64_t npart, double &bf, int64_t &bi) {
-    constexpr int kScan = 8;
+template <int kScan>
+__device__ __forceinline__ void scan_records_n(const double *__restrict__ part_f, const int64_t *__restrict__ part_i,
+                                               int64_t npart, double &bf, int64_t &bi) {
     for (int64_t k0 = threadIdx.x; k0 < npart; k0 += (int64_t)kFinalThreads * kScan) {
         double f[kScan];
         int64_t i[kScan];
@@ -387,13 +387,24 @@ __device__ __forceinline__ void scan_records(const double *__restrict__ part_f, 
         }
         // this trip's minimum (a tree), then the first record that holds it (k grows with u), then one lexicographic
         // step into the running pair: a chain of 8 compare-and-select steps otherwise
-        const double m = fmin(fmin(fmin(f[0], f[1]), fmin(f[2], f[3])), fmin(fmin(f[4], f[5]), fmin(f[6], f[7])));
+        double m = f[0];
+#pragma unroll
+        for (int u = 1; u < kScan; ++u) m = fmin(m, f[u]);  // (the minimum is the same in any order)
         int64_t first = i[0];  // (all NaN: the first record, as a sequential scan)
 #pragma unroll
         for (int u = kScan - 1; u >= 0; --u)
             if (f[u] == m) first = i[u];
         argmin_combine(bf, bi, m, first);
     }
+}
+// 8 records per thread and trip; all of config 5 on one GPU (131 072 rows = 16 384 records, 64 per thread) 32: two trips
+// instead of eight dependent ones
+__device__ __forceinline__ void scan_records(const double *__restrict__ part_f, const int64_t *__restrict__ part_i,
+                                             int64_t npart, double &bf, int64_t &bi) {
+    if (npart > (int64_t)kFinalThreads * 16)
+        scan_records_n<32>(part_f, part_i, npart, bf, bi);
+    else
+        scan_records_n<8>(part_f, part_i, npart, bf, bi);
 }
 
 __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
