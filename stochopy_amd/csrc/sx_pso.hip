@@ -278,7 +278,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
         const bool rad = RAD && best_rows != nullptr;  // (uniform) exactly pso_radius_kernel's reduction, behind the records' barrier
         if (rad) {
             racc = sqrt(row_sum<LPR>(racc));
-            if (id.l == 0) sr[id.slot] = id.active ? racc : 0.0;
+            if (id.l == 0) {
+                sr[id.slot] = id.active ? racc : 0.0;
+                if (id.active) best_rows[npart + id.row] = racc;  // (per row, behind the npart per-workgroup maxima)
+            }
         }
         block_partial<LPR>(better ? fc : fold, id, sf, si, a.part_f, a.part_i);
         if (rad && threadIdx.x < kWave) {
@@ -866,26 +869,59 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
         return;
     }
     // ---- the restart question, cpso/_cpso.py:405-412 ----
-    // (force_exact: SX_CPSO_FORCE_EXACT=1 at graph creation -- every generation takes the rare branch; tests)
+    // (force_exact: SX_CPSO_FORCE_EXACT=1 / 2 at graph creation -- every generation takes the rare branch / its all-rows form; tests)
     const unsigned long long dec = force_exact ? kRadiusExactNeeded : radius_decision(r, dx, delta, n);
     double m = r;
     if (dec == kRadiusExactNeeded) {
-        // rare: this workgroup's own pass over X against the new best (= pbest[best], what gbest holds from now on), row by
-        // row as pso_radius_kernel does it -- 8 rows per wavefront in flight
-        constexpr int RPW = kWave / LPR;
+        // Rare (4 of 1 199 generations at C3b): the radius against the new best (= pbest[best], what gbest holds from now on),
+        // row by row as pso_radius_kernel does it -- but only for the rows that can hold the maximum.  A row whose radius
+        // against the OLD best (left per row by the generation kernel, behind the per-workgroup maxima) is below
+        // r - 2 d - 1e-6 r ends below r - d - 1e-6 r, and the row that attains r ends at r - d or above: the maximum over the
+        // candidates is the maximum over all rows, the same floating-point values.  More candidates than the list holds (the
+        // first generations, when the best still jumps): all rows, 8 per wavefront in flight (~640 us at P = 16384).
+        constexpr int RPW = kWave / LPR, kCand = 4096;
+        __shared__ int s_cand[kCand];
+        __shared__ unsigned s_ncand;
+        const double *__restrict__ row_rold = part_rold + npart;
+        if (tid == 0) s_ncand = 0u;
+        __syncthreads();
+        const double cut = (r - 2.0 * dx) - 1.0e-6 * r;
+        if (force_exact != 2) {
+            for (int64_t i0 = tid; i0 < a.P; i0 += 8 * kSelThreads) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kSelThreads;
+                    v[u] = row_rold[i < a.P ? i : a.P - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kSelThreads;
+                    if (i < a.P && v[u] >= cut) {
+                        const unsigned k = atomicAdd(&s_ncand, 1u);
+                        if (k < (unsigned)kCand) s_cand[k] = (int)i;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned nc = s_ncand;
+        const bool listed = force_exact != 2 && nc <= (unsigned)kCand;  // (uniform)
+        const int64_t total = listed ? (int64_t)nc : a.P;
         const int l = lane & (LPR - 1), sub = lane / LPR;
         double gn[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) gn[t] = src[l + t * LPR];
         double mx = 0.0;
         constexpr int kRows = 8;
-        for (int64_t row0 = (int64_t)wv * RPW + sub; row0 < a.P; row0 += (int64_t)NW * RPW * kRows) {
+        for (int64_t j0 = (int64_t)wv * RPW + sub; j0 < total; j0 += (int64_t)NW * RPW * kRows) {
             double xv[kRows][4];
 #pragma unroll
             for (int q = 0; q < kRows; ++q) {
-                const int64_t row = row0 + (int64_t)q * NW * RPW, rc = row < a.P ? row : a.P - 1;
+                const int64_t j = j0 + (int64_t)q * NW * RPW, jc = j < total ? j : total - 1;
+                const int64_t row = listed ? (int64_t)s_cand[jc] : jc;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xv[q][t] = a.X[rc * a.ld + l + t * LPR];
+                for (int t = 0; t < 4; ++t) xv[q][t] = a.X[row * a.ld + l + t * LPR];
             }
 #pragma unroll
             for (int q = 0; q < kRows; ++q) {
@@ -896,7 +932,7 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
                     ac += d * d;
                 }
                 ac = sqrt(row_sum<LPR>(ac));
-                if (row0 + (int64_t)q * NW * RPW < a.P) mx = fmax(mx, ac);
+                if (j0 + (int64_t)q * NW * RPW < total) mx = fmax(mx, ac);
             }
         }
         mx = wave_max_f64(mx);
@@ -1084,8 +1120,9 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
                               !fused_radius_off();
     double *part_rold = nullptr;
     if (fused_radius) {
-        SX_HIP(hipMalloc(&gr->scratch, (size_t)g.blocks * sizeof(double)));
-        SX_HIP(hipMemset(gr->scratch, 0, (size_t)g.blocks * sizeof(double)));
+        // (npart per-workgroup maxima, then P per-row radii against the old best: what the rare exact branch looks at first)
+        SX_HIP(hipMalloc(&gr->scratch, ((size_t)g.blocks + (size_t)a->P) * sizeof(double)));
+        SX_HIP(hipMemset(gr->scratch, 0, ((size_t)g.blocks + (size_t)a->P) * sizeof(double)));
         part_rold = (double *)gr->scratch;
     }
     sx_pso_args args = *a;
@@ -1096,9 +1133,9 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     args_inline.pending_restart = sel3;
     double *no_rows_buf = nullptr;
     int izero = 0;
-    int64_t lzero = 0;
-    void *gen_args[] = {&args, &plan, fused_radius ? &part_rold : &no_rows_buf, &izero, &izero, &lzero};
-    void *gen_args_inline[] = {&args_inline, &plan, fused_radius ? &part_rold : &no_rows_buf, &izero, &izero, &lzero};
+    int64_t npart_gen = fused_radius ? (int64_t)g.blocks : 0;
+    void *gen_args[] = {&args, &plan, fused_radius ? &part_rold : &no_rows_buf, &izero, &izero, &npart_gen};
+    void *gen_args_inline[] = {&args_inline, &plan, fused_radius ? &part_rold : &no_rows_buf, &izero, &izero, &npart_gen};
     // restart kernels' arguments
     const double *fit = a->pbestfit;
     const double *pr = part_r;
@@ -1110,7 +1147,9 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     const double *cpart_f = a->part_f, *cpart_rold = part_rold;
     const int64_t *cpart_i = a->part_i;
     double xtol = a->xtol;
-    int force_exact = getenv("SX_CPSO_FORCE_EXACT") != nullptr ? 1 : 0;
+    // (tests: 1 = every generation through the exact branch, 2 = through its all-rows form)
+    const char *fe = getenv("SX_CPSO_FORCE_EXACT");
+    int force_exact = fe == nullptr ? 0 : (fe[0] == '2' ? 2 : 1);
     void *post_args[] = {&args, &cpart_f, &cpart_i, &cpart_rold, &npart, &xtol, &delta, &gamma, &sel, &force_exact};
     void *post_fn = nullptr;
     SX_DISPATCH_LPR(a->n, post_fn = post_kernel_ptr<LPR>())

@@ -195,7 +195,8 @@ def test_cpso_graph_two_launches_per_generation_all_three_forms_agree(sa, object
     cpso_post_kernel (best / termination + restart decision + selection) follows -- two launches per generation.  The run
     is, bit for bit, (a) the four-launch graph (SX_CPSO_FUSED_RADIUS=0: best / termination, radius pass over X, selection),
     (b) the same graph with every generation forced through the rare branch (SX_CPSO_FORCE_EXACT=1: the post kernel's own
-    pass over X, which the bound needs in ~0.3 % of generations) and (c) the generation-by-generation run; restarts fire
+    radii against the new best for the rows that can hold the maximum -- the bound needs it in ~0.3 % of generations; =2: for
+    all rows, what it falls back to when the candidates do not fit its list) and (c) the generation-by-generation run; restarts fire
     (counted by the oracle for the +,-,* objectives, which must agree as well)."""
     opts = {"maxiter": maxiter, "popsize": P, "seed": 5 + n, "updating": "deferred", "backend": "hip", "rng": "philox",
             "constraints": shrink}
@@ -204,12 +205,14 @@ def test_cpso_graph_two_launches_per_generation_all_three_forms_agree(sa, object
     fused = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
     monkeypatch.setenv("SX_CPSO_FORCE_EXACT", "1")
     forced = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
+    monkeypatch.setenv("SX_CPSO_FORCE_EXACT", "2")
+    forced_all = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
     monkeypatch.delenv("SX_CPSO_FORCE_EXACT")
     monkeypatch.setenv("SX_CPSO_FUSED_RADIUS", "0")
     four = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts))
     monkeypatch.delenv("SX_CPSO_FUSED_RADIUS")
     step = sa.optimize.minimize(fun, bounds, method="cpso", options=dict(opts, return_all=True))
-    for other in (forced, four, step):
+    for other in (forced, forced_all, four, step):
         assert fused.fun == other.fun and np.array_equal(fused.x, other.x)
         assert (fused.nit, fused.status) == (other.nit, other.status)
     if objective != "ackley":
