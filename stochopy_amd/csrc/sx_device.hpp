@@ -923,6 +923,21 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// row_sum<64>'s butterfly (v += lane ^ 1, ^ 2, ^ 4, ^ 8, ^ 16, ^ 32) without LDS traffic.  After the step with lane ^ k both
+// partners hold the same bits (a + b == b + a), so groups of 2k lanes are uniform: the mirrors stand in for ^ 4 and ^ 8, and
+// the last two steps take the other rows' values through readlane.  Same operands in every addition: same bits.
+__device__ __forceinline__ double wave_sum_butterfly(double v, int lane) {
+    v = v + dpp_f64<kDppXor1>(v);
+    v = v + dpp_f64<kDppXor2>(v);
+    v = v + dpp_f64<kDppHalfMirror>(v);
+    v = v + dpp_f64<kDppRowMirror>(v);
+    const double s0 = readlane_f64(v, 0), s1 = readlane_f64(v, 16), s2 = readlane_f64(v, 32), s3 = readlane_f64(v, 48);
+    const double partner = (lane & 16) ? ((lane & 32) ? s2 : s0) : ((lane & 32) ? s3 : s1);
+    v = v + partner;
+    const double lo = readlane_f64(v, 0), hi = readlane_f64(v, 32);
+    return v + ((lane & 32) ? lo : hi);
+}
+
 // What the best / termination kernel of a CPSO graph can say about the swarm radius R = max_i ||X_i - g_new|| from the
 // generation kernel's r = max_i ||X_i - g_old|| and the step of the best d = ||g_new - g_old|| (its dx):
 //   d == 0 (the best did not move: g_new IS g_old, bit for bit)  ->  R = r exactly, same operations as pso_radius_kernel;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
                                                                                 const int64_t npart) {
     static_assert(!CHAIN || (PLAIN && FULL), "the chained form exists for the whole-batch constraints=None kernel");
     // RAD (CPSO inside a graph; best_rows then points at npart doubles, see sx_pso_graph_create): the workgroup also leaves
-    // max_i ||X_i(new) - gbest(OLD)||_2 over its rows -- the swarm radius against the best the kernel was started with, in
+    // max_i ||X_i(new) - gbest(OLD)||_2^2 over its rows -- the (squared) swarm radius against the best the kernel was started with, in
     // pso_radius_kernel's own order of operations.  cpso_post_kernel turns that into the restart decision (radius_decision)
     // and the radius pass over X is skipped.
     constexpr bool RAD = FULL && !PLAIN && !CHAIN;
@@ -277,7 +277,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
         __shared__ double sr[kMaxRowsPerBlock];
         const bool rad = RAD && best_rows != nullptr;  // (uniform) exactly pso_radius_kernel's reduction, behind the records' barrier
         if (rad) {
-            racc = sqrt(row_sum<LPR>(racc));
+            // the SQUARED radius (the square root is monotone and correctly rounded: max sqrt = sqrt max, taken once by
+            // cpso_post_kernel); whole-wave rows add up without LDS traffic (same additions as row_sum)
+            if constexpr (LPR == kWave)
+                racc = wave_sum_butterfly(racc, id.lane);
+            else
+                racc = row_sum<LPR>(racc);
             if (id.l == 0) {
                 sr[id.slot] = id.active ? racc : 0.0;
                 if (id.active) best_rows[npart + id.row] = racc;  // (per row, behind the npart per-workgroup maxima)
@@ -830,6 +835,7 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
     __syncthreads();
     double r = sf[0];
     for (int k = 1; k < NW; ++k) r = fmax(r, sf[k]);
+    r = sqrt(r);  // (the generation kernel leaves squared radii)
     __syncthreads();
     // dx = ||g_old - pbest[best]||_2, thread t < 256 the elements t, t + 256, ... (n <= 256: one each), then the wave, then the waves
     const double *__restrict__ src = a.pbest + bi * a.ld;
@@ -885,7 +891,8 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
         const double *__restrict__ row_rold = part_rold + npart;
         if (tid == 0) s_ncand = 0u;
         __syncthreads();
-        const double cut = (r - 2.0 * dx) - 1.0e-6 * r;
+        const double cut1 = (r - 2.0 * dx) - 1.0e-6 * r;
+        const double cut = cut1 > 0.0 ? cut1 * cut1 * (1.0 - 1.0e-12) : -1.0;  // (against the SQUARED per-row radii)
         if (force_exact != 2) {
             for (int64_t i0 = tid; i0 < a.P; i0 += 8 * kSelThreads) {
                 double v[8];

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r4b
 timeout 1500 python -m pytest tests/test_gpu_pso.py tests/test_gpu_configs_philox.py -q -x 2>&1 | tail -3
-{ echo "fuzz_cpso_graph:"; timeout 600 python tools/fuzz_cpso_graph.py 90 4 2>&1 | tail -1
+{ echo "fuzz_cpso_graph:"; timeout 600 python tools/fuzz_cpso_graph.py 60 4 2>&1 | tail -1
   for k in 1 2; do
     echo "== fused radius decision"; timeout 300 python tools/bench_cpso.py 2>&1 | grep -v amdgpu.ids | tail -3
     echo "== SX_CPSO_FUSED_RADIUS=0"; SX_CPSO_FUSED_RADIUS=0 timeout 300 python tools/bench_cpso.py 2>&1 | grep -v amdgpu.ids | tail -3
