@@ -10,6 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstochopy_hip.so")
 
 SX_STATUS_NONE = 100
+# rows of more than NARROW_DIM elements are "wide" (csrc/sx_wide.hip: one workgroup per row): no chained / peer-exchange /
+# ordered-sweep kernels for those, everything else is served; WIDE_DIM is the longest row
+NARROW_DIM, WIDE_DIM = 4096, 262144
 SX_RNG_HOST, SX_RNG_PHILOX = 0, 1
 
 FUN_IDS = {

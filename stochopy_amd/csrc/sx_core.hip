@@ -12,6 +12,7 @@
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 #include "sx_rowops.hpp"
+#include "sx_wide.hpp"
 
 namespace sx {
 static thread_local std::string g_error;
@@ -102,12 +103,12 @@ extern "C" int64_t sx_fun_terms(int fun_id, int n) {
 }
 
 extern "C" int64_t sx_num_partials(int64_t P, int n) { return (int64_t)row_geometry(P, n).blocks; }
-extern "C" int sx_rows_per_workgroup(int n) { return rows_per_block(n); }
+extern "C" int sx_rows_per_workgroup(int n) { return n > kMaxDim ? 1 : rows_per_block(n); }
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out) {
-    if (n > kMaxDim) {
-        set_error("dimension above the kernel limit (n <= 4096)");
+    if (n > kMaxDim) {  // (wide rows take their plan from device memory: sx_wide.hip; callers branch before this)
+        set_error("internal: a narrow-row kernel was asked for a row of more than 4096 elements");
         return -1;
     }
     const int64_t m = sx_fun_terms(fun_id, n);
@@ -258,6 +259,7 @@ extern "C" int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ld
     SX_REQUIRE((xm == nullptr) == (xstd == nullptr), "sx_eval: xm and xstd must be given together");
     SX_REQUIRE((part_f == nullptr) == (part_i == nullptr), "sx_eval: part_f and part_i must be given together");
     hipStream_t s = (hipStream_t)stream;
+    if (is_wide(n)) return wide_eval(fun_id, X, P, n, ldx, xm, xstd, f, part_f, part_i, 0, nullptr, nullptr, s);
     PlanArg plan;
     if (make_plan_arg(fun_id, n, &plan)) return -1;
     switch (fun_id) {
@@ -286,6 +288,7 @@ extern "C" int sx_cmaes_eval_penalized(int fun_id, const double *X, int64_t P, i
     SX_REQUIRE(fun_id >= 0 && fun_id < SX_FUN_COUNT, "sx_cmaes_eval_penalized: unknown fun_id");
     SX_REQUIRE((v == nullptr) == (pen == nullptr), "sx_cmaes_eval_penalized: v and pen must be given together");
     hipStream_t s = (hipStream_t)stream;
+    if (is_wide(n)) return wide_eval(fun_id, X, P, n, n, xm, xstd, f_raw, nullptr, nullptr, 1, v, pen, s);
     PlanArg plan;
     if (make_plan_arg(fun_id, n, &plan)) return -1;
     switch (fun_id) {
@@ -425,17 +428,24 @@ __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
     // dx = ||xbest_prev - x[k]||_2 (np.linalg.norm, _common.py:135); all loads of a thread in flight together
     constexpr int kPer = (kMaxDim + kFinalThreads - 1) / kFinalThreads;
     double gv[kPer], sv[kPer];
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-        const int e = threadIdx.x + u * kFinalThreads;
-        gv[u] = e < n ? gbest[e] : 0.0;
-        sv[u] = e < n ? src[e] : 0.0;
-    }
     double acc = 0.0;
+    if (n <= kMaxDim) {
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-        if (threadIdx.x + u * kFinalThreads < n) {
-            const double d = gv[u] - sv[u];
+        for (int u = 0; u < kPer; ++u) {
+            const int e = threadIdx.x + u * kFinalThreads;
+            gv[u] = e < n ? gbest[e] : 0.0;
+            sv[u] = e < n ? src[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            if (threadIdx.x + u * kFinalThreads < n) {
+                const double d = gv[u] - sv[u];
+                acc += d * d;
+            }
+        }
+    } else {  // wide rows: the same per-thread order of additions, the row read again for the copy
+        for (int e = threadIdx.x; e < n; e += kFinalThreads) {
+            const double d = gbest[e] - src[e];
             acc += d * d;
         }
     }
@@ -446,9 +456,13 @@ __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
     double ss = 0.0;
     for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
     const double dx = sqrt(ss);
+    if (n <= kMaxDim) {
 #pragma unroll
-    for (int u = 0; u < kPer; ++u)
-        if (threadIdx.x + u * kFinalThreads < n) gbest[threadIdx.x + u * kFinalThreads] = sv[u];
+        for (int u = 0; u < kPer; ++u)
+            if (threadIdx.x + u * kFinalThreads < n) gbest[threadIdx.x + u * kFinalThreads] = sv[u];
+    } else {
+        for (int e = threadIdx.x; e < n; e += kFinalThreads) gbest[e] = src[e];
+    }
     if (threadIdx.x == 0) {
         int status = SX_STATUS_NONE;
         if (dx <= xtol && bf <= ftol)

@@ -15,6 +15,7 @@
 // unchanged row), so donor reads never race with selection writes.
 #define SX_DE_XM 0
 #include "sx_de_kernel.hpp"
+#include "sx_wide.hpp"
 
 namespace sx {
 // the chained (sx_de_chain.hip) and peer-exchange (sx_de_p2p.hip) kernels, as launchable function pointers
@@ -52,13 +53,17 @@ Geometry geometry(const sx_de_args *a) { return row_geometry(a->P, a->n); }
 extern "C" int sx_de_generation(const sx_de_args *a, int finalize, void *stream) {
     if (int rc = check_args(a)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    PlanArg plan;
-    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
-    hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, (const sx_state *)nullptr,
-                       (const double *)nullptr, (const int64_t *)nullptr, (int64_t)g.blocks, *a, plan, 0, 0,
-                       sx_xchg_args{});
-    SX_LAUNCH_CHECK();
+    if (is_wide(a->n)) {  // rows of more than 4096 elements: one workgroup per row (sx_wide.hip), one record per row
+        if (int rc = wide_de_launch(a, s)) return rc;
+    } else {
+        PlanArg plan;
+        if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+        hipLaunchKernelGGL(kernel_for(a), dim3(g.blocks), dim3(g.threads), g.lds, s, (const sx_state *)nullptr,
+                           (const double *)nullptr, (const int64_t *)nullptr, (int64_t)g.blocks, *a, plan, 0, 0,
+                           sx_xchg_args{});
+        SX_LAUNCH_CHECK();
+    }
     if (finalize) {
         SX_REQUIRE(a->gbest != nullptr, "sx_de_generation: the separate finalize kernel needs the gbest buffer");
         return sx_select_finalize(a->part_f, a->part_i, g.blocks, a->buf0, a->buf1, a->ld, a->n, a->gbest, a->state,
@@ -75,8 +80,9 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(out != nullptr && ngen >= 1 && a->gbest != nullptr, "sx_de_graph_create: bad arguments");
     SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_de_graph_create: graphs need in-kernel (Philox) draws");
-    PlanArg plan;
-    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    PlanArg plan = {};
+    const bool wide = is_wide(a->n);
+    if (!wide && make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a);
     sx_graph *gr = new sx_graph();
     SX_HIP(hipGraphCreate(&gr->graph, 0));
@@ -88,16 +94,20 @@ extern "C" int sx_de_graph_create(const sx_de_args *a, int ngen, sx_graph **out)
     void *kargs[] = {&none, &none, &none, &npart, &args, &plan, &zero, &zero, &nox};
     hipGraphNode_t prev = nullptr;
     for (int i = 0; i < ngen; ++i) {
-        hipKernelNodeParams kp = {};
-        kp.func = (void *)kernel_for(a);
-        kp.gridDim = dim3(g.blocks);
-        kp.blockDim = dim3(g.threads);
-        kp.sharedMemBytes = (unsigned)g.lds;
-        kp.kernelParams = kargs;
-        kp.extra = nullptr;
-        hipGraphNode_t node;
-        SX_HIP(hipGraphAddKernelNode(&node, gr->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
-        prev = node;
+        if (wide) {
+            if (int rc = wide_de_add_node(gr->graph, &prev, a)) return rc;
+        } else {
+            hipKernelNodeParams kp = {};
+            kp.func = (void *)kernel_for(a);
+            kp.gridDim = dim3(g.blocks);
+            kp.blockDim = dim3(g.threads);
+            kp.sharedMemBytes = (unsigned)g.lds;
+            kp.kernelParams = kargs;
+            kp.extra = nullptr;
+            hipGraphNode_t node;
+            SX_HIP(hipGraphAddKernelNode(&node, gr->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+            prev = node;
+        }
         if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->buf0, a->buf1, a->ld, a->n,
                                        a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
             return rc;
@@ -124,6 +134,7 @@ extern "C" int sx_de_shard_generation(const sx_de_args *a, double *record, void 
 static int check_chain(const sx_de_args *a, bool peer_exchange) {
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_de_chain: needs in-kernel (Philox) draws");
+    SX_REQUIRE(!is_wide(a->n), "sx_de_chain: rows of more than 4096 elements take the two-kernel path (sx_de_generation)");
     SX_REQUIRE(peer_exchange || sx_num_partials(a->P, a->n) <= 512,
                "sx_de_chain: more than 512 workgroup records (use the two-kernel path)");
     return 0;

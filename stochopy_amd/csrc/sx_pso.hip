@@ -16,6 +16,7 @@
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 #include "sx_rowops.hpp"
+#include "sx_wide.hpp"
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out);
@@ -1003,14 +1004,18 @@ __global__ __launch_bounds__(256) void pso_restart_apply_kernel(
 extern "C" int sx_pso_generation(const sx_pso_args *a, int finalize, void *stream) {
     if (int rc = check_args(a)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    PlanArg plan;
-    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a->P, a->n);
-    const bool plain = a->constraints == 0 && a->pending_restart == nullptr;
-    pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n, plain)
-                                                 : pick_kernel<SX_RNG_HOST>(a->fun_id, a->n, plain);
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan, (double *)nullptr, 0, 0, (int64_t)0);
-    SX_LAUNCH_CHECK();
+    if (is_wide(a->n)) {  // rows of more than 4096 elements: one workgroup per particle (sx_wide.hip)
+        if (int rc = wide_pso_launch(a, s)) return rc;
+    } else {
+        PlanArg plan;
+        if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+        const bool plain = a->constraints == 0 && a->pending_restart == nullptr;
+        pso_kernel_t kern = a->rng == SX_RNG_PHILOX ? pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n, plain)
+                                                     : pick_kernel<SX_RNG_HOST>(a->fun_id, a->n, plain);
+        hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.threads), g.lds, s, *a, plan, (double *)nullptr, 0, 0, (int64_t)0);
+        SX_LAUNCH_CHECK();
+    }
     if (finalize)
         return sx_select_finalize(a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld, a->n, a->gbest, a->state,
                                   a->maxiter, a->xtol, a->ftol, stream);
@@ -1115,8 +1120,9 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_pso_graph_create: graphs need in-kernel (Philox) draws");
     SX_REQUIRE((part_r == nullptr) == (sel3 == nullptr), "sx_pso_graph_create: restart needs part_r AND sel3");
     SX_REQUIRE(part_r == nullptr || (a->lower && a->upper), "sx_pso_graph_create: bounds missing");
-    PlanArg plan;
-    if (make_plan_arg(a->fun_id, a->n, &plan)) return -1;
+    PlanArg plan = {};
+    const bool wide = is_wide(a->n);
+    if (!wide && make_plan_arg(a->fun_id, a->n, &plan)) return -1;
     const Geometry g = geometry(a->P, a->n);
     sx_graph *gr = new sx_graph();
     SX_HIP(hipGraphCreate(&gr->graph, 0));
@@ -1171,10 +1177,13 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     for (int i = 0; i < ngen; ++i) {
         const bool inl = part_r != nullptr && i > 0;  // CPSO: generations 2.. carry out the restart decided before them
         // (the first generation of a fused-radius graph takes the general kernel too: the plain one leaves no radius)
-        if (int rc = add_kernel_node(gr->graph, &prev,
-                                     (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n,
-                                                                        a->constraints == 0 && !inl && !fused_radius),
-                                     dim3(g.blocks), dim3(g.threads), (unsigned)g.lds, inl ? gen_args_inline : gen_args))
+        if (wide) {
+            if (int rc = wide_pso_add_node(gr->graph, &prev, inl ? &args_inline : &args)) return rc;
+        } else if (int rc = add_kernel_node(gr->graph, &prev,
+                                            (void *)pick_kernel<SX_RNG_PHILOX>(a->fun_id, a->n,
+                                                                               a->constraints == 0 && !inl && !fused_radius),
+                                            dim3(g.blocks), dim3(g.threads), (unsigned)g.lds,
+                                            inl ? gen_args_inline : gen_args))
             return rc;
         if (fused_radius) {
             if (int rc = add_kernel_node(gr->graph, &prev, post_fn, dim3(1), dim3(kSelThreads), 0, post_args)) return rc;

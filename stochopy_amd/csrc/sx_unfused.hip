@@ -104,41 +104,71 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(cons
     const bool shrink = a.constraints != 0;
     double beta = __builtin_huge_val();
     const int nq = (n + LPR - 1) / LPR;
-    for (int q0 = 0; q0 < nq; q0 += 2) {  // two row steps share one Philox call
+    // wide rows (n > kMaxDim: one wavefront per row, no dynamic LDS): with Shrink the raw velocities are formed AGAIN
+    // behind the row-wide beta instead of waiting in LDS -- same operands, same operations, same bits
+    const bool stash = shrink && n <= kMaxDim;
+    // raw velocity of the two elements (q0 + t) * LPR + l, t = 0, 1 (one Philox call)
+    auto raw = [&](int q0, double(&x)[2], double(&vn)[2]) {
         U4 pw = {0u, 0u, 0u, 0u};
         if (RNG == SX_RNG_PHILOX)
             pw = philox4x32_10((uint32_t)(q0 >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR1, a.key0, a.key1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int e = (q0 + t) * LPR + l;
+            x[t] = 0.0, vn[t] = 0.0;
             if (e >= n) continue;
-            const double x = xr[e], v = vr[e], p = pb[e], g = gb[e];
+            const double v = vr[e], p = pb[e], g = gb[e];
+            x[t] = xr[e];
             double r1 = u32(t ? pw.z : pw.x), r2 = u32(t ? pw.w : pw.y);
             if (RNG == SX_RNG_HOST) {
                 r1 = a.r1[rowc * (int64_t)n + e];
                 r2 = a.r2[rowc * (int64_t)n + e];
             }
-            const double vn = pso_velocity(w, v, c1, r1, p, x, c2, r2, g);
+            vn[t] = pso_velocity(w, v, c1, r1, p, x[t], c2, r2, g);
+        }
+    };
+    for (int q0 = 0; q0 < nq; q0 += 2) {  // two row steps share one Philox call
+        double x[2], vn[2];
+        raw(q0, x, vn);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int e = (q0 + t) * LPR + l;
+            if (e >= n) continue;
             if (shrink) {  // cpso/_constraints.py:22-50
-                Vn[e] = vn;
-                const double xc = x + vn, lo = a.lower[e], hi = a.upper[e];
-                if (xc < lo) beta = fmin(beta, (lo - x) / vn);
-                if (xc > hi) beta = fmin(beta, (hi - x) / vn);
+                if (stash) Vn[e] = vn[t];
+                const double xc = x[t] + vn[t], lo = a.lower[e], hi = a.upper[e];
+                if (xc < lo) beta = fmin(beta, (lo - x[t]) / vn[t]);
+                if (xc > hi) beta = fmin(beta, (hi - x[t]) / vn[t]);
             } else if (id.active) {
-                vr[e] = vn;
-                xr[e] = x + vn;
+                vr[e] = vn[t];
+                xr[e] = x[t] + vn[t];
             }
         }
     }
     if (shrink) {
         beta = row_min<LPR>(beta);
         if (beta == __builtin_huge_val()) beta = 1.0;
-        for (int e = l; e < n; e += LPR) {  // own elements only
-            const double vn = Vn[e] * beta;
-            if (id.active) {
-                const double xn = xr[e] + vn;
-                vr[e] = vn;
-                xr[e] = xn;
+        if (stash) {
+            for (int e = l; e < n; e += LPR) {  // own elements only
+                const double vn = Vn[e] * beta;
+                if (id.active) {
+                    const double xn = xr[e] + vn;
+                    vr[e] = vn;
+                    xr[e] = xn;
+                }
+            }
+        } else {
+            for (int q0 = 0; q0 < nq; q0 += 2) {
+                double x[2], vn[2];
+                raw(q0, x, vn);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int e = (q0 + t) * LPR + l;
+                    if (e >= n || !id.active) continue;
+                    const double vb = vn[t] * beta;
+                    vr[e] = vb;
+                    xr[e] = x[t] + vb;
+                }
             }
         }
     }
@@ -175,7 +205,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void rows_select_kernel(
 extern "C" int sx_de_propose(const sx_de_args *a, double *cand, void *stream) {
     SX_REQUIRE(a != nullptr && cand != nullptr, "sx_de_propose: null pointer");
     SX_REQUIRE(a->buf0 && a->buf1 && a->state, "sx_de_propose: null device pointer");
-    SX_REQUIRE(a->P >= 2 && a->P < (int64_t)1 << 31 && a->n >= 1 && a->n <= kMaxDim && a->ld >= a->n, "sx_de_propose: bad shape");
+    SX_REQUIRE(a->P >= 2 && a->P < (int64_t)1 << 31 && a->n >= 1 && a->ld >= a->n, "sx_de_propose: bad shape");
     SX_REQUIRE(a->strategy >= 0 && a->strategy <= SX_DE_BEST2BIN, "sx_de_propose: unknown strategy");
     SX_REQUIRE(a->P - 1 >= donors_of(a->strategy), "sx_de_propose: population too small for the strategy");
     SX_REQUIRE(a->rng == SX_RNG_HOST || a->rng == SX_RNG_PHILOX, "sx_de_propose: unknown rng mode");
@@ -197,12 +227,12 @@ extern "C" int sx_de_propose(const sx_de_args *a, double *cand, void *stream) {
 extern "C" int sx_pso_move(const sx_pso_args *a, void *stream) {
     SX_REQUIRE(a != nullptr, "sx_pso_move: null args");
     SX_REQUIRE(a->X && a->V && a->pbest && a->gbest && a->state, "sx_pso_move: null device pointer");
-    SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->n <= kMaxDim && a->ld >= a->n, "sx_pso_move: bad shape");
+    SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->ld >= a->n, "sx_pso_move: bad shape");
     SX_REQUIRE(a->rng == SX_RNG_HOST || a->rng == SX_RNG_PHILOX, "sx_pso_move: unknown rng mode");
     SX_REQUIRE(a->rng != SX_RNG_HOST || (a->r1 && a->r2), "sx_pso_move: host draws missing");
     SX_REQUIRE(a->constraints == 0 || (a->lower && a->upper), "sx_pso_move: bounds missing");
     const Geometry g = row_geometry(a->P, a->n);
-    const size_t lds = (size_t)rows_per_block(a->n) * a->n * sizeof(double);
+    const size_t lds = a->n > kMaxDim ? 0 : (size_t)rows_per_block(a->n) * a->n * sizeof(double);
     if (a->rng == SX_RNG_PHILOX) {
         SX_DISPATCH_LPR(a->n, hipLaunchKernelGGL((pso_move_kernel<SX_RNG_PHILOX, LPR>), dim3(g.blocks), dim3(g.threads), lds,
                                                  (hipStream_t)stream, *a))
@@ -218,7 +248,7 @@ extern "C" int sx_rows_select(const double *cand, int64_t ldc, const double *f, 
                               int64_t ldx, double *xfun, double *candfit, int64_t P, int n, const sx_state *state,
                               double *part_f, int64_t *part_i, void *stream) {
     SX_REQUIRE(cand && f && xin && xout && xfun && state && part_f && part_i, "sx_rows_select: null pointer");
-    SX_REQUIRE(P >= 1 && n >= 1 && n <= kMaxDim && ldc >= n && ldx >= n, "sx_rows_select: bad shape");
+    SX_REQUIRE(P >= 1 && n >= 1 && ldc >= n && ldx >= n, "sx_rows_select: bad shape");
     const Geometry g = row_geometry(P, n);
     SX_DISPATCH_LPR(n, hipLaunchKernelGGL((rows_select_kernel<LPR>), dim3(g.blocks), dim3(g.threads), 0, (hipStream_t)stream,
                                           cand, ldc, f, xin, xout, ldx, xfun, candfit, P, n, state, part_f, part_i))

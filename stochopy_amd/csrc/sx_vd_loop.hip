@@ -36,7 +36,7 @@ constexpr int kVdWaves = kVdThreads / 64;
 constexpr int kVdPer = 8;  // elements per thread: n <= 4096, everything in registers (227 VGPRs; 1024 threads x 4 spill 154)
 
 // K values at once (kind[q]: 0 sum, 1 max, 2 min): one pair of barriers for all of them; every thread gets the results
-template <int K>
+template <int K, int NW = kVdWaves>
 __device__ void reduce_many(double (&v)[K], const int (&kind)[K], double (*red)[K]) {
 #pragma unroll
     for (int q = 0; q < K; ++q) {
@@ -55,7 +55,7 @@ __device__ void reduce_many(double (&v)[K], const int (&kind)[K], double (*red)[
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         double r = red[0][q];
-        for (int wv = 1; wv < kVdWaves; ++wv) {
+        for (int wv = 1; wv < NW; ++wv) {
             const double o = red[wv][q];
             r = kind[q] == 0 ? r + o : (kind[q] == 1 ? fmax(r, o) : fmin(r, o));
         }
@@ -380,6 +380,274 @@ __global__ __launch_bounds__(kVdThreads) void vd_update_kernel(const sx_vd_args 
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same two kernels for wide models (n > 4096, where VD-CMA matters most: vdcma/_vdcma.py:144-458 is the O(n) companion
+// of CMA-ES): the vectors no longer fit a workgroup's registers, so every phase walks them in memory (a few n-vectors, L2
+// resident) with 1 024 threads; p / q (later r, s, the natural-gradient steps) wait in two scratch vectors -- the partial
+// sums of sx_vdcma_moments, free once its finish kernel has run -- and y, avec, vn^2 are formed again where they are used.
+// Same expressions, same association; only the ORDER of the reductions' additions differs from the register kernel
+// (both are compared with the oracle to rounding, tests/test_gpu_wide.py).
+// ---------------------------------------------------------------------------
+constexpr int kVdWideThreads = 1024;
+constexpr int kVdWideWaves = kVdWideThreads / 64;
+
+__global__ __launch_bounds__(kVdWideThreads) void vd_inject_wide_kernel(const sx_vd_args a) {
+    __shared__ double red3[kVdWideWaves][3];
+    const sx_cma_state *state = (const sx_cma_state *)a.state;
+    if (state->done || state->reserved[3] == 0.0) return;
+    const int n = a.n, tid = threadIdx.x;
+    const double nv2 = state->reserved[1];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+    for (int e = tid; e < n; e += kVdWideThreads) {
+        const double ddx = a.dx[e] / a.dvec[e], z = a.zinj[e];
+        s1 += ddx * ddx;
+        s2 += ddx * a.vvec[e];
+        s3 += z * z;
+    }
+    double v3[3] = {s1, s2, s3};
+    const int k3[3] = {0, 0, 0};
+    reduce_many<3, kVdWideWaves>(v3, k3, red3);
+    const double mnorm = v3[0] - v3[1] * v3[1] / (1.0 + nv2);
+    const double fac = sqrt(v3[2]) / sqrt(mnorm);
+#pragma unroll 4
+    for (int e = tid; e < n; e += kVdWideThreads) a.dy[e] = fac * a.dx[e];
+}
+
+__global__ __launch_bounds__(kVdWideThreads) void vd_update_wide_kernel(const sx_vd_args a, int64_t gen,
+                                                                        double *__restrict__ sp, double *__restrict__ sq) {
+    constexpr int T = kVdWideThreads;
+    __shared__ double red1[kVdWideWaves][1];
+    __shared__ double red2[kVdWideWaves][2];
+    __shared__ double red4[kVdWideWaves][4];
+    __shared__ double red10[kVdWideWaves][10];
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    const int n = a.n, tid = threadIdx.x;
+    const double sigma0 = state->sigma, ps0 = state->reserved[0], nv2 = state->reserved[1], nv = state->reserved[2];
+    const bool inject = state->reserved[3] != 0.0;
+    const double fbest = state->fbest;
+    const double *wx = a.mout, *wy = a.mout + n, *pmu = a.mout + 2 * (int64_t)n, *qmu = a.mout + 3 * (int64_t)n;
+    auto rsum = [&](double x) {
+        double v[1] = {x};
+        const int k[1] = {0};
+        reduce_many<1, kVdWideWaves>(v, k, red1);
+        return v[0];
+    };
+    // ---- the injected pair in the ranking (:299-300), mean shift (:292-294) ----
+    double pos0 = 0.0, pos1 = 0.0;
+    if (inject) {
+        for (int64_t k = tid; k < a.P; k += T) {
+            const int64_t r = a.order[k];
+            if (r == 0) pos0 = (double)k;
+            if (r == 1) pos1 = (double)k;
+        }
+    }
+    double dx2 = 0.0, vmax = -__builtin_inf();
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) {
+        const double xm0 = a.xmean[e], v1 = a.vn[e];
+        const double dxe = wx[e] - a.wsum * xm0;
+        a.dx[e] = dxe;
+        a.xold[e] = xm0;
+        a.xmean[e] = xm0 + dxe;
+        dx2 += dxe * dxe;
+        vmax = fmax(vmax, v1 * v1);
+    }
+    {
+        double v4[4] = {pos0, pos1, dx2, vmax};
+        const int k4[4] = {0, 0, 0, 1};
+        reduce_many<4, kVdWideWaves>(v4, k4, red4);
+        pos0 = v4[0], pos1 = v4[1], dx2 = v4[2], vmax = v4[3];
+    }
+    // ---- step size from the rank gap (:298-306) ----
+    double ps = ps0, sigma = sigma0;
+    bool cond = true;
+    if (inject) {
+        const double gap = (pos1 - pos0) / ((double)a.P - 1.0);
+        ps = ps0 + a.cs * (gap - ps0);
+        sigma = sigma0 * exp(ps / a.ds);
+        cond = ps < 0.5;
+    }
+    // ---- model constants (:317-328) ----
+    const double gamma = 1.0 / sqrt(1.0 + nv2);
+    double alpha = sqrt(nv2 * nv2 + (1.0 + nv2) / vmax * (2.0 - gamma)) / (2.0 + nv2);
+    double beta = 0.0;
+    if (alpha < 1.0) {
+        const double t2 = 1.0 + 2.0 / nv2;
+        beta = (4.0 - (2.0 - gamma) / vmax) / (t2 * t2);
+    } else {
+        alpha = 1.0;
+    }
+    const double bsca = 2.0 * (alpha * alpha) - beta;
+    auto avec_of = [&](double vnn) { return 2.0 - (bsca + 2.0 * (alpha * alpha)) * vnn; };
+    // ---- evolution path (:309-314), y = pc / d, t = y . vn; avec (invavnn = vn^2 / avec) ----
+    const double cpc = sqrt(a.cc * (2.0 - a.cc) * a.mueff);
+    double t = 0.0, svi = 0.0;
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) {
+        double pce = a.pc[e] * (1.0 - a.cc);
+        if (cond) pce = pce + cpc * wy[e];
+        a.pc[e] = pce;
+        const double v1 = a.vn[e], y = pce / a.dvec[e];
+        t += y * v1;
+        const double vnn = v1 * v1;
+        svi += vnn * (vnn / avec_of(vnn));
+    }
+    {
+        double v2[2] = {t, svi};
+        const int k2[2] = {0, 0};
+        reduce_many<2, kVdWideWaves>(v2, k2, red2);
+        t = v2[0], svi = v2[1];
+    }
+    // ---- moments of the path (:340-345, :428-444), p and q (:348-352), vn . q ----
+    const double shrink = nv2 / (1.0 + nv2);
+    double vq = 0.0;
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) {
+        const double v1 = a.vn[e], y = a.pc[e] / a.dvec[e];
+        double p = a.cmu != 0.0 ? a.cmu * pmu[e] : 0.0;
+        double q = a.cmu != 0.0 ? a.cmu * qmu[e] : 0.0;
+        if (cond && a.c1 != 0.0) {
+            const double p_one = (y * y - shrink * ((t * y) * v1)) - 1.0;
+            const double q_one = t * y - (0.5 * ((t * t + 1.0) + nv2)) * v1;
+            p = p + a.c1 * p_one;
+            q = q + a.c1 * q_one;
+        }
+        sp[e] = p, sq[e] = q;
+        vq += v1 * q;
+    }
+    vq = rsum(vq);
+    const bool learn = a.cmu + a.c1 > 0.0;
+    // ---- natural gradient (:447-460): r overwrites p, then s overwrites r ----
+    double ri = 0.0;
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) {
+        const double v1 = a.vn[e], vnn = v1 * v1;
+        const double r = sp[e] - alpha / (1.0 + nv2) * (((2.0 + nv2) * sq[e]) * v1 - (nv2 * vq) * vnn);
+        sp[e] = r;
+        ri += r * (vnn / avec_of(vnn));
+    }
+    ri = rsum(ri);
+    double svn = 0.0;
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) {
+        const double v1 = a.vn[e], vnn = v1 * v1, av = avec_of(vnn);
+        const double sv = sp[e] / av - bsca * ri / (1.0 + bsca * svi) * (vnn / av);
+        sp[e] = sv;
+        svn += sv * vnn;
+    }
+    svn = rsum(svn);
+    double g2 = 0.0, mind = __builtin_inf();
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) {  // ngv overwrites q, ngd overwrites s
+        double qq = 0.0, pp = 0.0;
+        if (learn) {
+            const double v1 = a.vn[e], dv = a.dvec[e], sv = sp[e];
+            qq = sq[e] / nv - alpha / nv * ((2.0 + nv2) * (v1 * sv) - svn * v1);
+            pp = dv * sv;
+            g2 += qq * qq;
+            mind = fmin(mind, dv / fabs(pp));
+        }
+        sq[e] = qq, sp[e] = pp;
+    }
+    {
+        double v2[2] = {g2, mind};
+        const int k2[2] = {0, 2};
+        reduce_many<2, kVdWideWaves>(v2, k2, red2);
+        g2 = v2[0], mind = v2[1];
+    }
+    double up = 1.0;
+    if (learn) {
+        up = fmin(1.0, 0.7 * nv / sqrt(g2));
+        up = fmin(up, 0.7 * mind);
+    }
+    // ---- update of v and d (:371-378); the stopping rules' per-dimension counts; the best-fitness histories ----
+    double nv2n = 0.0, any3 = 0.0, any6 = 0.0, fail8 = 0.0, nan_sd = 0.0, sdmax = -__builtin_inf();
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) {
+        const double dv = a.dvec[e], vv0 = a.vvec[e];
+        const double sd = sqrt((dv * (1.0 + vv0 * vv0)) * dv);  // sqrt of diag D (I + v v^T) D (:249-254)
+        const double vv = vv0 + up * sq[e];
+        a.vvec[e] = vv;
+        a.dvec[e] = dv + up * sp[e];
+        nv2n += vv * vv;
+        if (0.2 * sigma * sd < 1.0e-10) any3 += 1.0;
+        if (sigma * sd > 1.0e3 * a.insigma) any6 += 1.0;
+        if (sd != sd) nan_sd += 1.0;
+        sdmax = fmax(sdmax, sd);
+        if (!(sigma * fabs(a.pc[e]) < 1.0e-11 * a.insigma)) fail8 += 1.0;
+    }
+    double wmax = -__builtin_inf(), wmin = __builtin_inf(), jmax = -__builtin_inf(), jmin = __builtin_inf();
+    if (gen >= a.ilim) {
+        const int64_t hi = gen + 1 < a.maxiter ? gen + 1 : a.maxiter;
+        for (int64_t k = gen - a.ilim + tid; k < hi; k += T) {
+            const double v = a.besthist[k];
+            wmax = fmax(wmax, v), wmin = fmin(wmin, v);
+        }
+    }
+    for (int64_t k = tid; k < a.maxiter; k += T) {
+        const double v = a.besthist[k];
+        jmax = fmax(jmax, v), jmin = fmin(jmin, v);
+    }
+    for (int64_t k = tid; k < a.P; k += T) {
+        const double v = a.fit[k];
+        jmax = fmax(jmax, v), jmin = fmin(jmin, v);
+    }
+    {
+        double v10[10] = {nv2n, any3, any6, fail8, nan_sd, sdmax, wmax, jmax, wmin, jmin};
+        const int k10[10] = {0, 0, 0, 0, 0, 1, 1, 1, 2, 2};
+        reduce_many<10, kVdWideWaves>(v10, k10, red10);
+        nv2n = v10[0], any3 = v10[1], any6 = v10[2], fail8 = v10[3], nan_sd = v10[4], sdmax = v10[5], wmax = v10[6];
+        jmax = v10[7], wmin = v10[8], jmin = v10[9];
+    }
+    const double nvn = sqrt(nv2n);
+#pragma unroll 4
+    for (int e = tid; e < n; e += T) a.vn[e] = a.vvec[e] / nvn;
+    int status = SX_STATUS_NONE;
+    if (gen >= a.maxiter)
+        status = -1;
+    else if (sqrt(dx2) <= a.xtol && fbest < a.ftol)
+        status = 0;
+    else if (fbest <= a.ftol)
+        status = 1;
+    else if (any3 > 0.0)
+        status = -3;
+    else if (gen >= a.ilim && wmax - wmin < 1.0e-10)
+        status = -5;
+    else if (any6 > 0.0)
+        status = -6;
+    else if (gen > 2 && jmax - jmin < 1.0e-12)
+        status = -7;
+    else if (fail8 == 0.0 && nan_sd == 0.0 && sigma * sdmax < 1.0e-11 * a.insigma)
+        status = -8;
+    if (status != SX_STATUS_NONE) {  // the caller's result: best candidate of THIS generation, un-standardised
+        const double *row = a.arx + state->best_row * (int64_t)n;
+        for (int e = tid; e < n; e += T) {
+            double x = row[e];
+            if (a.pen_ws != nullptr) x = fmin(fmax(x, -1.0), 1.0);
+            a.xbest[e] = x * a.xstd[e] + a.xm[e];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        state->sigma = sigma;
+        state->reserved[0] = ps;
+        state->reserved[1] = nv2n;
+        state->reserved[2] = nvn;
+        state->reserved[3] = 1.0;
+        state->reserved[4] = sqrt(1.0 + nv2n) - 1.0;
+        state->it = gen;
+        state->nfev = gen * a.P;
+        if (status != SX_STATUS_NONE) {
+            state->status = status;
+            state->stop_it = gen;
+            __threadfence();
+            state->done = 1;
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -388,9 +656,8 @@ int check_vd_args(const sx_vd_args *a, int64_t gen) {
                    a->pc && a->zinj && a->dy && a->w && a->mws && a->mout && a->besthist && a->xm && a->xstd && a->xbest &&
                    a->order && a->state,
                "sx_vdcma_generation: null pointer");
-    SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->n <= kVdPer * kVdThreads && a->mu >= 1 && a->mu <= a->P && gen >= 1 &&
-                   gen <= a->maxiter,
-               "sx_vdcma_generation: bad shape or generation number (n <= 4096)");
+    SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->mu >= 1 && a->mu <= a->P && gen >= 1 && gen <= a->maxiter,
+               "sx_vdcma_generation: bad shape or generation number");
     return 0;
 }
 
@@ -406,7 +673,10 @@ int vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t rows, 
     if ((rc = sx_cmaes_normals(a->Z, rows, n, row0, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
     // the injection's own normal row: "row P" of the generation, one past the population (:245)
     if ((rc = sx_cmaes_normals(a->zinj, 1, n, a->P, (uint32_t)gen, a->key0, a->key1, stream))) return rc;
-    hipLaunchKernelGGL(vd_inject_kernel, dim3(1), dim3(kVdThreads), 0, st, *a);
+    if (n <= kVdPer * kVdThreads)
+        hipLaunchKernelGGL(vd_inject_kernel, dim3(1), dim3(kVdThreads), 0, st, *a);
+    else
+        hipLaunchKernelGGL(vd_inject_wide_kernel, dim3(1), dim3(kVdWideThreads), 0, st, *a);
     if ((rc = sx::vd_sample_launch(a->Z, rows, n, a->dvec, a->vn, a->xmean, a->dy, ary_out, arx_out, state, stream, row0)))
         return rc;
     if (a->pen_ws == nullptr) return sx_eval(a->fun_id, arx_out, rows, n, n, a->xm, a->xstd, fit_out, nullptr, nullptr, stream);
@@ -457,7 +727,12 @@ int vd_model_update(const sx_vd_args *a, int64_t gen, void *stream) {
     if ((rc = sx::vd_moments_launch(a->arx, a->ary, a->order, a->w, a->mu, n, a->dvec, a->vn, 0.0, state, a->mws, a->mout,
                                     stream)))
         return rc;
-    hipLaunchKernelGGL(vd_update_kernel, dim3(1), dim3(kVdThreads), 0, st, *a, gen);
+    if (n <= kVdPer * kVdThreads) {
+        hipLaunchKernelGGL(vd_update_kernel, dim3(1), dim3(kVdThreads), 0, st, *a, gen);
+    } else {  // scratch: the partial sums of the moments kernels (4 x 64 x n doubles behind t_k), free by now
+        double *part = a->mws + ((a->mu + 7) / 8) * 8;
+        hipLaunchKernelGGL(vd_update_wide_kernel, dim3(1), dim3(kVdWideThreads), 0, st, *a, gen, part, part + n);
+    }
     SX_LAUNCH_CHECK();
     return 0;
 }

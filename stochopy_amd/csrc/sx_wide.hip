@@ -1,0 +1,702 @@
+// Wide rows: individuals of more than 4096 elements (sx_device.hpp kMaxDim), ONE WORKGROUP per individual.
+//
+// The reference has no dimension limit (stochopy/optimize/de/_de.py:208-218: rows are (n,) numpy vectors of any length;
+// stochopy/optimize/vdcma/_vdcma.py:144-458 exists for n >= 4096); the row kernels of sx_rowops.hpp do: one wavefront per
+// row, the whole trial vector in that wavefront's LDS slice, numpy's summation plan in the kernel arguments (<= 64
+// leaves).  Here
+//   * numpy does not hand a long reduction to its pairwise sum in one piece: the ufunc machinery feeds the inner loop
+//     np.getbufsize() = 8192 elements at a time, so `a.sum()` of m > 8192 terms is
+//         acc = 0.0;  for every 8192-term piece, in order:  acc = acc + pairwise_sum(piece)
+//     (checked against numpy for m = 8193 ... 65536, and against the reference's own objective values:
+//     tests/golden/vdcma_wide.json objective_kat).  Rows of up to 4096 elements never see this; wide rows do;
+//   * the plan lives in device memory (built once per number of terms, cached): for every 8192-term piece the leaf table
+//     of numpy's pairwise recursion (loops_utils.h.src: <= 128 terms per leaf, split at n/2 rounded down to a multiple of
+//     8) and the recursion's combines ordered by LEVEL -- combines of one level touch disjoint leaf slots, so a level is
+//     one parallel step for all pieces at once (6 barriers for a full piece instead of 63 dependent additions); the
+//     pieces' sums (a full piece has 64 leaves: piece c ends in slot 64 c) are then added up in order;
+//   * the row is walked in CHUNKS of whole leaves: the workgroup's threads produce the chunk's elements (coalesced runs,
+//     four elements and all their loads in flight per thread, the Philox layout of the whole-wave rows: element e is lane
+//     e % 64 at step e / 64), stage them in LDS, and every 8-lane group takes one leaf (eight accumulators over the
+//     8-blocks, the tree, the tail) exactly as row_reduce_leaves_fused does: same additions in the same order, same bits;
+//   * a row of up to ~18 000 elements stays RESIDENT in LDS (one chunk: the DE trial is stored from there when it wins,
+//     PSO's new position is copied to pbest from there); longer rows are STREAMED through a 4096-element stage: DE writes
+//     the trial into the next buffer as it is produced and copies the old row over it if the trial lost, PSO re-reads the
+//     position it has just written.
+// Objective values, draws, selection and records are those of the narrow kernels: a wide run is compared with the oracle
+// bit for bit (tests/test_gpu_wide.py).
+//
+// Reference code replaced: as sx_de.hip / sx_pso.hip / sx_core.hip (de/_de.py:314-351, cpso/_cpso.py:324-361,
+// _common.py:34-90, 123-130; factory/benchmark.py:14-156).
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "sx_device.hpp"
+#include "sx_host.hpp"
+#include "sx_rowops.hpp"
+#include "sx_wide.hpp"
+
+using namespace sx;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// the plan in device memory:  [0] nleaf  [1] tail  [2] mb  [3] nlevels  [4] npiece (8192-term pieces of the sum)
+//                             [5 .. 5+nleaf)            end block (exclusive) of leaf t
+//                             [.. + nlevels + 1)        first combine of level v (prefix sums)
+//                             [.. + 2 (nleaf-1))        (left, right) leaf slots of the combines, level by level
+// ---------------------------------------------------------------------------
+struct HostPlan {
+    std::vector<int32_t> end;
+    std::vector<std::pair<int32_t, int32_t>> merge;
+    std::vector<int32_t> level;
+    int blocks = 0;
+    // returns (slot of the sum, height of the subtree)
+    std::pair<int, int> rec(int64_t m) {
+        if (m <= 128) {
+            blocks += (int)(m / 8);
+            end.push_back(blocks);
+            return {(int)end.size() - 1, 0};
+        }
+        int64_t h = m / 2;
+        h -= h % 8;
+        const auto a = rec(h);
+        const auto b = rec(m - h);
+        const int lv = a.second > b.second ? a.second : b.second;
+        merge.push_back({a.first, b.first});
+        level.push_back(lv);
+        return {a.first, lv + 1};
+    }
+};
+
+constexpr int64_t kNumpyBuf = 8192;  // np.getbufsize(): the pieces numpy's reduction hands to its pairwise sum
+
+struct CachedPlan {
+    int32_t *dev = nullptr;
+    int nleaf = 0;
+};
+std::mutex g_plan_mutex;
+std::map<std::pair<int, int64_t>, CachedPlan> g_plans;  // (device, terms) -> plan; never freed (a few KB each)
+
+int get_plan(int64_t m, hipStream_t s, CachedPlan *out) {
+    int dev = 0;
+    SX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    auto it = g_plans.find({dev, m});
+    if (it != g_plans.end()) {
+        *out = it->second;
+        return 0;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        set_error("wide rows: the summation plan of this row length is built (allocation + upload) on first use, which "
+                  "cannot happen inside a stream capture -- evaluate once before capturing");
+        return -1;
+    }
+    HostPlan hp;
+    int npiece = 0;
+    for (int64_t c0 = 0; c0 < m; c0 += kNumpyBuf, ++npiece) {  // (a piece starts at a block boundary and at leaf slot 64 c)
+        hp.blocks = (int)(c0 / kGroup);
+        (void)hp.rec(m - c0 < kNumpyBuf ? m - c0 : kNumpyBuf);
+    }
+    const int nleaf = (int)hp.end.size();
+    int nlevels = 0;
+    for (int lv : hp.level) nlevels = lv + 1 > nlevels ? lv + 1 : nlevels;
+    std::vector<int32_t> buf(5 + (size_t)nleaf + (size_t)nlevels + 1 + 2 * hp.merge.size());
+    buf[0] = nleaf;
+    buf[1] = (int32_t)(m % 8);
+    buf[2] = (int32_t)(m / 8);
+    buf[3] = nlevels;
+    buf[4] = npiece;
+    for (int t = 0; t < nleaf; ++t) buf[5 + t] = hp.end[t];
+    int32_t *off = buf.data() + 5 + nleaf;
+    int32_t *pairs = off + nlevels + 1;
+    int pos = 0;
+    for (int lv = 0; lv < nlevels; ++lv) {
+        off[lv] = pos;
+        for (size_t k = 0; k < hp.merge.size(); ++k) {
+            if (hp.level[k] != lv) continue;
+            pairs[2 * pos] = hp.merge[k].first;
+            pairs[2 * pos + 1] = hp.merge[k].second;
+            ++pos;
+        }
+    }
+    off[nlevels] = pos;
+    CachedPlan cp;
+    cp.nleaf = nleaf;
+    SX_HIP(hipMalloc((void **)&cp.dev, buf.size() * sizeof(int32_t)));
+    SX_HIP(hipMemcpy(cp.dev, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    g_plans[{dev, m}] = cp;
+    *out = cp;
+    return 0;
+}
+
+struct WideCtx {
+    const int32_t *end, *lvl, *pairs;
+    int nleaf, tail, mb, nlevels, npiece;
+};
+__device__ __forceinline__ WideCtx wide_ctx(const int32_t *__restrict__ plan) {
+    WideCtx c;
+    c.nleaf = plan[0], c.tail = plan[1], c.mb = plan[2], c.nlevels = plan[3], c.npiece = plan[4];
+    c.end = plan + 5;
+    c.lvl = c.end + c.nleaf;
+    c.pairs = c.lvl + c.nlevels + 1;
+    return c;
+}
+
+// Leaves [leaf0, leaf1) of the row, elements staged at Sd[e] (Sd = stage - first staged element): one leaf per 8-lane
+// group and pass -- lane j walks accumulator j over the leaf's 8-blocks, forming the terms on the way
+// (row_reduce_leaves_fused's arithmetic) -> LA[t] (and LB[t]).
+template <int FUN, int T>
+__device__ __forceinline__ void wide_reduce_leaves(const double *Sd, int leaf0, int leaf1, const WideCtx &c, double *LA,
+                                                   double *LB) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    const int j = (int)threadIdx.x & (kGroup - 1), grp = (int)threadIdx.x >> 3;
+    const double identB = BMUL ? 1.0 : 0.0;
+    for (int t0 = leaf0; t0 < leaf1; t0 += T / kGroup) {
+        const bool on = t0 + grp < leaf1;
+        const int t = on ? t0 + grp : leaf1 - 1;  // idle groups shadow the last leaf and keep nothing
+        const int b0 = t > 0 ? c.end[t - 1] : 0, b1 = c.end[t];
+        const int cnt = b1 - b0;  // 8 .. 16 blocks (fewer only in a last piece of < 64 terms; none: its terms are all tail)
+        const double *U = Sd + b0 * kGroup + j;
+        double chA = 0.0, chB = identB;
+#pragma unroll
+        for (int h0 = 0; h0 < kLeafBlocks; h0 += 8) {
+            double x[8], xn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = h0 + u < cnt;
+                x[u] = in ? U[(h0 + u) * kGroup] : 0.0;
+                xn[u] = (O::NEXT && in) ? U[(h0 + u) * kGroup + 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (h0 + u < cnt) {
+                    double a, b;
+                    O::term(x[u], xn[u], (b0 + h0 + u) * kGroup + j, a, b);
+                    if (h0 + u == 0) {
+                        chA = a;
+                        chB = b;
+                    } else {
+                        chA = chA + a;
+                        if (TWO) chB = combine<BMUL>(chB, b);
+                    }
+                }
+            }
+        }
+        double curA = group_tree<false>(chA);
+        double curB = TWO ? group_tree<BMUL>(chB) : identB;
+        if (t == c.nleaf - 1) {  // the tail terms, one by one, after the last leaf's tree
+            const int e0 = c.mb * kGroup;
+            for (int k = 0; k < c.tail; ++k) {
+                double a, b;
+                O::term(Sd[e0 + k], O::NEXT ? Sd[e0 + k + 1] : 0.0, e0 + k, a, b);
+                curA = curA + a;
+                if (TWO) curB = combine<BMUL>(curB, b);
+            }
+        }
+        if (on && j == 0) {
+            LA[t] = curA;
+            if (TWO) LB[t] = curB;
+        }
+    }
+}
+
+// the recursion's combines, level by level (a level's combines touch disjoint slots); the row's sums end in slot 0
+template <int FUN, int T>
+__device__ __forceinline__ double wide_finish(const WideCtx &c, int n, double *LA, double *LB) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    __syncthreads();
+    for (int lv = 0; lv < c.nlevels; ++lv) {
+        const int o1 = c.lvl[lv + 1];
+        for (int i = c.lvl[lv] + (int)threadIdx.x; i < o1; i += T) {
+            const int l = c.pairs[2 * i], r = c.pairs[2 * i + 1];
+            LA[l] = LA[l] + LA[r];
+            if (TWO) LB[l] = combine<BMUL>(LB[l], LB[r]);
+        }
+        __syncthreads();
+    }
+    // add.reduce starts from the identity and takes the 8192-term pieces in order (piece c: slot 64 c)
+    constexpr int kPieceLeaves = kNumpyBuf / 128;
+    double sa = 0.0, sb = BMUL ? 1.0 : 0.0;
+    for (int p = 0; p < c.npiece; ++p) {
+        sa = sa + LA[p * kPieceLeaves];
+        if (TWO) sb = combine<BMUL>(sb, LB[p * kPieceLeaves]);
+    }
+    return O::finish(sa, sb, n);
+}
+
+// The row, chunk by chunk: produce(e0, e1, e1s, Sd) stages the elements [e0, e1s) at Sd[e] and commits whatever it
+// writes to memory for [e0, e1) only -- for an objective that reads the next element too, e1s = e1 + 1: that element is
+// staged again (and committed) by the next chunk.  chunk_leaves >= nleaf: the row is resident (one chunk).
+template <int FUN, int T, class Produce>
+__device__ __forceinline__ double wide_row(const WideCtx &c, int n, int chunk_leaves, double *S, double *LA, double *LB,
+                                           Produce &&produce) {
+    constexpr bool NEXT = Obj<FUN>::NEXT;
+    for (int leaf0 = 0; leaf0 < c.nleaf; leaf0 += chunk_leaves) {
+        const int leaf1 = leaf0 + chunk_leaves < c.nleaf ? leaf0 + chunk_leaves : c.nleaf;
+        const bool last = leaf1 == c.nleaf;
+        const int e0 = leaf0 > 0 ? c.end[leaf0 - 1] * kGroup : 0;
+        const int e1 = last ? n : c.end[leaf1 - 1] * kGroup;
+        const int e1s = last ? n : e1 + (NEXT ? 1 : 0);
+        if (leaf0 > 0) __syncthreads();  // the previous chunk's leaves have been read
+        produce(e0, e1, e1s, S - e0);
+        __syncthreads();
+        wide_reduce_leaves<FUN, T>(S - e0, leaf0, leaf1, c, LA, LB);
+    }
+    return wide_finish<FUN, T>(c, n, LA, LB);
+}
+
+constexpr int kEvalThreads = 256;
+constexpr int kGenThreads = 512;
+constexpr int kStreamLeaves = 32;             // leaves per chunk of a streamed row: <= 4096 elements staged
+constexpr size_t kResidentLds = 148 * 1024;   // a resident row + its leaf sums must fit here (160 KB per CU)
+constexpr int kStageElems = kStreamLeaves * 128 + 16;
+
+__host__ __device__ inline int wide_leaf_cap(int n) { return n / 64 + 2; }
+inline size_t wide_lds_bytes(int n, bool resident) {
+    return ((size_t)(resident ? n + 16 : kStageElems) + 2 * (size_t)wide_leaf_cap(n)) * sizeof(double);
+}
+inline bool wide_resident(int n) { return wide_lds_bytes(n, true) <= kResidentLds; }
+
+// ---------------------------------------------------------------------------
+// objective of rows of X (sx_eval; the CMA-ES family's un-standardisation / clipping / penalty sums as in eval_kernel)
+// ---------------------------------------------------------------------------
+template <int FUN>
+__global__ __launch_bounds__(kEvalThreads) void wide_eval_kernel(const double *__restrict__ X, int64_t P, int n, int64_t ldx,
+                                                                 const double *__restrict__ xm, const double *__restrict__ xstd,
+                                                                 double *__restrict__ f, const int32_t *__restrict__ plan,
+                                                                 double *__restrict__ part_f, int64_t *__restrict__ part_i,
+                                                                 const int clip, const double *__restrict__ pen_v,
+                                                                 double *__restrict__ pen_out) {
+    constexpr int T = kEvalThreads;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double s_pen[T / kWave];
+    const WideCtx c = wide_ctx(plan);
+    double *S = lds, *LA = lds + kStageElems, *LB = LA + wide_leaf_cap(n);
+    const int64_t row = blockIdx.x;
+    const double *__restrict__ xr = X + row * ldx;
+    const bool affine = xm != nullptr;
+    const int tid = (int)threadIdx.x;
+    double pacc = 0.0;
+    const double val = wide_row<FUN, T>(c, n, kStreamLeaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
+        for (int eb = e0 + tid; eb < e1s; eb += 8 * T) {  // eight row loads per thread in flight
+            double xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = eb + u * T < e1s ? xr[eb + u * T] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = eb + u * T;
+                if (e >= e1s) continue;
+                double v = xv[u];
+                if (clip) {  // cmaes/_constraints.py:29-31, :79
+                    const double cl = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+                    if (pen_v != nullptr && e < e1) pacc += ((cl - v) * (cl - v)) * pen_v[e];
+                    v = cl;
+                }
+                if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171
+                Sd[e] = v;
+            }
+        }
+    });
+    if (pen_out != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pacc += __shfl_xor(pacc, off, kWave);
+        if ((tid & 63) == 0) s_pen[tid >> 6] = pacc;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int w = 0; w < T / kWave; ++w) s += s_pen[w];
+            pen_out[row] = s;
+        }
+    }
+    if (tid == 0) {
+        f[row] = val;
+        if (part_f != nullptr) part_f[row] = val, part_i[row] = row;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// DE generation (de_generation_kernel<XM = 0> for wide rows): the state is ONE sx_state, the best / termination step a
+// kernel of its own; one record per row.
+// ---------------------------------------------------------------------------
+template <int FUN, int RNG>
+__global__ __launch_bounds__(kGenThreads) void wide_de_kernel(const sx_de_args a, const int32_t *__restrict__ plan,
+                                                              const int chunk_leaves) {
+    constexpr int T = kGenThreads;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const sx_state *sin = a.state;
+    if (sin->done) return;
+    const WideCtx c = wide_ctx(plan);
+    const int n = a.n;
+    const bool resident = chunk_leaves >= c.nleaf;
+    double *S = lds, *LA = lds + (resident ? n + 16 : kStageElems), *LB = LA + wide_leaf_cap(n);
+    const int64_t P = a.P, ld = a.ld, row = blockIdx.x, it = sin->it;
+    const int tid = (int)threadIdx.x;
+    const uint32_t gen = (uint32_t)(it + 1), grow = (uint32_t)(a.row0 + row);
+    const double *__restrict__ cur = (it & 1) ? a.buf1 : a.buf0;
+    double *__restrict__ nxt = (it & 1) ? a.buf0 : a.buf1;
+    const double fold = a.fit[row];
+    const double *__restrict__ xi = cur + row * ld;
+    double *__restrict__ xo = nxt + row * ld;
+    const int strategy = a.strategy, k = donors_of(strategy);
+    const bool repair = a.constraints != 0;
+    const bool use_best = strategy == SX_DE_BEST1BIN || strategy == SX_DE_BEST2BIN;
+    int64_t d[kMaxDonors];
+    int irand;
+    if (RNG == SX_RNG_PHILOX) {
+        philox_donors(P, k, row, grow, gen, a.key0, a.key1, n, d, irand);
+    } else {
+#pragma unroll
+        for (int t = 0; t < kMaxDonors; ++t) d[t] = t < k ? (int64_t)a.donors[(int64_t)t * P + row] : 0;
+        irand = a.irand[row];
+    }
+    const double *pd[kMaxDonors];
+#pragma unroll
+    for (int t = 0; t < kMaxDonors; ++t) pd[t] = cur + d[t] * ld;
+    const double *__restrict__ gb = a.gbest != nullptr ? a.gbest : cur + sin->gbidx * ld;
+    const double F = a.F, CR = a.CR;
+    const double *r1row = RNG == SX_RNG_HOST ? a.r1 + row * (int64_t)n : nullptr;
+    const double *rsrow = (RNG == SX_RNG_HOST && repair) ? a.resample + row * (int64_t)n : nullptr;
+
+    // thread -> (k256, l): the four elements 256 k256 + l + 64 t, t = 0..3 -- steps q = 4 k256 + t of lane l in the
+    // whole-wave layout, i.e. ONE Philox call (slot (q >> 2) * 64 + l = 64 k256 + l) for their crossover uniforms
+    const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
+        for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
+            const int eb = (g >> 6) * 256 + (g & 63);
+            double x[4], dv[kMaxDonors][4], gv[4], r[4], rs[4], lo[4], hi[4];
+            bool in[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = eb + 64 * t;
+                in[t] = e >= e0 && e < e1s;
+                x[t] = in[t] ? xi[e] : 0.0;
+                gv[t] = (use_best && in[t]) ? gb[e] : 0.0;
+#pragma unroll
+                for (int s = 0; s < kMaxDonors; ++s) dv[s][t] = (s < k && in[t]) ? pd[s][e] : 0.0;
+                r[t] = 2.0, rs[t] = 0.0, lo[t] = 0.0, hi[t] = 0.0;
+                if (RNG == SX_RNG_HOST && in[t]) {
+                    r[t] = r1row[e];
+                    if (repair) rs[t] = rsrow[e];
+                }
+                if (repair && in[t]) lo[t] = a.lower[e], hi[t] = a.upper[e];
+            }
+            if (RNG == SX_RNG_PHILOX) {
+                const U4 w = philox4x32_10((uint32_t)g, grow, gen, kPurposeDeCross, a.key0, a.key1);
+                r[0] = u32(w.x), r[1] = u32(w.y), r[2] = u32(w.z), r[3] = u32(w.w);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = eb + 64 * t;
+                if (!in[t]) continue;
+                const double v = de_mutant(strategy, gv[t], dv[0][t], dv[1][t], dv[2][t], dv[3][t], dv[4][t], F);
+                double cand = (e == irand || r[t] <= CR) ? v : x[t];  // de/_de.py:341-344
+                if (repair && (cand < lo[t] || cand > hi[t]))         // de/_constraints.py:21-26
+                    cand = RNG == SX_RNG_HOST
+                               ? rs[t]
+                               : lo[t] + (hi[t] - lo[t]) * philox_u53(e, kWave, grow, gen, kPurposeDeResample, a.key0, a.key1);
+                Sd[e] = cand;
+                if (!resident && e < e1) xo[e] = cand;  // streamed: the trial goes out as it is produced
+            }
+        }
+    });
+    const bool better = fc < fold;  // _common.py:127 strict <
+    if (resident || !better) {      // the row of the next generation: the trial (from LDS) or the old row
+        const double *src = better ? S : xi;
+        for (int eb = tid; eb < n; eb += 8 * T) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = eb + u * T < n ? src[eb + u * T] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (eb + u * T < n) xo[eb + u * T] = v[u];
+        }
+    }
+    if (tid == 0) {
+        if (better) a.fit[row] = fc;
+        if (a.candfit != nullptr) a.candfit[row] = fc;
+        a.part_f[row] = better ? fc : fold;
+        a.part_i[row] = row;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// PSO / CPSO generation (pso_generation_kernel's general form for wide rows): X, V, pbest in place; pending
+// restarts re-seeded here; Shrink takes the row-wide beta from a pass of its own and forms the velocities again.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wide_sort_key(double f) {  // (sx_pso.hip sort_key)
+    const unsigned long long b = (unsigned long long)__double_as_longlong(f);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+template <int FUN, int RNG>
+__global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args a, const int32_t *__restrict__ plan,
+                                                               const int chunk_leaves) {
+    constexpr int T = kGenThreads;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double s_beta[T / kWave];
+    const sx_state *st = a.state;
+    if (st->done) return;
+    const WideCtx c = wide_ctx(plan);
+    const int n = a.n;
+    const bool resident = chunk_leaves >= c.nleaf;
+    double *S = lds, *LA = lds + (resident ? n + 16 : kStageElems), *LB = LA + wide_leaf_cap(n);
+    const int64_t ld = a.ld, row = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const uint32_t gen = (uint32_t)(st->it + 1), grow = (uint32_t)(a.row0 + row);
+    double fold = a.pbestfit[row];
+    bool reseed = false;
+    if (RNG == SX_RNG_PHILOX && a.pending_restart != nullptr)
+        reseed = a.pending_restart[0] != 0ull && wide_sort_key(fold) >= a.pending_restart[1];
+    if (reseed) fold = 1.0e30;
+    double *__restrict__ xr = a.X + row * ld;
+    double *__restrict__ vr = a.V + row * ld;
+    double *__restrict__ pb = a.pbest + row * ld;
+    const double *__restrict__ gb = a.gbest;
+    const double w = a.w, c1 = a.c1, c2 = a.c2;
+    const bool shrink = a.constraints != 0;
+    const double *r1row = RNG == SX_RNG_HOST ? a.r1 + row * (int64_t)n : nullptr;
+    const double *r2row = RNG == SX_RNG_HOST ? a.r2 + row * (int64_t)n : nullptr;
+
+    // the four elements 256 k256 + l + 64 t of group g = 64 k256 + l (steps q = 4 k256 + t of lane l): position, raw new
+    // velocity (cpso/_cpso.py:326) -- two Philox calls (slot (q >> 1) * 64 + l: words (0,1) / (2,3) = (r1, r2) of even /
+    // odd q); a re-seeded row draws its position instead of loading it (pso_restart_apply_kernel's draws), V = 0, pbest = X
+    auto elems = [&](int g, int lo_e, int hi_e, double(&x)[4], double(&vn)[4], bool(&in)[4]) {
+        const int eb = (g >> 6) * 256 + (g & 63);
+        double v[4], p[4], gv[4], r1[4], r2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = eb + 64 * t;
+            in[t] = e >= lo_e && e < hi_e;
+            const bool ldrow = in[t] && !reseed;
+            x[t] = ldrow ? xr[e] : 0.0;
+            v[t] = ldrow ? vr[e] : 0.0;
+            p[t] = ldrow ? pb[e] : 0.0;
+            gv[t] = in[t] ? gb[e] : 0.0;
+            r1[t] = (RNG == SX_RNG_HOST && in[t]) ? r1row[e] : 0.0;
+            r2[t] = (RNG == SX_RNG_HOST && in[t]) ? r2row[e] : 0.0;
+        }
+        if (RNG == SX_RNG_PHILOX) {
+#pragma unroll
+            for (int t = 0; t < 4; t += 2) {
+                const uint32_t slot = (uint32_t)(((g >> 6) * 4 + t) >> 1) * 64u + (uint32_t)(g & 63);
+                const U4 wd = philox4x32_10(slot, grow, gen, kPurposePsoR1, a.key0, a.key1);
+                r1[t] = u32(wd.x), r2[t] = u32(wd.y), r1[t + 1] = u32(wd.z), r2[t + 1] = u32(wd.w);
+                if (reseed) {
+                    const U4 wr = philox4x32_10(slot, grow, gen - 1u, kPurposePsoRestart, a.key0, a.key1);
+                    const double u[2] = {u53(wr.x, wr.y), u53(wr.z, wr.w)};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = eb + 64 * (t + h);
+                        if (in[t + h]) {
+                            const double lo = a.lower[e];
+                            x[t + h] = lo + (a.upper[e] - lo) * u[h];
+                            p[t + h] = x[t + h];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vn[t] = pso_velocity(w, v[t], c1, r1[t], p[t], x[t], c2, r2[t], gv[t]);
+    };
+
+    double beta = 1.0;
+    if (shrink) {  // cpso/_constraints.py:22-50: beta = min over the violated dimensions of (bound - x) / v
+        double bmin = __builtin_huge_val();
+        for (int g = tid; g < ((n + 255) >> 8) * 64; g += T) {
+            double x[4], vn[4];
+            bool in[4];
+            elems(g, 0, n, x, vn, in);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!in[t]) continue;
+                const int e = (g >> 6) * 256 + (g & 63) + 64 * t;
+                const double xc = x[t] + vn[t], lo = a.lower[e], hi = a.upper[e];
+                if (xc < lo) bmin = fmin(bmin, (lo - x[t]) / vn[t]);
+                if (xc > hi) bmin = fmin(bmin, (hi - x[t]) / vn[t]);
+            }
+        }
+        bmin = wave_min_f64(bmin);
+        if ((tid & 63) == 0) s_beta[tid >> 6] = bmin;
+        __syncthreads();
+        bmin = s_beta[0];
+        for (int wv = 1; wv < T / kWave; ++wv) bmin = fmin(bmin, s_beta[wv]);
+        beta = bmin == __builtin_huge_val() ? 1.0 : bmin;
+    }
+    const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
+        for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
+            double x[4], vn[4];
+            bool in[4];
+            elems(g, e0, e1s, x, vn, in);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!in[t]) continue;
+                const int e = (g >> 6) * 256 + (g & 63) + 64 * t;
+                const double vf = shrink ? vn[t] * beta : vn[t];  // V *= beta[:, None]
+                const double xn = x[t] + vf;
+                Sd[e] = xn;
+                if (e < e1) {  // (the look-ahead element is committed by its own chunk: X and V are updated in place)
+                    vr[e] = vf;
+                    xr[e] = xn;
+                    if (reseed) pb[e] = x[t];  // pbest = X of the re-seeded row (kept unless the new position beats 1e30)
+                }
+            }
+        }
+    });
+    const bool better = fc < fold;  // _common.py:127 strict <
+    if (better) {
+        if (!resident) {
+            __threadfence_block();
+            __syncthreads();  // the positions written above, by other threads of this workgroup
+        }
+        const double *src = resident ? S : xr;
+        for (int eb = tid; eb < n; eb += 8 * T) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = eb + u * T < n ? src[eb + u * T] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (eb + u * T < n) pb[eb + u * T] = v[u];
+        }
+    }
+    if (tid == 0) {
+        if (better)
+            a.pbestfit[row] = fc;
+        else if (reseed)
+            a.pbestfit[row] = 1.0e30;
+        if (a.candfit != nullptr) a.candfit[row] = fc;
+        a.part_f[row] = better ? fc : fold;
+        a.part_i[row] = row;
+    }
+}
+
+template <template <int> class K>
+void *pick_fun(int fun_id) {
+    switch (fun_id) {
+        case SX_FUN_ACKLEY: return K<SX_FUN_ACKLEY>::ptr();
+        case SX_FUN_GRIEWANK: return K<SX_FUN_GRIEWANK>::ptr();
+        case SX_FUN_QUARTIC: return K<SX_FUN_QUARTIC>::ptr();
+        case SX_FUN_RASTRIGIN: return K<SX_FUN_RASTRIGIN>::ptr();
+        case SX_FUN_ROSENBROCK: return K<SX_FUN_ROSENBROCK>::ptr();
+        case SX_FUN_SPHERE: return K<SX_FUN_SPHERE>::ptr();
+        case SX_FUN_STYBLINSKI_TANG: return K<SX_FUN_STYBLINSKI_TANG>::ptr();
+    }
+    return nullptr;
+}
+template <int FUN> struct EvalK { static void *ptr() { return (void *)wide_eval_kernel<FUN>; } };
+template <int FUN> struct DePhK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX>; } };
+template <int FUN> struct DeHoK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_HOST>; } };
+template <int FUN> struct PsoPhK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX>; } };
+template <int FUN> struct PsoHoK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_HOST>; } };
+
+std::mutex g_attr_mutex;
+std::map<void *, size_t> g_attr;  // kernels whose dynamic LDS limit has been raised (per process; devices share code objects)
+int allow_lds(void *fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    auto it = g_attr.find(fn);
+    if (it != g_attr.end() && it->second >= bytes) return 0;
+    SX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResidentLds));
+    g_attr[fn] = kResidentLds;
+    return 0;
+}
+
+struct GenLaunch {
+    void *fn;
+    const int32_t *plan;
+    int chunk_leaves;
+    size_t lds;
+};
+int gen_launch_for(void *fn, int fun_id, int n, hipStream_t s, GenLaunch *out) {
+    SX_REQUIRE(fn != nullptr, "wide rows: unknown objective");
+    SX_REQUIRE(n <= kWideMaxDim, "dimension above the wide-row limit (n <= 262144)");
+    CachedPlan cp;
+    if (int rc = get_plan(sx_fun_terms(fun_id, n), s, &cp)) return rc;
+    const bool resident = wide_resident(n);
+    out->fn = fn;
+    out->plan = cp.dev;
+    out->chunk_leaves = resident ? cp.nleaf : kStreamLeaves;
+    out->lds = wide_lds_bytes(n, resident);
+    return allow_lds(fn, out->lds);
+}
+
+int add_node(hipGraph_t graph, hipGraphNode_t *prev, void *func, dim3 grid, dim3 block, unsigned lds, void **kargs) {
+    hipKernelNodeParams kp = {};
+    kp.func = func;
+    kp.gridDim = grid;
+    kp.blockDim = block;
+    kp.sharedMemBytes = lds;
+    kp.kernelParams = kargs;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    SX_HIP(hipGraphAddKernelNode(&node, graph, *prev ? prev : nullptr, *prev ? 1 : 0, &kp));
+    *prev = node;
+    return 0;
+}
+
+}  // namespace
+
+namespace sx {
+
+int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
+              double *part_f, int64_t *part_i, int clip, const double *pen_v, double *pen_out, hipStream_t s) {
+    SX_REQUIRE(n <= kWideMaxDim, "dimension above the wide-row limit (n <= 262144)");
+    void *fn = pick_fun<EvalK>(fun_id);
+    SX_REQUIRE(fn != nullptr, "wide rows: unknown objective");
+    CachedPlan cp;
+    if (int rc = get_plan(sx_fun_terms(fun_id, n), s, &cp)) return rc;
+    const size_t lds = wide_lds_bytes(n, false);
+    if (int rc = allow_lds(fn, lds)) return rc;
+    const int32_t *plan = cp.dev;
+    void *kargs[] = {&X, &P, &n, &ldx, &xm, &xstd, &f, &plan, &part_f, &part_i, &clip, &pen_v, &pen_out};
+    SX_HIP(hipLaunchKernel(fn, dim3((unsigned)P), dim3(kEvalThreads), kargs, lds, s));
+    return 0;
+}
+
+int wide_de_launch(const sx_de_args *a, hipStream_t s) {
+    GenLaunch g;
+    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id), a->fun_id,
+                                a->n, s, &g))
+        return rc;
+    sx_de_args args = *a;
+    void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
+    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
+    return 0;
+}
+
+int wide_de_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_de_args *a) {
+    GenLaunch g;
+    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id), a->fun_id,
+                                a->n, nullptr, &g))
+        return rc;
+    sx_de_args args = *a;
+    void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
+    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3(kGenThreads), (unsigned)g.lds, kargs);
+}
+
+int wide_pso_launch(const sx_pso_args *a, hipStream_t s) {
+    GenLaunch g;
+    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<PsoPhK>(a->fun_id) : pick_fun<PsoHoK>(a->fun_id),
+                                a->fun_id, a->n, s, &g))
+        return rc;
+    sx_pso_args args = *a;
+    void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
+    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
+    return 0;
+}
+
+int wide_pso_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_pso_args *a) {
+    GenLaunch g;
+    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<PsoPhK>(a->fun_id) : pick_fun<PsoHoK>(a->fun_id),
+                                a->fun_id, a->n, nullptr, &g))
+        return rc;
+    sx_pso_args args = *a;
+    void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
+    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3(kGenThreads), (unsigned)g.lds, kargs);
+}
+
+}  // namespace sx

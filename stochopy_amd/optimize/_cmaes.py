@@ -82,6 +82,11 @@ def minimize(
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
     workers = _common.resolve_workers(workers)
+    if len(lower) > _lib.NARROW_DIM:
+        # the one method that keeps a dimension cap: an n x n covariance, its eigenvectors and an O(n^3) decomposition per
+        # update (cmaes/_cmaes.py:290-309).  Every other method serves rows of up to _lib.WIDE_DIM elements.
+        raise ValueError(f"method='cmaes' keeps the full {len(lower)} x {len(lower)} covariance and its eigendecomposition on "
+                         f"the device: ndim <= {_lib.NARROW_DIM}.  method='vdcma' is the O(n) variant for long vectors.")
     if eigh is None:
         eigh = "host" if rng == "numpy-legacy" else "device"
     if not callable(eigh) and eigh not in ("host", "device"):

@@ -112,7 +112,7 @@ def resolve_objective(fun, args):
     return HostExternal(fun, args)
 
 
-def resolve_updating(updating, strict_updating, workers, fun):
+def resolve_updating(updating, strict_updating, workers, fun, ndim=0):
     """Is the run an ordered sweep (the reference's default ``updating="immediate"``: de_async / pso_async)?
 
     The reference runs it whenever no parallel backend is chosen (de/_de.py:142-145).  Here the sweep is one
@@ -125,19 +125,23 @@ def resolve_updating(updating, strict_updating, workers, fun):
     import os
 
     # (SX_FORCE_SHARDED=1: the test switch that runs a 1-rank process group through the sharded path)
-    possible = workers == 1 and isinstance(fun, int) and os.environ.get("SX_FORCE_SHARDED") != "1"
+    # (the sweep keeps the row of the individual at work in one workgroup's LDS: rows of up to _lib.NARROW_DIM elements)
+    from .._lib import NARROW_DIM
+
+    possible = (workers == 1 and isinstance(fun, int) and os.environ.get("SX_FORCE_SHARDED") != "1"
+                and ndim <= NARROW_DIM)
     if strict_updating is None:
         if not possible:
             warnings.warn('stochopy_amd: updating="immediate" is an ordered sweep on one GPU with a fused factory '
-                          'objective; this run (workers > 1 or a caller-supplied objective) uses "deferred" updating, '
+                          'objective and rows of <= 4096 elements; this run (workers > 1, a caller-supplied objective or longer rows) uses "deferred" updating, '
                           "as a parallel backend of the reference does (de/_de.py:142-145).", RuntimeWarning, stacklevel=3)
         if possible:
             _note_serial_sweep()
         return possible
     if strict_updating and not possible:
         raise ValueError('strict_updating=True: updating="immediate" is an ordered sweep on ONE GPU with a fused factory '
-                         "objective; this call (workers > 1, a caller-supplied objective or a sharded process group) "
-                         "cannot run it")
+                         "objective and rows of <= 4096 elements; this call (workers > 1, a caller-supplied objective, "
+                         "longer rows or a sharded process group) cannot run it")
     return bool(strict_updating)
 
 

@@ -87,7 +87,7 @@ def minimize(
     run = _PsoRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(inertia), float(cognitivity),
                   float(sociability), competitivity, constraints, float(xtol), float(ftol), bool(return_all),
                   float(verbosity), callback, rng, seed, workers,
-                  immediate=_common.resolve_updating(updating, strict_updating, workers, fun_id))
+                  immediate=_common.resolve_updating(updating, strict_updating, workers, fun_id, len(lower)))
     return run.result()
 
 

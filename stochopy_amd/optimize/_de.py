@@ -98,7 +98,7 @@ def minimize(
     run = _DeRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(mutation), float(recombination),
                  strategy, constraints, float(xtol), float(ftol), bool(return_all), float(verbosity), callback, rng,
                  seed, workers, exchange=exchange, donors=donors,
-                 immediate=_common.resolve_updating(updating, strict_updating, workers, fun_id))
+                 immediate=_common.resolve_updating(updating, strict_updating, workers, fun_id, len(lower)))
     return run.result()
 
 
@@ -148,8 +148,10 @@ class _DeRun:
         # ("chained finalize", include/stochopy_hip.h sx_de_chain_launch)
         # -- every wavefront re-reduces the per-workgroup records, so only while those are few (<= 512)
         npart = int(_lib.lib().sx_num_partials(self.P, self.n))
+        # (rows of more than 4096 elements -- csrc/sx_wide.hip, one workgroup per row -- take the two-kernel path)
+        self.wide = self.n > _lib.NARROW_DIM
         self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
-                      and npart <= 512 and not immediate and self.external is None)
+                      and npart <= 512 and not immediate and self.external is None and not self.wide)
         self.launches = 0
         self.ctx = _device.Context()
         # multi-GPU: the chained kernel with the peer exchange in its prologue, if the transport checks out
@@ -164,6 +166,11 @@ class _DeRun:
                 if exchange == "p2p" or self.global_donors:
                     raise ValueError("a caller-supplied objective runs between kernels: the peer exchange lives "
                                      'inside the fused generation kernel (use exchange="rccl", donors="shard")')
+                exchange = "rccl"
+            if self.wide:  # the peer exchange lives in the chained kernel, which serves rows of <= 4096 elements
+                if exchange == "p2p" or self.global_donors:
+                    raise ValueError(f"rows of {self.n} elements (> {_lib.NARROW_DIM}) exchange the global best with one "
+                                     'all-gather per generation (exchange="rccl", donors="shard")')
                 exchange = "rccl"
             if exchange != "rccl":
                 from ..parallel import PeerExchange

@@ -63,7 +63,7 @@ def minimize(
     _common.resolve_backend(backend)
     rng = _common.resolve_rng(rng)
     workers = _common.resolve_workers(workers)
-    if (rng == "philox" and isinstance(fun_id, int) and len(lower) <= 4096 and os.environ.get("SX_CMA_LOOP", "") != "host"
+    if (rng == "philox" and isinstance(fun_id, int) and os.environ.get("SX_CMA_LOOP", "") != "host"
             and (constraints is None or 20.0 + 3.0 * len(lower) / int(popsize) + 1.0 <= 256.0)):
         # nothing the host has to see between generations: the whole loop (and the history) stays on the device --
         # since round 3 including constraints="Penalize" (boundary-weight bookkeeping shared with CMA-ES: cma_penalty_kernel)

@@ -460,6 +460,52 @@ def vdcma():
 
 
 # --------------------------------------------------------------------------- #
+# 6b. WIDE rows (n > 4096): the reference has no dimension limit (de/_de.py:208-218), and VD-CMA exists for long vectors
+#     (vdcma/_vdcma.py:144-458).  One VD-CMA run at n = 8192, objective values of long rows (numpy's pairwise sums with
+#     hundreds of leaves), and short DE / PSO / CPSO runs at n = 4097 -- the first length the wide kernels serve.
+# --------------------------------------------------------------------------- #
+def vdcma_wide():
+    out = dict(STAMP)
+    arrays = {}
+    cases = []
+    n = 8192
+    o = {"maxiter": 12, "popsize": 16, "seed": 9, "sigma": 0.3}
+    entry, res, pops = run_ref("rosenbrock", n, "vdcma", o, bounds=[[-3.0, 3.0]] * n)
+    entry["tag"] = "vdcma_wide_rosen_n8192_p16"
+    arrays[entry["tag"] + "__x"] = res.x
+    cases.append(entry)
+    print(" ", entry["tag"], "fun", float(res.fun), "nit", res.nit, "status", res.status)
+    for tag, method, n, o in (
+        ("de_wide_rosen_n4097_p12", "de", 4097, {"maxiter": 6, "popsize": 12, "seed": 2, "strategy": "best1bin", "updating": "deferred"}),
+        ("de_wide_sphere_n9000_p10_random", "de", 9000, {"maxiter": 5, "popsize": 10, "seed": 4, "strategy": "rand1bin",
+                                                         "constraints": "Random", "updating": "deferred"}),
+        ("pso_wide_rosen_n4097_p12", "pso", 4097, {"maxiter": 6, "popsize": 12, "seed": 2, "updating": "deferred"}),
+        ("cpso_wide_sphere_n5000_p12_shrink", "cpso", 5000, {"maxiter": 8, "popsize": 12, "seed": 6, "constraints": "Shrink",
+                                                             "competitivity": 1.0, "updating": "deferred"}),
+    ):
+        fun = tag.split("_")[2].replace("rosen", "rosenbrock")
+        entry, res, pops = run_ref(fun, n, method, o, bounds=[[-2.0, 2.0]] * n)
+        entry["tag"] = tag
+        arrays[tag + "__x"] = res.x
+        arrays[tag + "__pop_last"] = pops[-1]
+        cases.append(entry)
+        print(" ", tag, "fun", float(res.fun), "nit", res.nit, "status", res.status)
+    # objective values of long rows straight from the reference's functions
+    rs = np.random.RandomState(20260929)
+    kat = {}
+    for n in (4097, 8192, 20001, 65536):
+        X = rs.uniform(-5.12, 5.12, (3, n))
+        arrays["kat_X_%d" % n] = X
+        for name in ("ackley", "griewank", "quartic", "rastrigin", "rosenbrock", "sphere", "styblinski_tang"):
+            kat["%s_%d" % (name, n)] = hx(np.array([getattr(stochopy.factory, name)(x) for x in X]))
+    out["cases"] = cases
+    out["objective_kat"] = kat
+    dump("vdcma_wide.json", out)
+    np.savez_compressed(os.path.join(HERE, "vdcma_wide.npz"), **arrays)
+    print("wrote vdcma_wide.npz", os.path.getsize(os.path.join(HERE, "vdcma_wide.npz")))
+
+
+# --------------------------------------------------------------------------- #
 # 7. updating="immediate" (de/_de.py:354-391 de_async, cpso/_cpso.py:364-402 pso_async,
 #    _common.py:163-194 selection_async): the reference's own test rows (tests/test_optimize.py:27-117) and
 #    mid-size problems for every strategy / constraint, incl. runs that stop on ftol / xtol
@@ -566,6 +612,8 @@ if __name__ == "__main__":
         immediate()
     if "vdcma" in which:
         vdcma()
+    if "vdcma_wide" in which:
+        vdcma_wide()
     if "penalize" in which:
         penalize()
     if "rng" in which:

@@ -177,13 +177,6 @@ def test_c5_full_population_properties(sa):
     assert np.all(np.abs(a2.xall) < 5.12 * 3)                                   # best1bin without repair stays near the box
 
 
-def test_dimension_limit_is_loud(sa):
-    from stochopy_amd._lib import HipLibraryError
-
-    with pytest.raises(HipLibraryError):
-        sa.optimize.minimize(sa.factory.sphere, [[-1.0, 1.0]] * 4097, method="de", options={"maxiter": 2, "popsize": 8, "seed": 0})
-
-
 def test_result_surface(sa):
     r = sa.optimize.minimize(sa.factory.rosenbrock, B2, method="cmaes", options={"maxiter": 100, "popsize": 10, "seed": 0})
     # README example of the reference (README.rst:93-105): nit 49, nfev 490, status 1

@@ -170,6 +170,34 @@ def test_vdcma_bit_exact(case):
         assert np.allclose(case["xref_from_reference_tests"], res.x)
 
 
+WIDE = load_golden("vdcma_wide.json")
+
+
+@pytest.mark.parametrize("case", WIDE["cases"], ids=lambda c: c["tag"])
+def test_wide_rows_bit_exact(case):
+    """Rows of more than 4096 elements (the reference has no dimension limit, de/_de.py:208-218): VD-CMA at n = 8192
+    (vdcma/_vdcma.py:144-458) and short DE / PSO / CPSO runs at n = 4097 ... 9000, captured from the reference."""
+    trace = []
+    res = _run(case, trace)
+    ref = case["result"]
+    assert np.array_equal(unhex(case["fun_trace"]), np.array([t[0] for t in trace]))
+    assert (res.nit, res.nfev, res.status, res.message) == (ref["nit"], ref["nfev"], ref["status"], ref["message"])
+    arrays = np.load(os.path.join(GOLDEN, "vdcma_wide.npz"))
+    assert np.array_equal(arrays[case["tag"] + "__x"], res.x) and float(res.fun).hex() == ref["fun"]
+    if case["tag"] + "__pop_last" in arrays:
+        assert np.array_equal(arrays[case["tag"] + "__pop_last"], trace[-1][1])
+
+
+def test_wide_objective_values_bit_exact():
+    """numpy's pairwise sums over rows of 4097 ... 65536 elements (32 ... 512 leaves), from the reference's functions."""
+    from oracle.objectives import OBJECTIVES
+
+    arrays = np.load(os.path.join(GOLDEN, "vdcma_wide.npz"))
+    for key, want in WIDE["objective_kat"].items():
+        name, n = key.rsplit("_", 1)
+        assert np.array_equal(OBJECTIVES[name](arrays["kat_X_" + n]), unhex(want)), key
+
+
 IMMEDIATE = load_golden("immediate.json")["cases"]
 
 
