@@ -685,7 +685,8 @@ __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *_
                                                                  const double *__restrict__ tk, int mu, int n,
                                                                  const double *__restrict__ dvec, const double *__restrict__ vn,
                                                                  double norm_v2, double *__restrict__ part,
-                                                                 const sx_cma_state *st) {
+                                                                 const sx_cma_state *st, const int tk_by_row) {
+    // tk_by_row: tk holds t of EVERY candidate row (left by the wide candidates kernel, sx_wide.hip), not of the selected ones
     if (st != nullptr) norm_v2 = st->reserved[1];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + tx;
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *_
     double awx = 0.0, awy = 0.0, ap = 0.0, aq = 0.0;
     for (int k = q; k < mu; k += kVdPart) {
         const int64_t row = idx[k] * (int64_t)n + col;
-        const double wk = w[k], t = tk[k], ax = arx[row], ay = ary[row];
+        const double wk = w[k], t = tk[tk_by_row ? idx[k] : k], ax = arx[row], ay = ary[row];
         const double y = ay / dv;
         awx += wk * ax;
         awy += wk * ay;
@@ -732,12 +733,13 @@ __global__ __launch_bounds__(256) void vd_moments_finish_kernel(const double *__
 namespace sx {
 int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
                       const double *dvec, const double *vn, double norm_v2, const sx_cma_state *state, double *ws,
-                      double *out, void *stream) {
+                      double *out, void *stream, const double *tk_rows) {
     hipStream_t st = (hipStream_t)stream;
     double *tk = ws, *part = ws + ((mu + 7) / 8) * 8;
-    hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
+    if (tk_rows == nullptr)
+        hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
     hipLaunchKernelGGL(vd_moments_partial_kernel, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
-                       w, tk, mu, n, dvec, vn, norm_v2, part, state);
+                       w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0);
     hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 63) / 64), 4), dim3(256), 0, st, part, n, out);
     SX_LAUNCH_CHECK();
     return 0;
@@ -747,5 +749,5 @@ int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, 
 extern "C" int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
                                 const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream) {
     SX_REQUIRE(arx && ary && idx && w && dvec && vn && ws && out && mu >= 1 && n >= 1, "sx_vdcma_moments: bad arguments");
-    return sx::vd_moments_launch(arx, ary, idx, w, mu, n, dvec, vn, norm_v2, nullptr, ws, out, stream);
+    return sx::vd_moments_launch(arx, ary, idx, w, mu, n, dvec, vn, norm_v2, nullptr, ws, out, stream, nullptr);
 }

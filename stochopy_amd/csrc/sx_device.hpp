@@ -203,6 +203,27 @@ __device__ __forceinline__ double cos_mid(double t) {
 #endif
 }
 
+// sine and cosine of one argument with cos_mid's reduction and kernels (|t| < 1e6; the wide VD-CMA candidates kernel's
+// Box-Muller angles 2 pi u, u in [0, 1): the library's sincos is ~200 instructions behind its large-argument branch)
+__device__ __forceinline__ void sincos_mid(double t, double &sn_out, double &cs_out) {
+    const double n = rint(t * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, t);
+    r = fma(-n, 6.07710050630396597660e-11, r);
+    r = fma(-n, 2.02226624871116645580e-21, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                        2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double sn = fma(r * z, fma(z, ps, -1.66666666666666324348e-01), r);
+    const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                   -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                     -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cs = 1.0 - fma(0.5, z, -(z * pc));
+    const int q = (int)n & 3;  // sin / cos (r + n pi/2)
+    const double c = (q & 1) ? sn : cs, s = (q & 1) ? cs : sn;
+    cs_out = (q == 1 || q == 2) ? -c : c;
+    sn_out = (q >= 2) ? -s : s;
+}
+
 template <int FUN>
 struct Obj;
 

@@ -27,6 +27,7 @@
 //
 // Reference code replaced: as sx_de.hip / sx_pso.hip / sx_core.hip (de/_de.py:314-351, cpso/_cpso.py:324-361,
 // _common.py:34-90, 123-130; factory/benchmark.py:14-156).
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -574,6 +575,114 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// VD-CMA candidates of wide models (vdcma/_vdcma.py:236-248 + the objective), one workgroup per candidate: the normals
+// never touch memory -- Philox / Box-Muller in the kernel, laid out as cma_normals_kernel lays them out (element pairs
+// (128 k + l, 128 k + 64 + l) = the cosine / sine half of call (slot 64 k + l)) -- the row z waits in LDS (resident rows;
+// longer ones park it in the y row they are about to write) for t = z . vn, then y = d o (z + coef t vn),
+// x = xmean + sigma y are written, the objective of the un-standardised (Penalize: clipped) x is formed from the staged
+// row, and t_k = (y / d) . vn -- what the moment sums need of a selected row (:428-444) -- is left per row.
+// Rows 0 and 1 of the generation are +-dy when the mean-shift injection is on (:241-247).
+// ---------------------------------------------------------------------------
+template <int FUN>
+__global__ __launch_bounds__(kGenThreads) void wide_vd_candidates_kernel(const sx_vd_args a, const int64_t gen,
+                                                                         const int64_t row0, double *__restrict__ ary_out,
+                                                                         double *__restrict__ arx_out,
+                                                                         double *__restrict__ fit_out,
+                                                                         double *__restrict__ tk_out,
+                                                                         const int32_t *__restrict__ plan,
+                                                                         const int chunk_leaves) {
+    constexpr int T = kGenThreads;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double s_red[T / kWave];
+    const sx_cma_state *st = (const sx_cma_state *)a.state;
+    if (st->done) return;
+    const WideCtx c = wide_ctx(plan);
+    const int n = a.n, tid = (int)threadIdx.x;
+    const bool resident = chunk_leaves >= c.nleaf;
+    double *S = lds, *LA = lds + (resident ? n + 16 : kStageElems), *LB = LA + wide_leaf_cap(n);
+    const int64_t row = blockIdx.x, grow = row0 + row;
+    const double sigma = st->sigma, coef = st->reserved[4];
+    const bool inj = st->reserved[3] != 0.0 && grow < 2;
+    const double sgn = grow == 0 ? 1.0 : -1.0;
+    const bool clip = a.pen_ws != nullptr;
+    double *__restrict__ yo = ary_out + row * (int64_t)n;
+    double *__restrict__ xo = arx_out + row * (int64_t)n;
+    auto block_sum = [&](double v) {
+        v = wave_sum_butterfly(v, tid & 63);
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = v;
+        __syncthreads();
+        double r = s_red[0];
+        for (int w = 1; w < T / kWave; ++w) r += s_red[w];
+        return r;
+    };
+    double t = 0.0;
+    if (!inj) {  // the normals of the row and t = z . vn
+        double tacc = 0.0;
+        for (int g = tid; g < ((n + 255) >> 8) * 64; g += T) {
+            const int eb = (g >> 6) * 256 + (g & 63);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e0 = eb + 128 * h, e1 = e0 + 64;
+                if (e0 >= n) continue;
+                const U4 w = philox4x32_10((uint32_t)((g >> 6) * 2 + h) * 64u + (uint32_t)(g & 63), (uint32_t)grow,
+                                           (uint32_t)gen, kPurposeCmaNormal, a.key0, a.key1);
+                const double d0 = u53(w.x, w.y), d1 = u53(w.z, w.w);
+                const double rad = sqrt(-2.0 * log(1.0 - d0));
+                double sn, cs;
+                sincos_mid(6.283185307179586 * d1, sn, cs);
+                const double z0 = rad * cs, z1 = rad * sn;
+                (resident ? S : yo)[e0] = z0;
+                tacc += z0 * a.vn[e0];
+                if (e1 < n) {
+                    (resident ? S : yo)[e1] = z1;
+                    tacc += z1 * a.vn[e1];
+                }
+            }
+        }
+        t = block_sum(tacc);  // (its barriers also order the z writes before the reads below)
+    }
+    double tkacc = 0.0;
+    const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
+        for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
+            const int eb = (g >> 6) * 256 + (g & 63);
+            double z[4], vv[4], dd[4], xm0[4], dj[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + 64 * u;
+                in[u] = e >= e0 && e < e1s;
+                z[u] = (in[u] && !inj) ? (resident ? Sd[e] : yo[e]) : 0.0;
+                vv[u] = in[u] ? a.vn[e] : 0.0;
+                dd[u] = in[u] ? a.dvec[e] : 1.0;
+                xm0[u] = in[u] ? a.xmean[e] : 0.0;
+                dj[u] = (in[u] && inj) ? a.dy[e] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + 64 * u;
+                if (!in[u]) continue;
+                const double yd = z[u] + coef * (t * vv[u]);  // y / d of an ordinary row
+                const double y = inj ? sgn * dj[u] : dd[u] * yd;
+                const double x = xm0[u] + sigma * y;
+                if (e < e1) {  // (the look-ahead element is written -- and its z read -- by its own chunk)
+                    yo[e] = y;
+                    xo[e] = x;
+                    tkacc += (inj ? y / dd[u] : yd) * vv[u];  // (the division only for the injected pair: rounding apart the same)
+                }
+                const double xc = clip ? fmin(fmax(x, -1.0), 1.0) : x;  // cmaes/_constraints.py:29-31
+                Sd[e] = xc * a.xstd[e] + a.xm[e];                        // cmaes/_cmaes.py:171
+            }
+        }
+    });
+    const double tk = block_sum(tkacc);
+    if (tid == 0) {
+        fit_out[row] = fc;
+        if (tk_out != nullptr) tk_out[row] = tk;
+    }
+}
 template <template <int> class K>
 void *pick_fun(int fun_id) {
     switch (fun_id) {
@@ -591,6 +700,7 @@ template <int FUN> struct EvalK { static void *ptr() { return (void *)wide_eval_
 template <int FUN> struct DePhK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX>; } };
 template <int FUN> struct DeHoK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_HOST>; } };
 template <int FUN> struct PsoPhK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX>; } };
+template <int FUN> struct VdCandK { static void *ptr() { return (void *)wide_vd_candidates_kernel<FUN>; } };
 template <int FUN> struct PsoHoK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_HOST>; } };
 
 std::mutex g_attr_mutex;
@@ -686,6 +796,22 @@ int wide_pso_launch(const sx_pso_args *a, hipStream_t s) {
     sx_pso_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
     SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
+    return 0;
+}
+
+int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t rows, double *ary_out, double *arx_out,
+                       double *fit_out, double *tk_out, hipStream_t s) {
+    GenLaunch g;
+    if (int rc = gen_launch_for(pick_fun<VdCandK>(a->fun_id), a->fun_id, a->n, s, &g)) return rc;
+    // Always STREAMED (z parked in the y row): a resident row's 128 KB of LDS leave ONE workgroup per CU, and the generator's
+    // arithmetic (Philox, log, sincos: ~65 us of VALU time chip-wide per 1 024 x 16 384 candidates), the row stores and
+    // the objective of a candidate then run one after the other -- 216 us per generation at n = 16 384, P = 1 024 against
+    // SX_VD_RESIDENT=0's figure in profiles/r5_vd_wide.txt.  (z in registers -- 8 items per thread -- spills: 256 VGPRs + 1.5 KB.)
+    static const bool resident_ok = getenv("SX_VD_RESIDENT") != nullptr && getenv("SX_VD_RESIDENT")[0] == '1';
+    if (!resident_ok) g.chunk_leaves = kStreamLeaves, g.lds = wide_lds_bytes(a->n, false);
+    sx_vd_args args = *a;
+    void *kargs[] = {&args, &gen, &row0, &ary_out, &arx_out, &fit_out, &tk_out, &g.plan, &g.chunk_leaves};
+    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)rows), dim3(kGenThreads), kargs, g.lds, s));
     return 0;
 }
 

@@ -19,6 +19,9 @@ int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const 
 int wide_de_launch(const sx_de_args *a, hipStream_t s);
 int wide_de_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_de_args *a);
 int wide_pso_launch(const sx_pso_args *a, hipStream_t s);
+// VD-CMA candidates [row0, row0 + rows) of generation `gen`: normals, steps y, candidates x, objective, t_k (tk_out may be NULL)
+int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t rows, double *ary_out, double *arx_out,
+                       double *fit_out, double *tk_out, hipStream_t s);
 int wide_pso_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_pso_args *a);
 
 }  // namespace sx

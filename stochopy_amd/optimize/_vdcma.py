@@ -104,7 +104,6 @@ class _VdDeviceRun:
         """``run=False`` only builds the device state (``self.buffers``, ``self.args``): tests drive single generations
         with ``step`` from a state of their choosing."""
         import ctypes as C
-        import time
 
         ctx = self.ctx = _device.Context()
         t = _device.torch()
@@ -154,7 +153,7 @@ class _VdDeviceRun:
             self.args, self.P = a, P
             if not run:
                 return
-            look, since, t0 = 1, 0, time.perf_counter()
+            look, since = 1, 0
             cb_pin = cb_hist = None
             state = st
             if world is not None:
@@ -192,10 +191,12 @@ class _VdDeviceRun:
                         callback(Xs, cres)
                     if state.done:
                         break
-                    now = time.perf_counter()
-                    if world is None and callback is None and now - t0 < 2.0e-3 and look < self.LOOK:  # cheap generations: look less often
-                        look *= 2  # (sharded: every generation, so that all ranks stop enqueueing collectives together)
-                    since, t0 = 0, now
+                    # looks get rarer (1, 2, 4, ... LOOK generations apart) whatever a generation costs: after a stop the
+                    # generations already enqueued are no-ops, and the interval no longer depends on the host's clock
+                    # (sharded: every generation, so that all ranks stop enqueueing collectives together)
+                    if world is None and callback is None and look < self.LOOK:
+                        look *= 2
+                    since = 0
             if not state.done:  # cannot happen: generation maxiter sets status -1
                 raise RuntimeError("VD-CMA device loop ended without a status")
             nit = int(state.stop_it)
