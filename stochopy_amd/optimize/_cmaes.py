@@ -45,6 +45,8 @@ def minimize(
     callback=None,
     rng=None,
     eigh=None,
+    host_workers=None,
+    host_backend=None,
 ):
     """Minimize an objective function using CMA-ES on MI355X (reference cmaes/_cmaes.py:12-30).
 
@@ -66,7 +68,7 @@ def minimize(
     returns all candidates and fitness values to every rank, and the O(n^2)/O(n^3) model update is replicated.
     Same result as ``workers=1`` on every rank.
     """
-    fun_id = _common.resolve_objective(fun, args)
+    fun_id = _common.resolve_objective(fun, args, workers, backend, host_workers, host_backend)
     lower, upper = _common.as_bounds(bounds)
     if x0 is not None:
         if np.ndim(x0) != 1 or len(x0) != len(bounds):
@@ -79,9 +81,9 @@ def minimize(
         raise KeyError(constraints)
     if callback is not None and not hasattr(callback, "__call__"):
         raise ValueError()
-    _common.resolve_backend(backend)
+    _common.resolve_backend(backend, fun_id)
     rng = _common.resolve_rng(rng)
-    workers = _common.resolve_workers(workers)
+    workers = _common.resolve_workers(workers, fun_id)
     if len(lower) > _lib.NARROW_DIM:
         # the one method that keeps a dimension cap: an n x n covariance, its eigenvectors and an O(n^3) decomposition per
         # update (cmaes/_cmaes.py:290-309).  Every other method serves rows of up to _lib.WIDE_DIM elements.

@@ -30,9 +30,12 @@ messages = {
 RNG_MODES = ("numpy-legacy", "philox")
 
 
-def resolve_backend(backend):
-    """`backend="hip"` (or None: this package has only that one)."""
+def resolve_backend(backend, fun_id=None):
+    """`backend="hip"` (or None: this package has only that one).  With a plain Python objective the reference's
+    "threading" / "loky" name the HOST pool that evaluates it (resolve_objective); the generation still runs on the GPU."""
     if backend in (None, "hip"):
+        return "hip"
+    if getattr(fun_id, "from_reference_options", False):
         return "hip"
     if backend in ("loky", "threading", "mpi"):
         raise ValueError(f"backend '{backend}' belongs to keurfonluu/stochopy (CPU); stochopy_amd only provides 'hip'")
@@ -58,58 +61,174 @@ class External:
         return f.to(t.float64).contiguous()
 
 
+class HostPool:
+    """Host workers for a plain Python objective (SURVEY.md section 8b case iii): what the reference's backend hook does
+    with ``workers`` and ``backend in {"threading", "loky"}`` (_common.py:38-43, 94-97: a joblib pool of threads /
+    processes, one ``fun(xx, *args)`` per individual).  Same calls on the same rows, so the same values as the serial
+    loop; the differences are mechanical: rows travel in contiguous blocks (one task per block instead of one per
+    individual: a 4096-row population is 4 x workers tasks, not 4096) and the pool outlives the generation.
+    ``threading``: a ThreadPoolExecutor (pays off when ``fun`` releases the GIL -- numpy, I/O, an external solver);
+    ``loky``: joblib's reusable process executor (``fun`` and ``args`` must pickle; cloudpickle takes lambdas / closures)."""
+
+    BACKENDS = ("threading", "loky")
+
+    def __init__(self, workers, backend=None):
+        import os
+
+        backend = backend if backend else "threading"  # the reference's default, _common.py:94
+        if backend not in self.BACKENDS:
+            raise ValueError(f"unknown host backend '{backend}' (expected one of {self.BACKENDS})")
+        workers = int(workers)
+        if workers < 0:  # joblib's convention: -1 = all cores, -2 = all but one
+            workers = max(1, (os.cpu_count() or 1) + 1 + workers)
+        if workers < 2:
+            raise ValueError(f"host_workers={workers}: a pool needs at least two workers")
+        self.workers, self.backend = workers, backend
+        self._threads = None
+
+    def executor(self):
+        if self.backend == "loky":
+            from joblib.externals.loky import get_reusable_executor
+
+            return get_reusable_executor(max_workers=self.workers, timeout=600)
+        if self._threads is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._threads = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="sx-host")
+        return self._threads
+
+    def close(self):
+        if self._threads is not None:
+            self._threads.shutdown(wait=True)
+            self._threads = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _eval_block(fun, block, args):
+    """One pool task: the reference's serial wrapper (_common.py:79-80) on a block of rows."""
+    return np.array([fun(xx, *args) for xx in block], dtype=np.float64)
+
+
 class HostExternal(External):
     """Any other Python callable (SURVEY.md section 8b case iii): the CALLER'S scalar function, evaluated the way
-    the reference's serial wrapper does it -- ``np.array([fun(xx, *args) for xx in x])`` (_common.py:79-80) -- on
-    a host copy of the candidates, between the propose and the select kernel.  Draws, mutation / velocity update,
-    selection and bookkeeping stay on the device; what is slow is the caller's Python, one call per individual, plus
-    a D2H / H2D round trip per generation (such a generation cannot be captured into a graph).  It is the caller's
-    function that runs on the host here, never this package's restatement of anything."""
+    the reference's wrappers do it -- serially, ``np.array([fun(xx, *args) for xx in x])`` (_common.py:79-80), or, with
+    a HostPool, by host threads / processes as its joblib backends do (_common.py:38-43) -- on a host copy of the
+    candidates, between the propose and the select kernel.  Draws, mutation / velocity update, selection and
+    bookkeeping stay on the device; what is slow is the caller's Python plus a D2H / H2D round trip per generation (such
+    a generation cannot be captured into a graph).  With a pool the candidates come down in pieces (asynchronous copies
+    into pinned memory, an event per piece) and the first pieces are being evaluated while the later ones still travel.
+    It is the caller's function that runs on the host here, never this package's restatement of anything."""
 
     capturable = False
     _warned = False
 
-    def __init__(self, fun, args):
+    def __init__(self, fun, args, pool=None, from_reference_options=False):
         self.fun = fun
         self.args = tuple(args) if args not in ((), None) else ()
         self.name = getattr(fun, "__name__", "objective")
+        self.pool = pool
+        self.from_reference_options = from_reference_options  # workers / backend named the HOST pool (reference spelling)
+        self._pinned = None
+
+    def _check(self, f, P):
+        if f.shape != (P,):
+            raise ValueError(f"objective {self.name}: expected one scalar per individual, got shape {f.shape}")
 
     def __call__(self, ctx, X):
         t = __import__("torch")
-        if not HostExternal._warned:
+        if not HostExternal._warned and self.pool is None:
             HostExternal._warned = True
             warnings.warn(
                 f"stochopy_amd: {self.name} is a plain Python callable -- it is evaluated on the host, one call per "
                 "individual, with a device-host round trip per generation.  Use stochopy_amd.factory objectives "
-                "(fused kernels) or factory.batched (device tensor in/out) for speed.", RuntimeWarning, stacklevel=3)
-        ctx.sync()
-        x = X.cpu().numpy()
-        f = np.array([self.fun(xx, *self.args) for xx in x], dtype=np.float64)  # reference _common.py:79-80
-        if f.shape != (x.shape[0],):
-            raise ValueError(f"objective {self.name}: expected one scalar per individual, got shape {f.shape}")
+                "(fused kernels) or factory.batched (device tensor in/out) for speed, or options['host_workers'] "
+                "(with 'host_backend' = 'threading' | 'loky') to spread the calls over host cores as the reference's "
+                "joblib backends do.", RuntimeWarning, stacklevel=3)
+        P = X.shape[0]
+        if self.pool is None:
+            ctx.sync()
+            x = X.cpu().numpy()
+            f = np.array([self.fun(xx, *self.args) for xx in x], dtype=np.float64)  # reference _common.py:79-80
+            self._check(f, P)
+            return t.from_numpy(np.ascontiguousarray(f)).to(X.device)
+        return self._pooled(ctx, X, t)
+
+    def _pooled(self, ctx, X, t):
+        P, n = X.shape
+        X = X.contiguous()
+        if self._pinned is None or self._pinned.shape != (P, n):
+            self._pinned = t.empty((P, n), dtype=t.float64).pin_memory()
+        host = self._pinned
+        ex = self.pool.executor()
+        # tasks: 4 per worker (load balance against uneven objectives); copies: up to 8 pieces of whole tasks
+        per_task = max(1, -(-P // (4 * self.pool.workers)))
+        bounds_ = list(range(0, P, per_task)) + [P]
+        ntask = len(bounds_) - 1
+        pieces = min(8, ntask)
+        cut = [bounds_[(ntask * j) // pieces] for j in range(pieces)] + [P]
+        events = []
+        with t.cuda.stream(ctx.stream):
+            for j in range(pieces):
+                host[cut[j]:cut[j + 1]].copy_(X[cut[j]:cut[j + 1]], non_blocking=True)
+                ev = t.cuda.Event()
+                ev.record(ctx.stream)
+                events.append(ev)
+        xh = host.numpy()
+        # processes receive a pickled copy of their block; threads read the pinned buffer in place
+        futures, k = [], 0
+        for j in range(pieces):
+            events[j].synchronize()
+            while k < ntask and bounds_[k + 1] <= cut[j + 1]:
+                futures.append(ex.submit(_eval_block, self.fun, xh[bounds_[k]:bounds_[k + 1]], self.args))
+                k += 1
+        parts = [fu.result() for fu in futures]
+        for part, a, b in zip(parts, bounds_[:-1], bounds_[1:]):
+            self._check(part, b - a)
+        f = np.concatenate(parts)
         return t.from_numpy(np.ascontiguousarray(f)).to(X.device)
 
 
-def resolve_objective(fun, args):
+def resolve_objective(fun, args, workers=1, backend=None, host_workers=None, host_backend=None):
     """Map the user's callable to a device kernel id, or to an External for caller-supplied objectives -- the
     three cases of the backend hook contract (reference _common.py:27-106):
 
     (i)   the factory objectives (stochopy_amd.factory, tagged with ``sx_id``) run fused in the generation kernels;
     (ii)  ``factory.batched(fun)`` (device tensor in, device tensor out) runs between a propose and a select kernel;
     (iii) any other callable is the reference's ``fun(x, *args)`` on ONE individual: it runs on the host, per row
-          (HostExternal), with a one-time warning naming the cost.
+          (HostExternal) -- serially with a one-time warning naming the cost, or on a pool of host threads / processes:
+          ``host_workers=N`` (``-1`` = all cores) with ``host_backend="threading"|"loky"``, or the REFERENCE'S OWN
+          spelling ``workers=N, backend="threading"|"loky"`` (_common.py:94-97), which for such an objective names
+          exactly what it names there (the run then uses one GPU).
     """
     from ..factory.benchmark import batched
 
     if not hasattr(fun, "__call__"):
         raise TypeError()
+    plain = not isinstance(fun, (Objective, batched))
+    if not plain and (host_workers not in (None, 0, 1) or host_backend is not None):
+        raise ValueError("host_workers / host_backend apply to plain Python objectives (evaluated on the host) only")
     if isinstance(fun, Objective):
         if args not in ((), None):
             raise TypeError("factory objectives take no extra args")
         return fun.sx_id
     if isinstance(fun, batched):
         return External(fun, args)
-    return HostExternal(fun, args)
+    if backend in HostPool.BACKENDS:  # the reference's spelling
+        if host_workers is not None or host_backend is not None:
+            raise ValueError("give either workers / backend in the reference's spelling or host_workers / host_backend")
+        if workers in (None, 0, 1):  # the reference runs serially then (_common.py:96)
+            return HostExternal(fun, args, None, True)
+        return HostExternal(fun, args, HostPool(workers, backend), True)
+    if host_workers in (None, 0, 1):
+        if host_backend is not None and host_backend not in HostPool.BACKENDS:
+            raise ValueError(f"unknown host backend '{host_backend}' (expected one of {HostPool.BACKENDS})")
+        return HostExternal(fun, args)
+    return HostExternal(fun, args, HostPool(host_workers, host_backend))
 
 
 def resolve_updating(updating, strict_updating, workers, fun, ndim=0):
@@ -190,9 +309,10 @@ def penalty_rows(ctx, fun, X, n, xm, xstd, v, f_raw, pen):
         pen.copy_((((X.clamp(-1.0, 1.0) - X) ** 2) * v).sum(dim=1))
 
 
-def resolve_workers(workers):
-    """`workers` = number of GPUs (processes are launched by torchrun; see parallel.py)."""
-    if workers in (None, 0, 1):
+def resolve_workers(workers, fun_id=None):
+    """`workers` = number of GPUs (processes are launched by torchrun; see parallel.py) -- unless the call named a host
+    pool in the reference's spelling (plain Python objective with backend="threading"|"loky"): one GPU then."""
+    if workers in (None, 0, 1) or getattr(fun_id, "from_reference_options", False):
         return 1
     if int(workers) == -1:  # "all": every rank of the initialised process group (one GPU without one)
         try:

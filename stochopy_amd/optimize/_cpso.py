@@ -47,6 +47,8 @@ def minimize(
     callback=None,
     rng=None,
     strict_updating=None,
+    host_workers=None,
+    host_backend=None,
 ):
     """Minimize an objective function using Competitive PSO on MI355X.
 
@@ -58,7 +60,7 @@ def minimize(
     run is deferred like with a parallel backend of the reference (cpso/_cpso.py:147-150), with a warning.
     ``updating="deferred"`` is the throughput mode; ``strict_updating=False`` forces it silently.
     """
-    fun_id = _common.resolve_objective(fun, args)
+    fun_id = _common.resolve_objective(fun, args, workers, backend, host_workers, host_backend)
     lower, upper = _common.as_bounds(bounds)
     if x0 is not None:
         if np.ndim(x0) != 2 or np.shape(x0)[1] != len(bounds):
@@ -81,9 +83,9 @@ def minimize(
         raise KeyError(constraints)
     if callback is not None and not hasattr(callback, "__call__"):
         raise ValueError()
-    _common.resolve_backend(backend)
+    _common.resolve_backend(backend, fun_id)
     rng = _common.resolve_rng(rng)
-    workers = _common.resolve_workers(workers)
+    workers = _common.resolve_workers(workers, fun_id)
     run = _PsoRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(inertia), float(cognitivity),
                   float(sociability), competitivity, constraints, float(xtol), float(ftol), bool(return_all),
                   float(verbosity), callback, rng, seed, workers,

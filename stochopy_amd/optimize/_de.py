@@ -46,6 +46,8 @@ def minimize(
     exchange=None,
     donors=None,
     strict_updating=None,
+    host_workers=None,
+    host_backend=None,
 ):
     """Minimize an objective function using Differential Evolution on MI355X.
 
@@ -68,7 +70,7 @@ def minimize(
     xGMI inside the generation kernel: the result of the unsharded run, at the price of remote row reads
     (needs the peer exchange).
     """
-    fun_id = _common.resolve_objective(fun, args)
+    fun_id = _common.resolve_objective(fun, args, workers, backend, host_workers, host_backend)
     lower, upper = _common.as_bounds(bounds)
     if x0 is not None:
         if np.ndim(x0) != 2 or np.shape(x0)[1] != len(bounds):
@@ -89,9 +91,9 @@ def minimize(
         raise KeyError(constraints)
     if callback is not None and not hasattr(callback, "__call__"):
         raise ValueError()
-    _common.resolve_backend(backend)
+    _common.resolve_backend(backend, fun_id)
     rng = _common.resolve_rng(rng)
-    workers = _common.resolve_workers(workers)
+    workers = _common.resolve_workers(workers, fun_id)
     if popsize - 1 < _lib.DE_DONORS[strategy]:
         raise ValueError()
 

@@ -38,11 +38,13 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
+    host_workers=None,
+    host_backend=None,
 ):
     """Minimize an objective function using the Neighbourhood Algorithm on MI355X (reference na/_na.py:11-27; its
     ``callback=True`` default -- which makes a direct call raise -- is not copied: ``None`` here, as through
     ``stochopy.optimize.minimize``).  One GPU (``workers=1``): the model store is shared by all walks."""
-    fun_id = _common.resolve_objective(fun, args)
+    fun_id = _common.resolve_objective(fun, args, workers, backend, host_workers, host_backend)
     lower, upper = _common.as_bounds(bounds)
     if x0 is not None:
         if np.ndim(x0) != 2 or np.shape(x0)[1] != len(bounds):
@@ -55,11 +57,11 @@ def minimize(
         raise ValueError()
     if callback is not None and not hasattr(callback, "__call__"):
         raise ValueError()
-    _common.resolve_backend(backend)
+    _common.resolve_backend(backend, fun_id)
     rng = _common.resolve_rng(rng)
     if popsize > 65535:
         raise ValueError("method 'na': popsize <= 65535 (one workgroup row of the cell-walk kernels per sample)")
-    if _common.resolve_workers(workers) != 1:
+    if _common.resolve_workers(workers, fun_id) != 1:
         raise ValueError("method 'na' runs on one GPU (workers=1): every walk reads the whole model store")
     return _NaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(nrperc), float(xtol), float(ftol),
                   bool(return_all), float(verbosity), callback, rng, seed).result()

@@ -31,11 +31,13 @@ def minimize(
     callback=None,
     rng=None,
     strict_updating=None,
+    host_workers=None,
+    host_backend=None,
 ):
     """Minimize an objective function using PSO on MI355X (reference pso/_pso.py:9-29)."""
     return _cpso.minimize(fun, bounds, x0, args, maxiter, popsize, inertia, cognitivity, sociability, None, seed,
                           xtol, ftol, constraints, updating, workers, backend, return_all, verbosity, callback, rng,
-                          strict_updating)
+                          strict_updating, host_workers, host_backend)
 
 
 register("pso", minimize)

@@ -45,9 +45,11 @@ def minimize(
     verbosity=1.0,
     callback=None,
     rng=None,
+    host_workers=None,
+    host_backend=None,
 ):
     """Minimize an objective function using VD-CMA on MI355X (reference vdcma/_vdcma.py:12-30)."""
-    fun_id = _common.resolve_objective(fun, args)
+    fun_id = _common.resolve_objective(fun, args, workers, backend, host_workers, host_backend)
     lower, upper = _common.as_bounds(bounds)
     if x0 is not None:
         if np.ndim(x0) != 1 or len(x0) != len(bounds):
@@ -60,9 +62,9 @@ def minimize(
         raise KeyError(constraints)
     if callback is not None and not hasattr(callback, "__call__"):
         raise ValueError()
-    _common.resolve_backend(backend)
+    _common.resolve_backend(backend, fun_id)
     rng = _common.resolve_rng(rng)
-    workers = _common.resolve_workers(workers)
+    workers = _common.resolve_workers(workers, fun_id)
     if (rng == "philox" and isinstance(fun_id, int) and os.environ.get("SX_CMA_LOOP", "") != "host"
             and (constraints is None or 20.0 + 3.0 * len(lower) / int(popsize) + 1.0 <= 256.0)):
         # nothing the host has to see between generations: the whole loop (and the history) stays on the device --

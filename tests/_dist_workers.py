@@ -88,6 +88,133 @@ def cpu_rows_worker(rank, world, port, cfg, out_dir):
         dist.destroy_process_group()
 
 
+def cpu_cpso_worker(rank, world, port, cfg, out_dir):
+    """CPU-only: competitive PSO with the swarm sharded by rows.  Every rank moves ITS particles with the oracle's
+    arithmetic (Philox draws keyed by the global row) and the two swarm-wide steps go through the product's exchange
+    code with the product's buffer layouts: the best record (World.all_gather_records of [f, global row, x]) and the
+    competitive restart's ONE gather of [pbestfit | per-part radii] (optimize/_cpso.py `fit_radius` ->
+    `fit_radius_all`), from which every rank derives the same radius and the same worst-nw rows."""
+    import torch
+
+    dist = _init(rank, world, port)
+    try:
+        import oracle
+        from oracle import engine as oe
+        from stochopy_amd import parallel
+
+        w = parallel.require_world(world)
+        n, P, maxiter, gamma, npart = cfg["n"], cfg["P"], cfg["maxiter"], cfg["gamma"], cfg["npart"]
+        lower, upper = np.full(n, -32.768), np.full(n, 32.768)
+        stream = oracle.PhiloxStream(cfg["seed"])
+        fobj = oracle.OBJECTIVES[cfg["objective"]]
+        row0, Pl = w.shard(P)
+        delta = np.log(1.0 + 0.003 * P) / np.max((0.2, np.log(0.01 * maxiter)))
+        X = oe.latin_hypercube(stream, P, n, lower, upper)[row0:row0 + Pl].copy()
+        V = np.zeros((Pl, n))
+        pbest, pbestfit = X.copy(), fobj(X)
+
+        def exchange_best():
+            g = int(np.argmin(pbestfit))
+            rec = torch.from_numpy(np.concatenate([[pbestfit[g], float(row0 + g)], pbest[g]]))
+            out = torch.empty((world, n + 2), dtype=torch.float64)
+            w.all_gather_records(rec, out)
+            wb, f, gi = parallel.best_of_records(out.numpy())
+            return out[wb, 2:].numpy().copy(), f
+
+        gbest, gfit = exchange_best()
+        it, restarts, rows_log, trace = 1, [], [], [gfit]
+        while True:
+            it += 1
+            r1, r2 = stream.pso_generation(it, Pl, n, row0=row0)
+            X, V = oe.pso_move(X, V, pbest, gbest, 0.7298, 1.49618, 1.49618, r1, r2, lower, upper, cfg["constraints"])
+            pfit = fobj(X)
+            better = pfit < pbestfit
+            pbest[better], pbestfit[better] = X[better], pfit[better]
+            new_best, new_fit = exchange_best()
+            # (engine.greedy_select / termination with the gathered best)
+            status = None
+            if new_fit < gfit:
+                dx = np.linalg.norm(new_best - gbest)
+                gbest, gfit = new_best, new_fit
+                status = oe.termination(it, maxiter, dx, gfit, cfg["xtol"], cfg["ftol"])
+            elif it >= maxiter:
+                status = -1
+            trace.append(gfit)
+            if status is not None:
+                break
+            # the restart: per-part radii of the shard (parts of consecutive rows, as the device's workgroups leave them)
+            d = X - gbest
+            rr = np.sqrt((d * d).sum(axis=1))
+            parts = np.array([rr[k::npart].max() if len(rr[k::npart]) else 0.0 for k in range(npart)])
+            fit_radius = torch.from_numpy(np.concatenate([pbestfit, parts]))
+            fit_radius_all = torch.empty((world, Pl + npart), dtype=torch.float64)
+            w.all_gather_records(fit_radius, fit_radius_all)
+            allv = fit_radius_all.numpy()
+            radius = allv[:, Pl:].max() / np.sqrt(4.0 * n)
+            if radius < delta:
+                nw = oe.restart_count(it, maxiter, P, gamma)
+                if nw > 0:
+                    rows = allv[:, :Pl].reshape(-1).argsort()[: -nw - 1 : -1]  # global rows, rank-major = row order
+                    mine = np.sort(rows[(rows >= row0) & (rows < row0 + Pl)]) - row0
+                    V[mine] = 0.0
+                    X[mine] = stream.restart_rows(it, lower, upper, mine, n, row0=row0)
+                    pbest[mine] = X[mine]
+                    pbestfit[mine] = 1.0e30
+                    restarts.append((it, nw))
+                    rows_log.append(np.sort(rows))
+        np.savez(os.path.join(out_dir, f"cpso_{rank}.npz"), x=gbest, fun=gfit, nit=it, status=status, trace=np.array(trace),
+                 restarts=np.array(restarts).reshape(-1, 2), rows=np.concatenate(rows_log) if rows_log else np.zeros(0))
+    finally:
+        dist.destroy_process_group()
+
+
+def cpu_cma_worker(rank, world, port, cfg, out_dir):
+    """CPU-only: CMA-ES (and its Penalize form) shards what the reference's parallel backends shard -- the candidates.
+    Every rank draws the normals of ITS rows (keyed by the global row) and evaluates ITS candidates; the product's
+    World.all_gather_rows returns all rows / fitness values in rank order and the model update is replicated.  The run
+    must be the unsharded oracle run bit for bit on every rank."""
+    import torch
+
+    dist = _init(rank, world, port)
+    try:
+        import oracle
+        from oracle import engine as oe
+        from stochopy_amd import parallel
+
+        w = parallel.require_world(world)
+        n, P = cfg["n"], cfg["P"]
+        lower, upper = np.full(n, -3.0), np.full(n, 3.0)
+        fobj = oracle.OBJECTIVES[cfg["objective"]]
+        row0, Pl = w.shard(P)
+        shard0 = row0
+
+        class ShardedStream(oracle.PhiloxStream):
+            def cma_normals(self, gen, P_, n_, row0=0):
+                if P_ != P:  # (VD-CMA's injection normals: one replicated row keyed past the population)
+                    return super().cma_normals(gen, P_, n_, row0=row0)
+                loc = torch.from_numpy(np.ascontiguousarray(super().cma_normals(gen, Pl, n_, row0=shard0)))
+                out = torch.empty((P_, n_), dtype=torch.float64)
+                w.all_gather_rows(loc, out)
+                return out.numpy().copy()
+
+        calls = []
+
+        def sharded_fobj(Xfull):
+            loc = torch.from_numpy(np.ascontiguousarray(fobj(Xfull[row0:row0 + Pl])))
+            out = torch.empty((len(Xfull),), dtype=torch.float64)
+            w.all_gather_rows(loc, out)
+            calls.append(len(Xfull))
+            return out.numpy().copy()
+
+        method = oe.run_vdcma if cfg.get("method") == "vdcma" else oe.run_cmaes
+        res = method(sharded_fobj, lower, upper, None, ShardedStream(cfg["seed"]), maxiter=cfg["maxiter"], popsize=P,
+                     sigma=0.3, constraints=cfg.get("constraints"), eigh="canonical")
+        np.savez(os.path.join(out_dir, f"cma_{rank}.npz"), x=res["x"], fun=res["fun"], nit=res["nit"], status=res["status"],
+                 calls=len(calls))
+    finally:
+        dist.destroy_process_group()
+
+
 def _spy_on_de_runs():
     """Record the _DeRun / _PsoRun objects minimize() creates (to see which exchange a run ended up with)."""
     from stochopy_amd.optimize import _cpso, _de

@@ -83,6 +83,45 @@ def test_world_row_gather_and_agreement_gloo_cpu():
         assert np.array_equal(np.load(os.path.join(out, f"fit_{r}.npy")), want[:, 0])
 
 
+@pytest.mark.parametrize("constraints", [None, "Shrink"])
+def test_cpso_fit_radius_gather_two_ranks_gloo_cpu(constraints):
+    """world_size 2 on CPU: the competitive restart's [pbestfit | radii] gather (optimize/_cpso.py `fit_radius_all`) and
+    the best-record exchange through parallel.World -- the sharded swarm IS the unsharded oracle run: same best-f trace,
+    same restarts (generation, nw) and the same re-seeded rows on every rank."""
+    from _dist_workers import cpu_cpso_worker
+
+    cfg = {"n": 4, "P": 40, "maxiter": 300, "gamma": 1.0, "npart": 3, "seed": 77, "objective": "ackley",
+           "constraints": constraints, "xtol": 1e-12, "ftol": 1e-12}
+    out = _spawn(cpu_cpso_worker, 2, cfg)
+    n = cfg["n"]
+    ref = oe.run_pso(oracle.OBJECTIVES["ackley"], np.full(n, -32.768), np.full(n, 32.768), None, oracle.PhiloxStream(77),
+                     maxiter=300, popsize=40, competitivity=1.0, xtol=1e-12, ftol=1e-12, constraints=constraints)
+    assert len(ref["_restarts"]) >= 2  # the case must exercise the restart
+    for r in range(2):
+        got = np.load(os.path.join(out, f"cpso_{r}.npz"))
+        assert int(got["nit"]) == ref["nit"] and int(got["status"]) == ref["status"]
+        assert float(got["fun"]) == ref["fun"] and np.array_equal(got["x"], ref["x"])
+        assert [tuple(v) for v in got["restarts"].astype(int)] == ref["_restarts"]
+        assert np.array_equal(got["rows"], np.concatenate(ref["_restart_rows"]))
+
+
+@pytest.mark.parametrize("method,constraints", [("cmaes", None), ("cmaes", "Penalize"), ("vdcma", None)])
+def test_cma_candidate_gather_two_ranks_gloo_cpu(method, constraints):
+    """world_size 2 on CPU: CMA-ES / VD-CMA shard the candidates (rows drawn and evaluated by their owner, gathered with
+    World.all_gather_rows, model update replicated) -- the unsharded oracle run bit for bit on every rank."""
+    from _dist_workers import cpu_cma_worker
+
+    cfg = {"n": 5, "P": 12, "maxiter": 30, "seed": 9, "objective": "rosenbrock", "constraints": constraints, "method": method}
+    out = _spawn(cpu_cma_worker, 2, cfg)
+    run = oe.run_vdcma if method == "vdcma" else oe.run_cmaes
+    ref = run(oracle.OBJECTIVES["rosenbrock"], np.full(5, -3.0), np.full(5, 3.0), None, oracle.PhiloxStream(9), maxiter=30,
+              popsize=12, sigma=0.3, constraints=constraints, eigh="canonical")
+    for r in range(2):
+        got = np.load(os.path.join(out, f"cma_{r}.npz"))
+        assert int(got["nit"]) == ref["nit"] and int(got["status"]) == ref["status"] and int(got["calls"]) >= ref["nit"]
+        assert float(got["fun"]) == ref["fun"] and np.array_equal(got["x"], ref["x"])
+
+
 def _de_reference(cfg, world):
     o = dict(cfg["options"])
     n = cfg["n"]

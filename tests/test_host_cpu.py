@@ -323,6 +323,32 @@ def test_api_surface_and_validation():
     from stochopy_amd.optimize import _common
 
     assert isinstance(_common.resolve_objective(lambda x: float(np.sum(x)), ()), _common.HostExternal)
+    # host pools for such an objective: explicit options, or the reference's own spelling (its _common.py:94-97)
+    plain = lambda x: float(np.sum(x))  # noqa: E731
+    ext = _common.resolve_objective(plain, (), host_workers=3, host_backend="loky")
+    assert (ext.pool.workers, ext.pool.backend, ext.from_reference_options) == (3, "loky", False)
+    ext = _common.resolve_objective(plain, (), host_workers=2)
+    assert ext.pool.backend == "threading"  # the reference's default backend
+    ext = _common.resolve_objective(plain, (), workers=5, backend="threading")
+    assert (ext.pool.workers, ext.from_reference_options) == (5, True)
+    assert _common.resolve_workers(5, ext) == 1 and _common.resolve_backend("threading", ext) == "hip"
+    assert _common.resolve_objective(plain, (), workers=1, backend="loky").pool is None  # serial, as in the reference
+    assert _common.resolve_objective(plain, (), host_workers=-1).pool.workers == (os.cpu_count() or 1) or (os.cpu_count() or 1) < 2
+    with pytest.raises(ValueError):
+        _common.resolve_objective(plain, (), host_workers=4, host_backend="mpi")
+    with pytest.raises(ValueError):
+        _common.resolve_objective(plain, (), workers=4, backend="loky", host_workers=2)
+    with pytest.raises(ValueError):  # a factory objective runs in the kernels: no host pool to configure
+        _common.resolve_objective(f, (), host_workers=4)
+    with pytest.raises(ValueError, match="belongs to keurfonluu/stochopy"):
+        sa.optimize.minimize(f, b, options={"backend": "loky", "workers": 4})
+    # the pool's tasks are the reference's serial wrapper on blocks of rows
+    rows = np.arange(12.0).reshape(4, 3)
+    for backend in ("threading", "loky"):
+        pool = _common.HostPool(2, backend)
+        got = pool.executor().submit(_common._eval_block, np.sum, rows, ()).result()
+        assert np.array_equal(got, rows.sum(axis=1))
+        pool.close()
     with pytest.raises(NoDeviceError):
         sa.optimize.minimize(lambda x: float(np.sum(x)), b, options={"backend": "hip", "updating": "deferred"})
     with pytest.raises(ValueError):
