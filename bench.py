@@ -374,42 +374,59 @@ def main():
                 "block_ms_median": block_ms[len(block_ms) // 2], "kern_ms": kern_ms, "nl": nl,
                 "kernels_per_gen": kernels_per_gen, "rows_total": Ptotal or world * P}
 
-    def measure_with_fallback(**kw):
+    # ---- N > 1: what the first contact with a second physical GPU must not cost ----------------
+    # The RCCL transport (one all-gather per generation: the library's own, exercised path) is measured FIRST and its
+    # line is ready before the peer-write transport (kernels of different processes writing into each other's HBM over
+    # IPC mappings: never run across a physical link before the driver's SCALE run) is even negotiated.  From then on a
+    # watchdog holds the line: if a later stage wedges -- a hang no timeout inside the exchange catches -- rank 0 still
+    # prints ONE line (the RCCL measurement, with what wedged in `transport_fallback`) and every rank leaves.
+    state = {"line": None, "stage": None, "deadline": None}
+
+    def watchdog():
+        while True:
+            time.sleep(1.0)
+            dl = state["deadline"]
+            if dl is not None and time.monotonic() > dl:
+                if rank == 0 and state["line"] is not None:
+                    ln = dict(state["line"])
+                    ln["transport_fallback"] = (f"stage '{state['stage']}' did not finish within its allowance: the line "
+                                                f"is the RCCL measurement taken before it")
+                    print(json.dumps(ln), flush=True)
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(0 if rank == 0 and state["line"] is not None else 3)
+
+    def guarded(stage, seconds, fn):
+        """Run fn() as `stage`; if it does not return within `seconds` the watchdog prints the line held so far."""
+        state["stage"], state["deadline"] = stage, time.monotonic() + seconds
         try:
-            return measure(None, **kw)
-        except RuntimeError as e:
-            # a peer-exchange wait that timed out mid-run (every rank sees it within one timeout): the transport
-            # passed its self-test but is not usable here -- measure through the RCCL transport instead and say so
-            if dist is None or "peer exchange timed out" not in str(e) or kw.get("donors") == "global":
-                raise
-            print(f"[bench] rank {rank}: {e}; falling back to exchange='rccl'", file=sys.stderr, flush=True)
-            m = measure("rccl", **kw)
-            m["run"].exchange_note = f"p2p failed mid-run ({e})"
-            return m
+            return fn()
+        finally:
+            state["deadline"] = None
 
-    m = measure_with_fallback()
-    run, dt, kern_ms, nl, kernels_per_gen = m["run"], m["dt"], m["kern_ms"], m["nl"], m["kernels_per_gen"]
-    value = m["rows_total"] * m["steps_timed"] / dt
+    def measure_p2p_or_none(stage, seconds, **kw):
+        """The peer-write transport, or None with the reason (negotiation failed on some rank, or a wait timed out)."""
+        try:
+            m = guarded(stage, seconds, lambda: measure("p2p", **kw))
+            return m, None
+        except Exception as e:  # noqa: BLE001  (every rank takes the same way: negotiate() agrees, time-outs reach all)
+            print(f"[bench] rank {rank}: {stage}: {e}", file=sys.stderr, flush=True)
+            return None, str(e)[:300]
 
-    # BASELINE config 5 with N > 1: DE n=1024, P=131072 IN TOTAL (strong scaling), both donor modes
-    c5 = None
-    if world > 1:
-        c5 = {"workload": "de_rosenbrock_n1024_p131072 (total), best1bin", "n_ranks_seen": dist.get_world_size(),
-              "rows_per_gpu": 131072 // world, "scaling": "strong"}
-        for mode in ("shard", "global"):
-            try:
-                r = measure_with_fallback(objective="rosenbrock", n=1024, Ptotal=131072, strategy="best1bin", donors=mode,
-                                          K=20, W=10, kernel_launches=50)
-                c5["donors_" + mode] = {
-                    "value": 131072 * r["steps_timed"] / r["dt"], "unit": "evals/s",
-                    "ms_per_step": r["dt"] / r["steps_timed"] * 1e3, "steps_timed": r["steps_timed"],
-                    "exchange": r["run"].exchange, "exchange_note": getattr(r["run"], "exchange_note", None),
-                    "semantics": ("island model with a shared global best (documented deviation)" if mode == "shard" else
-                                  "the unsharded run: donor rows read from their owners' HBM over xGMI")}
-            except Exception as e:  # noqa: BLE001  (e.g. no peer mapping for global donors): say so, keep the line
-                c5["donors_" + mode] = {"error": str(e)[:300]}
+    transports = None
+    if world == 1:
+        m = measure(None)
+    else:
+        import threading
 
-    if rank == 0:
+        threading.Thread(target=watchdog, daemon=True).start()
+        m_rccl = guarded("rccl", 600.0, lambda: measure("rccl"))
+        transports = {"rccl": {"value": m_rccl["rows_total"] * m_rccl["steps_timed"] / m_rccl["dt"],
+                               "ms_per_step": m_rccl["dt"] / m_rccl["steps_timed"] * 1e3}}
+        m = m_rccl
+    def build_line(m, c5=None, transport_fallback=None):
+        run, dt, kern_ms, nl, kernels_per_gen = m["run"], m["dt"], m["kern_ms"], m["nl"], m["kernels_per_gen"]
+        value = m["rows_total"] * m["steps_timed"] / dt
         bytes_per_launch = algorithmic_bytes_per_eval(n, k) * P
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
@@ -466,13 +483,74 @@ def main():
                 "timing": "HIP events on the engine stream around %d generations (%d kernel(s) each)" % (nl, kernels_per_gen),
             },
         }
-        # what actually ran, at the top level (the driver's SCALE run reads this, not the nested blocks)
+        # what actually ran, at the top level (the driver's SCALE run reads this, not the nested blocks): ranks seen, the
+        # transport behind `value`, BOTH transports' values when N > 1, and why if the peer transport is not the one
         line["n_ranks_seen"] = dist.get_world_size() if dist is not None else 1
         line["process_group"] = dist.get_backend() if dist is not None else None
         line["transport"] = None if run.world is None else run.exchange
-        line["transport_fallback"] = getattr(run, "exchange_note", None)
+        line["transports"] = transports
+        line["transport_fallback"] = transport_fallback or getattr(run, "exchange_note", None)
         if c5 is not None:
             line["c5"] = c5
+        return line
+
+    # BASELINE config 5 with N > 1: DE n=1024, P=131072 IN TOTAL (strong scaling; the N = 1 point is
+    # configs.C5_full_de_n1024_p131072_1gpu of the N = 1 line), shard-local donors through both transports and global
+    # donors (which need the peer mappings) -- RCCL first here too, every stage under the watchdog
+    c5 = None
+    p2p_note = None
+    if world > 1:
+        c5kw = dict(objective="rosenbrock", n=1024, Ptotal=131072, strategy="best1bin", K=20, W=10, kernel_launches=50)
+        c5 = {"workload": "de_rosenbrock_n1024_p131072 (total), best1bin", "n_ranks_seen": dist.get_world_size(),
+              "rows_per_gpu": 131072 // world, "scaling": "strong",
+              "n1_reference": "configs.C5_full_de_n1024_p131072_1gpu of the N = 1 line (profiles/r5_bench_N1.json)"}
+
+        def c5_entry(r, mode):
+            return {"value": 131072 * r["steps_timed"] / r["dt"], "unit": "evals/s",
+                    "ms_per_step": r["dt"] / r["steps_timed"] * 1e3, "steps_timed": r["steps_timed"],
+                    "exchange": r["run"].exchange, "exchange_note": getattr(r["run"], "exchange_note", None),
+                    "semantics": ("island model with a shared global best (documented deviation)" if mode == "shard" else
+                                  "the unsharded run: donor rows read from their owners' HBM over xGMI")}
+
+        if rank == 0:
+            state["line"] = build_line(m_rccl)
+        try:
+            r = guarded("c5 shard-local donors over rccl", 600.0, lambda: measure("rccl", donors="shard", **c5kw))
+            c5["donors_shard_rccl"] = c5_entry(r, "shard")
+        except Exception as e:  # noqa: BLE001
+            c5["donors_shard_rccl"] = {"error": str(e)[:300]}
+        if rank == 0:
+            state["line"] = build_line(m_rccl, c5)
+        p2p_off = ("SX_BENCH_P2P=0" if os.environ.get("SX_BENCH_P2P", "1") == "0" else
+                   "SX_EXCHANGE=rccl" if os.environ.get("SX_EXCHANGE") == "rccl" else None)
+        if p2p_off is None:
+            m_p2p, p2p_note = measure_p2p_or_none("p2p (peer writes over xGMI)", 300.0)
+            if m_p2p is not None:
+                v = m_p2p["rows_total"] * m_p2p["steps_timed"] / m_p2p["dt"]
+                transports["p2p"] = {"value": v, "ms_per_step": m_p2p["dt"] / m_p2p["steps_timed"] * 1e3}
+                if v > transports["rccl"]["value"]:
+                    m = m_p2p
+                if rank == 0:
+                    state["line"] = build_line(m, c5)
+                for mode in ("shard", "global"):
+                    r, note = measure_p2p_or_none(f"c5 {mode} donors over p2p", 300.0, donors=mode, **c5kw)
+                    c5[f"donors_{mode}_p2p"] = c5_entry(r, mode) if r is not None else {"error": note}
+                    if rank == 0:
+                        state["line"] = build_line(m, c5)
+            else:
+                transports["p2p"] = {"error": p2p_note}
+                c5["donors_global_p2p"] = {"error": "needs the peer mappings: " + (p2p_note or "")}
+        else:
+            p2p_note = p2p_off + " (switched off by the environment)"
+            transports["p2p"] = {"skipped": p2p_note}
+            c5["donors_global_p2p"] = {"error": "needs the peer exchange: " + p2p_note}
+        state["deadline"] = None
+
+    run = m["run"]
+    value = m["rows_total"] * m["steps_timed"] / m["dt"]
+    if rank == 0:
+        line = build_line(m, c5, None if (transports is None or "value" in transports.get("p2p", {})) else
+                          f"peer-write transport not used: {p2p_note}")
         if world == 1 and not args.no_minimize_wall:
             line["minimize_wall"] = minimize_wall(objective, n, P, strategy)
         if world == 1 and not args.no_configs:

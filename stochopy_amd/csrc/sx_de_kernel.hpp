@@ -479,7 +479,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     // ---- D. trial vector: mutation (de/_strategy.py, same association), crossover (de/_de.py:344 forced
     //      index OR r <= CR), Random repair (de/_constraints.py:21-26) -> LDS
     const int nq = (n + LPR - 1) / LPR;
-    double keep[kStep];  // NFIX (one batch per row): the trial stays in registers for the row store
+    // one batch per row -- NFIX, and (round 5) EVERY row of a short-row kernel, whatever its run-time length (lanes_per_row
+    // gives rows of up to 64 / 128 elements 16 / 32 lanes: n <= kStep * LPR): trial and own row stay in registers for the
+    // row store
+    constexpr bool kRegRow = NFIX != 0 || LPR < kWave;
+    double keep[kStep];
     auto trial_batch = [&](int q0, const Batch &bt) {
         const double(&bx)[kStep] = bt.x;
         const double(&bd)[kMaxDonors][kStep] = bt.d;
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
                 double cand = (e == irand || br[t] <= CR) ? v : bx[t];
                 if (repair && (cand < a.lower[e] || cand > a.upper[e])) cand = brs[t];
                 U[e] = cand;
-                if (NFIX) keep[t] = cand;
+                if (kRegRow) keep[t] = cand;
             }
         }
     };
@@ -571,9 +575,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const bool better = fc < fold;  // _common.py:127 strict <
     if (FULL || id.active) {
         double *__restrict__ xo = nxt + id.row * ld;
-        if constexpr (NFIX != 0) {  // both rows are in registers already: no load behind the objective; streaming stores
+        if constexpr (kRegRow) {  // both rows are in registers already: no load behind the objective; streaming stores
 #pragma unroll
-            for (int t = 0; t < kStep; ++t) st_stream(xo + l + t * LPR, better ? keep[t] : B0.x[t]);
+            for (int t = 0; t < kStep; ++t)
+                if (NFIX != 0 || l + t * LPR < n) st_stream(xo + l + t * LPR, better ? keep[t] : B0.x[t]);
         } else {
             const double *__restrict__ src = better ? U : xi;  // LDS or global: generic loads
             for (int e0 = l; e0 < n; e0 += kStep * LPR) {

@@ -33,7 +33,7 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
 
 // FULL: n == 4 * LPR (64, 128 or 256 -- BASELINE config 3): the row length is a compile-time constant, a row is exactly
 // one batch, and every bound check and loop over the row folds away.
-// PLAIN (with FULL): constraints=None and no restart pending (plain PSO, or the first generation of a CPSO graph): neither
+// PLAIN (round 5: with or without FULL): constraints=None and no restart pending (plain PSO, or the first generation of a CPSO graph): neither
 // the Shrink pass nor the re-seeding test is compiled in.
 // CHAIN (with PLAIN; round 3): ONE kernel per generation, the way DE runs (sx_de_kernel.hpp).  Launch L (parity
 // chain_p = L & 1) first finalises the generation its predecessor produced -- every workgroup reduces the per-workgroup
@@ -356,16 +356,20 @@ pso_kernel_t pick_kernel(int fun_id, int n, bool plain) {
     const int lpr = lanes_per_row(n);
     // whole-batch rows with in-kernel draws get the constant-length form (host draws: the run is bound by the host)
     const bool full = PH && n == 4 * lpr;
+    // round 5: rows of any other length get the PLAIN form too when nothing needs the general one (constraints=None, no
+    // restart pending): without the Shrink pass and the re-seeding code the kernel runs at 8 waves per SIMD instead of 6 --
+    // plain PSO at n = 250 / 300 was 0.75 / 0.67 of its n = 256 neighbour's HBM fraction (profiles/r5_shapes_before.txt)
+    const bool pl = PH && plain;
     switch (lpr) {
         case 16:
             if (full) return plain ? pick_kernel_lpr<RNG, 16, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 16, PH>(fun_id);
-            return pick_kernel_lpr<RNG, 16, false>(fun_id);
+            return pl ? pick_kernel_lpr<RNG, 16, false, PH>(fun_id) : pick_kernel_lpr<RNG, 16, false>(fun_id);
         case 32:
             if (full) return plain ? pick_kernel_lpr<RNG, 32, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 32, PH>(fun_id);
-            return pick_kernel_lpr<RNG, 32, false>(fun_id);
+            return pl ? pick_kernel_lpr<RNG, 32, false, PH>(fun_id) : pick_kernel_lpr<RNG, 32, false>(fun_id);
     }
     if (full) return plain ? pick_kernel_lpr<RNG, 64, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 64, PH>(fun_id);
-    return pick_kernel_lpr<RNG, 64, false>(fun_id);
+    return pl ? pick_kernel_lpr<RNG, 64, false, PH>(fun_id) : pick_kernel_lpr<RNG, 64, false>(fun_id);
 }
 
 int check_args(const sx_pso_args *a) {

@@ -168,6 +168,174 @@ __device__ __forceinline__ double row_objective_chain(const double *U, int l) {
     return O::finish(sa, sb, NFIX);
 }
 
+// objectives whose terms are a few multiplications (no cosine): for these the summation plan, not the arithmetic, is the
+// row's time, and long rows of the usual lengths get the plan as constants (row_reduce_long)
+template <int FUN>
+constexpr bool light_objective() {
+    return FUN == SX_FUN_ROSENBROCK || FUN == SX_FUN_SPHERE || FUN == SX_FUN_QUARTIC || FUN == SX_FUN_STYBLINSKI_TANG;
+}
+// The same register chains for rows whose length is only known at run time (round 5: shapes off the benchmark grid -- n = 100,
+// 130, 250 ... -- used to take the staged-terms path: term arrays written to LDS, the plan walked with scalar loads).  A row
+// that fits one batch (n <= 4 LPR, i.e. EVERY row of up to 256 elements) has at most three leaves in numpy's recursion, each
+// of at most 16 blocks, and only the last one has a tail:
+//   m <= 128: one leaf;   m in 129..256: split at n2 = (m/2) - (m/2) % 8 -- and the right part r = m - n2 once more if it
+//   is still above 128 (129..135: m = 249..255): 64 + (r - 64), two leaves of at most 8 blocks -- S0 + (S1 + S2).
+// A leaf of nb blocks from element e0 lives on a group of 8 SEG lanes exactly as in row_objective_chain -- lane SEG j + g forms
+// the terms of blocks 4g .. 4g+3 of accumulator j (leaf_terms_rt: every lane at most four terms, whatever the leaf layout), the
+// running sum hops from lane to lane by DPP (leaf_chain_rt) -- with the block count as a run-time value: a block beyond it
+// contributes nothing.  After leaf_chain_rt lane SEG-1 (SEG = 2: the whole tree) or lanes SEG-1 and 4 SEG + SEG-1 (SEG = 4:
+// the two halves of the last tree level) of the group hold the leaf's sums.  Same additions in the same order as numpy.
+template <int FUN>
+__device__ __forceinline__ void leaf_terms_rt(const double *U, int e0, int nb, int j, int g, double (&a)[4], double (&b)[4]) {
+    using O = Obj<FUN>;
+    double x[4], xn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool in = 4 * g + i < nb;
+        const int e = e0 + kGroup * (4 * g + i) + j;
+        x[i] = in ? U[e] : 0.0;
+        xn[i] = (O::NEXT && in) ? U[e + 1] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) O::term(x[i], xn[i], e0 + kGroup * (4 * g + i) + j, a[i], b[i]);
+}
+template <int FUN, int SEG>
+__device__ __forceinline__ void leaf_chain_rt(const double (&a)[4], const double (&b)[4], int nb, double &ra, double &rb) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    static_assert(SEG == 2 || SEG == 4, "16 or 32 lanes per leaf");
+    constexpr int kHop = SEG == 4 ? 0x90 : 0xA0;  // quad_perm [0,0,1,2] / [0,0,2,2]: lane L takes lane L-1's value
+    ra = a[0], rb = b[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const bool in = i < nb;
+        ra = in ? ra + a[i] : ra;
+        if (TWO) rb = in ? combine<BMUL>(rb, b[i]) : rb;
+    }
+#pragma unroll
+    for (int s = 1; s < SEG; ++s) {
+        ra = dpp_f64<kHop>(ra);
+        if (TWO) rb = dpp_f64<kHop>(rb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = 4 * s + i < nb;
+            ra = in ? ra + a[i] : ra;
+            if (TWO) rb = in ? combine<BMUL>(rb, b[i]) : rb;
+        }
+    }
+    constexpr int kShl1 = 0x100 + SEG, kShl2 = 0x100 + 2 * SEG;  // row_shl: lane L takes lane L+SEG / L+2 SEG
+    ra = combine<false>(ra, dpp_f64<kShl1>(ra));
+    ra = combine<false>(ra, dpp_f64<kShl2>(ra));
+    if (TWO) {
+        rb = combine<BMUL>(rb, dpp_f64<kShl1>(rb));
+        rb = combine<BMUL>(rb, dpp_f64<kShl2>(rb));
+    }
+    if constexpr (SEG == 2) {  // the group is one 16-lane DPP row: the last level is a DPP move too
+        ra = combine<false>(ra, dpp_f64<0x108>(ra));
+        if (TWO) rb = combine<BMUL>(rb, dpp_f64<0x108>(rb));
+    }
+}
+
+#ifndef SX_OBJ_CHAIN_RT
+#define SX_OBJ_CHAIN_RT 1  // A/B switch: 0 = one-batch rows of run-time length stage their terms (rounds 1-4)
+#endif
+
+template <int FUN, int LPR>
+__device__ __forceinline__ double row_objective_chain_rt(const double *U, int n, const PlanArg &plan, int l) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    const double identB = BMUL ? 1.0 : 0.0;
+    const int m = O::NEXT ? n - 1 : n;
+    const int nbt = m / kGroup, tail = m % kGroup;  // blocks in all leaves together; terms behind the last leaf's tree
+    // the tail terms a[8 nbt .. m-1] are added one by one to the last leaf's sum.  Cheap terms: every lane forms them itself from
+    // broadcast reads; a cosine per term: lane t of the row forms term t, and the sums below fetch it
+    constexpr bool kTailByLane = !light_objective<FUN>() || LPR == kWave;
+    double tla = 0.0, tlb = identB;
+    if (kTailByLane && tail > 0) {
+        const int e = kGroup * nbt + (l < tail ? l : 0);
+        O::term(U[e], O::NEXT ? U[e + 1] : 0.0, e, tla, tlb);
+    }
+    auto add_tail = [&](double &xa, double &xb) {
+#pragma unroll
+        for (int t = 0; t < kGroup - 1; ++t) {
+            if (t < tail) {  // (uniform)
+                double ta, tb;
+                if constexpr (kTailByLane) {
+                    ta = row_lane_value<LPR>(tla, t, l);
+                    tb = TWO ? row_lane_value<LPR>(tlb, t, l) : identB;
+                } else {
+                    const int e = kGroup * nbt + t;
+                    O::term(U[e], O::NEXT ? U[e + 1] : 0.0, e, ta, tb);
+                }
+                xa = xa + ta;
+                if (TWO) xb = combine<BMUL>(xb, tb);
+            }
+        }
+    };
+    double sa = 0.0, sb = identB;
+    double a[4], b[4], ra, rb;
+    if constexpr (LPR < kWave) {  // n <= 128: at most one leaf, on all of the row's lanes
+        constexpr int SEG = LPR / kGroup;
+        leaf_terms_rt<FUN>(U, 0, nbt, l / SEG, l % SEG, a, b);
+        leaf_chain_rt<FUN, SEG>(a, b, nbt, ra, rb);
+        if (nbt > 0) {
+            if constexpr (SEG == 2) {
+                sa = row_lane_value<LPR>(ra, SEG - 1, l);
+                if (TWO) sb = row_lane_value<LPR>(rb, SEG - 1, l);
+            } else {
+                sa = row_lane_value<LPR>(ra, SEG - 1, l) + row_lane_value<LPR>(ra, 4 * SEG + SEG - 1, l);
+                if (TWO) sb = combine<BMUL>(row_lane_value<LPR>(rb, SEG - 1, l), row_lane_value<LPR>(rb, 4 * SEG + SEG - 1, l));
+            }
+        }
+        add_tail(sa, sb);
+    } else {
+        // whole-wave rows of up to 256 elements.  One or two leaves: leaf 0 on lanes 0..31, leaf 1 on lanes 32..63 (32 lanes
+        // each: SEG = 4).  Three leaves: leaf 0 as before, leaves 1 and 2 (at most 8 blocks each) on lanes 32..47 and 48..63
+        // (16 lanes each: SEG = 2).  Terms are formed ONCE, four per lane; with three leaves both chain forms run over them and
+        // each half of the wave keeps the one that is its own.
+        const int nleaf = plan.nleaf;  // 0 (m < 8), 1, 2 or 3
+        const int end0 = nleaf > 0 ? plan.end[0] : 0, end1 = nleaf > 1 ? plan.end[1] : end0;
+        const bool three = nleaf > 2;  // (uniform)
+        const int half = l >> 5;
+        const bool narrow = three && half;  // this lane belongs to a 16-lane group
+        const int lg = narrow ? (l & 15) : (l & 31), grp = (l >> 4) & 1;
+        const int seg = narrow ? 2 : 4;
+        const int e0 = kGroup * (!half ? 0 : !three ? end0 : grp ? end1 : end0);
+        const int nb = !half ? end0 : !three ? end1 - end0 : grp ? nbt - end1 : end1 - end0;
+        leaf_terms_rt<FUN>(U, e0, nb, lg / seg, lg % seg, a, b);
+        leaf_chain_rt<FUN, 4>(a, b, nb, ra, rb);
+        const double s0a = readlane_f64(ra, 3) + readlane_f64(ra, 19);
+        double s1a = readlane_f64(ra, 35) + readlane_f64(ra, 51), s2a = 0.0;
+        double s0b = identB, s1b = identB, s2b = identB;
+        if (TWO) {
+            s0b = combine<BMUL>(readlane_f64(rb, 3), readlane_f64(rb, 19));
+            s1b = combine<BMUL>(readlane_f64(rb, 35), readlane_f64(rb, 51));
+        }
+        if (three) {  // (uniform)
+            leaf_chain_rt<FUN, 2>(a, b, nb, ra, rb);
+            s1a = readlane_f64(ra, 33), s2a = readlane_f64(ra, 49);
+            if (TWO) s1b = readlane_f64(rb, 33), s2b = readlane_f64(rb, 49);
+        }
+        // the last leaf takes the tail before the merges
+        double la = three ? s2a : nleaf > 1 ? s1a : s0a, lb = three ? s2b : nleaf > 1 ? s1b : s0b;
+        if (nleaf == 0) la = 0.0, lb = identB;
+        add_tail(la, lb);
+        // merges in recursion order: S0 + S1, or S0 + (S1 + S2)
+        if (three) {
+            sa = s0a + (s1a + la);
+            if (TWO) sb = combine<BMUL>(s0b, combine<BMUL>(s1b, lb));
+        } else if (nleaf > 1) {
+            sa = s0a + la;
+            if (TWO) sb = combine<BMUL>(s0b, lb);
+        } else {
+            sa = la, sb = lb;
+        }
+    }
+    sa = 0.0 + sa;  // add.reduce starts from the identity
+    sb = !TWO ? identB : (BMUL ? sb : 0.0 + sb);
+    return O::finish(sa, sb, n);
+}
+
 // rows whose objective needs nothing but the staged vector itself (row_objective_chain): kernels that stage for nobody else
 // (sx_eval) can then give a row n + 8 doubles of LDS instead of lds_row_stride(n) and fit twice the workgroups on a CU
 #ifndef SX_OBJ_CHAIN
@@ -176,12 +344,6 @@ __device__ __forceinline__ double row_objective_chain(const double *U, int l) {
 #ifndef SX_OBJ_CHAIN256
 #define SX_OBJ_CHAIN256 1  // A/B: 0 = rows of 256 elements stage their terms
 #endif
-// objectives whose terms are a few multiplications (no cosine): for these the summation plan, not the arithmetic, is the
-// row's time, and long rows of the usual lengths get the plan as constants (row_reduce_long)
-template <int FUN>
-constexpr bool light_objective() {
-    return FUN == SX_FUN_ROSENBROCK || FUN == SX_FUN_SPHERE || FUN == SX_FUN_QUARTIC || FUN == SX_FUN_STYBLINSKI_TANG;
-}
 #ifndef SX_LONG_STATIC
 #define SX_LONG_STATIC 1  // (0: long rows inside the generation kernels keep the run-time plan -- A/B builds)
 #endif
@@ -203,6 +365,12 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     lds_wave_fence();  // U complete (written and read by this wave only)
     if constexpr (chain_only<FUN, NFIX>())
         return row_objective_chain<FUN, LPR, NFIX>(U, l);
+    if constexpr (NFIX == 0 && SX_OBJ_CHAIN_RT) {  // one-batch rows of run-time length (every n <= 256): the same chains, run-time block counts
+        // (lanes_per_row gives 16 / 32 lanes to rows of up to 64 / 128 elements only: a short-row kernel never meets a longer row,
+        //  and the staged-terms code below is not even compiled for it)
+        if constexpr (LPR < kWave) return row_objective_chain_rt<FUN, LPR>(U, n, plan, l);
+        if (n <= 4 * LPR) return row_objective_chain_rt<FUN, LPR>(U, n, plan, l);
+    }
     if constexpr (NFIX > 256) {  // a long row of compile-time length: numpy's plan as constants (row_reduce_long)
         static_assert(LPR == kWave, "whole-wave rows");
         double sa, sb;

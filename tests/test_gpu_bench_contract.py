@@ -87,5 +87,8 @@ def test_bench_two_ranks_emits_the_c5_strong_scaling_figures():
     assert (d["n_ranks_seen"], d["transport"], d["process_group"]) == (2, "rccl", "gloo")
     c5 = d["c5"]
     assert c5["n_ranks_seen"] == 2 and c5["rows_per_gpu"] == 65536 and c5["scaling"] == "strong"
-    assert c5["donors_shard"].get("value", 0) > 0, c5["donors_shard"]
-    assert "donors_global" in c5 and ("value" in c5["donors_global"] or "peer exchange" in c5["donors_global"]["error"])
+    assert c5["donors_shard_rccl"].get("value", 0) > 0, c5["donors_shard_rccl"]
+    assert "peer exchange" in c5["donors_global_p2p"]["error"]
+    # both transports at the top level (round 5): RCCL is measured FIRST; the peer-write transport is switched off here
+    assert d["transports"]["rccl"]["value"] == d["value"] and "skipped" in d["transports"]["p2p"]
+    assert "SX_EXCHANGE=rccl" in d["transport_fallback"]

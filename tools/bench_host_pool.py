@@ -49,8 +49,8 @@ def per_generation(fun, args, gens, **pool):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, r.nit
 
-    run(1)
-    (t1, n1), (t2, n2) = run(1), run(1 + gens)
+    run(2)
+    (t1, n1), (t2, n2) = run(2), run(2 + gens)
     return (t2 - t1) / (n2 - n1)
 
 
