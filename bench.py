@@ -120,6 +120,31 @@ def minimize_wall(objective, n, P, strategy, maxiter=1000):
                     "device since round 3), uploads, graph replays, the result copy"}
 
 
+def eval_kernel_config(objective, n, P, reps=50):
+    """sx_eval alone: HIP events on the engine stream around `reps` launches over a resident (P, n) array; (8n + 8) B per evaluation."""
+    import torch
+
+    from stochopy_amd import _device, _lib
+
+    ctx = _device.Context()
+    X = torch.rand((P, n), dtype=torch.float64, device=ctx.device) * 10.24 - 5.12
+    f = ctx.empty((P,))
+    fid = _lib.FUN_IDS[objective]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(ctx.stream):
+        for _ in range(5):
+            _device.evaluate(ctx, fid, X, n, f=f)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(ctx.stream)
+        for _ in range(reps):
+            _device.evaluate(ctx, fid, X, n, f=f)
+        e1.record(ctx.stream)
+        ctx.sync()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    return {"evals_per_s": P / us * 1e6, "kernel_us": us, "bound": "hbm", "frac": (8 * n + 8) * P / us / 1e3 / HBM_PEAK_GBS,
+            "note": "the objective kernel alone (sx_eval), HIP events around %d launches; (8 n + 8) B per evaluation" % reps}
+
+
 def other_configs():
     """BASELINE.json configs 2-4 from the same process: evals/s = popsize / (wall per generation),
     wall per generation from TWO whole minimize() calls of different length (set-up and result copy cancel), best of
@@ -170,6 +195,20 @@ def other_configs():
         "evals_per_s": 4096 / t, "ms_per_generation": t * 1e3, "bound": "host",
         "note": "parity mode: same seed => the reference's trajectory bit for bit; per generation the host replays 23 M words of "
                 "numpy's legacy MT19937 stream (de/_de.py:304-311, P permutations of P-1 indices) -- csrc/sx_mt19937.cpp"}
+    # the metric's row length WITHOUT the launch-bound effects: DE at n = 128 with 2^20 individuals
+    # (4.3 GB algorithmic per generation, 1 GiB per population buffer: nothing of it fits a cache), and the objective
+    # kernel alone (rows a1 / a5 of SURVEY.md section 8a: the literal "objective-fn evals/s") at the same shape
+    t = per_gen("de", sa.factory.rosenbrock, 128, dict(de5, popsize=1 << 20), 10, 60, reps=2)
+    out["M_large_de_rosenbrock_n128_p1048576"] = {"evals_per_s": (1 << 20) / t, "us_per_generation": t * 1e6, "bound": "hbm",
+                                                  "frac": 4112 * (1 << 20) / t / (HBM_PEAK_GBS * 1e9)}
+    out["eval_rosenbrock_n128_p1048576"] = eval_kernel_config("rosenbrock", 128, 1 << 20)
+    out["eval_ackley_n256_p524288"] = eval_kernel_config("ackley", 256, 1 << 19)
+    # rows beyond 4096 elements (round 5: csrc/sx_wide.hip) where VD-CMA is the method of choice
+    t = per_gen("vdcma", sa.factory.rosenbrock, 16384, {"popsize": 1024, "sigma": 0.3}, 10, 60, reps=2)
+    out["VD_vdcma_rosenbrock_n16384_p1024"] = {
+        "evals_per_s": 1024 / t, "us_per_generation": t * 1e6, "bound": "hbm", "frac": 32 * 16384 * 1024 / t / (HBM_PEAK_GBS * 1e9),
+        "note": "algorithmic bytes 32 n per candidate: y and x written (16 n), x read by the objective (8 n), x and y of the "
+                "mu = P/2 selected rows read by the moment sums (8 n per candidate on average); DESIGN.md section 4"}
     c3 = {"popsize": 16384, "updating": "deferred"}
     t = per_gen("pso", sa.factory.ackley, 256, c3, 200, 1200)
     out["C3a_pso_ackley_n256_p16384"] = {"evals_per_s": 16384 / t, "us_per_generation": t * 1e6, "bound": "hbm",

@@ -5,6 +5,7 @@
 //   stochopy/factory/benchmark.py:14-156              the seven objectives
 //   stochopy/optimize/_common.py:34-90                population wrapper fun(X) -> f
 //   stochopy/optimize/_common.py:131-158              argmin + termination ladder
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -205,9 +206,131 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     if (part_f != nullptr) block_partial<LPR>(val, id, sf, si, part_f, part_i);
 }
 
+// Eight lanes per row (round 5).  What bounds one-batch rows at large P turned out to be instruction issue, not memory
+// (profiles/r5_eval_stream_ab.txt: a resident form of the one-visit kernel -- a fixed grid of wavefronts walking the row blocks
+// with the loads two visits ahead, 16-byte lane loads -- was built first and moved nothing: 0.49 -> 0.51 at n = 128; and
+// Rosenbrock n=64 needs 222 us where Sphere n=64 needs 167): with 16 / 32 / 64 lanes per row every wavefront instruction of the accumulator chains serves 4 / 2 / 1 rows --
+// the chains are sequential, so three quarters of the lanes idle through each of their 15 additions -- and the seven tail
+// terms are formed by every lane.  Here a row belongs to EIGHT lanes, one per accumulator of numpy's sum, and a wavefront
+// carries eight rows: lane (r, j) forms the terms of elements 8k + j of row r and adds them in order (16 terms and 15 additions
+// per lane at n = 128, none of them idle), the tree is three DPP steps inside the 8-lane group, the tail terms are formed by
+// lanes j = 0..6 (one term each) and added in order by a DPP scan along the group.  The rows reach LDS by 16-byte lane loads
+// (one instruction = 1 KB of consecutive memory).  Row stride n + 8 doubles: the 32 lanes of a ds_read_b64 group (4 rows x 8
+// accumulators) hit 32 different bank pairs.  Same terms, same additions in numpy's order: same bits.
+template <int FUN, int OFF, int MM>
+__device__ __forceinline__ void r8_sum(const double *U, int j, double &ra, double &rb) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    const double identB = BMUL ? 1.0 : 0.0;
+    if constexpr (MM <= 128) {
+        static_assert(MM >= 8, "shorter sums are plain loops");
+        constexpr int BLK = MM / kGroup, TAIL = MM % kGroup;
+        double chA = 0.0, chB = identB;
+#pragma unroll
+        for (int h0 = 0; h0 < BLK; h0 += 8) {  // eight blocks' reads in flight together
+            double x[8], xn[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (h0 + t < BLK) {
+                    x[t] = U[OFF + (h0 + t) * kGroup + j];
+                    xn[t] = O::NEXT ? U[OFF + (h0 + t) * kGroup + j + 1] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (h0 + t < BLK) {
+                    double a, b;
+                    O::term(x[t], xn[t], OFF + (h0 + t) * kGroup + j, a, b);
+                    if (h0 + t == 0) {
+                        chA = a, chB = b;
+                    } else {
+                        chA = chA + a;
+                        if (TWO) chB = combine<BMUL>(chB, b);
+                    }
+                }
+            }
+        }
+        ra = group_tree<false>(chA);
+        rb = TWO ? group_tree<BMUL>(chB) : identB;
+        if constexpr (TAIL > 0) {
+            // tail term t by lane t; the running sum walks along the group (row_shr:1 -- lane j takes lane j-1's value), so
+            // after step t lane t holds (((tree + a_0) + a_1) ... + a_t): the leaf's sum ends in lane TAIL-1
+            const int e = OFF + BLK * kGroup + (j < TAIL ? j : 0);
+            double ta, tb;
+            O::term(U[e], O::NEXT ? U[e + 1] : 0.0, e, ta, tb);
+            ra = ra + ta;
+            if (TWO) rb = combine<BMUL>(rb, tb);
+#pragma unroll
+            for (int t = 1; t < TAIL; ++t) {
+                const double pa = dpp_f64<0x111>(ra) + ta;
+                ra = j >= t ? pa : ra;
+                if (TWO) {
+                    const double pb = combine<BMUL>(dpp_f64<0x111>(rb), tb);
+                    rb = j >= t ? pb : rb;
+                }
+            }
+        }
+    } else {  // numpy's split: n/2 rounded down to a multiple of 8; only the right part can have a tail
+        constexpr int N2 = (MM / 2) - ((MM / 2) % kGroup);
+        double la, lb, qa, qb;
+        r8_sum<FUN, OFF, N2>(U, j, la, lb);
+        r8_sum<FUN, OFF + N2, MM - N2>(U, j, qa, qb);
+        ra = la + qa;
+        rb = TWO ? combine<BMUL>(lb, qb) : identB;
+    }
+}
+
+template <int FUN, int NFIX>
+__global__ __launch_bounds__(256) void eval_r8_kernel(const double *__restrict__ X, int64_t ldx, double *__restrict__ f) {
+    using O = Obj<FUN>;
+    constexpr int M = O::NEXT ? NFIX - 1 : NFIX, STRIDE = NFIX + 8, NLD = 8 * NFIX / 128;  // 16-byte lane loads per wavefront visit
+    constexpr int TAIL = M % kGroup;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    double *W = lds + wave * 8 * STRIDE;
+    const int64_t row0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 8;
+    double2 v[NLD];
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+        const int idx = t * 128 + 2 * lane, r = idx / NFIX, c = idx % NFIX;
+        v[t] = *reinterpret_cast<const double2 *>(X + (row0 + r) * ldx + c);
+    }
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+        const int idx = t * 128 + 2 * lane, r = idx / NFIX, c = idx % NFIX;
+        *reinterpret_cast<double2 *>(W + r * STRIDE + c) = v[t];
+    }
+    lds_wave_fence();
+    const int r = lane >> 3, j = lane & 7;
+    double sa, sb;
+    r8_sum<FUN, 0, M>(W + r * STRIDE, j, sa, sb);
+    sa = 0.0 + sa;  // add.reduce starts from the identity
+    sb = !O::TWO ? (O::BMUL ? 1.0 : 0.0) : (O::BMUL ? sb : 0.0 + sb);
+    const double val = O::finish(sa, sb, NFIX);
+    if (j == (TAIL > 0 ? TAIL - 1 : 0)) f[row0 + r] = val;
+}
+
 #ifndef SX_EVAL_HEAVY_STATIC
 #define SX_EVAL_HEAVY_STATIC 1  // (0: objectives with a cosine per term keep the run-time plan on long rows)
 #endif
+static int device_cus() {
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return cus;
+}
+// eight lanes per row: plain evaluations of whole wavefront loads of 16-byte aligned one-batch rows, from the population size at
+// which the chip is full either way (below it the one-visit kernel's 16 rows per workgroup spread a small population wider)
+static bool eval_r8_ok(const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *part_f) {
+    static const int mode = getenv("SX_EVAL_R8") ? atoi(getenv("SX_EVAL_R8")) : 1;
+    static const int64_t min_rows = getenv("SX_EVAL_R8_MIN") ? atoll(getenv("SX_EVAL_R8_MIN")) : 32768;
+    return mode != 0 && (n == 64 || n == 128 || n == 256) && xm == nullptr && part_f == nullptr && (ldx & 1) == 0 &&
+           ((uintptr_t)X & 15) == 0 && P % 32 == 0 && P >= min_rows;
+}
 template <int FUN>
 static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
                        const PlanArg &plan, double *part_f, int64_t *part_i, hipStream_t s, int clip = 0,
@@ -233,6 +356,16 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
             case 512: SX_EVAL_GO(64, true, 512); break;
             case 1024: SX_EVAL_GO(64, true, 1024); break;
             default: SX_EVAL_GO(64, true, 2048); break;
+        }
+    } else if (fix && FUN != SX_FUN_SPHERE && eval_r8_ok(X, P, n, ldx, xm, part_f)) {
+        // (Sphere -- one multiplication per element, no second stream -- is the one objective the one-visit kernel streams
+        //  faster: 0.81 / 0.84 against 0.78 / 0.77 of the HBM peak at n = 64 / 256, profiles/r5_eval_r8_ab.txt)
+        // plain evaluation of many one-batch rows: eight lanes per row, eight rows per wavefront
+        const unsigned blocks8 = (unsigned)(P / 32);
+        switch (n) {
+            case 64: hipLaunchKernelGGL((eval_r8_kernel<FUN, 64>), dim3(blocks8), dim3(256), 32 * (64 + 8) * sizeof(double), s, X, ldx, f); break;
+            case 128: hipLaunchKernelGGL((eval_r8_kernel<FUN, 128>), dim3(blocks8), dim3(256), 32 * (128 + 8) * sizeof(double), s, X, ldx, f); break;
+            default: hipLaunchKernelGGL((eval_r8_kernel<FUN, 256>), dim3(blocks8), dim3(256), 32 * (256 + 8) * sizeof(double), s, X, ldx, f); break;
         }
     } else if (fix) {
         // the register-chain objective reads the staged vector only: n + 8 doubles per row, not the term arrays' 3n + ...

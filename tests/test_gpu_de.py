@@ -34,6 +34,33 @@ def test_objectives_vs_oracle(sa, name, n):
         assert np.allclose(got, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
 
 
+@pytest.mark.parametrize("n", [64, 128, 256])
+@pytest.mark.parametrize("name", sorted(OBJECTIVES))
+def test_objectives_one_batch_rows_eight_lanes_per_row(sa, name, n):
+    """Round 5: large populations of one-batch rows (n = 64 / 128 / 256, P >= 32768, a multiple of 32) are evaluated by
+    eval_r8_kernel -- eight lanes per row, one per accumulator of numpy's sum, the tail terms added by a DPP scan, rows staged
+    through 16-byte lane loads -- : the same bits as the oracle (and as the 16 / 32 / 64-lane kernel, which the same
+    population minus 32 rows still takes: P % 32 != 0 ... here P = 32768 + 16 rows take it)."""
+    import torch
+    from stochopy_amd import _device, _lib
+
+    rs = np.random.RandomState(n + 3)
+    X = rs.uniform(-5.12, 5.12, (32768 + 16, n))
+    ref = OBJECTIVES[name](X)
+    ctx = _device.Context()
+    Xd = torch.as_tensor(X, device=ctx.device)
+    torch.cuda.synchronize()
+    got8 = _device.evaluate(ctx, _lib.FUN_IDS[name], Xd[:32768], n)  # eight lanes per row
+    got = _device.evaluate(ctx, _lib.FUN_IDS[name], Xd, n)            # P % 32 != 0: the one-visit kernel
+    ctx.sync()
+    got8, got = got8.cpu().numpy(), got.cpu().numpy()
+    assert np.array_equal(got8, got[:32768])  # the two kernels agree bit for bit, whatever the objective
+    if name in EXACT:
+        assert np.array_equal(got, ref)
+    else:
+        assert np.allclose(got, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
+
+
 @pytest.mark.parametrize("n", [512, 1024, 2048])
 @pytest.mark.parametrize("name", sorted(OBJECTIVES))
 def test_objectives_long_rows_compile_time_plan(sa, name, n):
