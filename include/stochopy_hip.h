@@ -493,9 +493,12 @@ typedef struct sx_cma_args {
 int sx_cmaes_generation(const sx_cma_args *a, int64_t gen, int do_eigh, void *stream);
 /* The same generation in two steps for candidates sharded over ranks (workers > 1; what the reference's parallel backends
  * shard: _common.py:58-72).  stage 0: this rank's candidates [row0, row0 + rows) -- Philox normals keyed by the global
- * row, sampling GEMM, objective -- into arx_loc (rows,n) / fit_loc (rows) (a->Z: scratch of >= rows x n); the caller
+ * row, sampling GEMM, objective -- into arx_loc (rows,n) / fit_loc (rows); the caller
  * all-gathers them into a->arx / a->fit; stage 1: everything else (ranking ... stop rules; Penalize's bookkeeping and
- * penalty pass), replicated on every rank.  stage 0 with all rows + stage 1 == sx_cmaes_generation. */
+ * penalty pass), replicated on every rank.  stage 0 with all rows + stage 1 == sx_cmaes_generation.
+ * a->Z must be the struct's full (P, n) buffer on EVERY rank, not a per-shard one: stage 0 uses its first rows x n doubles
+ * for the normals, and stage 1's covariance update takes 2 n n doubles of it as split-K scratch whenever P >= 2 n (always
+ * inside the (P, n) buffer then; with P < 2 n the update runs unsplit and needs none). */
 int sx_cmaes_generation_stage(const sx_cma_args *a, int64_t gen, int do_eigh, int stage, int64_t row0, int64_t rows,
                               double *arx_loc, double *fit_loc, void *stream);
 /* The generation with its decomposition (cmaes/_cmaes.py:301-309; do_eigh != 0) enqueued in pieces, one GPU: phase 0 =

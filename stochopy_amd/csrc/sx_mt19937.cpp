@@ -486,7 +486,9 @@ extern "C" void sx_mt_de_donors(sx_mt *g, int64_t P, int k, int32_t *donors) {
     // individual i: permutation of arange(P) without i; entry t becomes donor t (de/_de.py:304-311)
 #if SX_HAVE_X86
     if (have_avx512() && P >= 256 && P <= 0x40000000 && k <= 8) {
-        if (P <= 65535)
+        // (SX_MT_WIDE_INDEX=1: the 32-bit index form for every P -- tests pin it against the scalar replay at small P, where
+        //  it would otherwise only run for populations of more than 65535)
+        if (P <= 65535 && std::getenv("SX_MT_WIDE_INDEX") == nullptr)
             de_donors_avx512<uint16_t>(g, P, k, donors);
         else
             de_donors_avx512<uint32_t>(g, P, k, donors);

@@ -738,7 +738,10 @@ __device__ __forceinline__ void restart_threshold(const sx_pso_args &a, const do
 // One workgroup: radius = max(part_r)/sqrt(4n); if radius < delta, nw = int((P-1)/(1+exp((it/maxiter-gamma+0.5)/0.09)))
 // and the nw-th largest pbestfit is found by a radix descent over keys held in registers, starting at the first bit in
 // which the keys differ at all (see below).
-// out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits
+// out[0] = nw (0 = no restart), out[1] = threshold key (rows with key >= threshold restart), out[2] = radius bits: the exact
+// swarm radius here and in pso_restart_select_gathered; in cpso_post_kernel (the two-launch graph form) it is exact only when
+// the decision needed the radius (kRadiusKnown / the exact pass) and otherwise the radius against the OLD best, within
+// ||g_new - g_old|| / sqrt(4n) of it -- the restart decision is the same either way, the number is diagnostic
 // The swarm is `nseg` segments (one per rank; 1 on a single GPU) of `seg_len` fitness values followed by
 // `seg_npart` partial radii, `seg_stride` doubles apart: fit = base, part_r = base + seg_len.
 __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const sx_pso_args a,

@@ -214,6 +214,7 @@ class _CmaDeviceRun:
             phased = (world is None and callback is None and look_cap == 1 and rps > 0
                       and os.environ.get("SX_CMA_PHASED", "1") != "0")
             warm_rounds = None  # rounds the last phased decomposition needed
+            cap_hit = False     # the last phased decomposition was still open when the round cap was reached
             for gen in range(1, maxiter + 1):
                 due = gen * P - eigeneval > eig_every
                 if due:  # 1: first decomposition; 2: start from the previous eigenvectors (C changes by O(c1 + cmu))
@@ -242,13 +243,23 @@ class _CmaDeviceRun:
                                    "sx_cmaes_generation_phased")
                     if state.done:
                         break
+                    # (the look above also shows what the PREVIOUS generation's closing kernel made of a run that had hit the cap)
+                    fails = int(rec[510])  # (byte 2040) decompositions since the start that fell short of the tolerance
+                    if fails != fails_seen:
+                        if cap_hit:
+                            warnings.warn("stochopy_amd: the device eigensolver did not reach its tolerance in 60 sweeps; the "
+                                          "decomposition is used as it is", RuntimeWarning, stacklevel=3)
+                        fails_seen = fails
+                    cap_hit = False
                     _lib.check(L.sx_cmaes_generation_phased(C.byref(a), gen, int(due), 2, 0, r1, ctx.stream_ptr),
                                "sx_cmaes_generation_phased")
                     if rec[0] != 0:  # ended within what was enqueued: it carried out rec[1] sweeps and the two rounds that tell
                         warm_rounds = int(rec[1]) * rps + 2
                     else:
-                        warnings.warn("stochopy_amd: the device eigensolver did not reach its tolerance in 60 sweeps; the "
-                                      "decomposition is used as it is", RuntimeWarning, stacklevel=3)
+                        # the round cap was hit with the run still open.  Phase 2's closing kernel may yet accept the
+                        # result through the refinement criterion (eigh_close_kernel) and counts a short-fall on the device
+                        # otherwise: the verdict is read from that counter at the next look, not guessed here
+                        cap_hit = True
                         warm_rounds = None
                     decomposed, since = False, 0
                     continue
@@ -320,6 +331,9 @@ class _CmaDeviceRun:
                     since = 0
             if not state.done:  # (the phased loop sees a generation's record one look late)
                 state = _lib.SxCmaState.from_buffer_copy(d_state.cpu().numpy().tobytes())
+            if cap_hit and int(eig.ws[:256].cpu().numpy().view(np.int32)[510]) != fails_seen:  # the run's last decomposition
+                warnings.warn("stochopy_amd: the device eigensolver did not reach its tolerance in 60 sweeps; the "
+                              "decomposition is used as it is", RuntimeWarning, stacklevel=3)
             if not state.done:  # cannot happen: generation maxiter sets status -1
                 raise RuntimeError("CMA-ES device loop ended without a status")
             nit = int(state.stop_it)

@@ -129,13 +129,15 @@ def test_rng_matches_numpy_live(lib, seed):
 
 @pytest.mark.parametrize("P,k,seed,skip", [(256, 2, 1, 0), (300, 5, 2, 7), (1000, 3, 3, 1), (2048, 2, 5, 11), (4096, 2, 0, 5),
                                            (4097, 4, 9, 3), (257, 3, 4, 623)])
-@pytest.mark.parametrize("scalar", [False, True])
+@pytest.mark.parametrize("scalar", [False, True, "wide-index"])
 def test_large_population_donors_match_numpy(lib, P, k, seed, skip, scalar):
     """de/_de.py:304-311 at population sizes that take the wide form of the donor draws (csrc/sx_mt19937.cpp: masked
     rejection 64 words at a time, the permutation's first k entries by walking the swaps backwards -- no array is
     shuffled): the same donors as numpy's legacy permutation() of every individual's index list, and the stream left at
     the same word (the draws behind it agree).  Both forms (SX_MT_SCALAR=1: the plain replay) in a fresh process each,
-    the CPU check is made once per process."""
+    the CPU check is made once per process.  "wide-index" (SX_MT_WIDE_INDEX=1): the 32-bit-index instantiation
+    of the wide form -- what populations of more than 65535 individuals (BASELINE config 5 with rng="numpy-legacy") run -- at
+    these small sizes, where numpy itself can still be asked."""
     import subprocess
     import sys
 
@@ -159,7 +161,10 @@ print("ok")
 """
     env = dict(os.environ)
     env.pop("SX_MT_SCALAR", None)
-    if scalar:
+    env.pop("SX_MT_WIDE_INDEX", None)
+    if scalar == "wide-index":
+        env["SX_MT_WIDE_INDEX"] = "1"
+    elif scalar:
         env["SX_MT_SCALAR"] = "1"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
