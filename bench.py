@@ -26,6 +26,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Host BLAS on ONE thread (set before numpy loads).  The CPU baseline is quoted as "cores: 1", and on the GPU boxes the container
+# has a CPU quota of 16 on a 256-CPU host (cgroup cpu.max 1600000 100000) while OpenBLAS starts 64 spinning threads for any
+# vector of more than ~10^4 elements: a single np.dot of 16 384 elements got the whole process throttled for tens of
+# milliseconds (profiles/r5_host_blas_throttle.txt) -- VD-CMA's set-up does one, and the "configs" timings are wall clock.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
 
 import numpy as np  # noqa: E402
 

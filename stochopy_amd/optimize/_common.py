@@ -338,3 +338,19 @@ def as_bounds(bounds):
         raise ValueError()
     lower, upper = np.transpose(np.asarray(bounds, dtype=np.float64))
     return np.ascontiguousarray(lower), np.ascontiguousarray(upper)
+
+
+def host_blas_single_thread():
+    """Context manager: host BLAS calls inside run on one thread (threadpoolctl, when it is installed; a no-op otherwise).
+    The host side of a device-resident run touches a few n-vectors; a threaded BLAS answers a 16 384-element dot product by
+    waking every one of its spinning worker threads, which in a CPU-quota'd container (the GPU boxes here: 16 CPUs' quota on
+    a 256-CPU host) gets the process throttled for tens of milliseconds -- longer than 100 generations of device work
+    (profiles/r5_host_blas_throttle.txt)."""
+    try:
+        from threadpoolctl import threadpool_limits
+
+        return threadpool_limits(limits=1, user_api="blas")
+    except Exception:  # noqa: BLE001  (not installed, or a BLAS it does not know)
+        import contextlib
+
+        return contextlib.nullcontext()

@@ -123,7 +123,8 @@ class _VdDeviceRun:
             xmean = init.uniform(-1.0, 1.0, n) if x0 is None else (np.asarray(x0, dtype=np.float64) - xm) / xstd
             mu, w, mueff, cc, c1, cmu = _strategy_constants(n, P, muperc)
             vvec = init.randn(n) / np.sqrt(n)  # the first direction comes right after the initial mean in the stream
-            norm_v2 = float(np.dot(vvec, vvec))
+            with _common.host_blas_single_thread():  # (a threaded BLAS wakes 64+ spinning threads for this one dot product)
+                norm_v2 = float(np.dot(vvec, vvec))
             norm_v = float(np.sqrt(norm_v2))
             keep = self.buffers = dict(
                 Z=ctx.empty((P, n)), ary=ctx.empty((P, n)), arx=ctx.empty((P, n)), fit=ctx.empty((P,)),

