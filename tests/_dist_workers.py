@@ -391,3 +391,43 @@ def nccl_single_rank_worker(rank, world, port, cfg, out_dir):
         _minimize_and_save(rank, 1, cfg, out_dir)
     finally:
         dist.destroy_process_group()
+
+
+def nccl_single_rank_blocks_worker(rank, world, port, cfg, out_dir):
+    """One rank over RCCL, the run stepped in blocks of K < GRAPH_CHUNK generations the way `bench.py --steps 20` drives it:
+    from the second block on the block is one replay of a captured K-generation graph (kernels + all-gathers)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SX_FORCE_SHARDED"] = "1"
+    os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = os.environ["TORCH_FR_BUFFER_SIZE"] = "256"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from stochopy_amd import _lib
+        from stochopy_amd.optimize import _de
+
+        n, P, K, blocks = cfg["n"], cfg["P"], cfg["K"], cfg["blocks"]
+        out = {}
+        for label, steps in (("blocks", [K] * blocks), ("once", [K * blocks])):
+            run = _de._DeRun(_lib.FUN_IDS["rosenbrock"], np.full(n, -5.12), np.full(n, 5.12), None, 2**31 - 2, P, 0.5, 0.9,
+                             "best1bin", None, 0.0, -1.0, False, 1.0, None, "philox", cfg["seed"], 1, autorun=False, exchange="rccl")
+            try:
+                with torch.cuda.stream(run.ctx.stream):
+                    run._setup()
+                    for k in steps:
+                        run.enqueue(k)
+                    run.ctx.sync()
+                    st = run.read_state()
+                    out[label] = (int(st.it), float(st.gfit), sorted(run._rccl_graphs), run._rccl_graph_note)
+                    out[label + "_x"] = run.bufs[st.it & 1].cpu().numpy().copy()
+            finally:
+                run.close()
+        assert out["blocks"][0] == out["once"][0] == 1 + K * blocks, out
+        assert out["blocks"][1] == out["once"][1] and np.array_equal(out["blocks_x"], out["once_x"])
+        assert out["blocks"][3] is None and out["blocks"][2] == [K], out["blocks"]  # the K-generation graph was captured and used
+        np.save(os.path.join(out_dir, f"blocks_{rank}.npy"), np.array([out["blocks"][0], out["blocks"][1]]))
+    finally:
+        dist.destroy_process_group()

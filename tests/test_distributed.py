@@ -474,6 +474,18 @@ def test_rccl_path_graph_capture_single_rank():
 
 
 @pytest.mark.gpu
+def test_rccl_path_blocks_of_twenty_generations_replay_a_captured_graph():
+    """`bench.py --gpus N --steps 20` steps the RCCL transport in blocks of 20 generations (< GRAPH_CHUNK): from the second
+    block on a block is ONE replay of a captured 20-generation graph (round 5; it used to be 20 eager generations of two
+    library calls and a collective each).  Same population and best as 120 generations enqueued at once."""
+    from _dist_workers import nccl_single_rank_blocks_worker
+
+    out = _spawn(nccl_single_rank_blocks_worker, 1, {"n": 24, "P": 128, "K": 20, "blocks": 6, "seed": 5})
+    it, _ = np.load(os.path.join(out, "blocks_0.npy"))
+    assert int(it) == 121
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("method", ["pso", "cpso"])
 def test_sharded_pso_rccl_graph_capture_single_rank(method):
     """PSO / CPSO over RCCL with one rank, 70 generations: replays of the captured 16-generation graph
