@@ -88,6 +88,9 @@ int64_t sx_fun_terms(int fun_id, int n);
  * ------------------------------------------------------------------------- */
 int64_t sx_num_partials(int64_t P, int n);
 int sx_rows_per_workgroup(int n); /* rows of one workgroup of the row kernels = rows behind one (part_f, part_i) record */
+/* Rows of more than this many elements are served by the one-workgroup-per-row kernels (one record per row, no chained /
+ * peer-exchange form): what a host loop needs to know to size its record buffers and to pick the two-kernel path. */
+int sx_wide_from(void);
 int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd,
             double *f, double *part_f, int64_t *part_i, void *stream);
 

@@ -12,7 +12,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstochopy_hip.so")
 SX_STATUS_NONE = 100
 # rows of more than NARROW_DIM elements are "wide" (csrc/sx_wide.hip: one workgroup per row): no chained / peer-exchange /
 # ordered-sweep kernels for those, everything else is served; WIDE_DIM is the longest row
+# NARROW_DIM is what the wavefront-per-row kernels can serve (the limit of the ordered sweeps, the chained / peer-exchange
+# kernels and full CMA-ES); from which length on rows actually TAKE the wide kernels is the library's choice: wide_from()
 NARROW_DIM, WIDE_DIM = 4096, 262144
+
+
+def wide_from():
+    """Rows of more than this many elements are served by the one-workgroup-per-row kernels (csrc/sx_device.hpp kWideFrom)."""
+    return int(lib().sx_wide_from())
 SX_RNG_HOST, SX_RNG_PHILOX = 0, 1
 
 FUN_IDS = {
@@ -107,6 +114,7 @@ class SxCmaArgs(C.Structure):
 # name -> (restype, argtypes); every symbol include/stochopy_hip.h declares
 PROTOTYPES = {
     "sx_abi_version": (C.c_int, []),
+    "sx_wide_from": (C.c_int, []),
     "sx_last_error": (C.c_char_p, []),
     "sx_device_count": (C.c_int, []),
     "sx_struct_size": (C.c_int, [C.c_int]),

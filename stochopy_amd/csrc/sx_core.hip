@@ -104,12 +104,13 @@ extern "C" int64_t sx_fun_terms(int fun_id, int n) {
 }
 
 extern "C" int64_t sx_num_partials(int64_t P, int n) { return (int64_t)row_geometry(P, n).blocks; }
-extern "C" int sx_rows_per_workgroup(int n) { return n > kMaxDim ? 1 : rows_per_block(n); }
+extern "C" int sx_rows_per_workgroup(int n) { return n > kWideFrom ? 1 : rows_per_block(n); }
+extern "C" int sx_wide_from(void) { return kWideFrom; }
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out) {
-    if (n > kMaxDim) {  // (wide rows take their plan from device memory: sx_wide.hip; callers branch before this)
-        set_error("internal: a narrow-row kernel was asked for a row of more than 4096 elements");
+    if (n > kWideFrom) {  // (wide rows take their plan from device memory: sx_wide.hip; callers branch before this)
+        set_error("internal: a narrow-row kernel was asked for a row the wide kernels serve");
         return -1;
     }
     const int64_t m = sx_fun_terms(fun_id, n);

@@ -134,7 +134,7 @@ extern "C" int sx_de_shard_generation(const sx_de_args *a, double *record, void 
 static int check_chain(const sx_de_args *a, bool peer_exchange) {
     if (int rc = check_args(a)) return rc;
     SX_REQUIRE(a->rng == SX_RNG_PHILOX, "sx_de_chain: needs in-kernel (Philox) draws");
-    SX_REQUIRE(!is_wide(a->n), "sx_de_chain: rows of more than 4096 elements take the two-kernel path (sx_de_generation)");
+    SX_REQUIRE(!is_wide(a->n), "sx_de_chain: rows served by the one-workgroup-per-row kernels (n > sx_wide_from()) take the two-kernel path (sx_de_generation)");
     SX_REQUIRE(peer_exchange || sx_num_partials(a->P, a->n) <= 512,
                "sx_de_chain: more than 512 workgroup records (use the two-kernel path)");
     return 0;

@@ -27,6 +27,15 @@ constexpr int kMaxRowsPerBlock = 16;
 constexpr int kMaxWavesPerBlock = 8;
 constexpr int kMaxLeaf = 64;  // leaves carried in kernel arguments; also one lane per leaf in the merge (<= 64)
 constexpr int kMaxDim = 4096; // leaves hold > 64 terms, so n <= 4096 has at most 64; LDS: n+8+2(n/64+2) doubles per row
+// Rows of more than kWideFrom elements take the one-workgroup-per-row kernels (sx_wide.hip).  kMaxDim is what the wavefront-
+// per-row kernels CAN serve (and what the ordered sweeps, the chained / peer-exchange kernels and full CMA-ES are limited
+// to); kWideFrom is where the wide kernels become the faster ones (round 5, profiles/r5_wide_threshold.txt: sx_eval crosses over
+// at ~2300 elements, DE and PSO at ~2560; at n = 4096 the wide kernels are 1.5-1.75x faster).
+#ifndef SX_WIDE_FROM
+#define SX_WIDE_FROM 2560
+#endif
+constexpr int kWideFrom = SX_WIDE_FROM;
+static_assert(kWideFrom >= 256 && kWideFrom <= kMaxDim, "the wide kernels take over somewhere inside the narrow kernels' range");
 
 // Rows of more than 256 elements form their objective terms inside the reduction (row_reduce_leaves_fused:
 // one leaf of <= 128 terms per 8-lane group, so >= 3 of the 8 groups are busy); shorter rows have too few

@@ -104,9 +104,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(cons
     const bool shrink = a.constraints != 0;
     double beta = __builtin_huge_val();
     const int nq = (n + LPR - 1) / LPR;
-    // wide rows (n > kMaxDim: one wavefront per row, no dynamic LDS): with Shrink the raw velocities are formed AGAIN
+    // wide rows (n > kWideFrom: one wavefront per row, no dynamic LDS): with Shrink the raw velocities are formed AGAIN
     // behind the row-wide beta instead of waiting in LDS -- same operands, same operations, same bits
-    const bool stash = shrink && n <= kMaxDim;
+    const bool stash = shrink && n <= kWideFrom;
     // raw velocity of the two elements (q0 + t) * LPR + l, t = 0, 1 (one Philox call)
     auto raw = [&](int q0, double(&x)[2], double(&vn)[2]) {
         U4 pw = {0u, 0u, 0u, 0u};
@@ -232,7 +232,7 @@ extern "C" int sx_pso_move(const sx_pso_args *a, void *stream) {
     SX_REQUIRE(a->rng != SX_RNG_HOST || (a->r1 && a->r2), "sx_pso_move: host draws missing");
     SX_REQUIRE(a->constraints == 0 || (a->lower && a->upper), "sx_pso_move: bounds missing");
     const Geometry g = row_geometry(a->P, a->n);
-    const size_t lds = a->n > kMaxDim ? 0 : (size_t)rows_per_block(a->n) * a->n * sizeof(double);
+    const size_t lds = a->n > kWideFrom ? 0 : (size_t)rows_per_block(a->n) * a->n * sizeof(double);
     if (a->rng == SX_RNG_PHILOX) {
         SX_DISPATCH_LPR(a->n, hipLaunchKernelGGL((pso_move_kernel<SX_RNG_PHILOX, LPR>), dim3(g.blocks), dim3(g.threads), lds,
                                                  (hipStream_t)stream, *a))

@@ -1,4 +1,5 @@
-// Wide rows: individuals of more than 4096 elements (sx_device.hpp kMaxDim), ONE WORKGROUP per individual.
+// Wide rows: individuals of more than kWideFrom = 2560 elements (sx_device.hpp; the wavefront-per-row kernels can serve up to
+// kMaxDim = 4096 but lose to these from ~2560 on: profiles/r5_wide_threshold.txt), ONE WORKGROUP per individual.
 //
 // The reference has no dimension limit (stochopy/optimize/de/_de.py:208-218: rows are (n,) numpy vectors of any length;
 // stochopy/optimize/vdcma/_vdcma.py:144-458 exists for n >= 4096); the row kernels of sx_rowops.hpp do: one wavefront per

@@ -1,4 +1,4 @@
-// Wide rows (n > kMaxDim = 4096): one workgroup per individual, the summation plan in device memory (sx_wide.hip).
+// Wide rows (n > kWideFrom, sx_device.hpp): one workgroup per individual, the summation plan in device memory (sx_wide.hip).
 // The narrow entry points (sx_eval, sx_de_generation, sx_de_graph_create, sx_pso_generation, sx_pso_graph_create, ...)
 // branch here on is_wide(n); records are one per row (sx_num_partials(P, n) = P).
 #pragma once
@@ -12,7 +12,7 @@ namespace sx {
 
 constexpr int kWideMaxDim = 262144;  // leaf sums of a row (2 (n/64 + 2) doubles) share the LDS with the stage
 
-inline bool is_wide(int n) { return n > kMaxDim; }
+inline bool is_wide(int n) { return n > kWideFrom; }
 
 int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
               double *part_f, int64_t *part_i, int clip, const double *pen_v, double *pen_out, hipStream_t s);

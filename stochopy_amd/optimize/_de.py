@@ -151,7 +151,7 @@ class _DeRun:
         # -- every wavefront re-reduces the per-workgroup records, so only while those are few (<= 512)
         npart = int(_lib.lib().sx_num_partials(self.P, self.n))
         # (rows of more than 4096 elements -- csrc/sx_wide.hip, one workgroup per row -- take the two-kernel path)
-        self.wide = self.n > _lib.NARROW_DIM
+        self.wide = self.n > _lib.wide_from()
         self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
                       and npart <= 512 and not immediate and self.external is None and not self.wide)
         self.launches = 0
@@ -171,7 +171,7 @@ class _DeRun:
                 exchange = "rccl"
             if self.wide:  # the peer exchange lives in the chained kernel, which serves rows of <= 4096 elements
                 if exchange == "p2p" or self.global_donors:
-                    raise ValueError(f"rows of {self.n} elements (> {_lib.NARROW_DIM}) exchange the global best with one "
+                    raise ValueError(f"rows of {self.n} elements (> {_lib.wide_from()}) exchange the global best with one "
                                      'all-gather per generation (exchange="rccl", donors="shard")')
                 exchange = "rccl"
             if exchange != "rccl":
