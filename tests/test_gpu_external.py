@@ -206,7 +206,7 @@ def test_host_pool_spreads_a_slow_objective_over_workers(sa):
     for extra, ideal in (({"host_workers": 8, "host_backend": "threading"}, 8.0), ({"host_workers": 4, "host_backend": "loky"}, 4.0)):
         r, tp = run(**extra)
         assert np.array_equal(r.x, serial.x) and r.fun == serial.fun and r.nit == serial.nit and r.nfev == serial.nfev
-        assert ts / tp > 0.6 * ideal, (extra, ts, tp)
+        assert ts / tp > 0.5 * ideal, (extra, ts, tp)  # (measured 0.88-0.98 x workers on an idle box: tools/bench_host_pool.py)
 
 
 def test_plain_python_callable_gets_args_and_warns_once(sa):

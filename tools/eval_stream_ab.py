@@ -17,7 +17,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "arm":
     from stochopy_amd import _device, _lib
 
     ctx = _device.Context()
-    for name, n, P in SHAPES:
+    only = sys.argv[2].split(":") if len(sys.argv) > 2 else None  # e.g. rosenbrock:128:1048576 (counter passes: one kernel, one shape)
+    for name, n, P in (SHAPES if only is None else ((only[0], int(only[1]), int(only[2])),)):
         g = torch.Generator(device=ctx.device).manual_seed(1)
         X = torch.rand((P, n), dtype=torch.float64, device=ctx.device, generator=g) * 10.24 - 5.12
         f = ctx.empty((P,))

@@ -42,23 +42,30 @@ pmc c5_fetch FETCH_SIZE python $R/bench.py $BA --workload de_rosenbrock_n1024_p1
 pmc c5_write WRITE_SIZE python $R/bench.py $BA --workload de_rosenbrock_n1024_p16384 --steps 100 --warmup 10 --kernel-timing-launches 50
 pmc de_M_sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" python $R/bench.py $BA --kernel-timing-launches 50
 pmc c4_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES SQ_INSTS_VALU" python $R/tools/run_c4.py 12
+# the objective kernel on one-batch rows: is it instruction issue (round 5's reading) or memory?  the same counters for the
+# one-visit kernel with 16 / 32 / 64 lanes per row (SX_EVAL_R8=0) and for eight lanes per row, + the bytes fetched
+SQC="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES"
+SX_EVAL_R8=0 pmc eval_old_sq "$SQC" python $R/tools/eval_stream_ab.py arm rosenbrock:128:1048576
+pmc eval_r8_sq "$SQC" python $R/tools/eval_stream_ab.py arm rosenbrock:128:1048576
+pmc eval_r8_fetch FETCH_SIZE python $R/tools/eval_stream_ab.py arm rosenbrock:128:1048576
 python - <<PY
 import collections, csv, glob, json
 out = {}
-for tag in ("de_M_fetch", "de_M_write", "de_M_sq", "c5_fetch", "c5_write", "c4_mfma"):
+for tag in ("de_M_fetch", "de_M_write", "de_M_sq", "c5_fetch", "c5_write", "c4_mfma", "eval_old_sq", "eval_r8_sq", "eval_r8_fetch"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % tag, recursive=True):
         for row in csv.DictReader(open(f)):
             agg[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, d in agg.items():
-        if not any(s in k for s in ("de_generation", "eigh_round", "eigh_gemm", "cma_gemm")):
+        if not any(s in k for s in ("de_generation", "eigh_round", "eigh_gemm", "cma_gemm", "eval_kernel", "eval_r8_kernel")):
             continue
+        pre = "c5:" if tag.startswith("c5") else ("eval_old:" if tag.startswith("eval_old") else "eval_r8:" if tag.startswith("eval_r8") else "")
         for c, v in d.items():
-            out.setdefault(("c5:" if tag.startswith("c5") else "") + k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
+            out.setdefault(pre + k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
 json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
 def mean(sub, ctr, pre=""):
     for k, d in out.items():
-        if k.startswith("c5:") != (pre == "c5:"):
+        if k.startswith("c5:") != (pre == "c5:") or k.startswith("eval_"):
             continue
         if sub in k and ctr in d:
             return d[ctr]["mean"], d[ctr]["n"]
