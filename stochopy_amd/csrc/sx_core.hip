@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     __shared__ int64_t si[kMaxRowsPerBlock];
     const int n = NFIX ? NFIX : n_arg;
     const RowIds<LPR> id(P);
-    double *U = lds + id.slot * (chain_only<FUN, NFIX>() ? NFIX + 8 : lds_row_stride(n));  // (launch_eval sizes the LDS to match)
+    double *U = lds + id.slot * gen_row_stride(n);  // (n + 8 doubles up to 256 elements: launch_eval sizes the LDS to match)
     const double *xr = X + id.rowc * ldx;
     const bool affine = xm != nullptr;
     double pacc = 0.0;
@@ -342,7 +342,7 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
     const int lpr = lanes_per_row(n);
     const bool full = clip == 0 && n % (8 * lpr) == 0 && P % rows_per_block(n) == 0;
     const bool fix = clip == 0 && n == 4 * lpr && P % rows_per_block(n) == 0;
-    size_t lds = g.lds;
+    size_t lds = (size_t)rows_per_block(n) * gen_row_stride(n) * sizeof(double);  // (n + 8 doubles per row up to 256 elements)
     // (objectives with a cosine per term keep the run-time plan: eight inlined cosines side by side need more registers than
     //  a wavefront slot has, and their arithmetic, not the plan, is their time)
     constexpr bool kLight = light_objective<FUN>();
@@ -371,9 +371,9 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
     } else if (fix) {
         // the register-chain objective reads the staged vector only: n + 8 doubles per row, not the term arrays' 3n + ...
         switch (lpr) {
-            case 16: if (chain_only<FUN, 64>()) lds = (size_t)rows_per_block(n) * (64 + 8) * sizeof(double); SX_EVAL_GO(16, true, 64); break;
-            case 32: if (chain_only<FUN, 128>()) lds = (size_t)rows_per_block(n) * (128 + 8) * sizeof(double); SX_EVAL_GO(32, true, 128); break;
-            default: if (chain_only<FUN, 256>()) lds = (size_t)rows_per_block(n) * (256 + 8) * sizeof(double); SX_EVAL_GO(64, true, 256); break;
+            case 16: SX_EVAL_GO(16, true, 64); break;
+            case 32: SX_EVAL_GO(32, true, 128); break;
+            default: SX_EVAL_GO(64, true, 256); break;
         }
     } else if (full) {
         SX_DISPATCH_LPR(n, SX_EVAL_GO(LPR, true, 0))

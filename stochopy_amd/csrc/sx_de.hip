@@ -46,7 +46,12 @@ de_kernel_t kernel_for(const sx_de_args *a) {
                                    : pick_kernel<SX_RNG_HOST, 0>(a->fun_id, a->n, a->P, a->strategy, a->constraints);
 }
 
-Geometry geometry(const sx_de_args *a) { return row_geometry(a->P, a->n); }
+Geometry geometry(const sx_de_args *a) {
+    Geometry g = row_geometry(a->P, a->n);
+    // rows of up to 256 elements stage nothing but the trial vector (sx_device.hpp gen_row_stride)
+    if (!is_wide(a->n)) g.lds = (size_t)rows_per_block(a->n) * gen_row_stride(a->n) * sizeof(double);
+    return g;
+}
 
 }  // namespace
 

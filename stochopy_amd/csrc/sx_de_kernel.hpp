@@ -202,8 +202,13 @@ constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its l
 // STRAT: with NFIX and constraints=None, the strategy as a compile-time constant too (its donor count, the best-row
 // fetch and the mutant's formula are otherwise uniform branches inside the row's dependent chain: 9.03 -> 8.52 us per
 // generation at the headline shape), and no repair code; -1 = strategy and constraints read from the arguments.
+// SX_DE_NFIX_WAVES (A/B): minimum wavefronts per SIMD asked of the one-batch kernels -- 6 = three 512-thread workgroups per CU,
+// which caps them at 80 VGPRs (they take 84 uncapped: two workgroups per CU)
+#ifndef SX_DE_NFIX_WAVES
+#define SX_DE_NFIX_WAVES 1
+#endif
 template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
-__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel(const sx_state *const sin_pre,
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? SX_DE_NFIX_WAVES : 1) void de_generation_kernel(const sx_state *const sin_pre,
                                                                                  const double *const pf_pre,
                                                                                  const int64_t *const pi_pre,
                                                                                  const int64_t npart,
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     const RowIds<LPR> id(P, P2P ? 1 : 0);
     const int l = id.l;  // lane within the row
     const int64_t rowc = id.rowc;
-    double *U = lds + id.slot * lds_row_stride(n);
+    double *U = lds + id.slot * gen_row_stride(n);
 
     // ---- A. which generation?  (CHAIN) every wave fetches the predecessor's records right away (their
     //      addresses do not depend on the state word) and keeps them in registers until stage C
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
     struct Batch {
         double x[kStep], d[kMaxDonors][kStep], r[kStep], rs[kStep];
     };
-    Batch B0, B1;  // two batches in flight: the loads of the next one overlap the arithmetic of this one
+    Batch B0;  // (short rows: the row's only batch; whole-wave rows: the batch at work)
     auto load_batch = [&](int q0, Batch &bt) {
         double(&bx)[kStep] = bt.x;
         double(&bd)[kMaxDonors][kStep] = bt.d;
@@ -551,16 +556,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_generation_kernel
             }
         }
     };
-    if (LPR < kWave) {  // short rows: two batches in flight cover the latency at 2 waves per SIMD
-        for (int q0 = 0; q0 < nq; q0 += 2 * kStep) {
-            const bool more1 = q0 + kStep < nq, more2 = q0 + 2 * kStep < nq;
-            if (more1) load_batch(q0 + kStep, B1);
-            trial_batch(q0, B0);
-            if (more1) {
-                if (more2) load_batch(q0 + 2 * kStep, B0);
-                trial_batch(q0 + kStep, B1);
-            }
-        }
+    if constexpr (LPR < kWave) {
+        // short rows are ONE batch (lanes_per_row gives 16 / 32 lanes to rows of up to 64 / 128 elements only).  Round 5: said
+        // at compile time -- the general short-row kernels carried a second batch's 64 registers for a loop that never took a
+        // second trip (185 VGPRs: two wavefronts per SIMD)
+        trial_batch(0, B0);
     } else {  // whole-wave rows (n > 128): one batch and half the registers -- twice the waves hide it better
         trial_batch(0, B0);
         for (int q0 = kStep; q0 < nq; q0 += kStep) {

@@ -50,6 +50,11 @@ __host__ __device__ inline int leaf_cap(int n) { return n / 64 + 2; }
 __host__ __device__ inline int lds_row_stride(int n) {
     return fused_terms(n) ? n + 8 + 2 * leaf_cap(n) : 3 * n + 8 + 24 + 2 * leaf_cap(n);
 }
+// the DE / PSO generation kernels' and the objective kernel's rows: up to 256 elements the objective is a register chain over the staged vector alone
+// (row_objective_chain / row_objective_chain_rt), so a row needs n + 8 doubles instead of the term arrays' 3n + ... -- at the
+// metric's row length 17 KB per workgroup instead of 54 KB, which with <= 80 VGPRs is three resident workgroups per CU
+// instead of two (round 5: what bounds that kernel at large P is latency, profiles/r5_de_gather_probe.txt)
+__host__ __device__ inline int gen_row_stride(int n) { return n <= 256 ? n + 8 : lds_row_stride(n); }
 // lanes that own one row
 // (the smallest of 16/32/64 that covers the row in one batch of 4 steps, else the whole wave)
 __host__ __device__ inline int lanes_per_row(int n) { return n <= 64 ? 16 : (n <= 128 ? 32 : 64); }

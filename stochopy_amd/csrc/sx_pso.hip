@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     const RowIds<LPR> id(P);
     const int l = id.l;  // lane within the row
     const int64_t rowc = id.rowc;
-    double *U = lds + id.slot * lds_row_stride(n);
+    double *U = lds + id.slot * gen_row_stride(n);
     double *Vn = U;  // Shrink: the raw velocity waits in U[e] until the owning lane replaces it by the position
 
     double fold = a.pbestfit[rowc];
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             const bool changed = sb[ks] != 0 || bi != (myprev >> 1);
             const int64_t q = changed ? 1 - (myprev & 1) : (myprev & 1);
             if (changed) {  // the new pbest of a row that improved is its position, still in LDS
-                const double *src = sb[ks] ? lds + ks * lds_row_stride(n) : a.pbest + bi * ld;
+                const double *src = sb[ks] ? lds + ks * gen_row_stride(n) : a.pbest + bi * ld;
                 double *dst = best_rows + (q * npart + id.block) * (int64_t)n;
                 for (int e = k; e < n; e += kWave) dst[e] = src[e];
             }
@@ -384,7 +384,12 @@ int check_args(const sx_pso_args *a) {
     return 0;
 }
 
-Geometry geometry(int64_t P, int n) { return row_geometry(P, n); }
+Geometry geometry(int64_t P, int n) {
+    Geometry g = row_geometry(P, n);
+    // rows of up to 256 elements stage nothing but the new position (sx_device.hpp gen_row_stride)
+    if (!is_wide(n)) g.lds = (size_t)rows_per_block(n) * gen_row_stride(n) * sizeof(double);
+    return g;
+}
 
 // ---------------------------------------------------------------------------
 // Competitive restart, cpso/_cpso.py:405-426

@@ -365,7 +365,9 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
     lds_wave_fence();  // U complete (written and read by this wave only)
     if constexpr (chain_only<FUN, NFIX>())
         return row_objective_chain<FUN, LPR, NFIX>(U, l);
-    if constexpr (NFIX == 0 && SX_OBJ_CHAIN_RT) {  // one-batch rows of run-time length (every n <= 256): the same chains, run-time block counts
+    if constexpr ((NFIX == 0 || NFIX <= 256) && SX_OBJ_CHAIN_RT) {  // one-batch rows (every n <= 256) without a compile-time chain form: the same chains, run-time block counts
+        // (NFIX = 256 with an objective that reads the next element -- m = 255: three leaves -- comes here too: no kernel stages
+        //  terms for a row of up to 256 elements any more, so such rows need n + 8 doubles of LDS, sx_device.hpp de_row_stride)
         // (lanes_per_row gives 16 / 32 lanes to rows of up to 64 / 128 elements only: a short-row kernel never meets a longer row,
         //  and the staged-terms code below is not even compiled for it)
         if constexpr (LPR < kWave) return row_objective_chain_rt<FUN, LPR>(U, n, plan, l);
