@@ -637,6 +637,21 @@ de_kernel_t pick_kernel_fixed(int fun_id, int strategy, int constraints) {
     }
 }
 
+// the general (run-time row length) kernel with the strategy as a compile-time constant: single-GPU forms with in-kernel draws
+// (XM = 0: the two-kernel path, what populations of more than 8192 rows take; XM = 1: the chained kernel), and only for the two
+// strategies everyone uses.  Round 5:
+// with five donor slots and the repair code compiled in, the general short-row kernel takes 89 VGPRs -- two 512-thread
+// workgroups per CU; best1bin alone needs 2 donors: <= 80 VGPRs, three workgroups (what bounds these shapes is latency:
+// profiles/r5_de_gather_probe.txt)
+template <int RNG, int XM, int LPR>
+de_kernel_t pick_kernel_general(int fun_id, int strategy, int constraints) {
+    if constexpr (XM <= 1 && RNG == SX_RNG_PHILOX) {
+        if (constraints == 0 && strategy == SX_DE_BEST1BIN) return pick_kernel_lpr<RNG, XM, LPR, false, 0, SX_DE_BEST1BIN>(fun_id);
+        if (constraints == 0 && strategy == SX_DE_RAND1BIN) return pick_kernel_lpr<RNG, XM, LPR, false, 0, SX_DE_RAND1BIN>(fun_id);
+    }
+    return pick_kernel_lpr<RNG, XM, LPR, false>(fun_id);
+}
+
 template <int RNG, int XM>
 de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy, int constraints) {
     constexpr bool CH = XM >= 1;
@@ -648,13 +663,13 @@ de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy, int constrai
     switch (lpr) {
         case 16:
             if (fix) return pick_kernel_fixed<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id, strategy, constraints);
-            return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 16, false>(fun_id);
+            return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_general<RNG, XM, 16>(fun_id, strategy, constraints);
         case 32:
             if (fix) return pick_kernel_fixed<RNG, XM, 32, CH, FX ? kStep * 32 : 0>(fun_id, strategy, constraints);
-            return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 32, false>(fun_id);
+            return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_general<RNG, XM, 32>(fun_id, strategy, constraints);
     }
     if (fix) return pick_kernel_fixed<RNG, XM, 64, CH, FX ? kStep * 64 : 0>(fun_id, strategy, constraints);
-    return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_lpr<RNG, XM, 64, false>(fun_id);
+    return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_general<RNG, XM, 64>(fun_id, strategy, constraints);
 }
 
 }  // namespace
