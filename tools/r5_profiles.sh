@@ -31,6 +31,8 @@ prof eval_r8 python $R/tools/eval_stream_ab.py arm
 python $R/tools/bench_eval.py 2>&1 | grep -v amdgpu.ids > $OUT/eval_kernel.txt
 python $R/tools/bench_shapes.py 2>&1 | grep -v amdgpu.ids > $OUT/shapes.txt
 python $R/tools/bench_wide.py 2>&1 | grep -v amdgpu.ids > $OUT/wide_rows.txt
+python $R/tools/de_occupancy_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/de_population_sizes.txt
+(hipcc --offload-arch=gfx950 -O3 $R/tools/probes/de_gather_probe.cpp -o /tmp/dgp && /tmp/dgp) > $OUT/de_gather_probe.txt 2>&1
 pmc() { # tag counters -- command
   tag=$1; shift; ctr=$1; shift
   timeout 400 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$tag -o run -- "$@" > $OUT/pmc_$tag.log 2>&1 < /dev/null
