@@ -254,7 +254,10 @@ __device__ __forceinline__ double wide_row(const WideCtx &c, int n, int chunk_le
 
 constexpr int kEvalThreads = 256;
 constexpr int kGenThreads = 512;
-constexpr int kStreamLeaves = 32;             // leaves per chunk of a streamed row: <= 4096 elements staged
+#ifndef SX_WIDE_STREAM_LEAVES
+#define SX_WIDE_STREAM_LEAVES 32
+#endif
+constexpr int kStreamLeaves = SX_WIDE_STREAM_LEAVES;  // leaves per chunk of a streamed row: <= 4096 elements staged (A/B: 16)
 constexpr size_t kResidentLds = 148 * 1024;   // a resident row + its leaf sums must fit here (160 KB per CU)
 constexpr int kStageElems = kStreamLeaves * 128 + 16;
 
