@@ -207,8 +207,14 @@ constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its l
 #ifndef SX_DE_NFIX_WAVES
 #define SX_DE_NFIX_WAVES 1
 #endif
+// SX_DE_WAVE_ROWS_WAVES (A/B): the same for the whole-wave general kernels of the two-kernel path (88 / 107 VGPRs uncapped)
+#ifndef SX_DE_WAVE_ROWS_WAVES
+#define SX_DE_WAVE_ROWS_WAVES 1
+#endif
 template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
-__global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? SX_DE_NFIX_WAVES : 1) void de_generation_kernel(const sx_state *const sin_pre,
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? SX_DE_NFIX_WAVES
+                                                       : (NFIX == 0 && XM == 0 && STRAT >= 0 && LPR == kWave) ? SX_DE_WAVE_ROWS_WAVES
+                                                                                                                 : 1) void de_generation_kernel(const sx_state *const sin_pre,
                                                                                  const double *const pf_pre,
                                                                                  const int64_t *const pi_pre,
                                                                                  const int64_t npart,
