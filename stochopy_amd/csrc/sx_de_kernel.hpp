@@ -211,7 +211,9 @@ constexpr int kStep = 4;  // row steps per batch: one Philox call, and all its l
 #ifndef SX_DE_WAVE_ROWS_WAVES
 #define SX_DE_WAVE_ROWS_WAVES 1
 #endif
-template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
+// ONEB (round 5): a whole-wave kernel instantiated for rows of 129 ... 256 elements of run-time length -- one batch, rows in
+// registers for the store, the objective's run-time register chain only (as the short-row kernels are for n <= 128)
+template <int FUN, int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1, bool ONEB = false>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? SX_DE_NFIX_WAVES
                                                        : (NFIX == 0 && XM == 0 && STRAT >= 0 && LPR == kWave) ? SX_DE_WAVE_ROWS_WAVES
                                                                                                                  : 1) void de_generation_kernel(const sx_state *const sin_pre,
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? 
     // one batch per row -- NFIX, and (round 5) EVERY row of a short-row kernel, whatever its run-time length (lanes_per_row
     // gives rows of up to 64 / 128 elements 16 / 32 lanes: n <= kStep * LPR): trial and own row stay in registers for the
     // row store
-    constexpr bool kRegRow = NFIX != 0 || LPR < kWave;
+    constexpr bool kRegRow = NFIX != 0 || LPR < kWave || ONEB;
     double keep[kStep];
     auto trial_batch = [&](int q0, const Batch &bt) {
         const double(&bx)[kStep] = bt.x;
@@ -569,14 +571,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? 
         trial_batch(0, B0);
     } else {  // whole-wave rows (n > 128): one batch and half the registers -- twice the waves hide it better
         trial_batch(0, B0);
-        for (int q0 = kStep; q0 < nq; q0 += kStep) {
-            load_batch(q0, B0);
-            trial_batch(q0, B0);
+        if constexpr (!ONEB) {
+            for (int q0 = kStep; q0 < nq; q0 += kStep) {
+                load_batch(q0, B0);
+                trial_batch(q0, B0);
+            }
         }
     }
 
     SX_TP(2);
-    const double fc = row_objective<FUN, LPR, FULL, NFIX>(U, n, plan, l);
+    const double fc = row_objective<FUN, LPR, FULL, NFIX, SX_LONG_STATIC, ONEB>(U, n, plan, l);
     SX_TP(3);
     const bool better = fc < fold;  // _common.py:127 strict <
     if (FULL || id.active) {
@@ -609,16 +613,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? 
 typedef void (*de_kernel_t)(const sx_state *, const double *, const int64_t *, const int64_t, const sx_de_args,
                             const PlanArg, const int, const int, const sx_xchg_args);
 
-template <int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1>
+template <int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1, bool ONEB = false>
 de_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL, NFIX, STRAT>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL, NFIX, STRAT>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL, NFIX, STRAT>;
-        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL, NFIX, STRAT>;
-        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL, NFIX, STRAT>;
-        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL, NFIX, STRAT>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL, NFIX, STRAT>;
+        case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+        case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+        case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+        case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
     }
     return nullptr;
 }
@@ -650,8 +654,14 @@ de_kernel_t pick_kernel_fixed(int fun_id, int strategy, int constraints) {
 // workgroups per CU; best1bin alone needs 2 donors: <= 80 VGPRs, three workgroups (what bounds these shapes is latency:
 // profiles/r5_de_gather_probe.txt)
 template <int RNG, int XM, int LPR>
-de_kernel_t pick_kernel_general(int fun_id, int strategy, int constraints) {
+de_kernel_t pick_kernel_general(int fun_id, int strategy, int constraints, int n) {
     if constexpr (XM <= 1 && RNG == SX_RNG_PHILOX) {
+        if constexpr (LPR == kWave) {  // whole-wave rows of up to 256 elements: the one-batch form (ONEB)
+            if (n <= 4 * kWave && constraints == 0 && strategy == SX_DE_BEST1BIN)
+                return pick_kernel_lpr<RNG, XM, LPR, false, 0, SX_DE_BEST1BIN, true>(fun_id);
+            if (n <= 4 * kWave && constraints == 0 && strategy == SX_DE_RAND1BIN)
+                return pick_kernel_lpr<RNG, XM, LPR, false, 0, SX_DE_RAND1BIN, true>(fun_id);
+        }
         if (constraints == 0 && strategy == SX_DE_BEST1BIN) return pick_kernel_lpr<RNG, XM, LPR, false, 0, SX_DE_BEST1BIN>(fun_id);
         if (constraints == 0 && strategy == SX_DE_RAND1BIN) return pick_kernel_lpr<RNG, XM, LPR, false, 0, SX_DE_RAND1BIN>(fun_id);
     }
@@ -669,13 +679,13 @@ de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy, int constrai
     switch (lpr) {
         case 16:
             if (fix) return pick_kernel_fixed<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id, strategy, constraints);
-            return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_general<RNG, XM, 16>(fun_id, strategy, constraints);
+            return full ? pick_kernel_lpr<RNG, XM, 16, CH>(fun_id) : pick_kernel_general<RNG, XM, 16>(fun_id, strategy, constraints, n);
         case 32:
             if (fix) return pick_kernel_fixed<RNG, XM, 32, CH, FX ? kStep * 32 : 0>(fun_id, strategy, constraints);
-            return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_general<RNG, XM, 32>(fun_id, strategy, constraints);
+            return full ? pick_kernel_lpr<RNG, XM, 32, CH>(fun_id) : pick_kernel_general<RNG, XM, 32>(fun_id, strategy, constraints, n);
     }
     if (fix) return pick_kernel_fixed<RNG, XM, 64, CH, FX ? kStep * 64 : 0>(fun_id, strategy, constraints);
-    return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_general<RNG, XM, 64>(fun_id, strategy, constraints);
+    return full ? pick_kernel_lpr<RNG, XM, 64, CH>(fun_id) : pick_kernel_general<RNG, XM, 64>(fun_id, strategy, constraints, n);
 }
 
 }  // namespace

@@ -45,7 +45,10 @@ __device__ __forceinline__ unsigned long long sort_key(double f) {
 // when the workgroup's best row changed.  mode 1: one workgroup, finalise only, into state[2] (the host's view).
 constexpr int kChainRecPerThread = 8;
 
-template <int FUN, int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false>
+// ONEB (round 5): a whole-wave kernel instantiated for rows of 129 ... 256 elements of run-time length: one batch, the objective's
+// run-time register chain only -- the general whole-wave kernel carries the long rows' summation plans in its register budget
+// (111 VGPRs with Ackley: two workgroups per CU, where the n = 256 kernel runs four)
+template <int FUN, int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false, bool ONEB = false>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
                                                                                 const PlanArg plan,
                                                                                 double *__restrict__ best_rows,
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
     // with Shrink the raw velocity waits in LDS for the row-wide beta.
     constexpr int kStep = 4;
     double beta = __builtin_huge_val();
-    const int nq = (n + LPR - 1) / LPR;
+    const int nq = (ONEB || LPR < kWave) ? kStep : (n + LPR - 1) / LPR;  // (short rows and ONEB rows: one batch, said at compile time)
     for (int q0 = 0; q0 < nq; q0 += kStep) {
         double x[kStep], v[kStep], p[kStep], g[kStep], r1[kStep], r2[kStep];
 #pragma unroll
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             }
         }
     }
-    const double fc = row_objective<FUN, LPR, FULL, FULL ? 4 * LPR : 0>(U, n, plan, l);
+    const double fc = row_objective<FUN, LPR, FULL, FULL ? 4 * LPR : 0, SX_LONG_STATIC, ONEB>(U, n, plan, l);
     const bool better = fc < fold;  // _common.py:127 strict <
     if (id.active) {
         if (better)
@@ -327,16 +330,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
 
 typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg, double *, int, int, int64_t);
 
-template <int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false>
+template <int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false, bool ONEB = false>
 pso_kernel_t pick_kernel_lpr(int fun_id) {
     switch (fun_id) {
-        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL, PLAIN, CHAIN>;
-        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL, PLAIN, CHAIN>;
-        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL, PLAIN, CHAIN>;
-        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL, PLAIN, CHAIN>;
-        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL, PLAIN, CHAIN>;
-        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL, PLAIN, CHAIN>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL, PLAIN, CHAIN>;
+        case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+        case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+        case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+        case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
     }
     return nullptr;
 }
@@ -369,6 +372,8 @@ pso_kernel_t pick_kernel(int fun_id, int n, bool plain) {
             return pl ? pick_kernel_lpr<RNG, 32, false, PH>(fun_id) : pick_kernel_lpr<RNG, 32, false>(fun_id);
     }
     if (full) return plain ? pick_kernel_lpr<RNG, 64, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 64, PH>(fun_id);
+    if (PH && n <= 4 * kWave)  // rows of 129 ... 256 elements off the grid: the one-batch form of the whole-wave kernel
+        return pl ? pick_kernel_lpr<RNG, 64, false, PH, false, PH>(fun_id) : pick_kernel_lpr<RNG, 64, false, false, false, PH>(fun_id);
     return pl ? pick_kernel_lpr<RNG, 64, false, PH>(fun_id) : pick_kernel_lpr<RNG, 64, false>(fun_id);
 }
 

@@ -358,7 +358,9 @@ constexpr bool chain_only() {
 // NFIX: the row length when it is a compile-time constant (the PSO kernel's whole-batch rows), else 0
 // LONGSTATIC = 0: no branch to the compile-time plans of n = 512 / 1024 / 2048 (the one-workgroup kernels of
 // updating="immediate", 1 024 threads at the 128-VGPR cap, would spill for them)
-template <int FUN, int LPR, bool FULL = false, int NFIX = 0, int LONGSTATIC = SX_LONG_STATIC>
+// ONEBATCH: the caller guarantees n <= 4 LPR (a whole-wave kernel instantiated for rows of up to 256 elements): nothing but the
+// run-time register chain is compiled (the kernel then does not carry the long rows' plans in its register budget)
+template <int FUN, int LPR, bool FULL = false, int NFIX = 0, int LONGSTATIC = SX_LONG_STATIC, bool ONEBATCH = false>
 __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg &plan, int l) {
     using O = Obj<FUN>;
     const int m = O::NEXT ? n - 1 : n;
@@ -370,7 +372,7 @@ __device__ __forceinline__ double row_objective(double *U, int n, const PlanArg 
         //  terms for a row of up to 256 elements any more, so such rows need n + 8 doubles of LDS, sx_device.hpp de_row_stride)
         // (lanes_per_row gives 16 / 32 lanes to rows of up to 64 / 128 elements only: a short-row kernel never meets a longer row,
         //  and the staged-terms code below is not even compiled for it)
-        if constexpr (LPR < kWave) return row_objective_chain_rt<FUN, LPR>(U, n, plan, l);
+        if constexpr (LPR < kWave || ONEBATCH) return row_objective_chain_rt<FUN, LPR>(U, n, plan, l);
         if (n <= 4 * LPR) return row_objective_chain_rt<FUN, LPR>(U, n, plan, l);
     }
     if constexpr (NFIX > 256) {  // a long row of compile-time length: numpy's plan as constants (row_reduce_long)
