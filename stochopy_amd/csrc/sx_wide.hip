@@ -45,9 +45,17 @@ namespace {
 
 // ---------------------------------------------------------------------------
 // the plan in device memory:  [0] nleaf  [1] tail  [2] mb  [3] nlevels  [4] npiece (8192-term pieces of the sum)
-//                             [5 .. 5+nleaf)            end block (exclusive) of leaf t
+//                             [5] where the last piece's partner words start   [6] where the chunk table starts
+//                             [7 .. 7+nleaf)            end block (exclusive) of leaf t
 //                             [.. + nlevels + 1)        first combine of level v (prefix sums)
-//                             [.. + 2 (nleaf-1))        (left, right) leaf slots of the combines, level by level
+//                             [.. + 2 (nleaf-npiece))   (left, right) leaf slots of the combines, level by level
+//                             [.. + 128)                the LAST piece's combines as seen by its leaves: word w of leaf slot
+//                                                       l (slot within the piece) at [64 w + l], byte v & 3 of word v >> 2 =
+//                                                       the slot (<= 64) whose sum leaf l takes in at level v, 0xff: none
+//                             [.. + 2 + nchunk)         nchunk, then the first leaf of every chunk of a STREAMED row and nleaf:
+//                                                       as many whole leaves as fit kChunkElems elements.  (A fixed 32 leaves
+//                                                       per chunk left Rosenbrock rows of 2^k elements -- 2^k - 1 terms: 33
+//                                                       or 65 leaves in the last piece -- with a chunk of ONE leaf.)
 // ---------------------------------------------------------------------------
 struct HostPlan {
     std::vector<int32_t> end;
@@ -73,6 +81,9 @@ struct HostPlan {
 };
 
 constexpr int64_t kNumpyBuf = 8192;  // np.getbufsize(): the pieces numpy's reduction hands to its pairwise sum
+constexpr int kPieceLeaves = 64;     // leaves of a full piece (128 terms each)
+constexpr int kPlanHeader = 7;
+constexpr int kChunkElems = 4096;    // elements of a streamed row staged at a time (kStageElems below has the slack)
 
 struct CachedPlan {
     int32_t *dev = nullptr;
@@ -105,14 +116,29 @@ int get_plan(int64_t m, hipStream_t s, CachedPlan *out) {
     const int nleaf = (int)hp.end.size();
     int nlevels = 0;
     for (int lv : hp.level) nlevels = lv + 1 > nlevels ? lv + 1 : nlevels;
-    std::vector<int32_t> buf(5 + (size_t)nleaf + (size_t)nlevels + 1 + 2 * hp.merge.size());
+    const size_t partner_at = kPlanHeader + (size_t)nleaf + (size_t)nlevels + 1 + 2 * hp.merge.size();
+    std::vector<int32_t> chunks;  // first leaves of the chunks
+    for (int t0 = 0; t0 < nleaf;) {
+        const int64_t e0 = t0 > 0 ? (int64_t)hp.end[t0 - 1] * kGroup : 0;
+        int t = t0 + 1;  // (a leaf has at most 128 terms + the row's tail of 7)
+        while (t < nleaf && (t + 1 == nleaf ? m : (int64_t)hp.end[t] * kGroup) - e0 <= kChunkElems) ++t;
+        chunks.push_back(t0);
+        t0 = t;
+    }
+    chunks.push_back(nleaf);
+    const size_t chunk_at = partner_at + 2 * kPieceLeaves;
+    std::vector<int32_t> buf(chunk_at + 1 + chunks.size());
+    buf[6] = (int32_t)chunk_at;
+    buf[chunk_at] = (int32_t)chunks.size() - 1;
+    for (size_t k = 0; k < chunks.size(); ++k) buf[chunk_at + 1 + k] = chunks[k];
     buf[0] = nleaf;
     buf[1] = (int32_t)(m % 8);
     buf[2] = (int32_t)(m / 8);
     buf[3] = nlevels;
     buf[4] = npiece;
-    for (int t = 0; t < nleaf; ++t) buf[5 + t] = hp.end[t];
-    int32_t *off = buf.data() + 5 + nleaf;
+    buf[5] = (int32_t)partner_at;
+    for (int t = 0; t < nleaf; ++t) buf[kPlanHeader + t] = hp.end[t];
+    int32_t *off = buf.data() + kPlanHeader + nleaf;
     int32_t *pairs = off + nlevels + 1;
     int pos = 0;
     for (int lv = 0; lv < nlevels; ++lv) {
@@ -125,6 +151,23 @@ int get_plan(int64_t m, hipStream_t s, CachedPlan *out) {
         }
     }
     off[nlevels] = pos;
+    {  // the last piece's combines, per leaf slot and level.  A piece of m <= 8192 terms has at most 65 leaves and 7 levels
+       // (enumerated: 65 / 7 for 441 values of m, e.g. 8191 -- a node of 129..135 terms splits once more); a 65th leaf is
+       // the piece's last one and only ever the RIGHT operand of one combine (r = 64).
+        uint32_t *pw = (uint32_t *)buf.data() + partner_at;
+        for (int i = 0; i < 2 * kPieceLeaves; ++i) pw[i] = 0xffffffffu;
+        const int first = (npiece - 1) * kPieceLeaves;
+        for (size_t k = 0; k < hp.merge.size(); ++k) {
+            const int l = hp.merge[k].first - first, r = hp.merge[k].second - first, lv = hp.level[k];
+            if (l < 0) continue;  // a combine of an earlier (full) piece
+            if (lv >= 7 || l >= kPieceLeaves || r <= l || r > kPieceLeaves) {
+                set_error("wide rows: the summation plan of this row length does not fit the per-piece form");
+                return -1;
+            }
+            uint32_t &w = pw[(lv >> 2) * kPieceLeaves + l];
+            w = (w & ~(0xffu << (8 * (lv & 3)))) | ((uint32_t)r << (8 * (lv & 3)));
+        }
+    }
     CachedPlan cp;
     cp.nleaf = nleaf;
     SX_HIP(hipMalloc((void **)&cp.dev, buf.size() * sizeof(int32_t)));
@@ -135,18 +178,43 @@ int get_plan(int64_t m, hipStream_t s, CachedPlan *out) {
 }
 
 struct WideCtx {
-    const int32_t *end, *lvl, *pairs;
+    const int32_t *end, *lvl, *pairs, *chunk;  // chunk[0]: chunks of a streamed row, chunk[1 + k]: first leaf of chunk k
     int nleaf, tail, mb, nlevels, npiece;
+    uint32_t pw0, pw1;  // this lane's partner words of the last piece (loaded here, needed at the very end)
 };
 __device__ __forceinline__ WideCtx wide_ctx(const int32_t *__restrict__ plan) {
     WideCtx c;
     c.nleaf = plan[0], c.tail = plan[1], c.mb = plan[2], c.nlevels = plan[3], c.npiece = plan[4];
-    c.end = plan + 5;
+    const uint32_t *pw = (const uint32_t *)plan + plan[5] + ((int)threadIdx.x & (kWave - 1));
+    c.pw0 = pw[0], c.pw1 = pw[kPieceLeaves];
+    c.chunk = plan + plan[6];
+    c.end = plan + kPlanHeader;
     c.lvl = c.end + c.nleaf;
     c.pairs = c.lvl + c.nlevels + 1;
     return c;
 }
 
+// Where element e of the row sits in the stage.  A leaf of numpy's recursion is usually 128 elements = 1 KB, and the 8-lane
+// groups of a wavefront read consecutive leaves at the same block: four groups of a ds_read_b64 half on the same 16 banks
+// (a 4-way conflict on every read).  Eight doubles of padding per 128 elements move consecutive leaves 64 B apart in the
+// banks.  So that "the next element" stays ONE slot away for the reduction (Rosenbrock-like terms), the first element of
+// every 128-segment is staged twice: in its place and in the pad slot right after its predecessor.
+// Measured (profiles/r5_wide_ab3.txt, sx_eval Rosenbrock n = 4096): SQ_LDS_BANK_CONFLICT 23.8 M -> 1.2 M cycles per launch, and the
+// launch 4 % SLOWER (the address arithmetic: 96 M -> 117 M vector instructions) -- these kernels are bound by vector-instruction
+// issue, not by the LDS.  Kept behind the switch, off.
+#ifndef SX_WIDE_PAD
+#define SX_WIDE_PAD 0
+#endif
+__host__ __device__ __forceinline__ int stage_pos(int e) { return SX_WIDE_PAD ? e + ((e >> 7) << 3) : e; }
+template <bool NEXT>
+__device__ __forceinline__ void stage_put(double *Sd, int e, int e0, double v) {  // e0: the first element of the chunk
+    const int p = stage_pos(e);
+    Sd[p] = v;
+    if (SX_WIDE_PAD && NEXT && (e & 127) == 0 && e > e0) Sd[p - 8] = v;
+}
+#ifndef SX_WIDE_LEAF_BATCH
+#define SX_WIDE_LEAF_BATCH(FUN) 8  // (4 for the cosine objectives: 100 -> 95 VGPRs, one variant spills: not taken)
+#endif
 // Leaves [leaf0, leaf1) of the row, elements staged at Sd[e] (Sd = stage - first staged element): one leaf per 8-lane
 // group and pass -- lane j walks accumulator j over the leaf's 8-blocks, forming the terms on the way
 // (row_reduce_leaves_fused's arithmetic) -> LA[t] (and LB[t]).
@@ -158,24 +226,31 @@ __device__ __forceinline__ void wide_reduce_leaves(const double *Sd, int leaf0, 
     const int j = (int)threadIdx.x & (kGroup - 1), grp = (int)threadIdx.x >> 3;
     const double identB = BMUL ? 1.0 : 0.0;
     for (int t0 = leaf0; t0 < leaf1; t0 += T / kGroup) {
+        // (a pass that is one leaf over -- 33 or 65 leaves: Rosenbrock rows of 2^k elements -- costs one wavefront, not all)
+        if (t0 + (grp & ~(kWave / kGroup - 1)) >= leaf1) break;
         const bool on = t0 + grp < leaf1;
         const int t = on ? t0 + grp : leaf1 - 1;  // idle groups shadow the last leaf and keep nothing
         const int b0 = t > 0 ? c.end[t - 1] : 0, b1 = c.end[t];
         const int cnt = b1 - b0;  // 8 .. 16 blocks (fewer only in a last piece of < 64 terms; none: its terms are all tail)
-        const double *U = Sd + b0 * kGroup + j;
+        const double *UA = Sd + stage_pos(b0 * kGroup) + j, *UB = UA + 8;  // UB: blocks past the leaf's 128-boundary
+        const int ustar = 16 - (b0 & 15);
         double chA = 0.0, chB = identB;
+        constexpr int B = SX_WIDE_LEAF_BATCH(FUN);  // blocks whose elements are in flight together
+        if (light_objective<FUN>() && __all(cnt == kLeafBlocks)) {
+            // every leaf of this wavefront has its 16 blocks (the usual case: 128-term leaves): no predicates.  (Not for the
+            // cosine objectives: their terms dwarf the predicates, and eight unpredicated cosines side by side take 176-251
+            // VGPRs.)
 #pragma unroll
-        for (int h0 = 0; h0 < kLeafBlocks; h0 += 8) {
-            double x[8], xn[8];
+            for (int h0 = 0; h0 < kLeafBlocks; h0 += B) {
+                double x[B], xn[B];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = h0 + u < cnt;
-                x[u] = in ? U[(h0 + u) * kGroup] : 0.0;
-                xn[u] = (O::NEXT && in) ? U[(h0 + u) * kGroup + 1] : 0.0;
-            }
+                for (int u = 0; u < B; ++u) {
+                    const double *U = (SX_WIDE_PAD && h0 + u >= ustar) ? UB : UA;
+                    x[u] = U[(h0 + u) * kGroup];
+                    xn[u] = O::NEXT ? U[(h0 + u) * kGroup + 1] : 0.0;
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (h0 + u < cnt) {
+                for (int u = 0; u < B; ++u) {
                     double a, b;
                     O::term(x[u], xn[u], (b0 + h0 + u) * kGroup + j, a, b);
                     if (h0 + u == 0) {
@@ -187,16 +262,64 @@ __device__ __forceinline__ void wide_reduce_leaves(const double *Sd, int leaf0, 
                     }
                 }
             }
+        } else {
+            // some leaf of this wavefront is shorter: the blocks past a leaf's end are read all the same (they lie inside
+            // the workgroup's LDS: the stage's slack or the leaf sums behind it) and their terms are dropped from the chain
+#pragma unroll
+            for (int h0 = 0; h0 < kLeafBlocks; h0 += B) {
+                double x[B], xn[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const double *U = (SX_WIDE_PAD && h0 + u >= ustar) ? UB : UA;
+                    x[u] = U[(h0 + u) * kGroup];
+                    xn[u] = O::NEXT ? U[(h0 + u) * kGroup + 1] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const bool in = h0 + u < cnt;
+                    double a, b;
+                    if constexpr (light_objective<FUN>()) {
+                        O::term(x[u], xn[u], (b0 + h0 + u) * kGroup + j, a, b);
+                        if (h0 + u == 0) {
+                            chA = in ? a : 0.0;
+                            chB = in ? b : identB;
+                        } else {
+                            chA = in ? chA + a : chA;
+                            if (TWO) chB = in ? combine<BMUL>(chB, b) : chB;
+                        }
+                    } else if (in) {  // the cosine objectives: one term after the other (side by side they take 150-230 VGPRs)
+                        O::term(x[u], xn[u], (b0 + h0 + u) * kGroup + j, a, b);
+                        if (h0 + u == 0) {
+                            chA = a;
+                            chB = b;
+                        } else {
+                            chA = chA + a;
+                            if (TWO) chB = combine<BMUL>(chB, b);
+                        }
+                    }
+                }
+            }
         }
         double curA = group_tree<false>(chA);
         double curB = TWO ? group_tree<BMUL>(chB) : identB;
-        if (t == c.nleaf - 1) {  // the tail terms, one by one, after the last leaf's tree
+        if (t == c.nleaf - 1 && c.tail > 0) {
+            // the tail terms (fewer than 8), added one by one after the last leaf's tree: lane k of the group forms term k,
+            // the sums take them in order (one term's arithmetic instead of `tail` times that, for the whole wavefront)
             const int e0 = c.mb * kGroup;
-            for (int k = 0; k < c.tail; ++k) {
-                double a, b;
-                O::term(Sd[e0 + k], O::NEXT ? Sd[e0 + k + 1] : 0.0, e0 + k, a, b);
-                curA = curA + a;
-                if (TWO) curB = combine<BMUL>(curB, b);
+            double ta = 0.0, tb = identB;
+            if (j < c.tail) {
+                const double *te = Sd + stage_pos(e0 + j);
+                O::term(te[0], O::NEXT ? te[1] : 0.0, e0 + j, ta, tb);
+            }
+            const int g0 = (int)threadIdx.x & (kWave - kGroup);  // first lane of this group within the wavefront
+#pragma unroll
+            for (int k = 0; k < kGroup - 1; ++k) {
+                const double va = __shfl(ta, g0 + k, kWave);
+                if (k < c.tail) curA = curA + va;
+                if (TWO) {
+                    const double vb = __shfl(tb, g0 + k, kWave);
+                    if (k < c.tail) curB = combine<BMUL>(curB, vb);
+                }
             }
         }
         if (on && j == 0) {
@@ -206,12 +329,49 @@ __device__ __forceinline__ void wide_reduce_leaves(const double *Sd, int leaf0, 
     }
 }
 
-// the recursion's combines, level by level (a level's combines touch disjoint slots); the row's sums end in slot 0
+// The recursion's combines.  A piece (8192 terms) has 64 leaves (a last, shorter one up to 65): ONE WAVEFRONT takes a piece, leaf slot l on lane l,
+// and walks the levels of the recursion with lane shuffles -- at level v lane l takes in the sum of the slot the plan
+// names (a full piece: the perfect tree, l + 2^v into l when l is a multiple of 2^(v+1); the last piece: the partner
+// words) -- the same additions in the same tree as numpy's recursion, without a barrier or a table look-up per level
+// (the level-by-level form over all pieces in LDS -- SX_WIDE_FINISH_SHFL=0 -- costs a workgroup of a 4096-element row
+// about as long as loading the row).  Then add.reduce's own loop: the identity, then the pieces in order.
+#ifndef SX_WIDE_FINISH_SHFL
+#define SX_WIDE_FINISH_SHFL 1
+#endif
 template <int FUN, int T>
 __device__ __forceinline__ double wide_finish(const WideCtx &c, int n, double *LA, double *LB) {
     using O = Obj<FUN>;
     constexpr bool TWO = O::TWO, BMUL = O::BMUL;
     __syncthreads();
+#if SX_WIDE_FINISH_SHFL
+    const int lane = (int)threadIdx.x & (kWave - 1);
+    for (int p = (int)threadIdx.x >> 6; p < c.npiece; p += T / kWave) {
+        const bool lastp = p == c.npiece - 1;
+        const int nl = lastp ? c.nleaf - p * kPieceLeaves : kPieceLeaves;
+        double a = lane < nl ? LA[p * kPieceLeaves + lane] : 0.0;
+        double b = (TWO && lane < nl) ? LB[p * kPieceLeaves + lane] : (BMUL ? 1.0 : 0.0);
+#pragma unroll
+        for (int lv = 0; lv < 7; ++lv) {
+            const int named = (int)(((lv < 4 ? c.pw0 : c.pw1) >> (8 * (lv & 3))) & 0xffu);
+            const int full = (lv < 6 && (lane & ((2 << lv) - 1)) == 0) ? lane + (1 << lv) : 0xff;
+            const int r = lastp ? named : full;
+            const bool on = r != 0xff, extra = r == kPieceLeaves;  // (a last piece's 65th leaf: read where it lies)
+            double ra = __shfl(a, on ? (r & (kWave - 1)) : lane, kWave);
+            if (extra) ra = LA[p * kPieceLeaves + kPieceLeaves];
+            if (on) a = a + ra;
+            if (TWO) {
+                double rb = __shfl(b, on ? (r & (kWave - 1)) : lane, kWave);
+                if (extra) rb = LB[p * kPieceLeaves + kPieceLeaves];
+                if (on) b = combine<BMUL>(b, rb);
+            }
+        }
+        if (lane == 0) {
+            LA[p * kPieceLeaves] = a;
+            if (TWO) LB[p * kPieceLeaves] = b;
+        }
+    }
+    __syncthreads();
+#else
     for (int lv = 0; lv < c.nlevels; ++lv) {
         const int o1 = c.lvl[lv + 1];
         for (int i = c.lvl[lv] + (int)threadIdx.x; i < o1; i += T) {
@@ -221,8 +381,8 @@ __device__ __forceinline__ double wide_finish(const WideCtx &c, int n, double *L
         }
         __syncthreads();
     }
+#endif
     // add.reduce starts from the identity and takes the 8192-term pieces in order (piece c: slot 64 c)
-    constexpr int kPieceLeaves = kNumpyBuf / 128;
     double sa = 0.0, sb = BMUL ? 1.0 : 0.0;
     for (int p = 0; p < c.npiece; ++p) {
         sa = sa + LA[p * kPieceLeaves];
@@ -231,46 +391,63 @@ __device__ __forceinline__ double wide_finish(const WideCtx &c, int n, double *L
     return O::finish(sa, sb, n);
 }
 
-// The row, chunk by chunk: produce(e0, e1, e1s, Sd) stages the elements [e0, e1s) at Sd[e] and commits whatever it
+// The row, chunk by chunk: produce(e0, e1, e1s, Sd) stages the elements [e0, e1s) with stage_put(Sd, e, e0, .) and commits whatever it
 // writes to memory for [e0, e1) only -- for an objective that reads the next element too, e1s = e1 + 1: that element is
-// staged again (and committed) by the next chunk.  chunk_leaves >= nleaf: the row is resident (one chunk).
+// staged again (and committed) by the next chunk.  chunk_leaves > 0: the row is resident (one chunk); 0: streamed through the plan's chunks.
+__device__ __forceinline__ void wide_chunk(const WideCtx &c, int n, bool next, bool resident, int k, int &leaf0, int &leaf1,
+                                           int &e0, int &e1, int &e1s) {
+    leaf0 = resident ? 0 : c.chunk[1 + k];
+    leaf1 = resident ? c.nleaf : c.chunk[2 + k];
+    const bool last = leaf1 == c.nleaf;
+    e0 = leaf0 > 0 ? c.end[leaf0 - 1] * kGroup : 0;
+    e1 = last ? n : c.end[leaf1 - 1] * kGroup;
+    e1s = last ? n : e1 + (next ? 1 : 0);
+}
 template <int FUN, int T, class Produce>
 __device__ __forceinline__ double wide_row(const WideCtx &c, int n, int chunk_leaves, double *S, double *LA, double *LB,
                                            Produce &&produce) {
     constexpr bool NEXT = Obj<FUN>::NEXT;
-    for (int leaf0 = 0; leaf0 < c.nleaf; leaf0 += chunk_leaves) {
-        const int leaf1 = leaf0 + chunk_leaves < c.nleaf ? leaf0 + chunk_leaves : c.nleaf;
-        const bool last = leaf1 == c.nleaf;
-        const int e0 = leaf0 > 0 ? c.end[leaf0 - 1] * kGroup : 0;
-        const int e1 = last ? n : c.end[leaf1 - 1] * kGroup;
-        const int e1s = last ? n : e1 + (NEXT ? 1 : 0);
-        if (leaf0 > 0) __syncthreads();  // the previous chunk's leaves have been read
-        produce(e0, e1, e1s, S - e0);
+    const bool resident = chunk_leaves > 0;
+    const int nchunk = resident ? 1 : c.chunk[0];
+    for (int k = 0; k < nchunk; ++k) {
+        int leaf0, leaf1, e0, e1, e1s;
+        wide_chunk(c, n, NEXT, resident, k, leaf0, leaf1, e0, e1, e1s);
+        if (k > 0) __syncthreads();  // the previous chunk's leaves have been read
+        produce(e0, e1, e1s, S - stage_pos(e0));
         __syncthreads();
-        wide_reduce_leaves<FUN, T>(S - e0, leaf0, leaf1, c, LA, LB);
+        wide_reduce_leaves<FUN, T>(S - stage_pos(e0), leaf0, leaf1, c, LA, LB);
     }
     return wide_finish<FUN, T>(c, n, LA, LB);
 }
 
 constexpr int kEvalThreads = 256;
-constexpr int kGenThreads = 512;
-#ifndef SX_WIDE_STREAM_LEAVES
-#define SX_WIDE_STREAM_LEAVES 32
+#ifndef SX_WIDE_EVAL_PIPE_FROM
+#define SX_WIDE_EVAL_PIPE_FROM 8192  // rows longer than this (several chunks) of the light objectives take the pipelined form
 #endif
-constexpr int kStreamLeaves = SX_WIDE_STREAM_LEAVES;  // leaves per chunk of a streamed row: <= 4096 elements staged (A/B: 16)
+constexpr int kGenThreads = 512;
 constexpr size_t kResidentLds = 148 * 1024;   // a resident row + its leaf sums must fit here (160 KB per CU)
-constexpr int kStageElems = kStreamLeaves * 128 + 16;
+constexpr int kStageElems = kChunkElems + 16 + 128 + (SX_WIDE_PAD ? 8 * (kChunkElems / 128 + 2) : 0);
 
 __host__ __device__ inline int wide_leaf_cap(int n) { return n / 64 + 2; }
+// (+ 128: the blocks a short last leaf does not have are read all the same, wide_reduce_leaves)
+__host__ __device__ inline int wide_resident_elems(int n) { return n + 16 + 128 + (SX_WIDE_PAD ? 8 * (n / 128 + 2) : 0); }
 inline size_t wide_lds_bytes(int n, bool resident) {
-    return ((size_t)(resident ? n + 16 : kStageElems) + 2 * (size_t)wide_leaf_cap(n)) * sizeof(double);
+    return ((size_t)(resident ? wide_resident_elems(n) : kStageElems) + 2 * (size_t)wide_leaf_cap(n)) * sizeof(double);
 }
-inline bool wide_resident(int n) { return wide_lds_bytes(n, true) <= kResidentLds; }
+inline size_t wide_resident_limit() {  // SX_WIDE_RESIDENT_KB: measurement hook (tools/bench_wide.py)
+    static const size_t lim = [] {
+        const char *e = getenv("SX_WIDE_RESIDENT_KB");
+        const size_t v = e != nullptr ? (size_t)atol(e) * 1024 : kResidentLds;
+        return v < kResidentLds ? v : kResidentLds;
+    }();
+    return lim;
+}
+inline bool wide_resident(int n) { return wide_lds_bytes(n, true) <= wide_resident_limit(); }
 
 // ---------------------------------------------------------------------------
 // objective of rows of X (sx_eval; the CMA-ES family's un-standardisation / clipping / penalty sums as in eval_kernel)
 // ---------------------------------------------------------------------------
-template <int FUN>
+template <int FUN, bool PIPE>
 __global__ __launch_bounds__(kEvalThreads) void wide_eval_kernel(const double *__restrict__ X, int64_t P, int n, int64_t ldx,
                                                                  const double *__restrict__ xm, const double *__restrict__ xstd,
                                                                  double *__restrict__ f, const int32_t *__restrict__ plan,
@@ -287,26 +464,75 @@ __global__ __launch_bounds__(kEvalThreads) void wide_eval_kernel(const double *_
     const bool affine = xm != nullptr;
     const int tid = (int)threadIdx.x;
     double pacc = 0.0;
-    const double val = wide_row<FUN, T>(c, n, kStreamLeaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
-        for (int eb = e0 + tid; eb < e1s; eb += 8 * T) {  // eight row loads per thread in flight
-            double xv[8];
+    // The chunks, one after the other: fetch (16 row elements per thread, all their loads in flight; + the look-ahead
+    // element of an objective that reads its neighbour, thread 0's 17th) -> commit to the stage -> the chunk's leaves.
+    // PIPE: the loads of chunk k + 1 are issued BEFORE the leaves of chunk k are reduced, so a workgroup always has 32 KB on
+    // its way; costs 32-36 VGPRs: measured +4 ... +9 % for Rosenbrock / Sphere rows of 16 384 and 65 536 elements, -3 ... -10 %
+    // for one- and two-chunk rows and for the cosine objectives (three workgroups per CU instead of four) --
+    // profiles/r5_wide_ab2.txt; hence PIPE only for light objectives and n > SX_WIDE_EVAL_PIPE_FROM.  Either way the same
+    // elements are staged at the same places and the same leaves are formed: same bits.
+    // A chunk that has all its 16 x 256 elements (every chunk but a row's last) and a plain evaluation (no clipping, no
+    // un-standardisation: sx_eval's own calls) take unpredicated code: the general form spends ~23 vector instructions per
+    // ELEMENT on its run-time switches, as much as the objective itself (counters: profiles/r5_wide_ab3.txt).
+    constexpr bool NEXT = Obj<FUN>::NEXT;
+    constexpr int NV = kChunkElems / T;  // 16
+    static_assert(NV * T == kChunkElems, "a chunk is a whole number of elements per thread");
+    const bool plain = !clip && !affine;
+    double xv[NV], xlook = 0.0;
+    auto fetch = [&](int e0, int e1s) {
+        if (e1s - e0 >= NV * T) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = eb + u * T < e1s ? xr[eb + u * T] : 0.0;
+            for (int u = 0; u < NV; ++u) xv[u] = xr[e0 + tid + u * T];
+        } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = eb + u * T;
-                if (e >= e1s) continue;
-                double v = xv[u];
-                if (clip) {  // cmaes/_constraints.py:29-31, :79
-                    const double cl = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
-                    if (pen_v != nullptr && e < e1) pacc += ((cl - v) * (cl - v)) * pen_v[e];
-                    v = cl;
-                }
-                if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171
-                Sd[e] = v;
-            }
+            for (int u = 0; u < NV; ++u) xv[u] = e0 + tid + u * T < e1s ? xr[e0 + tid + u * T] : 0.0;
         }
-    });
+        if (NEXT) xlook = (tid == 0 && e0 + NV * T < e1s) ? xr[e0 + NV * T] : 0.0;
+    };
+    auto put = [&](int e, int e0c, int e1, double v, double *Sd) {
+        if (clip) {  // cmaes/_constraints.py:29-31, :79
+            const double cl = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+            if (pen_v != nullptr && e < e1) pacc += ((cl - v) * (cl - v)) * pen_v[e];
+            v = cl;
+        }
+        if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171
+        stage_put<NEXT>(Sd, e, e0c, v);
+    };
+    const int nchunk = c.chunk[0];
+    int leaf0, leaf1, e0, e1, e1s;
+    wide_chunk(c, n, NEXT, false, 0, leaf0, leaf1, e0, e1, e1s);
+    if (PIPE) fetch(e0, e1s);
+    for (int k = 0; k < nchunk; ++k) {
+        wide_chunk(c, n, NEXT, false, k, leaf0, leaf1, e0, e1, e1s);
+        double *Sd = S - stage_pos(e0);
+        if (!PIPE) fetch(e0, e1s);
+        if (plain && !SX_WIDE_PAD) {
+            if (e1s - e0 >= NV * T) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) Sd[e0 + tid + u * T] = xv[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NV; ++u)
+                    if (e0 + tid + u * T < e1s) Sd[e0 + tid + u * T] = xv[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NV; ++u)
+                if (e0 + tid + u * T < e1s) put(e0 + tid + u * T, e0, e1, xv[u], Sd);
+        }
+        if (NEXT && tid == 0 && e0 + NV * T < e1s) put(e0 + NV * T, e0, e1, xlook, Sd);
+        for (int e = e0 + NV * T + (NEXT ? 1 : 0) + tid; e < e1s; e += T) put(e, e0, e1, xr[e], Sd);  // (a last chunk's tail terms)
+        __syncthreads();
+        const bool more = k + 1 < nchunk;
+        if (PIPE && more) {
+            int nl0, nl1, ne0, ne1, ne1s;
+            wide_chunk(c, n, NEXT, false, k + 1, nl0, nl1, ne0, ne1, ne1s);
+            fetch(ne0, ne1s);
+        }
+        wide_reduce_leaves<FUN, T>(Sd, leaf0, leaf1, c, LA, LB);
+        if (more) __syncthreads();  // the chunk's leaves have been read
+    }
+    const double val = wide_finish<FUN, T>(c, n, LA, LB);
     if (pen_out != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pacc += __shfl_xor(pacc, off, kWave);
@@ -328,7 +554,9 @@ __global__ __launch_bounds__(kEvalThreads) void wide_eval_kernel(const double *_
 // DE generation (de_generation_kernel<XM = 0> for wide rows): the state is ONE sx_state, the best / termination step a
 // kernel of its own; one record per row.
 // ---------------------------------------------------------------------------
-template <int FUN, int RNG>
+// STRAT >= 0: best1bin / rand1bin with constraints=None at compile time (two or three donor rows in flight instead of five,
+// no bounds / resample registers: the generic form's 136-148 VGPRs leave ONE 512-thread workgroup per CU).
+template <int FUN, int RNG, int STRAT = -1, bool PRE = false>
 __global__ __launch_bounds__(kGenThreads) void wide_de_kernel(const sx_de_args a, const int32_t *__restrict__ plan,
                                                               const int chunk_leaves) {
     constexpr int T = kGenThreads;
@@ -337,8 +565,8 @@ __global__ __launch_bounds__(kGenThreads) void wide_de_kernel(const sx_de_args a
     if (sin->done) return;
     const WideCtx c = wide_ctx(plan);
     const int n = a.n;
-    const bool resident = chunk_leaves >= c.nleaf;
-    double *S = lds, *LA = lds + (resident ? n + 16 : kStageElems), *LB = LA + wide_leaf_cap(n);
+    const bool resident = chunk_leaves > 0;
+    double *S = lds, *LA = lds + (resident ? wide_resident_elems(n) : kStageElems), *LB = LA + wide_leaf_cap(n);
     const int64_t P = a.P, ld = a.ld, row = blockIdx.x, it = sin->it;
     const int tid = (int)threadIdx.x;
     const uint32_t gen = (uint32_t)(it + 1), grow = (uint32_t)(a.row0 + row);
@@ -347,8 +575,8 @@ __global__ __launch_bounds__(kGenThreads) void wide_de_kernel(const sx_de_args a
     const double fold = a.fit[row];
     const double *__restrict__ xi = cur + row * ld;
     double *__restrict__ xo = nxt + row * ld;
-    const int strategy = a.strategy, k = donors_of(strategy);
-    const bool repair = a.constraints != 0;
+    const int strategy = STRAT >= 0 ? STRAT : a.strategy, k = donors_of(strategy);
+    const bool repair = STRAT >= 0 ? false : a.constraints != 0;
     const bool use_best = strategy == SX_DE_BEST1BIN || strategy == SX_DE_BEST2BIN;
     int64_t d[kMaxDonors];
     int irand;
@@ -368,53 +596,78 @@ __global__ __launch_bounds__(kGenThreads) void wide_de_kernel(const sx_de_args a
     const double *rsrow = (RNG == SX_RNG_HOST && repair) ? a.resample + row * (int64_t)n : nullptr;
 
     // thread -> (k256, l): the four elements 256 k256 + l + 64 t, t = 0..3 -- steps q = 4 k256 + t of lane l in the
-    // whole-wave layout, i.e. ONE Philox call (slot (q >> 2) * 64 + l = 64 k256 + l) for their crossover uniforms
+    // whole-wave layout, i.e. ONE Philox call (slot (q >> 2) * 64 + l = 64 k256 + l) for their crossover uniforms.
+    // PRE: the loads of a thread's NEXT four elements (own row, donors, best row) are issued before the current four are
+    // worked on (Philox, mutation, crossover, staging) -- twice the bytes in flight for 32 more VGPRs.
+    struct DeLoads {
+        double x[4], dv[kMaxDonors][4], gv[4], r[4], rs[4], lo[4], hi[4];
+    };
+    auto de_issue = [&](int g, int e0, int e1s, DeLoads &L) {
+        const int eb = (g >> 6) * 256 + (g & 63);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = eb + 64 * t;
+            const bool in = e >= e0 && e < e1s;
+            L.x[t] = in ? xi[e] : 0.0;
+            L.gv[t] = (use_best && in) ? gb[e] : 0.0;
+#pragma unroll
+            for (int s = 0; s < kMaxDonors; ++s) L.dv[s][t] = (s < k && in) ? pd[s][e] : 0.0;
+            L.r[t] = 2.0, L.rs[t] = 0.0, L.lo[t] = 0.0, L.hi[t] = 0.0;
+            if (RNG == SX_RNG_HOST && in) {
+                L.r[t] = r1row[e];
+                if (repair) L.rs[t] = rsrow[e];
+            }
+            if (repair && in) L.lo[t] = a.lower[e], L.hi[t] = a.upper[e];
+        }
+    };
+    auto de_consume = [&](int g, int e0, int e1, int e1s, DeLoads &L, double *Sd) {
+        const int eb = (g >> 6) * 256 + (g & 63);
+        if (RNG == SX_RNG_PHILOX) {
+            const U4 w = philox4x32_10((uint32_t)g, grow, gen, kPurposeDeCross, a.key0, a.key1);
+            L.r[0] = u32(w.x), L.r[1] = u32(w.y), L.r[2] = u32(w.z), L.r[3] = u32(w.w);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = eb + 64 * t;
+            if (!(e >= e0 && e < e1s)) continue;
+            const double v = de_mutant(strategy, L.gv[t], L.dv[0][t], L.dv[1][t], L.dv[2][t], L.dv[3][t], L.dv[4][t], F);
+            double cand = (e == irand || L.r[t] <= CR) ? v : L.x[t];  // de/_de.py:341-344
+            if (repair && (cand < L.lo[t] || cand > L.hi[t]))         // de/_constraints.py:21-26
+                cand = RNG == SX_RNG_HOST ? L.rs[t]
+                                          : L.lo[t] + (L.hi[t] - L.lo[t]) *
+                                                philox_u53(e, kWave, grow, gen, kPurposeDeResample, a.key0, a.key1);
+            stage_put<Obj<FUN>::NEXT>(Sd, e, e0, cand);
+            if (!resident && e < e1) xo[e] = cand;  // streamed: the trial goes out as it is produced
+        }
+    };
     const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
-        for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
-            const int eb = (g >> 6) * 256 + (g & 63);
-            double x[4], dv[kMaxDonors][4], gv[4], r[4], rs[4], lo[4], hi[4];
-            bool in[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int e = eb + 64 * t;
-                in[t] = e >= e0 && e < e1s;
-                x[t] = in[t] ? xi[e] : 0.0;
-                gv[t] = (use_best && in[t]) ? gb[e] : 0.0;
-#pragma unroll
-                for (int s = 0; s < kMaxDonors; ++s) dv[s][t] = (s < k && in[t]) ? pd[s][e] : 0.0;
-                r[t] = 2.0, rs[t] = 0.0, lo[t] = 0.0, hi[t] = 0.0;
-                if (RNG == SX_RNG_HOST && in[t]) {
-                    r[t] = r1row[e];
-                    if (repair) rs[t] = rsrow[e];
+        const int g0 = (e0 >> 8) * 64 + tid, gend = ((e1s + 255) >> 8) * 64;
+        if constexpr (PRE) {
+            DeLoads A, B;
+            if (g0 < gend) de_issue(g0, e0, e1s, A);
+            for (int g = g0; g < gend; g += 2 * T) {
+                const bool second = g + T < gend;
+                if (second) de_issue(g + T, e0, e1s, B);
+                de_consume(g, e0, e1, e1s, A, Sd);
+                if (second) {
+                    if (g + 2 * T < gend) de_issue(g + 2 * T, e0, e1s, A);
+                    de_consume(g + T, e0, e1, e1s, B, Sd);
                 }
-                if (repair && in[t]) lo[t] = a.lower[e], hi[t] = a.upper[e];
             }
-            if (RNG == SX_RNG_PHILOX) {
-                const U4 w = philox4x32_10((uint32_t)g, grow, gen, kPurposeDeCross, a.key0, a.key1);
-                r[0] = u32(w.x), r[1] = u32(w.y), r[2] = u32(w.z), r[3] = u32(w.w);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int e = eb + 64 * t;
-                if (!in[t]) continue;
-                const double v = de_mutant(strategy, gv[t], dv[0][t], dv[1][t], dv[2][t], dv[3][t], dv[4][t], F);
-                double cand = (e == irand || r[t] <= CR) ? v : x[t];  // de/_de.py:341-344
-                if (repair && (cand < lo[t] || cand > hi[t]))         // de/_constraints.py:21-26
-                    cand = RNG == SX_RNG_HOST
-                               ? rs[t]
-                               : lo[t] + (hi[t] - lo[t]) * philox_u53(e, kWave, grow, gen, kPurposeDeResample, a.key0, a.key1);
-                Sd[e] = cand;
-                if (!resident && e < e1) xo[e] = cand;  // streamed: the trial goes out as it is produced
+        } else {
+            for (int g = g0; g < gend; g += T) {
+                DeLoads A;
+                de_issue(g, e0, e1s, A);
+                de_consume(g, e0, e1, e1s, A, Sd);
             }
         }
     });
     const bool better = fc < fold;  // _common.py:127 strict <
     if (resident || !better) {      // the row of the next generation: the trial (from LDS) or the old row
-        const double *src = better ? S : xi;
         for (int eb = tid; eb < n; eb += 8 * T) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = eb + u * T < n ? src[eb + u * T] : 0.0;
+            for (int u = 0; u < 8; ++u) v[u] = eb + u * T < n ? (better ? S[stage_pos(eb + u * T)] : xi[eb + u * T]) : 0.0;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (eb + u * T < n) xo[eb + u * T] = v[u];
@@ -437,7 +690,7 @@ __device__ __forceinline__ unsigned long long wide_sort_key(double f) {  // (sx_
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-template <int FUN, int RNG>
+template <int FUN, int RNG, bool PRE = false>
 __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args a, const int32_t *__restrict__ plan,
                                                                const int chunk_leaves) {
     constexpr int T = kGenThreads;
@@ -447,8 +700,8 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
     if (st->done) return;
     const WideCtx c = wide_ctx(plan);
     const int n = a.n;
-    const bool resident = chunk_leaves >= c.nleaf;
-    double *S = lds, *LA = lds + (resident ? n + 16 : kStageElems), *LB = LA + wide_leaf_cap(n);
+    const bool resident = chunk_leaves > 0;
+    double *S = lds, *LA = lds + (resident ? wide_resident_elems(n) : kStageElems), *LB = LA + wide_leaf_cap(n);
     const int64_t ld = a.ld, row = blockIdx.x;
     const int tid = (int)threadIdx.x;
     const uint32_t gen = (uint32_t)(st->it + 1), grow = (uint32_t)(a.row0 + row);
@@ -469,27 +722,39 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
     // the four elements 256 k256 + l + 64 t of group g = 64 k256 + l (steps q = 4 k256 + t of lane l): position, raw new
     // velocity (cpso/_cpso.py:326) -- two Philox calls (slot (q >> 1) * 64 + l: words (0,1) / (2,3) = (r1, r2) of even /
     // odd q); a re-seeded row draws its position instead of loading it (pso_restart_apply_kernel's draws), V = 0, pbest = X
-    auto elems = [&](int g, int lo_e, int hi_e, double(&x)[4], double(&vn)[4], bool(&in)[4]) {
+    // PRE: the loads of a thread's NEXT four elements are issued before the current four are worked on (as wide_de_kernel).
+    struct PsoLoads {
+        double x[4], v[4], p[4], gv[4], r1[4], r2[4];
+    };
+    auto pso_issue = [&](int g, int lo_e, int hi_e, PsoLoads &L) {
         const int eb = (g >> 6) * 256 + (g & 63);
-        double v[4], p[4], gv[4], r1[4], r2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = eb + 64 * t;
+            const bool in = e >= lo_e && e < hi_e;
+            const bool ldrow = in && !reseed;
+            L.x[t] = ldrow ? xr[e] : 0.0;
+            L.v[t] = ldrow ? vr[e] : 0.0;
+            L.p[t] = ldrow ? pb[e] : 0.0;
+            L.gv[t] = in ? gb[e] : 0.0;
+            L.r1[t] = (RNG == SX_RNG_HOST && in) ? r1row[e] : 0.0;
+            L.r2[t] = (RNG == SX_RNG_HOST && in) ? r2row[e] : 0.0;
+        }
+    };
+    auto pso_form = [&](int g, int lo_e, int hi_e, PsoLoads &L, double(&x)[4], double(&vn)[4], bool(&in)[4]) {
+        const int eb = (g >> 6) * 256 + (g & 63);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = eb + 64 * t;
             in[t] = e >= lo_e && e < hi_e;
-            const bool ldrow = in[t] && !reseed;
-            x[t] = ldrow ? xr[e] : 0.0;
-            v[t] = ldrow ? vr[e] : 0.0;
-            p[t] = ldrow ? pb[e] : 0.0;
-            gv[t] = in[t] ? gb[e] : 0.0;
-            r1[t] = (RNG == SX_RNG_HOST && in[t]) ? r1row[e] : 0.0;
-            r2[t] = (RNG == SX_RNG_HOST && in[t]) ? r2row[e] : 0.0;
+            x[t] = L.x[t];
         }
         if (RNG == SX_RNG_PHILOX) {
 #pragma unroll
             for (int t = 0; t < 4; t += 2) {
                 const uint32_t slot = (uint32_t)(((g >> 6) * 4 + t) >> 1) * 64u + (uint32_t)(g & 63);
                 const U4 wd = philox4x32_10(slot, grow, gen, kPurposePsoR1, a.key0, a.key1);
-                r1[t] = u32(wd.x), r2[t] = u32(wd.y), r1[t + 1] = u32(wd.z), r2[t + 1] = u32(wd.w);
+                L.r1[t] = u32(wd.x), L.r2[t] = u32(wd.y), L.r1[t + 1] = u32(wd.z), L.r2[t + 1] = u32(wd.w);
                 if (reseed) {
                     const U4 wr = philox4x32_10(slot, grow, gen - 1u, kPurposePsoRestart, a.key0, a.key1);
                     const double u[2] = {u53(wr.x, wr.y), u53(wr.z, wr.w)};
@@ -499,14 +764,19 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
                         if (in[t + h]) {
                             const double lo = a.lower[e];
                             x[t + h] = lo + (a.upper[e] - lo) * u[h];
-                            p[t + h] = x[t + h];
+                            L.p[t + h] = x[t + h];
                         }
                     }
                 }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vn[t] = pso_velocity(w, v[t], c1, r1[t], p[t], x[t], c2, r2[t], gv[t]);
+        for (int t = 0; t < 4; ++t) vn[t] = pso_velocity(w, L.v[t], c1, L.r1[t], L.p[t], x[t], c2, L.r2[t], L.gv[t]);
+    };
+    auto elems = [&](int g, int lo_e, int hi_e, double(&x)[4], double(&vn)[4], bool(&in)[4]) {
+        PsoLoads L;
+        pso_issue(g, lo_e, hi_e, L);
+        pso_form(g, lo_e, hi_e, L, x, vn, in);
     };
 
     double beta = 1.0;
@@ -532,23 +802,43 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
         for (int wv = 1; wv < T / kWave; ++wv) bmin = fmin(bmin, s_beta[wv]);
         beta = bmin == __builtin_huge_val() ? 1.0 : bmin;
     }
-    const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
-        for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
-            double x[4], vn[4];
-            bool in[4];
-            elems(g, e0, e1s, x, vn, in);
+    auto pso_commit = [&](int g, int e0, int e1, int e1s, PsoLoads &L, double *Sd) {
+        double x[4], vn[4];
+        bool in[4];
+        pso_form(g, e0, e1s, L, x, vn, in);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (!in[t]) continue;
-                const int e = (g >> 6) * 256 + (g & 63) + 64 * t;
-                const double vf = shrink ? vn[t] * beta : vn[t];  // V *= beta[:, None]
-                const double xn = x[t] + vf;
-                Sd[e] = xn;
-                if (e < e1) {  // (the look-ahead element is committed by its own chunk: X and V are updated in place)
-                    vr[e] = vf;
-                    xr[e] = xn;
-                    if (reseed) pb[e] = x[t];  // pbest = X of the re-seeded row (kept unless the new position beats 1e30)
+        for (int t = 0; t < 4; ++t) {
+            if (!in[t]) continue;
+            const int e = (g >> 6) * 256 + (g & 63) + 64 * t;
+            const double vf = shrink ? vn[t] * beta : vn[t];  // V *= beta[:, None]
+            const double xn = x[t] + vf;
+            stage_put<Obj<FUN>::NEXT>(Sd, e, e0, xn);
+            if (e < e1) {  // (the look-ahead element is committed by its own chunk: X and V are updated in place)
+                vr[e] = vf;
+                xr[e] = xn;
+                if (reseed) pb[e] = x[t];  // pbest = X of the re-seeded row (kept unless the new position beats 1e30)
+            }
+        }
+    };
+    const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
+        const int g0 = (e0 >> 8) * 64 + tid, gend = ((e1s + 255) >> 8) * 64;
+        if constexpr (PRE) {
+            PsoLoads A, B;
+            if (g0 < gend) pso_issue(g0, e0, e1s, A);
+            for (int g = g0; g < gend; g += 2 * T) {
+                const bool second = g + T < gend;
+                if (second) pso_issue(g + T, e0, e1s, B);
+                pso_commit(g, e0, e1, e1s, A, Sd);
+                if (second) {
+                    if (g + 2 * T < gend) pso_issue(g + 2 * T, e0, e1s, A);
+                    pso_commit(g + T, e0, e1, e1s, B, Sd);
                 }
+            }
+        } else {
+            for (int g = g0; g < gend; g += T) {
+                PsoLoads A;
+                pso_issue(g, e0, e1s, A);
+                pso_commit(g, e0, e1, e1s, A, Sd);
             }
         }
     });
@@ -558,11 +848,10 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
             __threadfence_block();
             __syncthreads();  // the positions written above, by other threads of this workgroup
         }
-        const double *src = resident ? S : xr;
         for (int eb = tid; eb < n; eb += 8 * T) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = eb + u * T < n ? src[eb + u * T] : 0.0;
+            for (int u = 0; u < 8; ++u) v[u] = eb + u * T < n ? (resident ? S[stage_pos(eb + u * T)] : xr[eb + u * T]) : 0.0;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (eb + u * T < n) pb[eb + u * T] = v[u];
@@ -604,8 +893,8 @@ __global__ __launch_bounds__(kGenThreads) void wide_vd_candidates_kernel(const s
     if (st->done) return;
     const WideCtx c = wide_ctx(plan);
     const int n = a.n, tid = (int)threadIdx.x;
-    const bool resident = chunk_leaves >= c.nleaf;
-    double *S = lds, *LA = lds + (resident ? n + 16 : kStageElems), *LB = LA + wide_leaf_cap(n);
+    const bool resident = chunk_leaves > 0;
+    double *S = lds, *LA = lds + (resident ? wide_resident_elems(n) : kStageElems), *LB = LA + wide_leaf_cap(n);
     const int64_t row = blockIdx.x, grow = row0 + row;
     const double sigma = st->sigma, coef = st->reserved[4];
     const bool inj = st->reserved[3] != 0.0 && grow < 2;
@@ -638,10 +927,10 @@ __global__ __launch_bounds__(kGenThreads) void wide_vd_candidates_kernel(const s
                 double sn, cs;
                 sincos_mid(6.283185307179586 * d1, sn, cs);
                 const double z0 = rad * cs, z1 = rad * sn;
-                (resident ? S : yo)[e0] = z0;
+                (resident ? S : yo)[resident ? stage_pos(e0) : e0] = z0;
                 tacc += z0 * a.vn[e0];
                 if (e1 < n) {
-                    (resident ? S : yo)[e1] = z1;
+                    (resident ? S : yo)[resident ? stage_pos(e1) : e1] = z1;
                     tacc += z1 * a.vn[e1];
                 }
             }
@@ -658,7 +947,7 @@ __global__ __launch_bounds__(kGenThreads) void wide_vd_candidates_kernel(const s
             for (int u = 0; u < 4; ++u) {
                 const int e = eb + 64 * u;
                 in[u] = e >= e0 && e < e1s;
-                z[u] = (in[u] && !inj) ? (resident ? Sd[e] : yo[e]) : 0.0;
+                z[u] = (in[u] && !inj) ? (resident ? Sd[stage_pos(e)] : yo[e]) : 0.0;
                 vv[u] = in[u] ? a.vn[e] : 0.0;
                 dd[u] = in[u] ? a.dvec[e] : 1.0;
                 xm0[u] = in[u] ? a.xmean[e] : 0.0;
@@ -677,7 +966,7 @@ __global__ __launch_bounds__(kGenThreads) void wide_vd_candidates_kernel(const s
                     tkacc += (inj ? y / dd[u] : yd) * vv[u];  // (the division only for the injected pair: rounding apart the same)
                 }
                 const double xc = clip ? fmin(fmax(x, -1.0), 1.0) : x;  // cmaes/_constraints.py:29-31
-                Sd[e] = xc * a.xstd[e] + a.xm[e];                        // cmaes/_cmaes.py:171
+                stage_put<Obj<FUN>::NEXT>(Sd, e, e0, xc * a.xstd[e] + a.xm[e]);  // cmaes/_cmaes.py:171
             }
         }
     });
@@ -700,12 +989,43 @@ void *pick_fun(int fun_id) {
     }
     return nullptr;
 }
-template <int FUN> struct EvalK { static void *ptr() { return (void *)wide_eval_kernel<FUN>; } };
+template <int FUN> struct EvalK { static void *ptr() { return (void *)wide_eval_kernel<FUN, false>; } };
+template <int FUN> struct EvalPipeK {
+    static void *ptr() { return (void *)wide_eval_kernel<FUN, light_objective<FUN>()>; }  // (heavy: the plain form again)
+};
 template <int FUN> struct DePhK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX>; } };
 template <int FUN> struct DeHoK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_HOST>; } };
-template <int FUN> struct PsoPhK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX>; } };
+// PRE (next elements' loads issued before the current ones are worked on; + 20-32 VGPRs) pays where a resident row's LDS leaves
+// ONE workgroup per CU anyway (n = 16 384: 0.54 -> 0.58 of the HBM peak); where two or three fit, the registers cost one of
+// them (n = 4096: 0.75 -> 0.64; streamed rows 0.49 -> 0.48) -- profiles/r5_wide_ab5.txt.
+template <int FUN> struct DePhBestK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, false>; } };
+template <int FUN> struct DePhRandK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, false>; } };
+template <int FUN> struct DePhBestPreK {
+    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, light_objective<FUN>()>; }
+};
+template <int FUN> struct DePhRandPreK {
+    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, light_objective<FUN>()>; }
+};
+template <int FUN> struct PsoPhK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, false>; } };
+template <int FUN> struct PsoPhPreK {
+    static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, light_objective<FUN>()>; }
+};
 template <int FUN> struct VdCandK { static void *ptr() { return (void *)wide_vd_candidates_kernel<FUN>; } };
 template <int FUN> struct PsoHoK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_HOST>; } };
+inline bool wide_one_workgroup_per_cu(int n) { return wide_resident(n) && wide_lds_bytes(n, true) > 76 * 1024; }
+void *pick_de(const sx_de_args *a) {
+    const bool ph = a->rng == SX_RNG_PHILOX;  // (host draws: the generation waits for the host's streams anyway)
+    const bool pre = wide_one_workgroup_per_cu(a->n);
+    if (ph && a->constraints == 0 && a->strategy == SX_DE_BEST1BIN)
+        return pre ? pick_fun<DePhBestPreK>(a->fun_id) : pick_fun<DePhBestK>(a->fun_id);
+    if (ph && a->constraints == 0 && a->strategy == SX_DE_RAND1BIN)
+        return pre ? pick_fun<DePhRandPreK>(a->fun_id) : pick_fun<DePhRandK>(a->fun_id);
+    return ph ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id);
+}
+void *pick_pso(const sx_pso_args *a) {
+    if (a->rng != SX_RNG_PHILOX) return pick_fun<PsoHoK>(a->fun_id);
+    return wide_one_workgroup_per_cu(a->n) ? pick_fun<PsoPhPreK>(a->fun_id) : pick_fun<PsoPhK>(a->fun_id);
+}
 
 std::mutex g_attr_mutex;
 std::map<void *, size_t> g_attr;  // kernels whose dynamic LDS limit has been raised (per process; devices share code objects)
@@ -733,7 +1053,7 @@ int gen_launch_for(void *fn, int fun_id, int n, hipStream_t s, GenLaunch *out) {
     const bool resident = wide_resident(n);
     out->fn = fn;
     out->plan = cp.dev;
-    out->chunk_leaves = resident ? cp.nleaf : kStreamLeaves;
+    out->chunk_leaves = resident ? cp.nleaf : 0;  // 0: streamed, chunk by chunk (the plan's chunk table)
     out->lds = wide_lds_bytes(n, resident);
     return allow_lds(fn, out->lds);
 }
@@ -759,7 +1079,7 @@ namespace sx {
 int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
               double *part_f, int64_t *part_i, int clip, const double *pen_v, double *pen_out, hipStream_t s) {
     SX_REQUIRE(n <= kWideMaxDim, "dimension above the wide-row limit (n <= 262144)");
-    void *fn = pick_fun<EvalK>(fun_id);
+    void *fn = n > SX_WIDE_EVAL_PIPE_FROM ? pick_fun<EvalPipeK>(fun_id) : pick_fun<EvalK>(fun_id);
     SX_REQUIRE(fn != nullptr, "wide rows: unknown objective");
     CachedPlan cp;
     if (int rc = get_plan(sx_fun_terms(fun_id, n), s, &cp)) return rc;
@@ -773,9 +1093,7 @@ int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const 
 
 int wide_de_launch(const sx_de_args *a, hipStream_t s) {
     GenLaunch g;
-    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id), a->fun_id,
-                                a->n, s, &g))
-        return rc;
+    if (int rc = gen_launch_for(pick_de(a), a->fun_id, a->n, s, &g)) return rc;
     sx_de_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
     SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
@@ -784,9 +1102,7 @@ int wide_de_launch(const sx_de_args *a, hipStream_t s) {
 
 int wide_de_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_de_args *a) {
     GenLaunch g;
-    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id), a->fun_id,
-                                a->n, nullptr, &g))
-        return rc;
+    if (int rc = gen_launch_for(pick_de(a), a->fun_id, a->n, nullptr, &g)) return rc;
     sx_de_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
     return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3(kGenThreads), (unsigned)g.lds, kargs);
@@ -794,8 +1110,7 @@ int wide_de_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_de_args *a
 
 int wide_pso_launch(const sx_pso_args *a, hipStream_t s) {
     GenLaunch g;
-    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<PsoPhK>(a->fun_id) : pick_fun<PsoHoK>(a->fun_id),
-                                a->fun_id, a->n, s, &g))
+    if (int rc = gen_launch_for(pick_pso(a), a->fun_id, a->n, s, &g))
         return rc;
     sx_pso_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
@@ -812,7 +1127,7 @@ int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t r
     // the objective of a candidate then run one after the other -- 216 us per generation at n = 16 384, P = 1 024 against
     // SX_VD_RESIDENT=0's figure in profiles/r5_vd_wide.txt.  (z in registers -- 8 items per thread -- spills: 256 VGPRs + 1.5 KB.)
     static const bool resident_ok = getenv("SX_VD_RESIDENT") != nullptr && getenv("SX_VD_RESIDENT")[0] == '1';
-    if (!resident_ok) g.chunk_leaves = kStreamLeaves, g.lds = wide_lds_bytes(a->n, false);
+    if (!resident_ok) g.chunk_leaves = 0, g.lds = wide_lds_bytes(a->n, false);
     sx_vd_args args = *a;
     void *kargs[] = {&args, &gen, &row0, &ary_out, &arx_out, &fit_out, &tk_out, &g.plan, &g.chunk_leaves};
     SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)rows), dim3(kGenThreads), kargs, g.lds, s));
@@ -821,8 +1136,7 @@ int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t r
 
 int wide_pso_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_pso_args *a) {
     GenLaunch g;
-    if (int rc = gen_launch_for(a->rng == SX_RNG_PHILOX ? pick_fun<PsoPhK>(a->fun_id) : pick_fun<PsoHoK>(a->fun_id),
-                                a->fun_id, a->n, nullptr, &g))
+    if (int rc = gen_launch_for(pick_pso(a), a->fun_id, a->n, nullptr, &g))
         return rc;
     sx_pso_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};

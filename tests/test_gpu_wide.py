@@ -29,7 +29,11 @@ def sa():
 # "at least"; 100003: beyond it
 # 2560 / 2561: the last row of the wavefront-per-row kernels and the first of these (kWideFrom, round 5); 3000, 4096: rows the
 # wavefront-per-row kernels served until then
-@pytest.mark.parametrize("n", [2560, 2561, 3000, 4096, 4097, 4104, 5000, 8192, 16384, 18400, 20001, 65536, 100003])
+# 8193 / 8199 / 8200: a second 8192-term piece of 1 / 7 / 8 terms (no leaf block / one block); 12295: a last piece of 4103
+# terms (33 leaves + a tail of 7); 16383 / 24575: last pieces of 8191 / 8190 terms -- 65 leaves in 7 levels, the most a piece
+# can have (the per-piece finish reads the 65th where it lies); 262144: the limit
+@pytest.mark.parametrize("n", [2560, 2561, 3000, 4096, 4097, 4104, 5000, 8192, 8193, 8199, 8200, 12295, 16383, 16384, 18400,
+                               20001, 24575, 65536, 100003, 262144])
 @pytest.mark.parametrize("name", sorted(OBJECTIVES))
 def test_wide_objectives_vs_oracle(sa, name, n):
     rs = np.random.RandomState(n % 1000 + 3)
