@@ -162,6 +162,9 @@ int make_plan_arg(int fun_id, int n, PlanArg *out) {
 // FULL: n is a whole number of 4-step batches and P a whole number of workgroups (no bounds test survives);
 // NFIX: FULL with n == 4 * LPR exactly (64 / 128 / 256): the row length, and with it numpy's summation plan, is a
 // compile-time constant (row_reduce_fixed / row_reduce_static, as in the one-batch DE / PSO kernels); 0 otherwise.
+#ifndef SX_EVAL_PLAIN_LOOP
+#define SX_EVAL_PLAIN_LOOP 1  // A/B switch (round 5)
+#endif
 template <int FUN, int LPR, bool FULL = false, int NFIX = 0>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const double *__restrict__ X, int64_t P, int n_arg, int64_t ldx, const double *__restrict__ xm,
@@ -177,25 +180,38 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const bool affine = xm != nullptr;
     double pacc = 0.0;
     constexpr int kBatch = (NFIX && NFIX <= 256) ? 4 : 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
-    for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
-        double xv[kBatch];
+    if (SX_EVAL_PLAIN_LOOP && !clip && !affine) {
+        // sx_eval's own calls: the row as it is.  (Left to the compiler, the run-time switches of the general loop below cost a
+        // plain row ~20 vector instructions per element -- measured on the wide form of this kernel, profiles/r5_wide_ab3.txt.)
+        for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
+            double xv[kBatch];
 #pragma unroll
-        for (int t = 0; t < kBatch; ++t) {
-            const int e = e0 + t * LPR;
-            xv[t] = (FULL || e < n) ? xr[e] : 0.0;
+            for (int t = 0; t < kBatch; ++t) xv[t] = (FULL || e0 + t * LPR < n) ? xr[e0 + t * LPR] : 0.0;
+#pragma unroll
+            for (int t = 0; t < kBatch; ++t)
+                if (FULL || e0 + t * LPR < n) U[e0 + t * LPR] = xv[t];
         }
+    } else {
+        for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
+            double xv[kBatch];
 #pragma unroll
-        for (int t = 0; t < kBatch; ++t) {
-            const int e = e0 + t * LPR;
-            if (!FULL && e >= n) continue;
-            double v = xv[t];
-            if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
-                const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
-                if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
-                v = c;
+            for (int t = 0; t < kBatch; ++t) {
+                const int e = e0 + t * LPR;
+                xv[t] = (FULL || e < n) ? xr[e] : 0.0;
             }
-            if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
-            U[e] = v;
+#pragma unroll
+            for (int t = 0; t < kBatch; ++t) {
+                const int e = e0 + t * LPR;
+                if (!FULL && e >= n) continue;
+                double v = xv[t];
+                if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
+                    const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+                    if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
+                    v = c;
+                }
+                if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
+                U[e] = v;
+            }
         }
     }
     if (pen_out != nullptr) {

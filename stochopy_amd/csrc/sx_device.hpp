@@ -29,10 +29,12 @@ constexpr int kMaxLeaf = 64;  // leaves carried in kernel arguments; also one la
 constexpr int kMaxDim = 4096; // leaves hold > 64 terms, so n <= 4096 has at most 64; LDS: n+8+2(n/64+2) doubles per row
 // Rows of more than kWideFrom elements take the one-workgroup-per-row kernels (sx_wide.hip).  kMaxDim is what the wavefront-
 // per-row kernels CAN serve (and what the ordered sweeps, the chained / peer-exchange kernels and full CMA-ES are limited
-// to); kWideFrom is where the wide kernels become the faster ones (round 5, profiles/r5_wide_threshold.txt: sx_eval crosses over
-// at ~2300 elements, DE and PSO at ~2560; at n = 4096 the wide kernels are 1.5-1.75x faster).
+// to); kWideFrom is where the wide kernels become the faster ones (round 5: first 2560, profiles/r5_wide_threshold.txt; after the
+// wide kernels' second pass -- fewer vector instructions, more workgroups per CU -- 2048, profiles/r5_wide_threshold2.txt: at
+// n = 2049 sx_eval 0.41 -> 0.47 of the HBM peak, DE 114 -> 99 us, PSO 199 -> 187 us per generation; n = 2048 keeps its compile-time
+// plan (sx_eval 0.69 against 0.39), rows of 1792 are a draw).
 #ifndef SX_WIDE_FROM
-#define SX_WIDE_FROM 2560
+#define SX_WIDE_FROM 2048
 #endif
 constexpr int kWideFrom = SX_WIDE_FROM;
 static_assert(kWideFrom >= 256 && kWideFrom <= kMaxDim, "the wide kernels take over somewhere inside the narrow kernels' range");
@@ -610,12 +612,22 @@ __device__ __forceinline__ void row_reduce_leaves(const double *A, const double 
 // rows per CU at n = 1024).  Same operations on the same values: same bits as the staged form.
 // PAIRED: some slot of the plan holds two leaves (PlanArg::nslot < nleaf -- only when that saves a pass); otherwise slot s
 // is leaf s and nothing of the pairing survives in the code.
+#ifndef SX_FUSED_SELECT
+#define SX_FUSED_SELECT 0  // A/B switch (round 5): 1 = a select per term instead of a branch per term in the chains (what the
+                           // wide kernels do, sx_wide.hip); here measured neutral (DE Rosenbrock n=300 43.8 -> 44.6 us,
+                           // n=1500 75.2 -> 74.4: profiles/r5_narrow_ab.txt, which has both switches on): off
+#endif
+#ifndef SX_FUSED_TAIL_BY_LANE
+#define SX_FUSED_TAIL_BY_LANE 1  // A/B switch (round 5): 0 = every lane of the last leaf's group forms every tail term
+                                 // (DE Rastrigin n=300 55.3 -> 52.3 us, n=700 44.7 -> 43.5: profiles/r5_narrow_ab.txt)
+#endif
 template <int FUN, int LPR, bool PAIRED>
 __device__ __forceinline__ void row_reduce_leaves_fused_impl(const double *U, double *L, int lcap, int m, const PlanArg &p,
                                                              int l, double &sa, double &sb) {
     using O = Obj<FUN>;
     constexpr bool TWO = O::TWO, BMUL = O::BMUL;
     constexpr int NG = LPR / kGroup;
+    constexpr bool kSelectOnChain = SX_FUSED_SELECT && !O::TWO && FUN != SX_FUN_RASTRIGIN;  // one cheap term per element
     const int j = l & (kGroup - 1), grp = l >> 3;
     const double identB = BMUL ? 1.0 : 0.0;
     const int t0 = p.mb * kGroup;
@@ -636,7 +648,30 @@ __device__ __forceinline__ void row_reduce_leaves_fused_impl(const double *U, do
         const int cntA = a1 - a0;  // 0 for groups beyond the last slot
         double chA = 0.0, chB = identB;
         // steps 0..7: the first (or only) leaf
-        {
+        if constexpr (kSelectOnChain) {
+            // cheap terms: the blocks a short leaf does not have are read all the same (inside the workgroup's LDS, or
+            // past it: zeros) and their terms dropped from the chain -- a select per term instead of a branch per term
+            double x[8], xn[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int e = (a0 + t) * kGroup + j;
+                x[t] = U[e];
+                xn[t] = O::NEXT ? U[e + 1] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool in = t < cntA;
+                double a, b;
+                O::term(x[t], xn[t], (a0 + t) * kGroup + j, a, b);
+                if (t == 0) {
+                    chA = in ? a : 0.0;
+                    chB = in ? b : identB;
+                } else {
+                    chA = in ? chA + a : chA;
+                    if (TWO) chB = in ? combine<BMUL>(chB, b) : chB;
+                }
+            }
+        } else {
             double x[8], xn[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -670,7 +705,28 @@ __device__ __forceinline__ void row_reduce_leaves_fused_impl(const double *U, do
         }
         // steps 8..15: the rest of the only leaf, or the second leaf of the pair from its first block
         const int base2 = two ? a1 - 8 : a0, lim2 = two ? 8 + (c1 - a1) : cntA;
-        {
+        if constexpr (kSelectOnChain) {
+            double x[8], xn[8];
+#pragma unroll
+            for (int t = 8; t < kLeafBlocks; ++t) {
+                const int e = (base2 + t) * kGroup + j;
+                x[t - 8] = U[e];
+                xn[t - 8] = O::NEXT ? U[e + 1] : 0.0;
+            }
+#pragma unroll
+            for (int t = 8; t < kLeafBlocks; ++t) {
+                const bool in = t < lim2;
+                double a, b;
+                O::term(x[t - 8], xn[t - 8], (base2 + t) * kGroup + j, a, b);
+                if (t == 8 && two) {
+                    chA = in ? a : chA;
+                    chB = in ? b : chB;
+                } else {
+                    chA = in ? chA + a : chA;
+                    if (TWO) chB = in ? combine<BMUL>(chB, b) : chB;
+                }
+            }
+        } else {
             double x[8], xn[8];
 #pragma unroll
             for (int t = 8; t < kLeafBlocks; ++t) {
@@ -697,13 +753,30 @@ __device__ __forceinline__ void row_reduce_leaves_fused_impl(const double *U, do
         const int leaf = lfA + (two ? 1 : 0);
         double curA = group_tree<false>(chA);
         double curB = TWO ? group_tree<BMUL>(chB) : identB;
-        if (leaf == p.nleaf - 1) {
+        if (leaf == p.nleaf - 1 && p.tail > 0) {
+#if SX_FUSED_TAIL_BY_LANE
+            // the tail terms: lane k of the group forms term k, the sums take them in order (one term's arithmetic, not
+            // `tail` times that, while the other seven groups wait)
+            double ta = 0.0, tb = identB;
+            if (j < p.tail) O::term(U[t0 + j], O::NEXT ? U[t0 + j + 1] : 0.0, t0 + j, ta, tb);
+#pragma unroll
+            for (int k = 0; k < kGroup - 1; ++k) {
+                const int src = (int)(threadIdx.x & (kWave - kGroup)) + k;  // lane k of this 8-lane group
+                const double va = __shfl(ta, src, kWave);
+                if (k < p.tail) curA = curA + va;
+                if (TWO) {
+                    const double vb = __shfl(tb, src, kWave);
+                    if (k < p.tail) curB = combine<BMUL>(curB, vb);
+                }
+            }
+#else
             for (int k = 0; k < p.tail; ++k) {
                 double a, b;
                 O::term(U[t0 + k], O::NEXT ? U[t0 + k + 1] : 0.0, t0 + k, a, b);
                 curA = curA + a;
                 if (TWO) curB = combine<BMUL>(curB, b);
             }
+#endif
         }
         if (nl > 0 && j == 0) {
             L[leaf] = curA;

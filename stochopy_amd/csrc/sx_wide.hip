@@ -1,5 +1,5 @@
-// Wide rows: individuals of more than kWideFrom = 2560 elements (sx_device.hpp; the wavefront-per-row kernels can serve up to
-// kMaxDim = 4096 but lose to these from ~2560 on: profiles/r5_wide_threshold.txt), ONE WORKGROUP per individual.
+// Wide rows: individuals of more than kWideFrom = 2048 elements (sx_device.hpp; the wavefront-per-row kernels can serve up to
+// kMaxDim = 4096 but lose to these from there on: profiles/r5_wide_threshold2.txt), ONE WORKGROUP per individual.
 //
 // The reference has no dimension limit (stochopy/optimize/de/_de.py:208-218: rows are (n,) numpy vectors of any length;
 // stochopy/optimize/vdcma/_vdcma.py:144-458 exists for n >= 4096); the row kernels of sx_rowops.hpp do: one wavefront per
@@ -425,6 +425,9 @@ constexpr int kEvalThreads = 256;
 #define SX_WIDE_EVAL_PIPE_FROM 8192  // rows longer than this (several chunks) of the light objectives take the pipelined form
 #endif
 constexpr int kGenThreads = 512;
+#ifndef SX_WIDE_ONE_WG_DEFAULT
+#define SX_WIDE_ONE_WG_DEFAULT 0
+#endif
 constexpr size_t kResidentLds = 148 * 1024;   // a resident row + its leaf sums must fit here (160 KB per CU)
 constexpr int kStageElems = kChunkElems + 16 + 128 + (SX_WIDE_PAD ? 8 * (kChunkElems / 128 + 2) : 0);
 
@@ -556,10 +559,9 @@ __global__ __launch_bounds__(kEvalThreads) void wide_eval_kernel(const double *_
 // ---------------------------------------------------------------------------
 // STRAT >= 0: best1bin / rand1bin with constraints=None at compile time (two or three donor rows in flight instead of five,
 // no bounds / resample registers: the generic form's 136-148 VGPRs leave ONE 512-thread workgroup per CU).
-template <int FUN, int RNG, int STRAT = -1, bool PRE = false>
-__global__ __launch_bounds__(kGenThreads) void wide_de_kernel(const sx_de_args a, const int32_t *__restrict__ plan,
-                                                              const int chunk_leaves) {
-    constexpr int T = kGenThreads;
+template <int FUN, int RNG, int STRAT = -1, bool PRE = false, int T = kGenThreads>
+__global__ __launch_bounds__(T) void wide_de_kernel(const sx_de_args a, const int32_t *__restrict__ plan,
+                                                    const int chunk_leaves) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const sx_state *sin = a.state;
     if (sin->done) return;
@@ -690,10 +692,9 @@ __device__ __forceinline__ unsigned long long wide_sort_key(double f) {  // (sx_
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-template <int FUN, int RNG, bool PRE = false>
-__global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args a, const int32_t *__restrict__ plan,
-                                                               const int chunk_leaves) {
-    constexpr int T = kGenThreads;
+template <int FUN, int RNG, bool PRE = false, int T = kGenThreads>
+__global__ __launch_bounds__(T) void wide_pso_kernel(const sx_pso_args a, const int32_t *__restrict__ plan,
+                                                     const int chunk_leaves) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double s_beta[T / kWave];
     const sx_state *st = a.state;
@@ -878,15 +879,14 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
 // row, and t_k = (y / d) . vn -- what the moment sums need of a selected row (:428-444) -- is left per row.
 // Rows 0 and 1 of the generation are +-dy when the mean-shift injection is on (:241-247).
 // ---------------------------------------------------------------------------
-template <int FUN>
-__global__ __launch_bounds__(kGenThreads) void wide_vd_candidates_kernel(const sx_vd_args a, const int64_t gen,
+template <int FUN, int T>
+__global__ __launch_bounds__(T) void wide_vd_candidates_kernel(const sx_vd_args a, const int64_t gen,
                                                                          const int64_t row0, double *__restrict__ ary_out,
                                                                          double *__restrict__ arx_out,
                                                                          double *__restrict__ fit_out,
                                                                          double *__restrict__ tk_out,
                                                                          const int32_t *__restrict__ plan,
                                                                          const int chunk_leaves) {
-    constexpr int T = kGenThreads;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double s_red[T / kWave];
     const sx_cma_state *st = (const sx_cma_state *)a.state;
@@ -1010,21 +1010,62 @@ template <int FUN> struct PsoPhK { static void *ptr() { return (void *)wide_pso_
 template <int FUN> struct PsoPhPreK {
     static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, light_objective<FUN>()>; }
 };
-template <int FUN> struct VdCandK { static void *ptr() { return (void *)wide_vd_candidates_kernel<FUN>; } };
+template <int FUN> struct VdCandK { static void *ptr() { return (void *)wide_vd_candidates_kernel<FUN, kGenThreads>; } };
 template <int FUN> struct PsoHoK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_HOST>; } };
 inline bool wide_one_workgroup_per_cu(int n) { return wide_resident(n) && wide_lds_bytes(n, true) > 76 * 1024; }
-void *pick_de(const sx_de_args *a) {
-    const bool ph = a->rng == SX_RNG_PHILOX;  // (host draws: the generation waits for the host's streams anyway)
-    const bool pre = wide_one_workgroup_per_cu(a->n);
-    if (ph && a->constraints == 0 && a->strategy == SX_DE_BEST1BIN)
-        return pre ? pick_fun<DePhBestPreK>(a->fun_id) : pick_fun<DePhBestK>(a->fun_id);
-    if (ph && a->constraints == 0 && a->strategy == SX_DE_RAND1BIN)
-        return pre ? pick_fun<DePhRandPreK>(a->fun_id) : pick_fun<DePhRandK>(a->fun_id);
-    return ph ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id);
+// A resident row whose LDS leaves one workgroup per CU: 1024 threads instead of 512 (sixteen wavefronts on the CU instead of
+// eight), with or without the prefetching loop -- SX_WIDE_ONE_WG = pre | big | bigpre (measurement hook)
+constexpr int kBigThreads = 1024;
+template <int FUN> struct DePhBestBigK {
+    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, false, kBigThreads>; }
+};
+template <int FUN> struct DePhRandBigK {
+    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, false, kBigThreads>; }
+};
+template <int FUN> struct DePhBestBigPreK {
+    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, light_objective<FUN>(), kBigThreads>; }
+};
+template <int FUN> struct DePhRandBigPreK {
+    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, light_objective<FUN>(), kBigThreads>; }
+};
+template <int FUN> struct PsoPhBigK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, false, kBigThreads>; } };
+template <int FUN> struct PsoPhBigPreK {
+    static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, light_objective<FUN>(), kBigThreads>; }
+};
+int one_wg_form() {  // 0: 512 threads + prefetch, 1: 1024 threads, 2: 1024 threads + prefetch
+    static const int form = [] {
+        const char *e = getenv("SX_WIDE_ONE_WG");
+        if (e == nullptr) return SX_WIDE_ONE_WG_DEFAULT;
+        return e[0] == 'p' ? 0 : (e[3] == 'p' ? 2 : 1);
+    }();
+    return form;
 }
-void *pick_pso(const sx_pso_args *a) {
-    if (a->rng != SX_RNG_PHILOX) return pick_fun<PsoHoK>(a->fun_id);
-    return wide_one_workgroup_per_cu(a->n) ? pick_fun<PsoPhPreK>(a->fun_id) : pick_fun<PsoPhK>(a->fun_id);
+struct Pick {
+    void *fn;
+    int threads;
+};
+Pick pick_de(const sx_de_args *a) {
+    const bool ph = a->rng == SX_RNG_PHILOX;  // (host draws: the generation waits for the host's streams anyway)
+    const bool one = wide_one_workgroup_per_cu(a->n);
+    const int form = one_wg_form();
+    if (ph && a->constraints == 0 && a->strategy == SX_DE_BEST1BIN) {
+        if (!one) return {pick_fun<DePhBestK>(a->fun_id), kGenThreads};
+        if (form == 0) return {pick_fun<DePhBestPreK>(a->fun_id), kGenThreads};
+        return {form == 1 ? pick_fun<DePhBestBigK>(a->fun_id) : pick_fun<DePhBestBigPreK>(a->fun_id), kBigThreads};
+    }
+    if (ph && a->constraints == 0 && a->strategy == SX_DE_RAND1BIN) {
+        if (!one) return {pick_fun<DePhRandK>(a->fun_id), kGenThreads};
+        if (form == 0) return {pick_fun<DePhRandPreK>(a->fun_id), kGenThreads};
+        return {form == 1 ? pick_fun<DePhRandBigK>(a->fun_id) : pick_fun<DePhRandBigPreK>(a->fun_id), kBigThreads};
+    }
+    return {ph ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id), kGenThreads};
+}
+Pick pick_pso(const sx_pso_args *a) {
+    if (a->rng != SX_RNG_PHILOX) return {pick_fun<PsoHoK>(a->fun_id), kGenThreads};
+    if (!wide_one_workgroup_per_cu(a->n)) return {pick_fun<PsoPhK>(a->fun_id), kGenThreads};
+    const int form = one_wg_form();
+    if (form == 0) return {pick_fun<PsoPhPreK>(a->fun_id), kGenThreads};
+    return {form == 1 ? pick_fun<PsoPhBigK>(a->fun_id) : pick_fun<PsoPhBigPreK>(a->fun_id), kBigThreads};
 }
 
 std::mutex g_attr_mutex;
@@ -1093,33 +1134,38 @@ int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const 
 
 int wide_de_launch(const sx_de_args *a, hipStream_t s) {
     GenLaunch g;
-    if (int rc = gen_launch_for(pick_de(a), a->fun_id, a->n, s, &g)) return rc;
+    const Pick k = pick_de(a);
+    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, s, &g)) return rc;
     sx_de_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
+    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), kargs, g.lds, s));
     return 0;
 }
 
 int wide_de_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_de_args *a) {
     GenLaunch g;
-    if (int rc = gen_launch_for(pick_de(a), a->fun_id, a->n, nullptr, &g)) return rc;
+    const Pick k = pick_de(a);
+    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, nullptr, &g)) return rc;
     sx_de_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3(kGenThreads), (unsigned)g.lds, kargs);
+    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), (unsigned)g.lds, kargs);
 }
 
 int wide_pso_launch(const sx_pso_args *a, hipStream_t s) {
     GenLaunch g;
-    if (int rc = gen_launch_for(pick_pso(a), a->fun_id, a->n, s, &g))
-        return rc;
+    const Pick k = pick_pso(a);
+    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, s, &g)) return rc;
     sx_pso_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
+    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), kargs, g.lds, s));
     return 0;
 }
 
 int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t rows, double *ary_out, double *arx_out,
                        double *fit_out, double *tk_out, hipStream_t s) {
+    // (Workgroups of 256 threads -- four per CU instead of three, a generation of ~1000 candidates resident at once -- were
+    // measured and lose: 273 against 255 us per generation at n = 16 384, P = 1024; 658 against 570 at n = 65 536, P = 512:
+    // profiles/r5_vd_threads.txt.)
     GenLaunch g;
     if (int rc = gen_launch_for(pick_fun<VdCandK>(a->fun_id), a->fun_id, a->n, s, &g)) return rc;
     // Always STREAMED (z parked in the y row): a resident row's 128 KB of LDS leave ONE workgroup per CU, and the generator's
@@ -1136,11 +1182,11 @@ int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t r
 
 int wide_pso_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_pso_args *a) {
     GenLaunch g;
-    if (int rc = gen_launch_for(pick_pso(a), a->fun_id, a->n, nullptr, &g))
-        return rc;
+    const Pick k = pick_pso(a);
+    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, nullptr, &g)) return rc;
     sx_pso_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3(kGenThreads), (unsigned)g.lds, kargs);
+    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), (unsigned)g.lds, kargs);
 }
 
 }  // namespace sx

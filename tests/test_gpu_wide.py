@@ -27,12 +27,13 @@ def sa():
 # 4097: first wide length (a tail term); 4104 / 5000: tails of 0 / 7 for Rosenbrock; 16384: a power of two (resident);
 # 18400: the longest resident row for most objectives; 20001: streamed, several chunks, a tail; 65536: the verdict's
 # "at least"; 100003: beyond it
-# 2560 / 2561: the last row of the wavefront-per-row kernels and the first of these (kWideFrom, round 5); 3000, 4096: rows the
+# 2048 / 2049: the last row of the wavefront-per-row kernels and the first of these (kWideFrom, round 5; 2560 / 2561 until the
+# wide kernels' second pass); 3000, 4096: rows the
 # wavefront-per-row kernels served until then
 # 8193 / 8199 / 8200: a second 8192-term piece of 1 / 7 / 8 terms (no leaf block / one block); 12295: a last piece of 4103
 # terms (33 leaves + a tail of 7); 16383 / 24575: last pieces of 8191 / 8190 terms -- 65 leaves in 7 levels, the most a piece
 # can have (the per-piece finish reads the 65th where it lies); 262144: the limit
-@pytest.mark.parametrize("n", [2560, 2561, 3000, 4096, 4097, 4104, 5000, 8192, 8193, 8199, 8200, 12295, 16383, 16384, 18400,
+@pytest.mark.parametrize("n", [2048, 2049, 2056, 2560, 2561, 3000, 4096, 4097, 4104, 5000, 8192, 8193, 8199, 8200, 12295, 16383, 16384, 18400,
                                20001, 24575, 65536, 100003, 262144])
 @pytest.mark.parametrize("name", sorted(OBJECTIVES))
 def test_wide_objectives_vs_oracle(sa, name, n):
@@ -95,7 +96,8 @@ def _same_run(r_ref, r_got, t_ref, t_got):
 
 @pytest.mark.parametrize("strategy,constraints", [("best1bin", None), ("rand1bin", "Random"), ("rand2bin", None),
                                                   ("best2bin", "Random")])
-@pytest.mark.parametrize("n,P", [(2560, 24), (2561, 24), (3000, 20), (4097, 24), (8192, 16), (16384, 12), (20001, 10)])
+@pytest.mark.parametrize("n,P", [(2048, 24), (2049, 24), (2560, 24), (2561, 24), (3000, 20), (4097, 24), (8192, 16), (16384, 12),
+                                 (20001, 10)])
 def test_wide_de_philox_matches_oracle(sa, strategy, constraints, n, P):
     """DE with in-kernel draws, whole populations of every generation, resident (<= ~18 000) and streamed rows."""
     opts = {"maxiter": 6, "popsize": P, "seed": 77 + n, "strategy": strategy, "constraints": constraints,
@@ -139,7 +141,7 @@ def test_wide_default_call_defers_with_a_warning(sa):
 
 
 @pytest.mark.parametrize("constraints", [None, "Shrink"])
-@pytest.mark.parametrize("n,P", [(2560, 20), (2561, 20), (3500, 16), (4097, 20), (8192, 16), (20001, 9)])
+@pytest.mark.parametrize("n,P", [(2048, 20), (2049, 20), (2560, 20), (2561, 20), (3500, 16), (4097, 20), (8192, 16), (20001, 9)])
 def test_wide_pso_philox_matches_oracle(sa, constraints, n, P):
     opts = {"maxiter": 6, "popsize": P, "seed": 11 + n, "constraints": constraints, "updating": "deferred"}
     _same_run(*_trace_pair(sa, "rosenbrock", [[-2.0, 2.0]] * n, "pso", opts))
@@ -208,7 +210,9 @@ def test_wide_rows_sharded_one_rank_group(sa, monkeypatch):
 
 
 # (3000: VD-CMA's narrow model kernels -- n <= 4096 -- with the objective through the one-workgroup-per-row kernel)
-@pytest.mark.parametrize("n,P,maxiter", [(3000, 12, 10), (4097, 12, 12), (8192, 20, 10), (16384, 16, 8), (70000, 8, 5)])
+# (2100, 1100): more candidates than a round of workgroups
+@pytest.mark.parametrize("n,P,maxiter", [(2100, 12, 10), (2100, 1100, 4), (3000, 12, 10), (4097, 12, 12), (8192, 20, 10),
+                                         (16384, 16, 8), (70000, 8, 5)])
 def test_wide_vdcma_device_loop_matches_oracle(sa, n, P, maxiter, monkeypatch):
     """VD-CMA's device-resident loop with the wide model-update kernel (csrc/sx_vd_loop.hip vd_update_wide_kernel) and the
     wide objective, against the oracle's numpy loop: best-f of every generation within 1e-6; the host-driven loop

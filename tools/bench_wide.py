@@ -1,7 +1,7 @@
 """Wide rows (n > 4096, csrc/sx_wide.hip): sx_eval, DE, PSO and VD-CMA generations -- us per launch / generation and the
 fraction of the HBM peak on the ALGORITHMIC bytes (eval 8n + 8 B per evaluation; DE (k + 2) rows + 16 B;
 PSO X, V, pbest read + X, V written + 16 B = 40 n + 16 (pbest rewritten only when it improves); VD-CMA: see DESIGN.md).
-Usage: python tools/bench_wide.py [eval] [de] [pso] [vdcma]"""
+Usage: python tools/bench_wide.py [eval] [de] [pso] [vdcma] [de16] [pso16]"""
 import sys
 import time
 
@@ -67,6 +67,19 @@ if "de" in which:
         byts = (8 * n * (k + 2) + 16) * P
         print(f"DE {strat} {name:10s} n={n:6d} P={P:6d}: {t*1e6:9.1f} us/generation  {P/t:.3e} evals/s  "
               f"{byts/t/1e9:8.1f} GB/s ({byts/t/1e9/PEAK:.2f} of 8 TB/s)", flush=True)
+
+if "de16" in which:  # rows whose LDS leaves one workgroup per CU
+    for name, n, P, strat in (("rosenbrock", 12000, 3072, "best1bin"), ("rosenbrock", 16384, 2048, "best1bin"),
+                              ("rastrigin", 16384, 2048, "rand1bin"), ("sphere", 18000, 2048, "best1bin")):
+        t = per_gen("de", getattr(sa.factory, name), n, {"popsize": P, "updating": "deferred", "strategy": strat}, 20, 120, reps=3)
+        k = _lib.DE_DONORS[strat]
+        byts = (8 * n * (k + 2) + 16) * P
+        print(f"DE {strat} {name:10s} n={n:6d} P={P:6d}: {t*1e6:9.1f} us/generation  {byts/t/1e9/PEAK:.2f} of 8 TB/s", flush=True)
+if "pso16" in which:
+    for name, n, P in (("rosenbrock", 12000, 3072), ("rosenbrock", 16384, 2048), ("ackley", 16384, 2048)):
+        t = per_gen("pso", getattr(sa.factory, name), n, {"popsize": P, "updating": "deferred"}, 20, 120, reps=3)
+        byts = (40 * n + 16) * P
+        print(f"PSO {name:10s} n={n:6d} P={P:6d}: {t*1e6:9.1f} us/generation  {byts/t/1e9/PEAK:.2f} of 8 TB/s", flush=True)
 
 if "pso" in which:
     for name, n, P, extra in (("ackley", 8192, 4096, {}), ("rosenbrock", 16384, 2048, {}), ("rosenbrock", 65536, 512, {}),

@@ -25,7 +25,8 @@ def per_gen(method, fun, n, opts, short, long_, reps=2):
     return (t2 - t1) / (n2 - n1)
 
 
-for n in (2049, 2304, 2560, 3072, 3584, 4096):
+NS = [int(a) for a in sys.argv[1:]] or [2049, 2304, 2560, 3072, 3584, 4096]
+for n in NS:
     P = ((1 << 27) // n) // 64 * 64
     row = [f"n={n:5d}"]
     for name in ("rosenbrock", "ackley"):
