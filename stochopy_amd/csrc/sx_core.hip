@@ -162,9 +162,6 @@ int make_plan_arg(int fun_id, int n, PlanArg *out) {
 // FULL: n is a whole number of 4-step batches and P a whole number of workgroups (no bounds test survives);
 // NFIX: FULL with n == 4 * LPR exactly (64 / 128 / 256): the row length, and with it numpy's summation plan, is a
 // compile-time constant (row_reduce_fixed / row_reduce_static, as in the one-batch DE / PSO kernels); 0 otherwise.
-#ifndef SX_EVAL_PLAIN_LOOP
-#define SX_EVAL_PLAIN_LOOP 1  // A/B switch (round 5)
-#endif
 template <int FUN, int LPR, bool FULL = false, int NFIX = 0>
 __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const double *__restrict__ X, int64_t P, int n_arg, int64_t ldx, const double *__restrict__ xm,
@@ -180,38 +177,27 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void eval_kernel(
     const bool affine = xm != nullptr;
     double pacc = 0.0;
     constexpr int kBatch = (NFIX && NFIX <= 256) ? 4 : 8;  // row loads of a lane in flight together (the kernel is a pure stream of rows)
-    if (SX_EVAL_PLAIN_LOOP && !clip && !affine) {
-        // sx_eval's own calls: the row as it is.  (Left to the compiler, the run-time switches of the general loop below cost a
-        // plain row ~20 vector instructions per element -- measured on the wide form of this kernel, profiles/r5_wide_ab3.txt.)
-        for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
-            double xv[kBatch];
+    // (An explicit copy of this loop without the CMA-ES switches for plain calls was measured: no gain -- the compiler already
+    // unswitches it here, unlike in the wide form of this kernel; profiles/r5_eval_mid_ab.txt.)
+    for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
+        double xv[kBatch];
 #pragma unroll
-            for (int t = 0; t < kBatch; ++t) xv[t] = (FULL || e0 + t * LPR < n) ? xr[e0 + t * LPR] : 0.0;
-#pragma unroll
-            for (int t = 0; t < kBatch; ++t)
-                if (FULL || e0 + t * LPR < n) U[e0 + t * LPR] = xv[t];
+        for (int t = 0; t < kBatch; ++t) {
+            const int e = e0 + t * LPR;
+            xv[t] = (FULL || e < n) ? xr[e] : 0.0;
         }
-    } else {
-        for (int e0 = id.l; e0 < n; e0 += kBatch * LPR) {
-            double xv[kBatch];
 #pragma unroll
-            for (int t = 0; t < kBatch; ++t) {
-                const int e = e0 + t * LPR;
-                xv[t] = (FULL || e < n) ? xr[e] : 0.0;
+        for (int t = 0; t < kBatch; ++t) {
+            const int e = e0 + t * LPR;
+            if (!FULL && e >= n) continue;
+            double v = xv[t];
+            if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
+                const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+                if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
+                v = c;
             }
-#pragma unroll
-            for (int t = 0; t < kBatch; ++t) {
-                const int e = e0 + t * LPR;
-                if (!FULL && e >= n) continue;
-                double v = xv[t];
-                if (clip) {  // cmaes/_constraints.py:29-31 (clip to the standardised box), :79 (weighted squared excess)
-                    const double c = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
-                    if (pen_v != nullptr) pacc += ((c - v) * (c - v)) * pen_v[e];
-                    v = c;
-                }
-                if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
-                U[e] = v;
-            }
+            if (affine) v = v * xstd[e] + xm[e];  // cmaes/_cmaes.py:171 unstandardize
+            U[e] = v;
         }
     }
     if (pen_out != nullptr) {
@@ -327,6 +313,118 @@ __global__ __launch_bounds__(256) void eval_r8_kernel(const double *__restrict__
     if (j == (TAIL > 0 ? TAIL - 1 : 0)) f[row0 + r] = val;
 }
 
+// The same mapping for one-batch rows of ANY length (n <= 256: at most three leaves of at most 16 blocks, PlanArg), straight from
+// memory: lane (r, j) of a wavefront owns accumulator j of row r, so the elements it needs -- 8k + j -- are exactly the ones it
+// loads (eight rows x 64 consecutive bytes per load instruction, consecutive blocks in consecutive instructions: every 128-byte
+// line is fetched once and hit once); nothing is staged.  The neighbour of a Rosenbrock-like term is a second load of the
+// same lines.  Rows off the compile-time grid (n = 100, 200, ...) otherwise take the 16 / 32 / 64-lanes-per-row kernel:
+// Rosenbrock n = 100 / 130 / 200 / 250 at large P: 0.40 / 0.20 / 0.28 / 0.34 of the HBM peak -> 0.65 / 0.62 / 0.64 / 0.61; Ackley 0.20 / 0.12
+// / 0.20 / 0.22 -> 0.47 / 0.48 / 0.54 / 0.52 (profiles/r5_eval_r8_rt.txt).
+template <int FUN>
+__global__ __launch_bounds__(256) void eval_r8_rt_kernel(const double *__restrict__ X, int64_t P, int n, int64_t ldx,
+                                                         double *__restrict__ f, const PlanArg plan) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    const double identB = BMUL ? 1.0 : 0.0;
+    const int lane = (int)(threadIdx.x & 63), j = lane & 7;
+    const int64_t row = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    const bool live = row < P;
+    const double *__restrict__ xr = X + (live ? row : P - 1) * ldx;
+    const int nbt = plan.mb, tail = plan.tail, nleaf = plan.nleaf;
+    double sA[3] = {0.0, 0.0, 0.0}, sB[3] = {identB, identB, identB};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (t >= nleaf) break;  // (uniform)
+        const int b0 = t > 0 ? plan.end[t - 1] : 0, cnt = plan.end[t] - b0;
+        double chA = 0.0, chB = identB;
+#pragma unroll
+        for (int h0 = 0; h0 < kLeafBlocks; h0 += 8) {
+            double x[8], xn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = h0 + u < cnt;
+                const int e = (b0 + h0 + u) * kGroup + j;
+                x[u] = in ? xr[e] : 0.0;
+                xn[u] = (O::NEXT && in) ? xr[e + 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = h0 + u < cnt;
+                const int e = (b0 + h0 + u) * kGroup + j;
+                double a, b;
+                if constexpr (light_objective<FUN>()) {  // a select per term; the cosine objectives branch (registers)
+                    O::term(x[u], xn[u], e, a, b);
+                    if (h0 + u == 0) {
+                        chA = in ? a : 0.0;
+                        chB = in ? b : identB;
+                    } else {
+                        chA = in ? chA + a : chA;
+                        if (TWO) chB = in ? combine<BMUL>(chB, b) : chB;
+                    }
+                } else if (in) {
+                    O::term(x[u], xn[u], e, a, b);
+                    if (h0 + u == 0) {
+                        chA = a;
+                        chB = b;
+                    } else {
+                        chA = chA + a;
+                        if (TWO) chB = combine<BMUL>(chB, b);
+                    }
+                }
+            }
+        }
+        sA[t] = group_tree<false>(chA);
+        sB[t] = TWO ? group_tree<BMUL>(chB) : identB;
+    }
+    // the last leaf takes the tail terms one by one: term t by lane t, the running sum walks along the group (r8_sum's scan)
+    double la = nleaf == 0 ? 0.0 : nleaf == 1 ? sA[0] : nleaf == 2 ? sA[1] : sA[2];
+    double lb = nleaf == 0 ? identB : nleaf == 1 ? sB[0] : nleaf == 2 ? sB[1] : sB[2];
+    if (tail > 0) {  // (uniform)
+        const int e = kGroup * nbt + (j < tail ? j : 0);
+        double ta, tb;
+        O::term(xr[e], O::NEXT ? xr[e + 1] : 0.0, e, ta, tb);
+        la = la + ta;
+        if (TWO) lb = combine<BMUL>(lb, tb);
+#pragma unroll
+        for (int t = 1; t < kGroup - 1; ++t) {
+            const double pa = dpp_f64<0x111>(la) + ta;
+            const bool on = t < tail && j >= t;
+            la = on ? pa : la;
+            if (TWO) {
+                const double pb = combine<BMUL>(dpp_f64<0x111>(lb), tb);
+                lb = on ? pb : lb;
+            }
+        }
+        const int src = (lane & ~(kGroup - 1)) + tail - 1;  // the sum ends in lane tail - 1 of the group
+        la = __shfl(la, src, kWave);
+        if (TWO) lb = __shfl(lb, src, kWave);
+    }
+    // merges in recursion order: S0 + S1, or S0 + (S1 + S2)
+    double sa, sb;
+    if (nleaf > 2) {
+        sa = sA[0] + (sA[1] + la);
+        sb = TWO ? combine<BMUL>(sB[0], combine<BMUL>(sB[1], lb)) : identB;
+    } else if (nleaf > 1) {
+        sa = sA[0] + la;
+        sb = TWO ? combine<BMUL>(sB[0], lb) : identB;
+    } else {
+        sa = la, sb = lb;
+    }
+    sa = 0.0 + sa;  // add.reduce starts from the identity
+    sb = !TWO ? identB : (BMUL ? sb : 0.0 + sb);
+    const double val = O::finish(sa, sb, n);
+    if (live && j == 0) f[row] = val;
+}
+// mode 1: rows off the compile-time grid; 2: every one-batch row (measurement: against eval_r8_kernel at n = 64 / 128 / 256)
+static int eval_r8_rt_mode() {
+    static const int mode = getenv("SX_EVAL_R8RT") ? atoi(getenv("SX_EVAL_R8RT")) : 1;
+    return mode;
+}
+static bool eval_r8_rt_ok(int64_t P, int n, const double *xm, const double *part_f, int clip) {
+    static const int64_t min_rows = getenv("SX_EVAL_R8_MIN") ? atoll(getenv("SX_EVAL_R8_MIN")) : 32768;
+    return eval_r8_rt_mode() != 0 && n >= 16 && n <= 256 && xm == nullptr && part_f == nullptr && clip == 0 && P >= min_rows;
+}
+
 #ifndef SX_EVAL_HEAVY_STATIC
 #define SX_EVAL_HEAVY_STATIC 1  // (0: objectives with a cosine per term keep the run-time plan on long rows)
 #endif
@@ -374,6 +472,11 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
             case 1024: SX_EVAL_GO(64, true, 1024); break;
             default: SX_EVAL_GO(64, true, 2048); break;
         }
+    } else if (fix && (eval_r8_rt_mode() == 2 || (n == 256 && !kLight)) && eval_r8_rt_ok(P, n, xm, part_f, clip)) {
+        // rows of 256 elements with a cosine per term: the run-time form (no staging, 16 terms at a time) is the faster one --
+        // Ackley 0.45 -> 0.57 of the HBM peak, Rastrigin 0.46 -> 0.59; at n = 64 / 128 and for the cheap objectives the
+        // compile-time form below stays ahead (Rosenbrock 0.75-0.78 against 0.48-0.63): profiles/r5_eval_r8_rt.txt
+        hipLaunchKernelGGL((eval_r8_rt_kernel<FUN>), dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, X, P, n, ldx, f, plan);
     } else if (fix && FUN != SX_FUN_SPHERE && eval_r8_ok(X, P, n, ldx, xm, part_f)) {
         // (Sphere -- one multiplication per element, no second stream -- is the one objective the one-visit kernel streams
         //  faster: 0.81 / 0.84 against 0.78 / 0.77 of the HBM peak at n = 64 / 256, profiles/r5_eval_r8_ab.txt)
@@ -384,6 +487,9 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
             case 128: hipLaunchKernelGGL((eval_r8_kernel<FUN, 128>), dim3(blocks8), dim3(256), 32 * (128 + 8) * sizeof(double), s, X, ldx, f); break;
             default: hipLaunchKernelGGL((eval_r8_kernel<FUN, 256>), dim3(blocks8), dim3(256), 32 * (256 + 8) * sizeof(double), s, X, ldx, f); break;
         }
+    } else if (!fix && eval_r8_rt_ok(P, n, xm, part_f, clip) && plan.nleaf <= 3) {
+        // many one-batch rows of a length off the compile-time grid: eight lanes per row, straight from memory
+        hipLaunchKernelGGL((eval_r8_rt_kernel<FUN>), dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, X, P, n, ldx, f, plan);
     } else if (fix) {
         // the register-chain objective reads the staged vector only: n + 8 doubles per row, not the term arrays' 3n + ...
         switch (lpr) {

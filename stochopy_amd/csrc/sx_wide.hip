@@ -13,16 +13,23 @@
 //   * the plan lives in device memory (built once per number of terms, cached): for every 8192-term piece the leaf table
 //     of numpy's pairwise recursion (loops_utils.h.src: <= 128 terms per leaf, split at n/2 rounded down to a multiple of
 //     8) and the recursion's combines ordered by LEVEL -- combines of one level touch disjoint leaf slots, so a level is
-//     one parallel step for all pieces at once (6 barriers for a full piece instead of 63 dependent additions); the
-//     pieces' sums (a full piece has 64 leaves: piece c ends in slot 64 c) are then added up in order;
-//   * the row is walked in CHUNKS of whole leaves: the workgroup's threads produce the chunk's elements (coalesced runs,
-//     four elements and all their loads in flight per thread, the Philox layout of the whole-wave rows: element e is lane
-//     e % 64 at step e / 64), stage them in LDS, and every 8-lane group takes one leaf (eight accumulators over the
-//     8-blocks, the tree, the tail) exactly as row_reduce_leaves_fused does: same additions in the same order, same bits;
-//   * a row of up to ~18 000 elements stays RESIDENT in LDS (one chunk: the DE trial is stored from there when it wins,
-//     PSO's new position is copied to pbest from there); longer rows are STREAMED through a 4096-element stage: DE writes
-//     the trial into the next buffer as it is produced and copies the old row over it if the trial lost, PSO re-reads the
-//     position it has just written.
+//     one parallel step (6 steps for a full piece instead of 63 dependent additions); the pieces' sums (a full piece has
+//     64 leaves: piece c ends in slot 64 c) are then added up in order;
+//   * the row is walked in CHUNKS of whole leaves (as many as fit 4096 elements: the plan's chunk table): the workgroup's
+//     threads produce the chunk's elements (coalesced runs, four elements and all their loads in flight per thread, the Philox
+//     layout of the whole-wave rows: element e is lane e % 64 at step e / 64), stage them in LDS, and every 8-lane group takes
+//     one leaf (eight accumulators over the 8-blocks, the tree, the tail) exactly as row_reduce_leaves_fused does: same
+//     additions in the same order, same bits;
+//   * the recursion's combines: one wavefront per 8192-term piece, leaf slot l on lane l, the levels walked with lane shuffles
+//     (wide_finish), then add.reduce's own loop over the pieces;
+//   * a row whose stage fits twice on a CU (72 KB: up to ~8 900 elements) stays RESIDENT in LDS (one chunk: the DE trial is
+//     stored from there when it wins, PSO's new position is copied to pbest from there); longer rows are STREAMED through the
+//     4096-element stage: DE writes the trial into the next buffer as it is produced and copies the old row over it if the
+//     trial lost, PSO re-reads the position it has just written.
+// What bounds these kernels is vector-instruction issue and the number of workgroups a CU holds, not the LDS or the bytes in
+// flight (counters: profiles/r5_wide_ab3.txt ... r5_wide_ab5.txt) -- hence: strategy-specialised DE kernels (63 VGPRs for
+// Rosenbrock best1bin: four workgroups per CU), unpredicated code for full chunks and full leaves, a select instead of a
+// branch per term in short leaves (cheap terms only), tail terms by lane.
 // Objective values, draws, selection and records are those of the narrow kernels: a wide run is compared with the oracle
 // bit for bit (tests/test_gpu_wide.py).
 //
@@ -425,10 +432,13 @@ constexpr int kEvalThreads = 256;
 #define SX_WIDE_EVAL_PIPE_FROM 8192  // rows longer than this (several chunks) of the light objectives take the pipelined form
 #endif
 constexpr int kGenThreads = 512;
-#ifndef SX_WIDE_ONE_WG_DEFAULT
-#define SX_WIDE_ONE_WG_DEFAULT 0
-#endif
-constexpr size_t kResidentLds = 148 * 1024;   // a resident row + its leaf sums must fit here (160 KB per CU)
+// A resident row + its leaf sums must fit here: TWO workgroups per CU.  (Up to 148 KB -- one workgroup per CU, rows of up to
+// ~18 000 elements -- was the first form; with one workgroup on the CU the phases of a row run one after the other: n = 12 000 ...
+// 18 000 streamed instead: DE 0.53-0.58 -> 0.60-0.64 of the HBM peak, PSO 0.48-0.52 -> 0.52-0.64, although a streamed DE row
+// that loses is copied back; a prefetching loop and 1024-thread workgroups for the one-workgroup case reached 0.54-0.58 / 0.52.
+// At n = 8192 -- two resident workgroups per CU -- resident wins: DE Rastrigin 0.65 against 0.55, PSO Ackley 0.62 against 0.57.
+// profiles/r5_wide_resident_ab.txt, r5_wide_onewg.txt.)
+constexpr size_t kResidentLds = 72 * 1024;
 constexpr int kStageElems = kChunkElems + 16 + 128 + (SX_WIDE_PAD ? 8 * (kChunkElems / 128 + 2) : 0);
 
 __host__ __device__ inline int wide_leaf_cap(int n) { return n / 64 + 2; }
@@ -559,9 +569,10 @@ __global__ __launch_bounds__(kEvalThreads) void wide_eval_kernel(const double *_
 // ---------------------------------------------------------------------------
 // STRAT >= 0: best1bin / rand1bin with constraints=None at compile time (two or three donor rows in flight instead of five,
 // no bounds / resample registers: the generic form's 136-148 VGPRs leave ONE 512-thread workgroup per CU).
-template <int FUN, int RNG, int STRAT = -1, bool PRE = false, int T = kGenThreads>
-__global__ __launch_bounds__(T) void wide_de_kernel(const sx_de_args a, const int32_t *__restrict__ plan,
-                                                    const int chunk_leaves) {
+template <int FUN, int RNG, int STRAT = -1>
+__global__ __launch_bounds__(kGenThreads, 4) void wide_de_kernel(const sx_de_args a, const int32_t *__restrict__ plan,
+                                                              const int chunk_leaves) {
+    constexpr int T = kGenThreads;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const sx_state *sin = a.state;
     if (sin->done) return;
@@ -599,16 +610,18 @@ __global__ __launch_bounds__(T) void wide_de_kernel(const sx_de_args a, const in
 
     // thread -> (k256, l): the four elements 256 k256 + l + 64 t, t = 0..3 -- steps q = 4 k256 + t of lane l in the
     // whole-wave layout, i.e. ONE Philox call (slot (q >> 2) * 64 + l = 64 k256 + l) for their crossover uniforms.
-    // PRE: the loads of a thread's NEXT four elements (own row, donors, best row) are issued before the current four are
-    // worked on (Philox, mutation, crossover, staging) -- twice the bytes in flight for 32 more VGPRs.
+    // The per-strategy kernels (two or three donor rows, no bounds) have the four elements' loads in flight together; the
+    // generic one (up to five donor rows, bounds, resample draws: 36 doubles per four elements) takes them two at a time --
+    // 114-157 VGPRs otherwise, one 512-thread workgroup per CU.
+    constexpr int NT = STRAT >= 0 ? 4 : 2;
     struct DeLoads {
-        double x[4], dv[kMaxDonors][4], gv[4], r[4], rs[4], lo[4], hi[4];
+        double x[NT], dv[kMaxDonors][NT], gv[NT], r[NT], rs[NT], lo[NT], hi[NT];
     };
-    auto de_issue = [&](int g, int e0, int e1s, DeLoads &L) {
+    auto de_issue = [&](int g, int t0, int e0, int e1s, DeLoads &L) {
         const int eb = (g >> 6) * 256 + (g & 63);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int e = eb + 64 * t;
+        for (int t = 0; t < NT; ++t) {
+            const int e = eb + 64 * (t0 + t);
             const bool in = e >= e0 && e < e1s;
             L.x[t] = in ? xi[e] : 0.0;
             L.gv[t] = (use_best && in) ? gb[e] : 0.0;
@@ -622,15 +635,16 @@ __global__ __launch_bounds__(T) void wide_de_kernel(const sx_de_args a, const in
             if (repair && in) L.lo[t] = a.lower[e], L.hi[t] = a.upper[e];
         }
     };
-    auto de_consume = [&](int g, int e0, int e1, int e1s, DeLoads &L, double *Sd) {
+    auto de_consume = [&](int g, int t0, const U4 &w, int e0, int e1, int e1s, DeLoads &L, double *Sd) {
         const int eb = (g >> 6) * 256 + (g & 63);
         if (RNG == SX_RNG_PHILOX) {
-            const U4 w = philox4x32_10((uint32_t)g, grow, gen, kPurposeDeCross, a.key0, a.key1);
-            L.r[0] = u32(w.x), L.r[1] = u32(w.y), L.r[2] = u32(w.z), L.r[3] = u32(w.w);
+            const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) L.r[t] = u32(wd[t0 + t]);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int e = eb + 64 * t;
+        for (int t = 0; t < NT; ++t) {
+            const int e = eb + 64 * (t0 + t);
             if (!(e >= e0 && e < e1s)) continue;
             const double v = de_mutant(strategy, L.gv[t], L.dv[0][t], L.dv[1][t], L.dv[2][t], L.dv[3][t], L.dv[4][t], F);
             double cand = (e == irand || L.r[t] <= CR) ? v : L.x[t];  // de/_de.py:341-344
@@ -643,24 +657,14 @@ __global__ __launch_bounds__(T) void wide_de_kernel(const sx_de_args a, const in
         }
     };
     const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
-        const int g0 = (e0 >> 8) * 64 + tid, gend = ((e1s + 255) >> 8) * 64;
-        if constexpr (PRE) {
-            DeLoads A, B;
-            if (g0 < gend) de_issue(g0, e0, e1s, A);
-            for (int g = g0; g < gend; g += 2 * T) {
-                const bool second = g + T < gend;
-                if (second) de_issue(g + T, e0, e1s, B);
-                de_consume(g, e0, e1, e1s, A, Sd);
-                if (second) {
-                    if (g + 2 * T < gend) de_issue(g + 2 * T, e0, e1s, A);
-                    de_consume(g + T, e0, e1, e1s, B, Sd);
-                }
-            }
-        } else {
-            for (int g = g0; g < gend; g += T) {
+        for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
+            U4 w = {0u, 0u, 0u, 0u};
+            if (RNG == SX_RNG_PHILOX) w = philox4x32_10((uint32_t)g, grow, gen, kPurposeDeCross, a.key0, a.key1);
+#pragma unroll
+            for (int t0 = 0; t0 < 4; t0 += NT) {
                 DeLoads A;
-                de_issue(g, e0, e1s, A);
-                de_consume(g, e0, e1, e1s, A, Sd);
+                de_issue(g, t0, e0, e1s, A);
+                de_consume(g, t0, w, e0, e1, e1s, A, Sd);
             }
         }
     });
@@ -692,9 +696,10 @@ __device__ __forceinline__ unsigned long long wide_sort_key(double f) {  // (sx_
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-template <int FUN, int RNG, bool PRE = false, int T = kGenThreads>
-__global__ __launch_bounds__(T) void wide_pso_kernel(const sx_pso_args a, const int32_t *__restrict__ plan,
-                                                     const int chunk_leaves) {
+template <int FUN, int RNG>
+__global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args a, const int32_t *__restrict__ plan,
+                                                               const int chunk_leaves) {
+    constexpr int T = kGenThreads;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double s_beta[T / kWave];
     const sx_state *st = a.state;
@@ -723,7 +728,6 @@ __global__ __launch_bounds__(T) void wide_pso_kernel(const sx_pso_args a, const 
     // the four elements 256 k256 + l + 64 t of group g = 64 k256 + l (steps q = 4 k256 + t of lane l): position, raw new
     // velocity (cpso/_cpso.py:326) -- two Philox calls (slot (q >> 1) * 64 + l: words (0,1) / (2,3) = (r1, r2) of even /
     // odd q); a re-seeded row draws its position instead of loading it (pso_restart_apply_kernel's draws), V = 0, pbest = X
-    // PRE: the loads of a thread's NEXT four elements are issued before the current four are worked on (as wide_de_kernel).
     struct PsoLoads {
         double x[4], v[4], p[4], gv[4], r1[4], r2[4];
     };
@@ -822,25 +826,10 @@ __global__ __launch_bounds__(T) void wide_pso_kernel(const sx_pso_args a, const 
         }
     };
     const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
-        const int g0 = (e0 >> 8) * 64 + tid, gend = ((e1s + 255) >> 8) * 64;
-        if constexpr (PRE) {
-            PsoLoads A, B;
-            if (g0 < gend) pso_issue(g0, e0, e1s, A);
-            for (int g = g0; g < gend; g += 2 * T) {
-                const bool second = g + T < gend;
-                if (second) pso_issue(g + T, e0, e1s, B);
-                pso_commit(g, e0, e1, e1s, A, Sd);
-                if (second) {
-                    if (g + 2 * T < gend) pso_issue(g + 2 * T, e0, e1s, A);
-                    pso_commit(g + T, e0, e1, e1s, B, Sd);
-                }
-            }
-        } else {
-            for (int g = g0; g < gend; g += T) {
-                PsoLoads A;
-                pso_issue(g, e0, e1s, A);
-                pso_commit(g, e0, e1, e1s, A, Sd);
-            }
+        for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
+            PsoLoads A;
+            pso_issue(g, e0, e1s, A);
+            pso_commit(g, e0, e1, e1s, A, Sd);
         }
     });
     const bool better = fc < fold;  // _common.py:127 strict <
@@ -879,6 +868,7 @@ __global__ __launch_bounds__(T) void wide_pso_kernel(const sx_pso_args a, const 
 // row, and t_k = (y / d) . vn -- what the moment sums need of a selected row (:428-444) -- is left per row.
 // Rows 0 and 1 of the generation are +-dy when the mean-shift injection is on (:241-247).
 // ---------------------------------------------------------------------------
+// (A cap at 64 VGPRs -- four workgroups per CU instead of three -- spills: 24 ... 180 bytes per lane.)
 template <int FUN, int T>
 __global__ __launch_bounds__(T) void wide_vd_candidates_kernel(const sx_vd_args a, const int64_t gen,
                                                                          const int64_t row0, double *__restrict__ ary_out,
@@ -995,78 +985,18 @@ template <int FUN> struct EvalPipeK {
 };
 template <int FUN> struct DePhK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX>; } };
 template <int FUN> struct DeHoK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_HOST>; } };
-// PRE (next elements' loads issued before the current ones are worked on; + 20-32 VGPRs) pays where a resident row's LDS leaves
-// ONE workgroup per CU anyway (n = 16 384: 0.54 -> 0.58 of the HBM peak); where two or three fit, the registers cost one of
-// them (n = 4096: 0.75 -> 0.64; streamed rows 0.49 -> 0.48) -- profiles/r5_wide_ab5.txt.
-template <int FUN> struct DePhBestK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, false>; } };
-template <int FUN> struct DePhRandK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, false>; } };
-template <int FUN> struct DePhBestPreK {
-    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, light_objective<FUN>()>; }
-};
-template <int FUN> struct DePhRandPreK {
-    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, light_objective<FUN>()>; }
-};
-template <int FUN> struct PsoPhK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, false>; } };
-template <int FUN> struct PsoPhPreK {
-    static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, light_objective<FUN>()>; }
-};
+template <int FUN> struct DePhBestK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN>; } };
+template <int FUN> struct DePhRandK { static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN>; } };
+template <int FUN> struct PsoPhK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX>; } };
 template <int FUN> struct VdCandK { static void *ptr() { return (void *)wide_vd_candidates_kernel<FUN, kGenThreads>; } };
 template <int FUN> struct PsoHoK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_HOST>; } };
-inline bool wide_one_workgroup_per_cu(int n) { return wide_resident(n) && wide_lds_bytes(n, true) > 76 * 1024; }
-// A resident row whose LDS leaves one workgroup per CU: 1024 threads instead of 512 (sixteen wavefronts on the CU instead of
-// eight), with or without the prefetching loop -- SX_WIDE_ONE_WG = pre | big | bigpre (measurement hook)
-constexpr int kBigThreads = 1024;
-template <int FUN> struct DePhBestBigK {
-    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, false, kBigThreads>; }
-};
-template <int FUN> struct DePhRandBigK {
-    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, false, kBigThreads>; }
-};
-template <int FUN> struct DePhBestBigPreK {
-    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_BEST1BIN, light_objective<FUN>(), kBigThreads>; }
-};
-template <int FUN> struct DePhRandBigPreK {
-    static void *ptr() { return (void *)wide_de_kernel<FUN, SX_RNG_PHILOX, SX_DE_RAND1BIN, light_objective<FUN>(), kBigThreads>; }
-};
-template <int FUN> struct PsoPhBigK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, false, kBigThreads>; } };
-template <int FUN> struct PsoPhBigPreK {
-    static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_PHILOX, light_objective<FUN>(), kBigThreads>; }
-};
-int one_wg_form() {  // 0: 512 threads + prefetch, 1: 1024 threads, 2: 1024 threads + prefetch
-    static const int form = [] {
-        const char *e = getenv("SX_WIDE_ONE_WG");
-        if (e == nullptr) return SX_WIDE_ONE_WG_DEFAULT;
-        return e[0] == 'p' ? 0 : (e[3] == 'p' ? 2 : 1);
-    }();
-    return form;
-}
-struct Pick {
-    void *fn;
-    int threads;
-};
-Pick pick_de(const sx_de_args *a) {
+void *pick_de(const sx_de_args *a) {
     const bool ph = a->rng == SX_RNG_PHILOX;  // (host draws: the generation waits for the host's streams anyway)
-    const bool one = wide_one_workgroup_per_cu(a->n);
-    const int form = one_wg_form();
-    if (ph && a->constraints == 0 && a->strategy == SX_DE_BEST1BIN) {
-        if (!one) return {pick_fun<DePhBestK>(a->fun_id), kGenThreads};
-        if (form == 0) return {pick_fun<DePhBestPreK>(a->fun_id), kGenThreads};
-        return {form == 1 ? pick_fun<DePhBestBigK>(a->fun_id) : pick_fun<DePhBestBigPreK>(a->fun_id), kBigThreads};
-    }
-    if (ph && a->constraints == 0 && a->strategy == SX_DE_RAND1BIN) {
-        if (!one) return {pick_fun<DePhRandK>(a->fun_id), kGenThreads};
-        if (form == 0) return {pick_fun<DePhRandPreK>(a->fun_id), kGenThreads};
-        return {form == 1 ? pick_fun<DePhRandBigK>(a->fun_id) : pick_fun<DePhRandBigPreK>(a->fun_id), kBigThreads};
-    }
-    return {ph ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id), kGenThreads};
+    if (ph && a->constraints == 0 && a->strategy == SX_DE_BEST1BIN) return pick_fun<DePhBestK>(a->fun_id);
+    if (ph && a->constraints == 0 && a->strategy == SX_DE_RAND1BIN) return pick_fun<DePhRandK>(a->fun_id);
+    return ph ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id);
 }
-Pick pick_pso(const sx_pso_args *a) {
-    if (a->rng != SX_RNG_PHILOX) return {pick_fun<PsoHoK>(a->fun_id), kGenThreads};
-    if (!wide_one_workgroup_per_cu(a->n)) return {pick_fun<PsoPhK>(a->fun_id), kGenThreads};
-    const int form = one_wg_form();
-    if (form == 0) return {pick_fun<PsoPhPreK>(a->fun_id), kGenThreads};
-    return {form == 1 ? pick_fun<PsoPhBigK>(a->fun_id) : pick_fun<PsoPhBigPreK>(a->fun_id), kBigThreads};
-}
+void *pick_pso(const sx_pso_args *a) { return a->rng == SX_RNG_PHILOX ? pick_fun<PsoPhK>(a->fun_id) : pick_fun<PsoHoK>(a->fun_id); }
 
 std::mutex g_attr_mutex;
 std::map<void *, size_t> g_attr;  // kernels whose dynamic LDS limit has been raised (per process; devices share code objects)
@@ -1134,38 +1064,35 @@ int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const 
 
 int wide_de_launch(const sx_de_args *a, hipStream_t s) {
     GenLaunch g;
-    const Pick k = pick_de(a);
-    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, s, &g)) return rc;
+    if (int rc = gen_launch_for(pick_de(a), a->fun_id, a->n, s, &g)) return rc;
     sx_de_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), kargs, g.lds, s));
+    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
     return 0;
 }
 
 int wide_de_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_de_args *a) {
     GenLaunch g;
-    const Pick k = pick_de(a);
-    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, nullptr, &g)) return rc;
+    if (int rc = gen_launch_for(pick_de(a), a->fun_id, a->n, nullptr, &g)) return rc;
     sx_de_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), (unsigned)g.lds, kargs);
+    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3(kGenThreads), (unsigned)g.lds, kargs);
 }
 
 int wide_pso_launch(const sx_pso_args *a, hipStream_t s) {
     GenLaunch g;
-    const Pick k = pick_pso(a);
-    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, s, &g)) return rc;
+    if (int rc = gen_launch_for(pick_pso(a), a->fun_id, a->n, s, &g)) return rc;
     sx_pso_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), kargs, g.lds, s));
+    SX_HIP(hipLaunchKernel(g.fn, dim3((unsigned)a->P), dim3(kGenThreads), kargs, g.lds, s));
     return 0;
 }
 
 int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t rows, double *ary_out, double *arx_out,
                        double *fit_out, double *tk_out, hipStream_t s) {
-    // (Workgroups of 256 threads -- four per CU instead of three, a generation of ~1000 candidates resident at once -- were
-    // measured and lose: 273 against 255 us per generation at n = 16 384, P = 1024; 658 against 570 at n = 65 536, P = 512:
-    // profiles/r5_vd_threads.txt.)
+    // (Workgroups of 256 or 384 threads -- four per CU instead of three, a generation of ~1000 candidates resident at once --
+    // were measured and lose: 273 / 270 against 255-260 us per generation at n = 16 384, P = 1024; 658 / 620 against 570 at
+    // n = 65 536, P = 512: profiles/r5_vd_threads.txt.)
     GenLaunch g;
     if (int rc = gen_launch_for(pick_fun<VdCandK>(a->fun_id), a->fun_id, a->n, s, &g)) return rc;
     // Always STREAMED (z parked in the y row): a resident row's 128 KB of LDS leave ONE workgroup per CU, and the generator's
@@ -1182,11 +1109,10 @@ int wide_vd_candidates(const sx_vd_args *a, int64_t gen, int64_t row0, int64_t r
 
 int wide_pso_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_pso_args *a) {
     GenLaunch g;
-    const Pick k = pick_pso(a);
-    if (int rc = gen_launch_for(k.fn, a->fun_id, a->n, nullptr, &g)) return rc;
+    if (int rc = gen_launch_for(pick_pso(a), a->fun_id, a->n, nullptr, &g)) return rc;
     sx_pso_args args = *a;
     void *kargs[] = {&args, &g.plan, &g.chunk_leaves};
-    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3((unsigned)k.threads), (unsigned)g.lds, kargs);
+    return add_node(graph, prev, g.fn, dim3((unsigned)a->P), dim3(kGenThreads), (unsigned)g.lds, kargs);
 }
 
 }  // namespace sx

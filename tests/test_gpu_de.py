@@ -61,6 +61,34 @@ def test_objectives_one_batch_rows_eight_lanes_per_row(sa, name, n):
         assert np.allclose(got, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
 
 
+# 16 / 17: one leaf of two blocks (+ a tail); 63 / 100 / 129: one leaf; 135 ... 200: two leaves; 249 / 250 / 255: three leaves
+# (numpy cuts a right part of 129 ... 135 terms once more); 256 with P % 32 != 0: two full leaves
+@pytest.mark.parametrize("n", [16, 17, 63, 100, 129, 135, 136, 200, 249, 250, 255, 256])
+@pytest.mark.parametrize("name", sorted(OBJECTIVES))
+def test_objectives_one_batch_rows_of_any_length_eight_lanes_per_row(sa, name, n):
+    """Round 5: large populations (P >= 32768) of one-batch rows OFF the compile-time grid are evaluated by eval_r8_rt_kernel --
+    eight lanes per row straight from memory, numpy's plan (at most three leaves) at run time: the same bits as the oracle and
+    as the 16 / 32 / 64-lanes-per-row kernel, which a smaller population of the same rows takes."""
+    import torch
+    from stochopy_amd import _device, _lib
+
+    rs = np.random.RandomState(n + 5)
+    X = rs.uniform(-5.12, 5.12, (32768 + 13, n))
+    ref = OBJECTIVES[name](X)
+    ctx = _device.Context()
+    Xd = torch.as_tensor(X, device=ctx.device)
+    torch.cuda.synchronize()
+    got8 = _device.evaluate(ctx, _lib.FUN_IDS[name], Xd, n)          # eight lanes per row, a last wavefront of 5 rows
+    got = _device.evaluate(ctx, _lib.FUN_IDS[name], Xd[:4099], n)    # fewer rows: the lanes-per-row kernel
+    ctx.sync()
+    got8, got = got8.cpu().numpy(), got.cpu().numpy()
+    assert np.array_equal(got8[:4099], got)
+    if name in EXACT:
+        assert np.array_equal(got8, ref)
+    else:
+        assert np.allclose(got8, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
+
+
 @pytest.mark.parametrize("n", [512, 1024, 2048])
 @pytest.mark.parametrize("name", sorted(OBJECTIVES))
 def test_objectives_long_rows_compile_time_plan(sa, name, n):

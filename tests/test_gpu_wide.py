@@ -1,5 +1,5 @@
 """GPU parity for WIDE rows (n > 4096; csrc/sx_wide.hip: one workgroup per individual, the summation plan in device
-memory, the row resident in LDS up to ~18 000 elements and streamed through a 4096-element stage above).  The reference
+memory, the row resident in LDS up to 8794 elements -- two workgroups per CU -- and streamed through a 4096-element stage above).  The reference
 has no dimension limit (de/_de.py:208-218; vdcma/_vdcma.py:144-458 exists for long vectors): objectives, DE, PSO, CPSO
 and the unfused / sharded paths are compared with the oracle BIT FOR BIT (+, -, * objectives), VD-CMA within 1e-6 and
 against a vector captured from the reference at n = 8192 (tests/golden/vdcma_wide.json)."""
@@ -24,8 +24,8 @@ def sa():
     return stochopy_amd
 
 
-# 4097: first wide length (a tail term); 4104 / 5000: tails of 0 / 7 for Rosenbrock; 16384: a power of two (resident);
-# 18400: the longest resident row for most objectives; 20001: streamed, several chunks, a tail; 65536: the verdict's
+# 4097: first wide length (a tail term); 4104 / 5000: tails of 0 / 7 for Rosenbrock; 16384: a power of two;
+# 18400, 20001: several chunks, a tail (sx_eval always streams); 65536: the verdict's
 # "at least"; 100003: beyond it
 # 2048 / 2049: the last row of the wavefront-per-row kernels and the first of these (kWideFrom, round 5; 2560 / 2561 until the
 # wide kernels' second pass); 3000, 4096: rows the
@@ -96,10 +96,11 @@ def _same_run(r_ref, r_got, t_ref, t_got):
 
 @pytest.mark.parametrize("strategy,constraints", [("best1bin", None), ("rand1bin", "Random"), ("rand2bin", None),
                                                   ("best2bin", "Random")])
-@pytest.mark.parametrize("n,P", [(2048, 24), (2049, 24), (2560, 24), (2561, 24), (3000, 20), (4097, 24), (8192, 16), (16384, 12),
-                                 (20001, 10)])
+# (8794 / 8795: the longest resident row and the first streamed one)
+@pytest.mark.parametrize("n,P", [(2048, 24), (2049, 24), (2560, 24), (2561, 24), (3000, 20), (4097, 24), (8192, 16), (8794, 12),
+                                 (8795, 12), (16384, 12), (20001, 10)])
 def test_wide_de_philox_matches_oracle(sa, strategy, constraints, n, P):
-    """DE with in-kernel draws, whole populations of every generation, resident (<= ~18 000) and streamed rows."""
+    """DE with in-kernel draws, whole populations of every generation, resident (<= 8794 elements) and streamed rows."""
     opts = {"maxiter": 6, "popsize": P, "seed": 77 + n, "strategy": strategy, "constraints": constraints,
             "mutation": 0.7, "recombination": 0.6, "updating": "deferred"}
     _same_run(*_trace_pair(sa, "rosenbrock", [[-2.0, 2.0]] * n, "de", opts))
@@ -141,7 +142,8 @@ def test_wide_default_call_defers_with_a_warning(sa):
 
 
 @pytest.mark.parametrize("constraints", [None, "Shrink"])
-@pytest.mark.parametrize("n,P", [(2048, 20), (2049, 20), (2560, 20), (2561, 20), (3500, 16), (4097, 20), (8192, 16), (20001, 9)])
+@pytest.mark.parametrize("n,P", [(2048, 20), (2049, 20), (2560, 20), (2561, 20), (3500, 16), (4097, 20), (8192, 16), (8794, 10),
+                                 (8795, 10), (20001, 9)])
 def test_wide_pso_philox_matches_oracle(sa, constraints, n, P):
     opts = {"maxiter": 6, "popsize": P, "seed": 11 + n, "constraints": constraints, "updating": "deferred"}
     _same_run(*_trace_pair(sa, "rosenbrock", [[-2.0, 2.0]] * n, "pso", opts))

@@ -68,6 +68,16 @@ if "de" in which:
         print(f"DE {strat} {name:10s} n={n:6d} P={P:6d}: {t*1e6:9.1f} us/generation  {P/t:.3e} evals/s  "
               f"{byts/t/1e9:8.1f} GB/s ({byts/t/1e9/PEAK:.2f} of 8 TB/s)", flush=True)
 
+if "degen" in which:  # strategies / constraints without a kernel of their own
+    for name, n, P, strat, cons in (("rosenbrock", 8192, 4096, "rand2bin", None), ("rosenbrock", 8192, 4096, "best1bin", "Random"),
+                                    ("rastrigin", 8192, 4096, "best2bin", None), ("rosenbrock", 32768, 1024, "rand2bin", None)):
+        o = {"popsize": P, "updating": "deferred", "strategy": strat}
+        if cons:
+            o["constraints"] = cons
+        t = per_gen("de", getattr(sa.factory, name), n, o, 20, 120)
+        k = _lib.DE_DONORS[strat]
+        byts = (8 * n * (k + 2) + 16) * P
+        print(f"DE {strat} {cons} {name:10s} n={n:6d} P={P:6d}: {t*1e6:9.1f} us/generation  {byts/t/1e9/PEAK:.2f} of 8 TB/s", flush=True)
 if "de16" in which:  # rows whose LDS leaves one workgroup per CU
     for name, n, P, strat in (("rosenbrock", 12000, 3072, "best1bin"), ("rosenbrock", 16384, 2048, "best1bin"),
                               ("rastrigin", 16384, 2048, "rand1bin"), ("sphere", 18000, 2048, "best1bin")):
