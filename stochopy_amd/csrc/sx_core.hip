@@ -109,7 +109,8 @@ extern "C" int sx_wide_from(void) { return kWideFrom; }
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out) {
-    if (n > kWideFrom) {  // (wide rows take their plan from device memory: sx_wide.hip; callers branch before this)
+    if (n > kMaxDim) {  // (rows the wide kernels serve take their plan from device memory: sx_wide.hip; callers branch before this --
+                        //  except sx_eval's eight-lanes-per-row form, which walks rows of up to kMaxDim elements with this plan)
         set_error("internal: a narrow-row kernel was asked for a row the wide kernels serve");
         return -1;
     }
@@ -415,6 +416,111 @@ __global__ __launch_bounds__(256) void eval_r8_rt_kernel(const double *__restric
     const double val = O::finish(sa, sb, n);
     if (live && j == 0) f[row] = val;
 }
+// ... and for rows of 257 ... kMaxDim = 4096 elements of any length: the group walks its row's leaves one after the other (numpy's plan
+// has up to 17 of them at n = 2048), leaves its sums in LDS (2 nleaf doubles per row) and lane 0 of the group performs the
+// recursion's combines in order.  Against the wavefront-per-row kernel (row staged in LDS, one leaf per 8-lane group, plan
+// walked with scalar loads and selects): profiles/r5_eval_r8_rt.txt, part 3.
+template <int FUN>
+__global__ __launch_bounds__(256) void eval_r8_long_kernel(const double *__restrict__ X, int64_t P, int n, int64_t ldx,
+                                                           double *__restrict__ f, const PlanArg plan) {
+    using O = Obj<FUN>;
+    constexpr bool TWO = O::TWO, BMUL = O::BMUL;
+    const double identB = BMUL ? 1.0 : 0.0;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = (int)(threadIdx.x & 63), j = lane & 7, grp = (int)(threadIdx.x >> 3);
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 3) + grp;
+    const bool live = row < P;
+    const double *__restrict__ xr = X + (live ? row : P - 1) * ldx;
+    const int nbt = plan.mb, tail = plan.tail, nleaf = plan.nleaf;
+    double *LA = lds + (size_t)grp * 2 * nleaf, *LB = LA + nleaf;
+    for (int t = 0; t < nleaf; ++t) {  // (uniform)
+        const int b0 = t > 0 ? plan.end[t - 1] : 0, cnt = plan.end[t] - b0;
+        double chA = 0.0, chB = identB;
+#pragma unroll
+        for (int h0 = 0; h0 < kLeafBlocks; h0 += 8) {
+            double x[8], xn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = h0 + u < cnt;
+                const int e = (b0 + h0 + u) * kGroup + j;
+                x[u] = in ? xr[e] : 0.0;
+                xn[u] = (O::NEXT && in) ? xr[e + 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = h0 + u < cnt;
+                const int e = (b0 + h0 + u) * kGroup + j;
+                double a, b;
+                if constexpr (light_objective<FUN>()) {
+                    O::term(x[u], xn[u], e, a, b);
+                    if (h0 + u == 0) {
+                        chA = in ? a : 0.0;
+                        chB = in ? b : identB;
+                    } else {
+                        chA = in ? chA + a : chA;
+                        if (TWO) chB = in ? combine<BMUL>(chB, b) : chB;
+                    }
+                } else if (in) {
+                    O::term(x[u], xn[u], e, a, b);
+                    if (h0 + u == 0) {
+                        chA = a;
+                        chB = b;
+                    } else {
+                        chA = chA + a;
+                        if (TWO) chB = combine<BMUL>(chB, b);
+                    }
+                }
+            }
+        }
+        double la = group_tree<false>(chA), lb = TWO ? group_tree<BMUL>(chB) : identB;
+        if (t == nleaf - 1 && tail > 0) {  // (uniform) the tail terms: term k by lane k, the running sum walks along the group
+            const int e = kGroup * nbt + (j < tail ? j : 0);
+            double ta, tb;
+            O::term(xr[e], O::NEXT ? xr[e + 1] : 0.0, e, ta, tb);
+            la = la + ta;
+            if (TWO) lb = combine<BMUL>(lb, tb);
+#pragma unroll
+            for (int k = 1; k < kGroup - 1; ++k) {
+                const double pa = dpp_f64<0x111>(la) + ta;
+                const bool on = k < tail && j >= k;
+                la = on ? pa : la;
+                if (TWO) {
+                    const double pb = combine<BMUL>(dpp_f64<0x111>(lb), tb);
+                    lb = on ? pb : lb;
+                }
+            }
+            if (j == tail - 1) {
+                LA[t] = la;
+                if (TWO) LB[t] = lb;
+            }
+        } else if (j == 0) {
+            LA[t] = la;
+            if (TWO) LB[t] = lb;
+        }
+    }
+    lds_wave_fence();
+    if (j == 0) {  // the recursion's combines in order (slots = leaf indices; the total ends in slot 0)
+        for (int mm = 0; mm + 1 < nleaf; ++mm) {
+            const int left = plan.mleft[mm], right = plan.mright[mm];
+            LA[left] = LA[left] + LA[right];
+            if (TWO) LB[left] = combine<BMUL>(LB[left], LB[right]);
+        }
+        double sa = 0.0 + LA[0];  // add.reduce starts from the identity
+        double sb = !TWO ? identB : (BMUL ? LB[0] : 0.0 + LB[0]);
+        if (live) f[row] = O::finish(sa, sb, n);
+    }
+}
+// mode 2 (measurement): also the cheap objectives at n = 512 / 1024 / 2048 and beyond 3584 elements
+static int eval_r8_long_mode() {
+    static const int mode = getenv("SX_EVAL_R8LONG") ? atoi(getenv("SX_EVAL_R8LONG")) : 1;
+    return mode;
+}
+static bool eval_r8_long_ok(int64_t P, int n, const double *xm, const double *part_f, int clip, int nleaf) {
+    static const int64_t min_rows = getenv("SX_EVAL_R8_MIN") ? atoll(getenv("SX_EVAL_R8_MIN")) : 32768;
+    return eval_r8_long_mode() != 0 && n > 256 && n <= kMaxDim && nleaf >= 1 && nleaf <= kMaxLeaf && xm == nullptr &&
+           part_f == nullptr && clip == 0 && P >= min_rows;
+}
+
 // mode 1: rows off the compile-time grid; 2: every one-batch row (measurement: against eval_r8_kernel at n = 64 / 128 / 256)
 static int eval_r8_rt_mode() {
     static const int mode = getenv("SX_EVAL_R8RT") ? atoi(getenv("SX_EVAL_R8RT")) : 1;
@@ -463,7 +569,14 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
 #define SX_EVAL_GO(...)                                                                                              \
     hipLaunchKernelGGL((eval_kernel<FUN, __VA_ARGS__>), dim3(g.blocks), dim3(g.threads), lds, s, X, P, n, ldx, xm, xstd, f, \
                        plan, part_f, part_i, clip, pen_v, pen_out)
-    if ((kLight || SX_EVAL_HEAVY_STATIC) && clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0) {
+    const bool grid_long = clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0;
+    if (eval_r8_long_ok(P, n, xm, part_f, clip, plan.nleaf) && (eval_r8_long_mode() == 2 || !(kLight && grid_long))) {
+        // many long rows: eight lanes per row, straight from memory.  Not the cheap objectives at n = 512 / 1024 / 2048: their
+        // compile-time plan below stays ahead (Rosenbrock 0.61 / 0.76 / 0.66 of the HBM peak against 0.58 / 0.54 / 0.55);
+        // the cosine objectives gain there too (Ackley 0.30 / 0.47 / 0.35 -> 0.49 / 0.50 / 0.48): profiles/r5_eval_r8_rt.txt
+        hipLaunchKernelGGL((eval_r8_long_kernel<FUN>), dim3((unsigned)((P + 31) / 32)), dim3(256),
+                           (size_t)32 * 2 * plan.nleaf * sizeof(double), s, X, P, n, ldx, f, plan);
+    } else if ((kLight || SX_EVAL_HEAVY_STATIC) && grid_long) {
         // long rows of a compile-time length: numpy's plan as constants (row_reduce_long).  Rosenbrock n = 1024: 0.54 -> 0.84
         // of the HBM peak, n = 512: 0.44 -> 0.76, n = 2048: 0.43 -> 0.70 (profiles/r4_eval_long_rows.txt; a resident,
         // software-pipelined form of the same kernel stayed at 0.72 and was dropped)
@@ -515,7 +628,15 @@ extern "C" int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ld
     SX_REQUIRE((xm == nullptr) == (xstd == nullptr), "sx_eval: xm and xstd must be given together");
     SX_REQUIRE((part_f == nullptr) == (part_i == nullptr), "sx_eval: part_f and part_i must be given together");
     hipStream_t s = (hipStream_t)stream;
-    if (is_wide(n)) return wide_eval(fun_id, X, P, n, ldx, xm, xstd, f, part_f, part_i, 0, nullptr, nullptr, s);
+    // Large populations of rows of 2049 ... 4096 elements: the eight-lanes-per-row kernel (launch_eval) instead of one workgroup
+    // per row -- Rosenbrock n = 2049 / 3000 0.45 / 0.49 -> 0.56 / 0.54 of the HBM peak, Ackley n = 2049 / 4096 0.28 / 0.43 ->
+    // 0.50 / 0.48; the cheap objectives from ~3600 elements on stay with the workgroup per row (n = 4096: 0.59-0.74 against
+    // 0.56-0.63: rows a power of two apart meet in the same memory channels).  profiles/r5_eval_r8_rt.txt, part 4.
+    const bool cheap = fun_id == SX_FUN_ROSENBROCK || fun_id == SX_FUN_SPHERE || fun_id == SX_FUN_QUARTIC ||
+                       fun_id == SX_FUN_STYBLINSKI_TANG;  // (light_objective<FUN>())
+    const bool long_rows = n <= kMaxDim && eval_r8_long_ok(P, n, xm, part_f, 0, 1) &&
+                           (eval_r8_long_mode() == 2 || !cheap || n <= 3584);
+    if (is_wide(n) && !long_rows) return wide_eval(fun_id, X, P, n, ldx, xm, xstd, f, part_f, part_i, 0, nullptr, nullptr, s);
     PlanArg plan;
     if (make_plan_arg(fun_id, n, &plan)) return -1;
     switch (fun_id) {

@@ -89,6 +89,44 @@ def test_objectives_one_batch_rows_of_any_length_eight_lanes_per_row(sa, name, n
         assert np.allclose(got8, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
 
 
+# 257: three leaves (129 -> 64 + 65 for Rosenbrock's 256 terms: two); 300 / 700 / 1023 / 1500: plans of 4 ... 16 leaves with tails;
+# 2047: 17 leaves; 2000 with a row stride of 2001 doubles (rows 8-byte aligned only)
+# 512 / 2048: the cosine objectives take this kernel there too (the cheap ones their compile-time plan); 2049 ... 4096: the smaller
+# population goes through the one-workgroup-per-row kernel (the cheap objectives beyond 3584 elements: both populations do)
+@pytest.mark.parametrize("n", [257, 300, 512, 700, 1023, 1500, 2000, 2047, 2048, 2049, 3000, 3584, 4095, 4096])
+@pytest.mark.parametrize("name", sorted(OBJECTIVES))
+def test_objectives_long_rows_of_any_length_eight_lanes_per_row(sa, name, n):
+    """Round 5: large populations (P >= 32768) of rows of 257 ... 4096 elements are evaluated by eval_r8_long_kernel -- eight
+    lanes per row straight from memory, the leaves one after the other, the recursion's combines by one lane: the same bits
+    as the oracle and as the wavefront-per-row / workgroup-per-row kernels, which a smaller population takes."""
+    import torch
+    from stochopy_amd import _device, _lib
+
+    P = 32768 + 5
+    rs = np.random.RandomState(n + 9)
+    ld = n + 1 if n == 2000 else n
+    Xh = rs.uniform(-5.12, 5.12, (P, ld))
+    ref = OBJECTIVES[name](Xh[:2051, :n])
+    ctx = _device.Context()
+    Xd = torch.as_tensor(Xh, device=ctx.device)
+    torch.cuda.synchronize()
+    got8 = _device.evaluate(ctx, _lib.FUN_IDS[name], Xd[:, :n], n)        # eight lanes per row
+    got = _device.evaluate(ctx, _lib.FUN_IDS[name], Xd[:2051, :n], n)     # fewer rows: one wavefront per row
+    ctx.sync()
+    got8, got = got8.cpu().numpy(), got.cpu().numpy()
+    assert np.array_equal(got8[:2051], got)
+    if name in EXACT:
+        assert np.array_equal(got, ref)
+    else:
+        assert np.allclose(got, ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
+    # the last rows too (a last workgroup of 5 rows), against the oracle
+    tail_ref = OBJECTIVES[name](Xh[P - 37:, :n])
+    if name in EXACT:
+        assert np.array_equal(got8[P - 37:], tail_ref)
+    else:
+        assert np.allclose(got8[P - 37:], tail_ref, rtol=RTOL_TRANSCENDENTAL, atol=1e-13)
+
+
 @pytest.mark.parametrize("n", [512, 1024, 2048])
 @pytest.mark.parametrize("name", sorted(OBJECTIVES))
 def test_objectives_long_rows_compile_time_plan(sa, name, n):

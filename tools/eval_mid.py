@@ -9,8 +9,9 @@ ctx = _device.Context()
 print("library:", _lib.LIB_PATH, flush=True)
 SHORT = len(sys.argv) > 1 and sys.argv[1] == "short"
 GRID = len(sys.argv) > 1 and sys.argv[1] == "grid"
+LONG = len(sys.argv) > 1 and sys.argv[1] == "long"
 for name in ("rosenbrock", "sphere", "rastrigin", "ackley", "griewank", "quartic", "styblinski_tang"):
-    for n in ((64, 128, 256) if GRID else (20, 50, 100, 130, 200, 250, 256) if SHORT else (100, 200, 300, 500, 700, 1000, 1500, 2000)):
+    for n in ((512, 1024, 2048, 2049, 3000, 4096) if LONG else (64, 128, 256) if GRID else (20, 50, 100, 130, 200, 250, 256) if SHORT else (100, 200, 300, 500, 700, 1000, 1500, 2000)):
         P = ((1 << 27) // n) // 64 * 64 + (8 if SHORT else 0)
         X = torch.rand((P, n), dtype=torch.float64, device=ctx.device) * 10.24 - 5.12
         f = ctx.empty((P,))
