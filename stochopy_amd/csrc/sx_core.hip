@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void eval_r8_kernel(const double *__restrict__
 // memory: lane (r, j) of a wavefront owns accumulator j of row r, so the elements it needs -- 8k + j -- are exactly the ones it
 // loads (eight rows x 64 consecutive bytes per load instruction, consecutive blocks in consecutive instructions: every 128-byte
 // line is fetched once and hit once); nothing is staged.  The neighbour of a Rosenbrock-like term is a second load of the
-// same lines.  Rows off the compile-time grid (n = 100, 200, ...) otherwise take the 16 / 32 / 64-lanes-per-row kernel:
+// same lines (taking it from the next lane by a DPP move, with lane 7 alone loading, was measured: 0.58 -> 0.36 of the HBM peak --
+// the eight-lane loads cost more than the full ones they replace; profiles/r5_eval_r8_rt.txt, part 5).  Rows off the compile-time grid (n = 100, 200, ...) otherwise take the 16 / 32 / 64-lanes-per-row kernel:
 // Rosenbrock n = 100 / 130 / 200 / 250 at large P: 0.40 / 0.20 / 0.28 / 0.34 of the HBM peak -> 0.65 / 0.62 / 0.64 / 0.61; Ackley 0.20 / 0.12
 // / 0.20 / 0.22 -> 0.47 / 0.48 / 0.54 / 0.52 (profiles/r5_eval_r8_rt.txt).
 template <int FUN>
