@@ -12,6 +12,8 @@
 //   stochopy/optimize/_common.py:163-194      selection_async (<=, best/status update per individual;
 //                                             only the LAST individual's status survives the sweep)
 //   stochopy/optimize/cpso/_constraints.py:56-64  Shrink, one-row form
+// (the ordered sweeps sit at their 128-VGPR cap: the reduction keeps the form with fewer live values -- tools/isa_survey.py)
+#define SX_FUSED_TAIL_BY_LANE 0
 #include "sx_device.hpp"
 #include "sx_host.hpp"
 #include "sx_rowops.hpp"
