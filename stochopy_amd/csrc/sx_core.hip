@@ -516,10 +516,17 @@ static int eval_r8_long_mode() {
     static const int mode = getenv("SX_EVAL_R8LONG") ? atoi(getenv("SX_EVAL_R8LONG")) : 1;
     return mode;
 }
-static bool eval_r8_long_ok(int64_t P, int n, const double *xm, const double *part_f, int clip, int nleaf) {
-    static const int64_t min_rows = getenv("SX_EVAL_R8_MIN") ? atoll(getenv("SX_EVAL_R8_MIN")) : 32768;
+// From which population size on (profiles/r5_eval_small_p.txt: a row is a serial walk of n / 8 blocks here, so a small population
+// is faster one wavefront per row): off the compile-time grid 8192 rows (a cosine per term: 16 384); where the alternative is a
+// compile-time plan or the workgroup per row (n = 512 / 1024 / 2048, n > 2048), measured at large P only: 32 768.
+static int64_t eval_r8_min_rows(int64_t dflt) {
+    static const int64_t forced = getenv("SX_EVAL_R8_MIN") ? atoll(getenv("SX_EVAL_R8_MIN")) : -1;
+    return forced >= 0 ? forced : dflt;
+}
+static bool eval_r8_long_ok(int64_t P, int n, const double *xm, const double *part_f, int clip, int nleaf, bool cheap) {
+    const bool has_rival = n > kWideFrom || n == 512 || n == 1024 || n == 2048;
     return eval_r8_long_mode() != 0 && n > 256 && n <= kMaxDim && nleaf >= 1 && nleaf <= kMaxLeaf && xm == nullptr &&
-           part_f == nullptr && clip == 0 && P >= min_rows;
+           part_f == nullptr && clip == 0 && P >= eval_r8_min_rows(has_rival ? 32768 : cheap ? 8192 : 16384);
 }
 
 // mode 1: rows off the compile-time grid; 2: every one-batch row (measurement: against eval_r8_kernel at n = 64 / 128 / 256)
@@ -528,8 +535,9 @@ static int eval_r8_rt_mode() {
     return mode;
 }
 static bool eval_r8_rt_ok(int64_t P, int n, const double *xm, const double *part_f, int clip) {
-    static const int64_t min_rows = getenv("SX_EVAL_R8_MIN") ? atoll(getenv("SX_EVAL_R8_MIN")) : 32768;
-    return eval_r8_rt_mode() != 0 && n >= 16 && n <= 256 && xm == nullptr && part_f == nullptr && clip == 0 && P >= min_rows;
+    const bool on_grid = n == 64 || n == 128 || n == 256;
+    return eval_r8_rt_mode() != 0 && n >= 16 && n <= 256 && xm == nullptr && part_f == nullptr && clip == 0 &&
+           P >= eval_r8_min_rows(on_grid ? 32768 : 8192);
 }
 
 #ifndef SX_EVAL_HEAVY_STATIC
@@ -571,7 +579,7 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
     hipLaunchKernelGGL((eval_kernel<FUN, __VA_ARGS__>), dim3(g.blocks), dim3(g.threads), lds, s, X, P, n, ldx, xm, xstd, f, \
                        plan, part_f, part_i, clip, pen_v, pen_out)
     const bool grid_long = clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0;
-    if (eval_r8_long_ok(P, n, xm, part_f, clip, plan.nleaf) && (eval_r8_long_mode() == 2 || !(kLight && grid_long))) {
+    if (eval_r8_long_ok(P, n, xm, part_f, clip, plan.nleaf, kLight) && (eval_r8_long_mode() == 2 || !(kLight && grid_long))) {
         // many long rows: eight lanes per row, straight from memory.  Not the cheap objectives at n = 512 / 1024 / 2048: their
         // compile-time plan below stays ahead (Rosenbrock 0.61 / 0.76 / 0.66 of the HBM peak against 0.58 / 0.54 / 0.55);
         // the cosine objectives gain there too (Ackley 0.30 / 0.47 / 0.35 -> 0.49 / 0.50 / 0.48): profiles/r5_eval_r8_rt.txt
@@ -635,7 +643,7 @@ extern "C" int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ld
     // 0.56-0.63: rows a power of two apart meet in the same memory channels).  profiles/r5_eval_r8_rt.txt, part 4.
     const bool cheap = fun_id == SX_FUN_ROSENBROCK || fun_id == SX_FUN_SPHERE || fun_id == SX_FUN_QUARTIC ||
                        fun_id == SX_FUN_STYBLINSKI_TANG;  // (light_objective<FUN>())
-    const bool long_rows = n <= kMaxDim && eval_r8_long_ok(P, n, xm, part_f, 0, 1) &&
+    const bool long_rows = n <= kMaxDim && eval_r8_long_ok(P, n, xm, part_f, 0, 1, cheap) &&
                            (eval_r8_long_mode() == 2 || !cheap || n <= 3584);
     if (is_wide(n) && !long_rows) return wide_eval(fun_id, X, P, n, ldx, xm, xstd, f, part_f, part_i, 0, nullptr, nullptr, s);
     PlanArg plan;
