@@ -23,6 +23,6 @@ for d in ("sq","sq2","lds","fetch"):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[(k, r["Counter_Name"])] += 1
         for k, v in acc.items():
-            if "wide" in k or "eval" in k:
+            if "wide" in k or "eval" in k or "generation" in k:
                 print(d, k, {c: round(x / max(1, cnt[(k, c)])) for c, x in v.items()})
 PY
