@@ -796,6 +796,39 @@ __device__ __forceinline__ void scan_records(const double *__restrict__ part_f, 
         scan_records_n<8>(part_f, part_i, npart, bf, bi);
 }
 
+// dst[e] = src[e] / sum of (a[e] - b[e])^2 over the elements of this thread (e = thread, thread + 256, ...: in that order), eight
+// loads in flight per thread: the one-workgroup steps of the sharded path walk whole rows (up to 262 144 elements) with these
+__device__ __forceinline__ void final_copy(double *__restrict__ dst, const double *__restrict__ src, int n) {
+    for (int eb = threadIdx.x; eb < n; eb += 8 * kFinalThreads) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = eb + u * kFinalThreads < n ? src[eb + u * kFinalThreads] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (eb + u * kFinalThreads < n) dst[eb + u * kFinalThreads] = v[u];
+    }
+}
+__device__ __forceinline__ double final_dist2(const double *__restrict__ a, const double *__restrict__ b, int n) {
+    double acc = 0.0;
+    for (int eb = threadIdx.x; eb < n; eb += 8 * kFinalThreads) {
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = eb + u * kFinalThreads < n;
+            x[u] = in ? a[eb + u * kFinalThreads] : 0.0;
+            y[u] = in ? b[eb + u * kFinalThreads] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (eb + u * kFinalThreads < n) {
+                const double d = x[u] - y[u];
+                acc += d * d;
+            }
+        }
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
     const double *__restrict__ part_f, const int64_t *__restrict__ part_i, int64_t npart,
     const double *__restrict__ rows0, const double *__restrict__ rows1, int64_t ld, int n,
@@ -829,11 +862,8 @@ __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
                 acc += d * d;
             }
         }
-    } else {  // wide rows: the same per-thread order of additions, the row read again for the copy
-        for (int e = threadIdx.x; e < n; e += kFinalThreads) {
-            const double d = gbest[e] - src[e];
-            acc += d * d;
-        }
+    } else {  // (longer rows take the three-launch form below: sx_select_finalize / add_finalize_node)
+        acc = final_dist2(gbest, src, n);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
@@ -847,7 +877,7 @@ __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
         for (int u = 0; u < kPer; ++u)
             if (threadIdx.x + u * kFinalThreads < n) gbest[threadIdx.x + u * kFinalThreads] = sv[u];
     } else {
-        for (int e = threadIdx.x; e < n; e += kFinalThreads) gbest[e] = src[e];
+        final_copy(gbest, src, n);
     }
     if (threadIdx.x == 0) {
         int status = SX_STATUS_NONE;
@@ -866,11 +896,105 @@ __global__ __launch_bounds__(kFinalThreads) void select_finalize_kernel(
     }
 }
 
+// The same step for rows of more than kMaxDim elements, in three launches: one workgroup walking a row of 65 536 elements twice
+// (the step of the best, then the copy) took 160 us per generation -- a third of a DE generation at that length
+// (profiles/r5_wide_finalize.txt: select_finalize_kernel 47.6 us on average over the wide benchmark).  (1) the best record ->
+// state->gbidx / gfit; (2) up to 64 workgroups: a slice of the row each -- its share of |gbest - x[best]|^2 (a fixed order: per
+// thread, the wavefront's tree, the workgroup's four sums) into the first slots of the record buffer, which (1) has consumed,
+// and the copy; (3) the shares added in order, the termination rules, the state.
+constexpr int kWideFinalBlocks = 64;
+__global__ __launch_bounds__(kFinalThreads) void wide_finalize_best_kernel(const double *__restrict__ part_f,
+                                                                           const int64_t *__restrict__ part_i, int64_t npart,
+                                                                           sx_state *__restrict__ state) {
+    __shared__ double sf[kFinalThreads / kWave];
+    __shared__ int64_t si[kFinalThreads / kWave];
+    double bf = __builtin_huge_val();
+    int64_t bi = INT64_MAX;
+    scan_records(part_f, part_i, npart, bf, bi);
+    if (state->done) return;
+    block_argmin(bf, bi, sf, si);
+    if (threadIdx.x == 0) {
+        state->gbidx = bi;
+        state->gfit = bf;
+    }
+}
+__global__ __launch_bounds__(kFinalThreads) void wide_finalize_row_kernel(const double *__restrict__ rows0,
+                                                                          const double *__restrict__ rows1, int64_t ld, int n,
+                                                                          double *__restrict__ gbest,
+                                                                          const sx_state *__restrict__ state,
+                                                                          double *__restrict__ share) {
+    __shared__ double sf[kFinalThreads / kWave];
+    if (state->done) return;
+    const int64_t it = state->it + 1;  // the generation being finalised
+    const double *__restrict__ src = ((it & 1) ? rows1 : rows0) + state->gbidx * ld;
+    const int per = (((n + (int)gridDim.x - 1) / (int)gridDim.x + kFinalThreads - 1) / kFinalThreads) * kFinalThreads;
+    const int e0 = (int)blockIdx.x * per, e1 = e0 + per < n ? e0 + per : n;
+    double acc = 0.0;
+    for (int eb = e0 + (int)threadIdx.x; eb < e1; eb += 8 * kFinalThreads) {
+        double g[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = eb + u * kFinalThreads;
+            g[u] = e < e1 ? gbest[e] : 0.0;
+            x[u] = e < e1 ? src[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = eb + u * kFinalThreads;
+            if (e < e1) {
+                const double d = g[u] - x[u];
+                acc += d * d;
+                gbest[e] = x[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ss = 0.0;
+        for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
+        share[blockIdx.x] = ss;
+    }
+}
+__global__ __launch_bounds__(kWave) void wide_finalize_state_kernel(const double *__restrict__ share, int nshare,
+                                                                    sx_state *__restrict__ state, int maxiter, double xtol,
+                                                                    double ftol) {
+    if (threadIdx.x != 0 || state->done) return;
+    double ss = 0.0;
+    for (int k = 0; k < nshare; ++k) ss += share[k];
+    const double dx = sqrt(ss), bf = state->gfit;
+    const int64_t it = state->it + 1;
+    int status = SX_STATUS_NONE;
+    if (dx <= xtol && bf <= ftol)
+        status = 0;
+    else if (bf <= ftol)
+        status = 1;
+    else if (it >= maxiter)
+        status = -1;
+    state->it = it;
+    state->dx = dx;
+    state->status = status;
+    state->done = status != SX_STATUS_NONE;
+}
+static inline int wide_final_blocks(int64_t npart) { return npart < kWideFinalBlocks ? (int)npart : kWideFinalBlocks; }
+
 extern "C" int sx_select_finalize(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
                                   const double *rows1, int64_t ld, int n, double *gbest, sx_state *state, int maxiter,
                                   double xtol, double ftol, void *stream) {
     SX_REQUIRE(part_f && part_i && rows0 && rows1 && gbest && state && npart >= 1 && n >= 1,
                "sx_select_finalize: bad arguments");
+    if (n > kMaxDim) {
+        hipStream_t s = (hipStream_t)stream;
+        const int nb = wide_final_blocks(npart);
+        double *share = const_cast<double *>(part_f);  // (consumed by the first launch)
+        hipLaunchKernelGGL(wide_finalize_best_kernel, dim3(1), dim3(kFinalThreads), 0, s, part_f, part_i, npart, state);
+        hipLaunchKernelGGL(wide_finalize_row_kernel, dim3(nb), dim3(kFinalThreads), 0, s, rows0, rows1, ld, n, gbest, state, share);
+        hipLaunchKernelGGL(wide_finalize_state_kernel, dim3(1), dim3(kWave), 0, s, share, nb, state, maxiter, xtol, ftol);
+        SX_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(select_finalize_kernel, dim3(1), dim3(kFinalThreads), 0, (hipStream_t)stream, part_f, part_i,
                        npart, rows0, rows1, ld, n, gbest, state, maxiter, xtol, ftol);
     SX_LAUNCH_CHECK();
@@ -893,7 +1017,7 @@ __global__ __launch_bounds__(kFinalThreads) void shard_best_kernel(
     const int64_t it = state->it + 1;  // the generation being finalised
     block_argmin(bf, bi, sf, si);
     const double *src = ((it & 1) ? rows1 : rows0) + bi * ld;
-    for (int e = threadIdx.x; e < n; e += kFinalThreads) record[2 + e] = src[e];
+    final_copy(record + 2, src, n);
     if (threadIdx.x == 0) {
         record[0] = bf;
         record[1] = (double)(row0 + bi);  // exact below 2^53
@@ -921,11 +1045,7 @@ __global__ __launch_bounds__(kFinalThreads) void gather_finalize_kernel(const do
         }
     }
     const double *src = records + best * stride + 2;
-    double acc = 0.0;
-    for (int e = threadIdx.x; e < n; e += kFinalThreads) {
-        const double d = gbest[e] - src[e];
-        acc += d * d;
-    }
+    double acc = final_dist2(gbest, src, n);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
     if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = acc;
@@ -933,7 +1053,7 @@ __global__ __launch_bounds__(kFinalThreads) void gather_finalize_kernel(const do
     double ss = 0.0;
     for (int k = 0; k < kFinalThreads / kWave; ++k) ss += sf[k];
     const double dx = sqrt(ss);
-    for (int e = threadIdx.x; e < n; e += kFinalThreads) gbest[e] = src[e];
+    final_copy(gbest, src, n);
     if (threadIdx.x == 0) {
         const int64_t it = state->it + 1;
         int status = SX_STATUS_NONE;
@@ -976,6 +1096,29 @@ namespace sx {
 int add_finalize_node(hipGraph_t graph, hipGraphNode_t *prev, const double *part_f, const int64_t *part_i,
                       int64_t npart, const double *rows0, const double *rows1, int64_t ld, int n, double *gbest,
                       sx_state *state, int maxiter, double xtol, double ftol) {
+    if (n > kMaxDim) {  // the three launches of sx_select_finalize's wide form
+        int nb = wide_final_blocks(npart);
+        double *share = const_cast<double *>(part_f);
+        auto add = [&](void *fn, unsigned grid, unsigned block, void **ka) -> int {
+            hipKernelNodeParams kq = {};
+            kq.func = fn;
+            kq.gridDim = dim3(grid);
+            kq.blockDim = dim3(block);
+            kq.sharedMemBytes = 0;
+            kq.kernelParams = ka;
+            kq.extra = nullptr;
+            hipGraphNode_t nd;
+            SX_HIP(hipGraphAddKernelNode(&nd, graph, *prev ? prev : nullptr, *prev ? 1 : 0, &kq));
+            *prev = nd;
+            return 0;
+        };
+        void *k1[] = {&part_f, &part_i, &npart, &state};
+        if (int rc = add((void *)wide_finalize_best_kernel, 1, kFinalThreads, k1)) return rc;
+        void *k2[] = {&rows0, &rows1, &ld, &n, &gbest, &state, &share};
+        if (int rc = add((void *)wide_finalize_row_kernel, (unsigned)nb, kFinalThreads, k2)) return rc;
+        void *k3[] = {&share, &nb, &state, &maxiter, &xtol, &ftol};
+        return add((void *)wide_finalize_state_kernel, 1, kWave, k3);
+    }
     void *kargs[] = {&part_f, &part_i, &npart, &rows0, &rows1, &ld, &n, &gbest, &state, &maxiter, &xtol, &ftol};
     hipKernelNodeParams kp = {};
     kp.func = (void *)select_finalize_kernel;
