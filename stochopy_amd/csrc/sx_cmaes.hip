@@ -680,6 +680,9 @@ __global__ __launch_bounds__(256) void vd_t_kernel(const double *__restrict__ ar
 }
 
 // grid: ceil(n/64) x 16; part[o][q][e], o = 0..3 (wx, wy, p, q), q = k mod 64
+// W = 2: two adjacent columns per thread (16-byte loads: a wavefront takes 1 KB of a selected row, not 512 bytes -- the kernel is a
+// gather of row pieces); n even.  Per column the same operations in the same order as W = 1.
+template <int W>
 __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *__restrict__ arx, const double *__restrict__ ary,
                                                                  const int64_t *__restrict__ idx, const double *__restrict__ w,
                                                                  const double *__restrict__ tk, int mu, int n,
@@ -689,23 +692,41 @@ __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *_
     // tk_by_row: tk holds t of EVERY candidate row (left by the wide candidates kernel, sx_wide.hip), not of the selected ones
     if (st != nullptr) norm_v2 = st->reserved[1];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + tx;
+    const int col = (blockIdx.x * 64 + tx) * W;
     const int q = blockIdx.y * 4 + ty;
     if (col >= n) return;
     const double shrink = norm_v2 / (1.0 + norm_v2);
-    const double dv = dvec[col], v = vn[col];
-    double awx = 0.0, awy = 0.0, ap = 0.0, aq = 0.0;
+    double dv[W], v[W], awx[W], awy[W], ap[W], aq[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) dv[c] = dvec[col + c], v[c] = vn[col + c], awx[c] = 0.0, awy[c] = 0.0, ap[c] = 0.0, aq[c] = 0.0;
     for (int k = q; k < mu; k += kVdPart) {
         const int64_t row = idx[k] * (int64_t)n + col;
-        const double wk = w[k], t = tk[tk_by_row ? idx[k] : k], ax = arx[row], ay = ary[row];
-        const double y = ay / dv;
-        awx += wk * ax;
-        awy += wk * ay;
-        ap += wk * (y * y - shrink * (t * (y * v)) - 1.0);
-        aq += wk * (t * y - (0.5 * (t * t + 1.0 + norm_v2)) * v);
+        const double wk = w[k], t = tk[tk_by_row ? idx[k] : k];
+        double ax[W], ay[W];
+        if constexpr (W >= 2) {
+#pragma unroll
+            for (int c = 0; c < W; c += 2) {
+                const double2 a2 = *reinterpret_cast<const double2 *>(arx + row + c), y2 = *reinterpret_cast<const double2 *>(ary + row + c);
+                ax[c] = a2.x, ax[c + 1] = a2.y, ay[c] = y2.x, ay[c + 1] = y2.y;
+            }
+        } else {
+            ax[0] = arx[row], ay[0] = ary[row];
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const double y = ay[c] / dv[c];
+            awx[c] += wk * ax[c];
+            awy[c] += wk * ay[c];
+            ap[c] += wk * (y * y - shrink * (t * (y * v[c])) - 1.0);
+            aq[c] += wk * (t * y - (0.5 * (t * t + 1.0 + norm_v2)) * v[c]);
+        }
     }
-    const int64_t o = (int64_t)q * n + col, plane = (int64_t)kVdPart * n;
-    part[o] = awx, part[plane + o] = awy, part[2 * plane + o] = ap, part[3 * plane + o] = aq;
+    const int64_t plane = (int64_t)kVdPart * n;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+        const int64_t o = (int64_t)q * n + col + c;
+        part[o] = awx[c], part[plane + o] = awy[c], part[2 * plane + o] = ap[c], part[3 * plane + o] = aq[c];
+    }
 }
 
 // grid: ceil(n/64) x 4 outputs; the 64 partial rows of a column are added in their order (four slices of 16, then the
@@ -738,8 +759,15 @@ int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, 
     double *tk = ws, *part = ws + ((mu + 7) / 8) * 8;
     if (tk_rows == nullptr)
         hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
-    hipLaunchKernelGGL(vd_moments_partial_kernel, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
-                       w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0);
+    // (four columns per thread were measured too: 33.9 / 148 us against 33.2 / 128.5 with two, 44.1 / 168.7 with one --
+    //  n = 16 384, mu = 512 / 2048: profiles/r5_vdcma_moments_note.txt)
+    const bool pairs = n % 2 == 0 && (((uintptr_t)arx | (uintptr_t)ary) & 15) == 0;
+    if (pairs)
+        hipLaunchKernelGGL(vd_moments_partial_kernel<2>, dim3((unsigned)((n / 2 + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary,
+                           idx, w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0);
+    else
+        hipLaunchKernelGGL(vd_moments_partial_kernel<1>, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
+                           w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0);
     hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 63) / 64), 4), dim3(256), 0, st, part, n, out);
     SX_LAUNCH_CHECK();
     return 0;
