@@ -538,6 +538,14 @@ int sx_cmaes_generation_phased(const sx_cma_args *a, int64_t gen, int do_eigh, i
  * mode 1: always allowed; 0: never; -1 (initial): allowed inside the CMA-ES generation loops (sx_cmaes_generation*),
  * not in sx_eigh itself; the environment variable SX_EIGH_REFINE = 0 / 1 sets the initial mode.  Returns the
  * previous mode.  Process-wide, not thread-safe.
+ * sx_eigh_set_flow(mode): how the rounds of a run are enqueued (n > 32).  0 (the default): one launch per round.
+ * 1: ONE resident launch works through all rounds -- pair workgroups hand their rotations to their two successors through
+ * agent-scope words, tile workgroups follow behind counters; every wait is bounded (SX_EIGH_FLOW_TIMEOUT_MS, default 2000: a
+ * run whose wait ran out is reported like one that did not converge).  Identical results, bit for bit; measured on MI355X it
+ * is no faster (profiles/r6_eigh_flow.txt), hence not the default.  The resident form needs its whole grid (at most one
+ * workgroup per CU) on the chip at once: PROCESSES THAT SHARE ONE GPU MUST NOT USE IT.  -1: back to the initial mode
+ * (environment variable SX_EIGH_FLOW = 0 / 1, else 0).  Returns the previous mode; -2 changes nothing and returns the mode in
+ * effect (0 / 1).  Process-wide, not thread-safe.
  * ------------------------------------------------------------------------- */
 int64_t sx_eigh_workspace_bytes(int n);
 int sx_eigh(const double *C, int n, const double *V0, double *w, double *B, void *ws, int64_t ws_bytes, int max_sweeps,
@@ -548,6 +556,7 @@ int sx_eigh_refined(const double *C, int n, const double *V0, double *w, double 
                     int max_sweeps, double tol, int refine, void *stream);
 int sx_eigh_info(const void *ws, int *sweeps, int *converged, double *off_rel, void *stream);
 int sx_eigh_set_refine(int mode);
+int sx_eigh_set_flow(int mode);
 
 /* VD-CMA: everything of the model update that is O(mu n), on the device.
  * replaces vdcma/_vdcma.py:289-295 (w . arx[arindex[:mu]]), :317 (w . ary[arindex[:mu]]) and :331-339 with :428-444 (the

@@ -187,6 +187,7 @@ PROTOTYPES = {
     "sx_eigh_refined": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, i64, C.c_int, f64, C.c_int, vp]),
     "sx_eigh_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f64), vp]),
     "sx_eigh_set_refine": (C.c_int, [C.c_int]),
+    "sx_eigh_set_flow": (C.c_int, [C.c_int]),
     "sx_mt_create": (vp, [C.c_uint32]),
     "sx_mt_destroy": (None, [vp]),
     "sx_mt_seed": (None, [vp, C.c_uint32]),

@@ -54,9 +54,31 @@ extern "C" int sx_eigh_trace_read(unsigned long long *out) {
     do {                                                                                      \
         if ((cond) && blockIdx.x < 64) sx_eigh_trace_buf[blockIdx.x * 16 + (k)] = clock64(); \
     } while (0)
+// the resident kernel (tools/trace_eigh_flow.py): wall-clock stamps (100 MHz, the same clock on every CU) of workgroups
+// 0..63 in launch numbers [kFtRound0, kFtRound0 + 8): [workgroup][round][slot]
+__device__ unsigned long long sx_eigh_ftrace_buf[64 * 8 * 16];
+__device__ int sx_eigh_ftrace_round0 = 40;
+__shared__ int g_ft_round;
+#define SX_FT_BEGIN(k)                                                                        \
+    do {                                                                                      \
+        if (threadIdx.x == 0) g_ft_round = (k) - sx_eigh_ftrace_round0;                       \
+    } while (0)
+#define SX_FTP(slot)                                                                          \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && g_ft_round >= 0 && g_ft_round < 8)         \
+            sx_eigh_ftrace_buf[(blockIdx.x * 8 + g_ft_round) * 16 + (slot)] = wall_clock64(); \
+    } while (0)
+extern "C" int sx_eigh_ftrace_read(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sx_eigh_ftrace_buf), sizeof(unsigned long long) * 64 * 8 * 16);
+}
+extern "C" int sx_eigh_ftrace_set_round(int k) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sx_eigh_ftrace_round0), &k, sizeof(int));
+}
 #else
 #define SX_ETP(k) do {} while (0)
 #define SX_ETQ(cond, k) do {} while (0)
+#define SX_FT_BEGIN(k) do {} while (0)
+#define SX_FTP(slot) do {} while (0)
 #endif
 
 namespace {
@@ -79,7 +101,7 @@ struct EighInfo {  // first bytes of the workspace
     double offm[kEighMaxSweeps];  // squared off-diagonal mass of M AFTER each sweep, measured exactly by the tile
                                   // workgroups that apply the sweep's last rotations
     int32_t refine;     // 1: the run ended with the first-order refinement step still to be applied (see below)
-    int32_t pad_;
+    int32_t fault;      // resident kernel only: a bounded wait ran out (kFlowWait*): the run record is not to be trusted
     unsigned long long kmax2[kEighMaxSweeps];  // bits of max (M_ij / (M_jj - M_ii))^2 over the significant elements
                                                // of M after each sweep (same launch as offm)
 };
@@ -798,196 +820,332 @@ struct RoundLds {
     double scale;                // power of two that brings |C|_F (hence every pivot entry) below 1
     double tolel2;               // square of the size below which an off-diagonal element does not count (tol |C|_F / npad)
     int flag;
+    int ok;                      // (the resident kernel: a wait came back without its condition)
 };
 
-// One launch per round.  blockIdx < np: pair workgroups (rotation U_cur of the round rcur from the current pivot);
-// then np*np tiles of M and nr*np tiles of V, which apply the rotations U_prev of the round rprev.
-// flush != 0: no pair workgroups' sweeps (the last rotations are applied and the run is closed by the host).
+// (namespace scope: the resident kernel's pair round is a function of its own, see flow_pair_round)
+__shared__ RoundLds g_round_lds;
+
 constexpr int kRoundThreads = jacobi_threads<kM2>() + 64;  // 256 updating threads + the rotation wave of the pivot
                                                             // sweep + a sixth wave: the pivot products split six ways
+constexpr int kTileRegs = (kUU + kRoundThreads - 1) / kRoundThreads;  // elements of a 32x32 tile per thread
 
-__global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double *__restrict__ Min, const double *__restrict__ Vin,
-                                                         double *__restrict__ Mout, double *__restrict__ Vout, int npad,
-                                                         int nb, const double *__restrict__ Uprev,
-                                                         double *__restrict__ Ucur, EighInfo *info, int sweep, int rprev,
-                                                         int rcur, int parity_out, double tol, int flush, int seq,
-                                                         int refine) {
-    __shared__ RoundLds L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int np = nb / 2;
-    // ---- run state: every workgroup derives the same decision from what earlier launches left ----
-    // The record is a miss in every cache after the kernel boundary (~1 us).  Nothing below waits for it before the
-    // pair workgroups' own loads are in flight: those do not depend on it (a launch that turns out to be a no-op has
-    // read a few valid tiles for nothing).
-    int ended = 0;
-    double nrm2 = 0.0, left = 0.0, met1 = 0.0, met0 = 0.0, kmax2 = 0.0;
-    if (tid == 0) {
-        ended = info->done_seq, nrm2 = info->norm2;
-        if (sweep > 0) left = info->offm[sweep - 1], met1 = info->acc[sweep - 1];
-        if (sweep > 0 && refine) kmax2 = __longlong_as_double((long long)info->kmax2[sweep - 1]);
-        if (sweep > 1) met0 = info->acc[sweep - 2];
-    }
-    // pair workgroups: source tiles (pairs of rprev) 0: (PI,PI)  1: (PI,PJ)  2: (PJ,PJ) and the rotations of PI and PJ.
-    // 256 threads x 4 elements of each: 20 loads in flight per thread.
-    const bool is_pair = (int)blockIdx.x < np && !flush;
-    int I = 0, Jb = 0, PI = 0, posI = 0, PJ = 0, posJ = 0;
-    double x0[4], x1[4], x2[4], ua[4], ub[4];
-    if (is_pair) {
-        rr_pair((int)blockIdx.x, rcur, nb, I, Jb);
-        rr_find(I, rprev, nb, PI, posI);
-        rr_find(Jb, rprev, nb, PJ, posJ);
-        int aI, bI, aJ, bJ;
-        rr_pair(PI, rprev, nb, aI, bI);
-        rr_pair(PJ, rprev, nb, aJ, bJ);
-        if (tid < 256) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = tid + 256 * u, i = e / kM2, j = e % kM2;
-                const int giI = pair_index(i, aI, bI), giJ = pair_index(i, aJ, bJ);
-                const int gjI = pair_index(j, aI, bI), gjJ = pair_index(j, aJ, bJ);
-                x0[u] = Min[(int64_t)giI * npad + gjI];
-                x1[u] = Min[(int64_t)giI * npad + gjJ];
-                x2[u] = Min[(int64_t)giJ * npad + gjJ];
-                ua[u] = Uprev[(int64_t)PI * kUU + e];
-                ub[u] = Uprev[(int64_t)PJ * kUU + e];
-            }
-        }
-    }
-    if (tid == 0) {
-        const double thr2 = tol * tol * nrm2;
-        int flag = (ended != 0 && ended < seq) ? 2 : 0;  // 2: the run ended in an EARLIER launch: nothing to do
-        if (!flag && rcur == 1 && sweep > 0 && !flush && left <= thr2) {
+// Global accesses of the round's work.  FLOW = false: one launch per round, the kernel boundary makes everything visible:
+// plain loads and stores.  FLOW = true: all rounds inside ONE resident launch (eigh_flow_kernel): whatever one workgroup writes
+// and another reads in the same launch goes as agent-scope accesses -- write-through stores, loads that bypass this CU's vector
+// L1 (cdna_hip_programming.md section 6, Guideline 16, form R1) -- ordered by counters, never by placement.
+template <bool FLOW>
+__device__ __forceinline__ double gld(const double *p) {
+    if constexpr (FLOW)  // (a GLOBAL access: through a generic pointer it would be a flat_load, counted as an LDS access too)
+        return __hip_atomic_load((__attribute__((address_space(1))) double *)const_cast<double *>(p), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+    else
+        return *p;
+}
+template <bool FLOW>
+__device__ __forceinline__ void gst(double *p, double v) {
+    if constexpr (FLOW)
+        __hip_atomic_store((__attribute__((address_space(1))) double *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+// 16-byte agent-scope accesses (buffer instructions with the sc1 bit: what Guideline 16 prescribes for payloads; an 8-byte
+// write-through store costs 2.7x a 16-byte one per byte on this fabric).  Offsets are bytes from the buffer's base.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int kAuxSc1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const void *base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(bytes > 0x7fffffffll ? 0x7fffffffll : bytes), 0x00020000);
+}
+__device__ __forceinline__ f64x2 ld16(__amdgpu_buffer_rsrc_t r, int off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kAuxSc1);
+    f64x2 d;
+    __builtin_memcpy(&d, &v, 16);
+    return d;
+}
+__device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, int off, f64x2 d) {
+    u32x4 v;
+    __builtin_memcpy(&v, &d, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, kAuxSc1);
+}
+
+// What launch number k (0-based) of a run means -- the same for the launch-per-round form and the resident one: it reads
+// the buffer pair k & 1, applies the rotations of round (k - 1) % rps (identities for k = 0 under any pairing), works out
+// those of round k % rps, and its launch number is k + 1.  Rotations live in THREE buffers (k % 3): inside the resident
+// kernel a fast pair workgroup may publish round k + 2 while a slow one still reads round k.
+struct RoundPar {
+    const double *Min, *Vin;
+    double *Mout, *Vout;
+    const double *Uprev;
+    double *Ucur;
+    int sweep, rprev, rcur, parity_out, seq;
+};
+
+// Thread 0 of every workgroup: what this launch has to do, from what earlier launches left in the run record.  Every
+// workgroup derives the same answer (the sums it reads are final).  0: a round as usual; 1: apply the last rotations of
+// the sweep that just ended and start no new ones; 2: nothing -- the run has ended.  `writer` (workgroup 0) records it.
+template <bool FLOW>
+__device__ int round_state(EighInfo *info, int ended, double nrm2, const RoundPar &R, double tol, int flush, int refine,
+                           bool writer) {
+    if (ended != 0 && ended < R.seq) return 2;  // the run ended in an EARLIER launch: nothing to do
+    if (flush || R.sweep == 0 || R.rcur > 1) return 0;
+    const int sweep = R.sweep;
+    const double thr2 = tol * tol * nrm2;
+    if (R.rcur == 1) {
+        const double left = gld<FLOW>(&info->offm[sweep - 1]);
+        if (left <= thr2) {
             // The previous launch applied the last rotations of sweep `sweep - 1` and measured what that sweep left
             // behind: nothing above the tolerance.  The matrix this launch would read IS the result; the rotations of
             // round 0 that were worked out beside the measurement are dropped.  (Costs one round, not a whole
             // verifying sweep.)
-            flag = 2;
-            if (blockIdx.x == 0) {
-                info->sweeps = sweep, info->parity = parity_out ^ 1, info->converged = 1;
+            if (writer) {
+                info->sweeps = sweep, info->parity = R.parity_out ^ 1, info->converged = 1;
                 info->thr2 = thr2;
-                info->done_seq = seq;
+                info->done_seq = R.seq;
             }
+            return 2;
         }
-        if (!flag && refine && rcur == 1 && sweep > 0 && !flush && left <= kRefineOff * kRefineOff * nrm2 &&
-            kmax2 <= kRefineCap * kRefineCap && kmax2 * left <= kRefineProd * kRefineProd * nrm2) {
-            // what is left is first order against every gap: the run ends here and the refinement step finishes it
-            flag = 2;
-            if (blockIdx.x == 0) {
-                info->sweeps = sweep, info->parity = parity_out ^ 1, info->converged = 1;
-                info->thr2 = thr2;
-                info->refine = 1;
-                info->done_seq = seq;
-            }
-        }
-        if (!flag && rcur == 0 && sweep > 0 && !flush) {
-            // second rule, from the mass met DURING the last two sweeps (eigh_last_sweep)
-            const bool last = met1 <= thr2 || (met1 <= 1.0e-20 * nrm2 && (sweep == 1 || met1 * met1 <= thr2 * met0));
-            if (last) {
-                flag = 1;  // apply the last rotations of the sweep that just ended, start no new ones
-                if (blockIdx.x == 0) {
-                    info->sweeps = sweep, info->parity = parity_out, info->converged = 1;
+        if (refine) {
+            unsigned long long kb;
+            if constexpr (FLOW)
+                kb = __hip_atomic_load(&info->kmax2[sweep - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                kb = info->kmax2[sweep - 1];
+            const double kmax2 = __longlong_as_double((long long)kb);
+            if (left <= kRefineOff * kRefineOff * nrm2 && kmax2 <= kRefineCap * kRefineCap &&
+                kmax2 * left <= kRefineProd * kRefineProd * nrm2) {
+                // what is left is first order against every gap: the run ends here and the refinement step finishes it
+                if (writer) {
+                    info->sweeps = sweep, info->parity = R.parity_out ^ 1, info->converged = 1;
                     info->thr2 = thr2;
-                    info->done_seq = seq;
+                    info->refine = 1;
+                    info->done_seq = R.seq;
                 }
+                return 2;
             }
         }
-        L.flag = flag;
-        L.tolel2 = tol * tol * nrm2 / ((double)npad * (double)npad);
-        int ex = 0;
-        const double nrm = sqrt(nrm2);
-        if (nrm > 0.0 && nrm < __builtin_inf()) (void)frexp(nrm, &ex);
-        L.scale = ldexp(1.0, -ex);
+        return 0;
     }
-    __syncthreads();
-    const int state = L.flag;
-    if (state == 2) return;
-    const int lr = lane & 15, lk = lane >> 4;
-    if ((int)blockIdx.x >= np) {
-        // =========================== tile workgroups ===========================
-        const int tile = (int)blockIdx.x - np;
-        const bool is_m = tile < np * np;
-        const int P = is_m ? tile / np : (tile - np * np) / np;  // M: pair of rprev; V: chunk of 32 rows
-        const int Q = is_m ? tile % np : (tile - np * np) % np;
-        int aq, bq, ap = 0, bp = 0;
-        rr_pair(Q, rprev, nb, aq, bq);
-        if (is_m) rr_pair(P, rprev, nb, ap, bp);
-        const double *src = is_m ? Min : Vin;
-        double *dst = is_m ? Mout : Vout;
-        for (int e = tid; e < kUU; e += kRoundThreads) {
+    // rcur == 0: second rule, from the mass met DURING the last two sweeps (eigh_last_sweep)
+    const double met1 = gld<FLOW>(&info->acc[sweep - 1]);
+    const double met0 = sweep > 1 ? gld<FLOW>(&info->acc[sweep - 2]) : 0.0;
+    const bool last = met1 <= thr2 || (met1 <= 1.0e-20 * nrm2 && (sweep == 1 || met1 * met1 <= thr2 * met0));
+    if (last) {  // apply the last rotations of the sweep that just ended, start no new ones
+        if (writer) {
+            info->sweeps = sweep, info->parity = R.parity_out, info->converged = 1;
+            info->thr2 = thr2;
+            info->done_seq = R.seq;
+        }
+        return 1;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ void round_scales(RoundLds &L, double nrm2, double tol, int npad) {
+    L.tolel2 = tol * tol * nrm2 / ((double)npad * (double)npad);
+    int ex = 0;
+    const double nrm = sqrt(nrm2);
+    if (nrm > 0.0 && nrm < __builtin_inf()) (void)frexp(nrm, &ex);
+    L.scale = ldexp(1.0, -ex);
+}
+
+// ---- tile work: tile (P, Q) of M becomes U_P^T (X U_Q), tile (R = P, Q) of V becomes X U_Q, with U the rotations of
+// round rprev; three steps so that a caller can keep several tiles' loads in flight ----
+struct TileIdx {
+    int P, Q, ap, bp, aq, bq;
+    bool is_m;
+};
+__device__ __forceinline__ TileIdx tile_index(bool is_m, int P, int Q, int rprev, int nb) {
+    TileIdx t{P, Q, 0, 0, 0, 0, is_m};
+    rr_pair(Q, rprev, nb, t.aq, t.bq);
+    if (is_m) rr_pair(P, rprev, nb, t.ap, t.bp);
+    return t;
+}
+template <bool FLOW>
+__device__ __forceinline__ void tile_fetch(const TileIdx &t, const double *__restrict__ src, const double *__restrict__ Uprev,
+                                           int npad, int tid, bool want_uq, double (&x)[kTileRegs], double (&uq)[kTileRegs],
+                                           double (&up)[kTileRegs]) {
+#pragma unroll
+    for (int u = 0; u < kTileRegs; ++u) {
+        const int e = tid + kRoundThreads * u;
+        if (e < kUU) {
             const int i = e / kM2, j = e % kM2;
-            const int gi = is_m ? pair_index(i, ap, bp) : P * kM2 + i;
-            L.t.X[i * LDX + j] = src[(int64_t)gi * npad + pair_index(j, aq, bq)];
-            L.t.UQ[i * LDU + j] = Uprev[(int64_t)Q * kUU + e];
-            if (is_m) L.t.UP[i * LDU + j] = Uprev[(int64_t)P * kUU + e];
+            const int gi = t.is_m ? pair_index(i, t.ap, t.bp) : t.P * kM2 + i;
+            x[u] = gld<FLOW>(src + (int64_t)gi * npad + pair_index(j, t.aq, t.bq));
+            if (want_uq) uq[u] = gld<FLOW>(Uprev + (int64_t)t.Q * kUU + e);
+            if (t.is_m) up[u] = gld<FLOW>(Uprev + (int64_t)t.P * kUU + e);
+        }
+    }
+}
+// the same with 16-byte loads (the resident kernel's workers): thread t holds elements (i, 2 j2), (i, 2 j2 + 1) for
+// e2 = t + kRoundThreads u = 16 i + j2 -- two columns of one 16-block, adjacent in memory
+constexpr int kTileRegs2 = (kUU / 2 + kRoundThreads - 1) / kRoundThreads;
+__device__ __forceinline__ void tile_fetch16(const TileIdx &t, __amdgpu_buffer_rsrc_t src, __amdgpu_buffer_rsrc_t ures, int npad,
+                                             int tid, bool want_uq, f64x2 (&x)[kTileRegs2], f64x2 (&uq)[kTileRegs2],
+                                             f64x2 (&up)[kTileRegs2]) {
+#pragma unroll
+    for (int u = 0; u < kTileRegs2; ++u) {
+        const int e2 = tid + kRoundThreads * u;
+        if (e2 < kUU / 2) {
+            const int i = e2 / (kM2 / 2), j = 2 * (e2 % (kM2 / 2));
+            const int gi = t.is_m ? pair_index(i, t.ap, t.bp) : t.P * kM2 + i;
+            x[u] = ld16(src, (gi * npad + pair_index(j, t.aq, t.bq)) * 8);
+            if (want_uq) uq[u] = ld16(ures, (t.Q * kUU + 2 * e2) * 8);
+            if (t.is_m) up[u] = ld16(ures, (t.P * kUU + 2 * e2) * 8);
+        }
+    }
+}
+__device__ __forceinline__ void tile_stage16(RoundLds &L, bool is_m, int tid, bool want_uq, const f64x2 (&x)[kTileRegs2],
+                                             const f64x2 (&uq)[kTileRegs2], const f64x2 (&up)[kTileRegs2]) {
+#pragma unroll
+    for (int u = 0; u < kTileRegs2; ++u) {
+        const int e2 = tid + kRoundThreads * u;
+        if (e2 < kUU / 2) {
+            const int i = e2 / (kM2 / 2), j = 2 * (e2 % (kM2 / 2));
+            *(f64x2 *)&L.t.X[i * LDX + j] = x[u];  // (LDX, LDU even: 16-byte aligned)
+            if (want_uq) *(f64x2 *)&L.t.UQ[i * LDU + j] = uq[u];
+            if (is_m) *(f64x2 *)&L.t.UP[i * LDU + j] = up[u];
+        }
+    }
+}
+__device__ __forceinline__ void tile_stage(RoundLds &L, bool is_m, int tid, bool want_uq, const double (&x)[kTileRegs],
+                                           const double (&uq)[kTileRegs], const double (&up)[kTileRegs]) {
+#pragma unroll
+    for (int u = 0; u < kTileRegs; ++u) {
+        const int e = tid + kRoundThreads * u;
+        if (e < kUU) {
+            const int i = e / kM2, j = e % kM2;
+            L.t.X[i * LDX + j] = x[u];
+            if (want_uq) L.t.UQ[i * LDU + j] = uq[u];
+            if (is_m) L.t.UP[i * LDU + j] = up[u];
+        }
+    }
+}
+// (after the staging and a barrier; ends with every global store and atomic of the tile ISSUED, not necessarily complete)
+template <bool FLOW>
+__device__ __forceinline__ void tile_compute(RoundLds &L, const TileIdx &t, const double *__restrict__ Min,
+                                             double *__restrict__ dst, int npad, EighInfo *info, const RoundPar &R,
+                                             int refine, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const bool is_m = t.is_m;
+    const int i0 = (wave >> 1) * 16, j0 = (wave & 1) * 16;  // waves 0..3: one 16x16 quadrant each
+    // the launch that measures what a sweep left also measures max |M_ij / (d_j - d_i)| (refinement rule); the
+    // diagonal is taken from the matrix BEFORE this round's rotations -- in this phase it moves by second-order amounts
+    const bool measure_k = refine && is_m && R.rcur == 0 && R.sweep > 0 && wave < 4;
+    double dgi[4] = {0.0, 0.0, 0.0, 0.0}, dgj = 0.0;
+    if (measure_k) {
+        const int gj = pair_index(j0 + lr, t.aq, t.bq);
+        dgj = gld<FLOW>(Min + (int64_t)gj * npad + gj);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = pair_index(i0 + lk + 4 * r, t.ap, t.bp);
+            dgi[r] = gld<FLOW>(Min + (int64_t)gi * npad + gi);
+        }
+    }
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (wave < 4) acc = mma_ab(L.t.X, LDX, i0, L.t.UQ, LDU, j0, lane);
+    if (is_m) {
+        if (wave < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L.t.Y[(i0 + lk + 4 * r) * LDU + j0 + lr] = acc[r];
         }
         __syncthreads();
-        const int i0 = (wave >> 1) * 16, j0 = (wave & 1) * 16;  // waves 0..3: one 16x16 quadrant each
-        // the launch that measures what a sweep left also measures max |M_ij / (d_j - d_i)| (refinement rule); the
-        // diagonal is taken from the matrix BEFORE this round's rotations -- in this phase it moves by second-order amounts
-        const bool measure_k = refine && is_m && rcur == 0 && sweep > 0 && wave < 4;
-        double dgi[4] = {0.0, 0.0, 0.0, 0.0}, dgj = 0.0;
-        if (measure_k) {
-            const int gj = pair_index(j0 + lr, aq, bq);
-            dgj = Min[(int64_t)gj * npad + gj];
+        if (wave < 4) acc = mma_atb(L.t.UP, LDU, i0, L.t.Y, LDU, j0, lane);
+    }
+    double m2 = 0.0, k2 = 0.0;
+    if (wave < 4) {
+        const int gj = pair_index(j0 + lr, t.aq, t.bq);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = pair_index(i0 + lk + 4 * r, ap, bp);
-                dgi[r] = Min[(int64_t)gi * npad + gi];
-            }
-        }
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        if (wave < 4) acc = mma_ab(L.t.X, LDX, i0, L.t.UQ, LDU, j0, lane);
-        if (is_m) {
-            if (wave < 4) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) L.t.Y[(i0 + lk + 4 * r) * LDU + j0 + lr] = acc[r];
-            }
-            __syncthreads();
-            if (wave < 4) acc = mma_atb(L.t.UP, LDU, i0, L.t.Y, LDU, j0, lane);
-        }
-        double m2 = 0.0, k2 = 0.0;
-        if (wave < 4) {
-            const int gj = pair_index(j0 + lr, aq, bq);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + lk + 4 * r;
-                const int gi = is_m ? pair_index(i, ap, bp) : P * kM2 + i;
-                dst[(int64_t)gi * npad + gj] = acc[r];
-                if (gi != gj) {
-                    m2 = fma(acc[r], acc[r], m2);
-                    if (measure_k) {
-                        const double a2 = acc[r] * acc[r], g = dgj - dgi[r];
-                        if (a2 > L.tolel2) k2 = fmax(k2, a2 / (g * g));  // (a zero gap under a significant element: inf)
-                    }
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + lk + 4 * r;
+            const int gi = is_m ? pair_index(i, t.ap, t.bp) : t.P * kM2 + i;
+            gst<FLOW>(dst + (int64_t)gi * npad + gj, acc[r]);
+            if (gi != gj) {
+                m2 = fma(acc[r], acc[r], m2);
+                if (measure_k) {
+                    const double a2 = acc[r] * acc[r], g = dgj - dgi[r];
+                    if (a2 > L.tolel2) k2 = fmax(k2, a2 / (g * g));  // (a zero gap under a significant element: inf)
                 }
             }
         }
-        // this launch applies the LAST rotations of sweep `sweep - 1`: what it writes is the matrix after that sweep,
-        // and its off-diagonal mass decides (in the next launch) whether the run is over
-        if (is_m && rcur == 0 && sweep > 0) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
-            if (refine) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) k2 = fmax(k2, __shfl_xor(k2, off, kWave));
-            }
-            if (lane == 0 && wave < 4) L.red[wave] = m2, L.red[4 + wave] = k2;
-            __syncthreads();
-            if (tid == 0) {
-                const double t = (L.red[0] + L.red[1]) + (L.red[2] + L.red[3]);
-                if (t != 0.0) atomicAdd(&info->offm[sweep - 1], t);
-                const double km = fmax(fmax(L.red[4], L.red[5]), fmax(L.red[6], L.red[7]));
-                // (non-negative doubles order like their bit patterns; NaN -- 0/0 cannot occur, a2 > 0 -- would read as huge)
-                if (refine && km > 0.0) atomicMax(&info->kmax2[sweep - 1], (unsigned long long)__double_as_longlong(km));
-            }
-        }
-        return;
     }
-    // =========================== pair workgroups ===========================
-    if (state == 1 || flush) return;
+    // this launch applies the LAST rotations of sweep `sweep - 1`: what it writes is the matrix after that sweep,
+    // and its off-diagonal mass decides (in the next launch) whether the run is over
+    if (is_m && R.rcur == 0 && R.sweep > 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
+        if (refine) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) k2 = fmax(k2, __shfl_xor(k2, off, kWave));
+        }
+        if (lane == 0 && wave < 4) L.red[wave] = m2, L.red[4 + wave] = k2;
+        __syncthreads();
+        if (tid == 0) {
+            const double tt = (L.red[0] + L.red[1]) + (L.red[2] + L.red[3]);
+            if (tt != 0.0) atomicAdd(&info->offm[R.sweep - 1], tt);
+            const double km = fmax(fmax(L.red[4], L.red[5]), fmax(L.red[6], L.red[7]));
+            // (non-negative doubles order like their bit patterns; NaN -- 0/0 cannot occur, a2 > 0 -- would read as huge)
+            if (refine && km > 0.0) atomicMax(&info->kmax2[R.sweep - 1], (unsigned long long)__double_as_longlong(km));
+        }
+    }
+}
+
+// ---- pair work: the rotation U of pair (I, J) of round rcur from the current pivot ----
+struct PairIdx {
+    int I, J, PI, posI, PJ, posJ, aI, bI, aJ, bJ;
+};
+__device__ __forceinline__ PairIdx pair_lookup(int k, const RoundPar &R, int nb) {
+    PairIdx q;
+    rr_pair(k, R.rcur, nb, q.I, q.J);
+    rr_find(q.I, R.rprev, nb, q.PI, q.posI);
+    rr_find(q.J, R.rprev, nb, q.PJ, q.posJ);
+    rr_pair(q.PI, R.rprev, nb, q.aI, q.bI);
+    rr_pair(q.PJ, R.rprev, nb, q.aJ, q.bJ);
+    return q;
+}
+// source tiles (pairs of rprev) 0: (PI,PI)  1: (PI,PJ)  2: (PJ,PJ); 256 threads x 4 elements of each
+template <bool FLOW>
+__device__ __forceinline__ void pair_fetch_tiles(const PairIdx &q, const double *__restrict__ Min, int npad, int tid,
+                                                 double (&x0)[4], double (&x1)[4], double (&x2)[4]) {
+    if (tid < 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, i = e / kM2, j = e % kM2;
+            const int giI = pair_index(i, q.aI, q.bI), giJ = pair_index(i, q.aJ, q.bJ);
+            const int gjI = pair_index(j, q.aI, q.bI), gjJ = pair_index(j, q.aJ, q.bJ);
+            x0[u] = gld<FLOW>(Min + (int64_t)giI * npad + gjI);
+            x1[u] = gld<FLOW>(Min + (int64_t)giI * npad + gjJ);
+            x2[u] = gld<FLOW>(Min + (int64_t)giJ * npad + gjJ);
+        }
+    }
+}
+template <bool FLOW>
+__device__ __forceinline__ void pair_fetch_u(const PairIdx &q, const double *__restrict__ Uprev, int tid, double (&ua)[4],
+                                             double (&ub)[4]) {
+    if (tid < 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            ua[u] = gld<FLOW>(Uprev + (int64_t)q.PI * kUU + e);
+            ub[u] = gld<FLOW>(Uprev + (int64_t)q.PJ * kUU + e);
+        }
+    }
+}
+// (ends with the rotation's stores and the sweep's atomic ISSUED)
+// FLOW: u_staged = the needed columns of both rotations are already in L.p.UA / L.p.UB (pair_poll_granules); Go = this
+// pair's granule slot (the rotation goes there FIRST: tagged halves, see pair_poll_granules); false: a wait had run out.
+template <bool FLOW>
+__device__ __forceinline__ bool pair_compute(RoundLds &L, const PairIdx &q, const double (&x0)[4], const double (&x1)[4],
+                                             const double (&x2)[4], const double (&ua)[4], const double (&ub)[4],
+                                             double *__restrict__ Uo, EighInfo *info, const RoundPar &R, int tid,
+                                             bool u_staged = false, unsigned long long *Go = nullptr) {
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int posI = q.posI, posJ = q.posJ;
     // (a pair workgroup shares its CU with a tile workgroup of the same launch; the round waits for the pair)
     __builtin_amdgcn_s_setprio(1);
     SX_ETP(0);
+    if constexpr (FLOW) SX_FTP(5);
     constexpr int LD = kM2 + 1;
     if (tid < 256) {
 #pragma unroll
@@ -996,19 +1154,25 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
             L.p.X[0][i * LDX + j] = x0[u];
             L.p.X[1][i * LDX + j] = x1[u];
             L.p.X[2][i * LDX + j] = x2[u];
-            L.p.UA[i * LDU + j] = ua[u];
-            L.p.UB[i * LDU + j] = ub[u];
+            if (!u_staged) {
+                L.p.UA[i * LDU + j] = ua[u];
+                L.p.UB[i * LDU + j] = ub[u];
+            }
         }
     }
     __syncthreads();
     SX_ETP(1);
+    if constexpr (FLOW) {
+        SX_FTP(6);
+        if (L.ok == 0) return false;  // (a wave's wait for the predecessors' rotations had run out)
+    }
     // The current pivot: T_II = A_I^T X0 A_I, T_IJ = A_I^T X1 A_J, T_JJ = A_J^T X2 A_J with A_X the 16 columns of the
     // previous rotation that belong to block X.  Wave w < 3 forms sub-block w.  The pivot is stored INTERLEAVED:
     // member i of block I at position 2i, member j of block J at position 2j+1 (what the systolic sweep expects).
     // full != 0 (first round of a sweep): every pair of the 32 indices is rotated; otherwise only the pairs
     // (I-member, J-member) -- over the rounds of a sweep every off-diagonal element is then targeted exactly once,
     // and the mass met (all off-diagonal entries in the full round, the I x J block otherwise) adds up to off(M)^2.
-    const bool full = rcur == 0;
+    const bool full = R.rcur == 0;
     {   // first products, six ways: wave w forms half h = w & 1 of Y_b = X_b * A_right, b = w >> 1
         const int b = wave >> 1, h = wave & 1;
         const double *UR = b == 0 ? L.p.UA : L.p.UB;
@@ -1046,6 +1210,7 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
     SX_ETP(15);
     __syncthreads();  // stage 1 is over: its LDS is reused for the sweep
     SX_ETP(3);
+    if constexpr (FLOW) SX_FTP(7);
     const SweepView view{L.S0, L.j.S1, L.cs, L.j.W0};
     if (full)
         (void)pivot_sweep<0>(view, tid);
@@ -1053,26 +1218,497 @@ __global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double 
         (void)pivot_sweep<1>(view, tid);
     __syncthreads();  // the accumulated rotations have left the registers of the last wave
     SX_ETP(4);
+    if constexpr (FLOW) SX_FTP(8);
     // U in the order the tiles use (block I first, then block J): gathered index g <-> position 2g or 2(g-16)+1
     const double *Wf = L.j.W0;
-    double *Uo = Ucur + (int64_t)blockIdx.x * kUU;
-    for (int e = tid; e < kUU; e += kRoundThreads) {
-        const int i = e / kM2, j = e % kM2;
-        const int pi = i < kBS ? 2 * i : 2 * (i - kBS) + 1, pj = j < kBS ? 2 * j : 2 * (j - kBS) + 1;
-        Uo[e] = Wf[pi * LD + pj];
+    if constexpr (FLOW) {
+        // what the two successors wait for goes first: every double as ONE 16-byte store {low half, tag, high half, tag} --
+        // two 8-byte granules side by side (pair_poll_granules); then the plain copy the tile workers read, two doubles a store
+        const unsigned tag = (unsigned)R.seq;
+        const __amdgpu_buffer_rsrc_t ur = flow_rsrc(Uo, (int64_t)kUU * 8);
+        if (Go != nullptr) {
+            const __amdgpu_buffer_rsrc_t gr = flow_rsrc(Go, (int64_t)kUU * 16);
+            for (int e = tid; e < kUU; e += kRoundThreads) {
+                const int i = e / kM2, j = e % kM2;
+                const int pi = i < kBS ? 2 * i : 2 * (i - kBS) + 1, pj = j < kBS ? 2 * j : 2 * (j - kBS) + 1;
+                const unsigned long long b = (unsigned long long)__double_as_longlong(Wf[pi * LD + pj]);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){(unsigned)b, tag, (unsigned)(b >> 32), tag}, gr, e * 16, 0, kAuxSc1);
+            }
+        }
+        for (int e2 = tid; e2 < kUU / 2; e2 += kRoundThreads) {
+            const int i = e2 / (kM2 / 2), j = 2 * (e2 % (kM2 / 2));
+            const int pi = i < kBS ? 2 * i : 2 * (i - kBS) + 1;
+            const int pj0 = j < kBS ? 2 * j : 2 * (j - kBS) + 1, pj1 = pj0 + 2;
+            st16(ur, e2 * 16, (f64x2){Wf[pi * LD + pj0], Wf[pi * LD + pj1]});
+        }
+    } else {
+        for (int e = tid; e < kUU; e += kRoundThreads) {
+            const int i = e / kM2, j = e % kM2;
+            const int pi = i < kBS ? 2 * i : 2 * (i - kBS) + 1, pj = j < kBS ? 2 * j : 2 * (j - kBS) + 1;
+            Uo[e] = Wf[pi * LD + pj];
+        }
     }
     // (the global atomic waits for nothing here; before a barrier it would stall the whole pivot phase)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, kWave);
-    if (wave < 3 && lane == 0 && m2 != 0.0) atomicAdd(&info->acc[sweep], m2);
+    if (wave < 3 && lane == 0 && m2 != 0.0) atomicAdd(&info->acc[R.sweep], m2);
     SX_ETP(5);
+    if constexpr (FLOW) SX_FTP(9);
+    return true;
+}
+
+// One launch per round.  blockIdx < np: pair workgroups (rotation U_cur of the round rcur from the current pivot);
+// then np*np tiles of M and nr*np tiles of V, which apply the rotations U_prev of the round rprev.
+// flush != 0: no pair workgroups' sweeps (the last rotations are applied and the run is closed by the host).
+__global__ __launch_bounds__(kRoundThreads) void eigh_round_kernel(const double *__restrict__ Min, const double *__restrict__ Vin,
+                                                         double *__restrict__ Mout, double *__restrict__ Vout, int npad,
+                                                         int nb, const double *__restrict__ Uprev,
+                                                         double *__restrict__ Ucur, EighInfo *info, int sweep, int rprev,
+                                                         int rcur, int parity_out, double tol, int flush, int seq,
+                                                         int refine) {
+    RoundLds &L = g_round_lds;
+    const int tid = threadIdx.x;
+    const int np = nb / 2;
+    const RoundPar R{Min, Vin, Mout, Vout, Uprev, Ucur, sweep, rprev, rcur, parity_out, seq};
+    // ---- run state: every workgroup derives the same decision from what earlier launches left ----
+    // The record is a miss in every cache after the kernel boundary (~1 us).  Nothing below waits for it before the
+    // pair workgroups' own loads are in flight: those do not depend on it (a launch that turns out to be a no-op has
+    // read a few valid tiles for nothing).
+    int ended = 0;
+    double nrm2 = 0.0;
+    if (tid == 0) ended = info->done_seq, nrm2 = info->norm2;
+    const bool is_pair = (int)blockIdx.x < np && !flush;
+    PairIdx q{};
+    double x0[4], x1[4], x2[4], ua[4], ub[4];
+    if (is_pair) {
+        q = pair_lookup((int)blockIdx.x, R, nb);
+        pair_fetch_tiles<false>(q, Min, npad, tid, x0, x1, x2);
+        pair_fetch_u<false>(q, Uprev, tid, ua, ub);
+    }
+    if (tid == 0) {
+        L.flag = round_state<false>(info, ended, nrm2, R, tol, flush, refine, blockIdx.x == 0);
+        round_scales(L, nrm2, tol, npad);
+    }
+    __syncthreads();
+    const int state = L.flag;
+    if (state == 2) return;
+    if ((int)blockIdx.x >= np) {
+        // =========================== tile workgroups ===========================
+        const int tile = (int)blockIdx.x - np;
+        const bool is_m = tile < np * np;
+        const int P = is_m ? tile / np : (tile - np * np) / np;  // M: pair of rprev; V: chunk of 32 rows
+        const int Q = is_m ? tile % np : (tile - np * np) % np;
+        const TileIdx t = tile_index(is_m, P, Q, rprev, nb);
+        double x[kTileRegs], uq[kTileRegs], up[kTileRegs];
+        tile_fetch<false>(t, is_m ? Min : Vin, Uprev, npad, tid, true, x, uq, up);
+        tile_stage(L, is_m, tid, true, x, uq, up);
+        __syncthreads();
+        tile_compute<false>(L, t, Min, is_m ? Mout : Vout, npad, info, R, refine, tid);
+        return;
+    }
+    // =========================== pair workgroups ===========================
+    if (state == 1 || flush) return;
+    (void)pair_compute<false>(L, q, x0, x1, x2, ua, ub, Ucur + (int64_t)blockIdx.x * kUU, info, R, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// All rounds [k0, k1) of a run inside ONE launch (round 6).  The launch-per-round form pays a kernel boundary per round
+// -- 2.5 us plus the skew of 16 pair workgroups -- for a dependency that is much narrower than "everything": the pivot
+// of pair (I, J) of round k needs the rotations of exactly TWO pair workgroups of round k - 1 and tiles that were
+// finished a whole round earlier.  Here every workgroup is resident for the whole run:
+//   * np pair workgroups (blockIdx < np): round after round, pair k of round r waits for the rotations of its two
+//     predecessors (a per-slot word uflag[slot] = launch number + 1), forms the pivot, sweeps, publishes its rotation;
+//   * `workers` tile workgroups: worker w owns the tile columns c = w, w + workers, ... (c = P * np + Q: tile (P, Q) of
+//     M and tile (P, Q) of V, which share U_Q); per launch number k it waits for ALL rotations of round k - 1
+//     (ucnt[k - 1] == np) and ALL tiles of launch k - 1 (tcnt[k - 1], eight shards), applies, counts itself in.
+// Same arithmetic on the same operands as eigh_round_kernel: the two forms return identical bits.
+// Why the buffers cannot be overwritten too early: tiles of launch k go to pair (k + 1) & 1, last read by the tiles of
+// launch k - 1 (all done: tcnt) and by the pairs of round k - 1 (all done: ucnt); rotations of round k go to slot k % 3,
+// last read by the pairs of round k - 2 -- all done before any tile of launch k - 1 started, which every pair of round k
+// has waited for -- and by the tiles of launch k - 2.
+// Visibility: Guideline 16, form R1 -- write-through stores, every storing wave drains (s_waitcnt vmcnt(0)), a barrier, ONE
+// lane bumps the counter; readers poll relaxed and then load past their L1.  Every wait is bounded (tmo wall-clock ticks):
+// a wait that runs out sets info->fault, and every other wait ends as soon as it sees that word.
+// ---------------------------------------------------------------------------------------------------
+struct FlowSync {
+    uint32_t *uflag;  // [pairs]      launch number + 1 of the newest rotation in the slot (kept for diagnosis: nothing polls it)
+    uint32_t *ucnt;   // [rounds]     pair workgroups that have published launch k's rotations
+    uint32_t *tcnt;   // [rounds][8]  tile columns finished in launch k, by worker & 7
+    unsigned long long *gran;  // [3][pairs][2 * kUU]  the rotations once more, as tagged halves (pair_poll_granules)
+    int64_t gstride;           // words per buffer
+};
+constexpr int kFlowWaitUflag = 1, kFlowWaitUcnt = 2, kFlowWaitTcnt = 3, kFlowWaitGran = 4;
+
+__device__ __forceinline__ uint32_t flow_ld(const uint32_t *p) {
+    return __hip_atomic_load((__attribute__((address_space(1))) uint32_t *)const_cast<uint32_t *>(p), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+// every lane of ONE wave: lanes with `mine` poll their word until all of them read >= want (sum: until the words add up to
+// want).  false: gave up (the fault word is set).
+__device__ __forceinline__ bool flow_wait(const uint32_t *p, bool mine, uint32_t want, bool sum, EighInfo *info,
+                                          long long tmo, int code) {
+    const long long t0 = wall_clock64();
+    for (unsigned it = 0;; ++it) {
+        uint32_t v = mine ? flow_ld(p) : (sum ? 0u : want);
+        bool ok;
+        if (sum) {
+            v += __shfl_xor(v, 1, kWave);
+            v += __shfl_xor(v, 2, kWave);
+            v += __shfl_xor(v, 4, kWave);
+            ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)v) >= want;
+        } else {
+            ok = __all(v >= want);
+        }
+        if (ok) return true;
+        if ((it & 15) == 15) {
+            if (flow_ld((const uint32_t *)&info->fault) != 0u) return false;
+            if (wall_clock64() - t0 > tmo) {
+                __hip_atomic_store((__attribute__((address_space(1))) uint32_t *)&info->fault, (uint32_t)code, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// the whole workgroup: wave 0 waits, everybody learns the outcome (one barrier)
+__device__ __forceinline__ bool flow_wait_block(RoundLds &L, const uint32_t *p, bool mine, uint32_t want, bool sum,
+                                                EighInfo *info, long long tmo, int code, int tid) {
+    if (tid < kWave) {
+        const bool ok = flow_wait(p, mine, want, sum, info, tmo, code);
+        if (tid == 0) L.ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return L.ok != 0;
+}
+// The rotation of a pair travels to its two successors as "granules" (Guideline 16, form R2): every double as two aligned
+// 8-byte words {launch number + 1 : 32 | half of the value : 32}, each ONE agent-scope store.  A reader that finds the
+// expected tag in a word has its data: arrival is detected on the data itself -- no drain, no flag, no second trip.  The
+// buffers are zeroed at the start of a run and tags are never 0; a slot is reused every third round with another tag.
+// Threads 0..255, two elements (four words) per predecessor: rows t / 16 and t / 16 + 16, column t % 16 of the sixteen
+// columns that belong to the block this pair inherits.  Every wave polls for itself and then writes what it has read
+// into L.p.UA / L.p.UB.  A wave whose wait runs out clears L.ok (checked behind the staging barrier).
+struct GranPtr {
+    __amdgpu_buffer_rsrc_t r;
+    int off[4];
+};
+__device__ __forceinline__ GranPtr pair_gran_ptrs(const PairIdx &q, const unsigned long long *Gprev, int64_t gstride, int tid) {
+    const int c = tid & 15, r0 = (tid & 255) >> 4;
+    const int ea0 = r0 * kM2 + 16 * q.posI + c, ea1 = ea0 + 16 * kM2;
+    const int eb0 = r0 * kM2 + 16 * q.posJ + c, eb1 = eb0 + 16 * kM2;
+    return GranPtr{flow_rsrc(Gprev, gstride * 8),
+                   {(q.PI * kUU + ea0) * 16, (q.PI * kUU + ea1) * 16, (q.PJ * kUU + eb0) * 16, (q.PJ * kUU + eb1) * 16}};
+}
+__device__ __forceinline__ void pair_gran_load(const GranPtr &g, unsigned long long (&v)[8]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(g.r, g.off[u], 0, kAuxSc1);
+        v[2 * u] = ((unsigned long long)w.y << 32) | w.x;
+        v[2 * u + 1] = ((unsigned long long)w.w << 32) | w.z;
+    }
+}
+// v: a first pass that is already on its way (pair_gran_load); re-read until every word carries the tag
+__device__ __forceinline__ void pair_poll_granules(RoundLds &L, const PairIdx &q, const GranPtr &g, unsigned long long (&v)[8],
+                                                   uint32_t tag, EighInfo *info, long long tmo, int tid) {
+    if (tid >= 256) return;
+    const int c = tid & 15, r0 = tid >> 4;
+    const long long t0 = wall_clock64();
+    for (unsigned it = 0;; ++it) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ok = ok && (uint32_t)(v[u] >> 32) == tag;
+        if (__all(ok)) break;
+        if ((it & 15) == 15) {
+            bool give_up = flow_ld((const uint32_t *)&info->fault) != 0u;
+            if (!give_up && wall_clock64() - t0 > tmo) {
+                __hip_atomic_store((__attribute__((address_space(1))) uint32_t *)&info->fault, (uint32_t)kFlowWaitGran,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                give_up = true;
+            }
+            if (give_up) {
+                L.ok = 0;
+                break;
+            }
+        }
+        if (it != 0) __builtin_amdgcn_s_sleep(1);
+        pair_gran_load(g, v);
+    }
+    auto join = [](unsigned long long lo, unsigned long long hi) {
+        return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+    };
+    L.p.UA[r0 * LDU + 16 * q.posI + c] = join(v[0], v[1]);
+    L.p.UA[(r0 + 16) * LDU + 16 * q.posI + c] = join(v[2], v[3]);
+    L.p.UB[r0 * LDU + 16 * q.posJ + c] = join(v[4], v[5]);
+    L.p.UB[(r0 + 16) * LDU + 16 * q.posJ + c] = join(v[6], v[7]);
+}
+
+// every storing wave has drained; then ONE lane publishes
+#define SX_FLOW_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ RoundPar flow_round_par(double *M0, double *M1, double *V0, double *V1, double *U, int64_t us, int nb,
+                                                   int k) {
+    const int cur = k & 1, rps = nb - 1;
+    return RoundPar{cur ? M1 : M0, cur ? V1 : V0, cur ? M0 : M1, cur ? V0 : V1, U + (int64_t)((k + 2) % 3) * us,
+                    U + (int64_t)(k % 3) * us, k / rps, k == 0 ? 0 : (k - 1) % rps, k % rps, cur ^ 1, k + 1};
+}
+
+// (The pair rounds were also tried as a function of their own, to keep them at eigh_round_kernel's 120 VGPRs so that two
+// workgroups fit a CU: the 42 callee-saved registers such a function saves and restores through scratch memory cost 2.1 us
+// per round -- tools/trace_eigh_flow.py.  Inlined the kernel takes ~160 VGPRs and ONE workgroup per CU is all that is counted
+// on: the grid is kept within the number of CUs.)
+__global__ __launch_bounds__(kRoundThreads) void eigh_flow_kernel(double *M0, double *M1, double *V0, double *V1, double *U,
+                                                                  int64_t ustride, int npad, int nb, EighInfo *info,
+                                                                  FlowSync S, int k0, int k1, double tol, int refine,
+                                                                  int workers, long long tmo, int use_gran) {
+    RoundLds &L = g_round_lds;
+    const int np = nb / 2, ncol = np * np;
+    const bool is_pair = (int)blockIdx.x < np;
+    const int widx = (int)blockIdx.x - np;
+    if (threadIdx.x == 0) {
+        const int ended = (int)flow_ld((const uint32_t *)&info->done_seq);
+        const double nrm2 = gld<true>(&info->norm2);
+        L.flag = ended;
+        L.red[16] = nrm2;
+        L.ok = 1;
+        round_scales(L, nrm2, tol, npad);
+    }
+    __syncthreads();
+    // Launch number k + 1 does nothing once a launch with a SMALLER number has ended the run (eigh_round_kernel's rule, also
+    // how a skipped decomposition -- done_seq = 1 from eigh_prepare_kernel -- is passed over).  A workgroup that starts late
+    // may read what THIS launch has meanwhile recorded (k' + 1 at round k'): it then still works through the rounds up to
+    // k', as everybody else did, and takes the same decision there.
+    const int ended0 = L.flag;
+    const double nrm2 = L.red[16];
+    __syncthreads();
+    if (is_pair) {
+        // ---- pair workgroups: a software pipeline over the rounds.  What the two successors wait for -- the rotation as
+        // tagged halves -- leaves first; then the NEXT round's loads are issued (its tiles, a look at their counter, a first pass
+        // over the predecessors' words), and only then the stores are drained and counted: one trip to memory covers both.
+        if (k0 >= k1 || (ended0 != 0 && ended0 <= k0)) return;
+        RoundPar R = flow_round_par(M0, M1, V0, V1, U, ustride, nb, k0);
+        PairIdx q = pair_lookup((int)blockIdx.x, R, nb);
+        double x0[4], x1[4], x2[4], ua[4], ub[4];
+        {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            if (R.sweep > 0 && R.rcur <= 1) {  // (a launch may start at a round that can end the run: everything it reads is final)
+                if (tid == 0) L.flag = round_state<true>(info, 0, nrm2, R, tol, 0, refine, blockIdx.x == 0);
+                __syncthreads();
+                if (L.flag != 0) return;
+            }
+            pair_fetch_tiles<true>(q, R.Min, npad, tid, x0, x1, x2);
+            pair_fetch_u<true>(q, R.Uprev, tid, ua, ub);
+        }
+        for (int k = k0;; ++k) {
+            // (the thread index made opaque in every round: otherwise every thread-invariant address of the pivot sweep is
+            // hoisted out of the round loop and kept alive across it)
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63;
+            SX_FT_BEGIN(k);
+            unsigned long long *Go = (use_gran & 1) ? S.gran + (int64_t)(k % 3) * S.gstride + (int64_t)blockIdx.x * (2 * kUU) : nullptr;
+            if (!pair_compute<true>(L, q, x0, x1, x2, ua, ub, R.Ucur + (int64_t)blockIdx.x * kUU, info, R, tid, (use_gran & 1) && k > k0, Go))
+                return;
+            const int kn = k + 1;
+            const bool more = kn < k1 && !(ended0 != 0 && ended0 <= kn);
+            GranPtr g = pair_gran_ptrs(q, S.gran, S.gstride, tid);
+            unsigned long long gv[8];
+            uint32_t tcv = 0;
+            bool decide = false;
+            if (more) {
+                R = flow_round_par(M0, M1, V0, V1, U, ustride, nb, kn);
+                q = pair_lookup((int)blockIdx.x, R, nb);
+                decide = R.sweep > 0 && R.rcur <= 1;
+                g = pair_gran_ptrs(q, S.gran + (int64_t)(k % 3) * S.gstride, S.gstride, tid);
+            }
+            const bool early = (use_gran & 2) == 0;  // (bit 1 of the switch: the next round's loads only behind the drain)
+            if (more && early) {
+                if (!decide) {
+                    // The tiles of launch k were finished well before this pair's predecessors were (they only needed the
+                    // rotations of round k - 1), so they are loaded at once, beside the look at their counter -- and loaded again
+                    // in the rare case that the counter says they were not complete (the loads bypass the vector L1)
+                    pair_fetch_tiles<true>(q, R.Min, npad, tid, x0, x1, x2);
+                    if (tid < 8) tcv = flow_ld(S.tcnt + (int64_t)k * 8 + lane);
+                }
+                if ((use_gran & 1) && tid < 256) pair_gran_load(g, gv);
+            }
+            SX_FTP(2);
+            SX_FLOW_DRAIN();
+            __syncthreads();
+            SX_FTP(10);
+            if (more && !early) {
+                if (!decide) {
+                    pair_fetch_tiles<true>(q, R.Min, npad, tid, x0, x1, x2);
+                    if (tid < 8) tcv = flow_ld(S.tcnt + (int64_t)k * 8 + lane);
+                }
+                if ((use_gran & 1) && tid < 256) pair_gran_load(g, gv);
+            }
+            if (tid == 0) {
+                L.ok = 1;
+                __hip_atomic_store((__attribute__((address_space(1))) uint32_t *)(S.uflag + blockIdx.x), (uint32_t)(k + 1),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) uint32_t *)(S.ucnt + k), 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            SX_FTP(11);
+            if (!more) return;
+            if (decide) {
+                // a round that may end the run (2 of a sweep's rounds): first the sums the rules read -- the tiles of launch k,
+                // and for the rule of round 0 the mass met by ALL pairs of the sweep that just ended
+                if (!flow_wait_block(L, S.tcnt + (int64_t)k * 8 + lane, lane < 8, (uint32_t)ncol, true, info, tmo, kFlowWaitTcnt, tid))
+                    return;
+                if (R.rcur == 0 && !flow_wait_block(L, S.ucnt + k, lane == 0, (uint32_t)np, false, info, tmo, kFlowWaitUcnt, tid))
+                    return;
+                if (tid == 0) L.flag = round_state<true>(info, 0, nrm2, R, tol, 0, refine, blockIdx.x == 0);
+                __syncthreads();
+                if (L.flag != 0) return;
+                pair_fetch_tiles<true>(q, R.Min, npad, tid, x0, x1, x2);
+            } else {
+                if (tid < kWave) {
+                    tcv += __shfl_xor(tcv, 1, kWave);
+                    tcv += __shfl_xor(tcv, 2, kWave);
+                    tcv += __shfl_xor(tcv, 4, kWave);
+                    if (tid == 0) L.flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)tcv) >= (uint32_t)ncol ? 0 : 1;
+                }
+                __syncthreads();
+                if (L.flag != 0) {  // (rare) the tiles were not complete when they were loaded: wait, load again
+                    if (!flow_wait_block(L, S.tcnt + (int64_t)k * 8 + lane, lane < 8, (uint32_t)ncol, true, info, tmo, kFlowWaitTcnt, tid))
+                        return;
+                    pair_fetch_tiles<true>(q, R.Min, npad, tid, x0, x1, x2);
+                }
+            }
+            // the rotations of the two pairs of round k that held blocks I and J
+            if (use_gran & 1) {  // (as tagged halves, into L.p.UA / L.p.UB)
+                pair_poll_granules(L, q, g, gv, (uint32_t)(k + 1), info, tmo, tid);
+            } else {         // (the plain copy, behind the slots' words)
+                const uint32_t *pf = S.uflag + (lane == 1 ? q.PJ : q.PI);
+                if (!flow_wait_block(L, pf, lane < 2, (uint32_t)(k + 1), false, info, tmo, kFlowWaitUflag, tid)) return;
+                pair_fetch_u<true>(q, R.Uprev, tid, ua, ub);
+            }
+            SX_FTP(3);
+        }
+    }
+    for (int k = k0; k < k1; ++k) {
+        if (ended0 != 0 && ended0 <= k) return;
+        // (the thread index made opaque in every round: otherwise every thread-invariant address is hoisted out of the
+        // round loop and kept alive across it)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const RoundPar R = flow_round_par(M0, M1, V0, V1, U, ustride, nb, k);
+        const bool inside = k > k0;
+        SX_FT_BEGIN(k);
+        __syncthreads();
+        SX_FTP(0);
+        // the tiles of launch k - 1 (what the tiles of launch k read, and the sums the stopping rules read) and ALL rotations
+        // of round k - 1, in one wait: lanes 0..7 add up the tile counter's shards, lane 8 looks at the rotations' counter
+        if (inside) {
+            if (tid < kWave) {
+                const uint32_t *p = lane < 8 ? S.tcnt + (int64_t)(k - 1) * 8 + lane : S.ucnt + (k - 1);
+                const long long t0 = wall_clock64();
+                bool ok = false;
+                for (unsigned it = 0;; ++it) {
+                    const uint32_t v = lane < 9 ? flow_ld(p) : 0u;
+                    uint32_t sum = lane < 8 ? v : 0u;
+                    sum += __shfl_xor(sum, 1, kWave);
+                    sum += __shfl_xor(sum, 2, kWave);
+                    sum += __shfl_xor(sum, 4, kWave);
+                    const uint32_t tdone = (uint32_t)__builtin_amdgcn_readfirstlane((int)sum);
+                    const uint32_t udone = (uint32_t)__builtin_amdgcn_readlane((int)v, 8);
+                    if (tdone >= (uint32_t)ncol && udone >= (uint32_t)np) {
+                        ok = true;
+                        break;
+                    }
+                    if ((it & 15) == 15) {
+                        if (flow_ld((const uint32_t *)&info->fault) != 0u) break;
+                        if (wall_clock64() - t0 > tmo) {
+                            __hip_atomic_store((__attribute__((address_space(1))) uint32_t *)&info->fault,
+                                               (uint32_t)(tdone >= (uint32_t)ncol ? kFlowWaitUcnt : kFlowWaitTcnt), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (tid == 0) L.ok = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (L.ok == 0) return;
+        }
+        SX_FTP(2);
+        int state = 0;
+        if (R.sweep > 0 && R.rcur <= 1) {
+            if (tid == 0) L.flag = round_state<true>(info, 0, nrm2, R, tol, 0, refine, false);
+            __syncthreads();
+            state = L.flag;
+            if (state == 2) return;
+        }
+        uint32_t mine = 0;
+        const int64_t mbytes = (int64_t)npad * npad * 8;
+        const __amdgpu_buffer_rsrc_t rm = flow_rsrc(R.Min, mbytes), rv = flow_rsrc(R.Vin, mbytes), ru = flow_rsrc(R.Uprev, ustride * 8);
+        // two tile columns at a time, all their loads in flight at once (one workgroup per CU has nothing else to hide a
+        // trip to memory behind)
+        for (int c = widx; c < ncol; c += 2 * workers) {
+            const int c1 = c + workers;
+            const bool two = c1 < ncol;
+            const int P = c / np, Q = c % np, P1 = two ? c1 / np : P, Q1 = two ? c1 % np : Q;
+            const TileIdx tm = tile_index(true, P, Q, R.rprev, nb), tv = tile_index(false, P, Q, R.rprev, nb);
+            const TileIdx sm = tile_index(true, P1, Q1, R.rprev, nb), sv = tile_index(false, P1, Q1, R.rprev, nb);
+            f64x2 xm[kTileRegs2], uq[kTileRegs2], up[kTileRegs2], xv[kTileRegs2];
+            f64x2 ym[kTileRegs2], vq[kTileRegs2], vp[kTileRegs2], yv[kTileRegs2];
+            tile_fetch16(tm, rm, ru, npad, tid, true, xm, uq, up);
+            tile_fetch16(tv, rv, ru, npad, tid, false, xv, uq, up);
+            if (two) {
+                tile_fetch16(sm, rm, ru, npad, tid, true, ym, vq, vp);
+                tile_fetch16(sv, rv, ru, npad, tid, false, yv, vq, vp);
+            }
+            tile_stage16(L, true, tid, true, xm, uq, up);
+            __syncthreads();
+            SX_FTP(4);
+            tile_compute<true>(L, tm, R.Min, R.Mout, npad, info, R, refine, tid);
+            __syncthreads();
+            SX_FTP(5);
+            tile_stage16(L, false, tid, false, xv, uq, up);
+            __syncthreads();
+            tile_compute<true>(L, tv, R.Min, R.Vout, npad, info, R, refine, tid);
+            __syncthreads();
+            SX_FTP(6);
+            ++mine;
+            if (two) {
+                tile_stage16(L, true, tid, true, ym, vq, vp);
+                __syncthreads();
+                tile_compute<true>(L, sm, R.Min, R.Mout, npad, info, R, refine, tid);
+                __syncthreads();
+                tile_stage16(L, false, tid, false, yv, vq, vp);
+                __syncthreads();
+                tile_compute<true>(L, sv, R.Min, R.Vout, npad, info, R, refine, tid);
+                __syncthreads();
+                ++mine;
+            }
+        }
+        SX_FLOW_DRAIN();
+        __syncthreads();
+        SX_FTP(7);
+        if (tid == 0 && mine != 0)
+            __hip_atomic_fetch_add((__attribute__((address_space(1))) uint32_t *)(S.tcnt + (int64_t)k * 8 + (widx & 7)), mine,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SX_FTP(8);
+        if (state == 1) return;
+    }
 }
 
 // the run ends without the rule having fired: record where the result lives
 // `fails` (a word of the info block that sx_eigh does not clear) counts the runs of this workspace that ended short of
 // their tolerance: a loop that reads the record only every few decompositions still learns that one of them fell short.
 __global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double tol, int refine, int *fails) {
-    if (threadIdx.x != 0 || info->done_seq) return;
+    if (threadIdx.x != 0) return;
+    if (info->fault) {  // the resident kernel gave up on a wait: whatever the record says, the result is not a decomposition
+        info->sweeps = sweeps, info->parity = parity, info->converged = 0, info->refine = 0;
+        atomicAdd(fails, 1);
+        info->done_seq = 1;
+        return;
+    }
+    if (info->done_seq) return;
     info->sweeps = sweeps, info->parity = parity, info->thr2 = tol * tol * info->norm2;
     int conv = (sweeps > 0 && (info->offm[sweeps - 1] <= info->thr2 ||
                                eigh_last_sweep(info->acc, sweeps - 1, info->norm2, tol))) ? 1 : 0;
@@ -1196,9 +1832,13 @@ inline int eigh_npad(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 64 ? 6
 
 struct EighWs {
     EighInfo *info;
-    double *M[2], *V[2], *U[2], *lam, *scl;
+    double *M[2], *V[2], *U[3], *lam, *scl;
     int *inv;
-    int64_t ucount;  // doubles in both rotation buffers
+    int64_t ustride;  // doubles per rotation buffer
+    int64_t ucount;   // doubles in all three rotation buffers
+    uint32_t *sync;   // the resident kernel's words: uflag[pairs16] | ucnt[rounds] | tcnt[rounds][8] | (64-byte aligned)
+                      // gran[3][pairs][2 * kUU] 8-byte words
+    int64_t sync_words, pairs16, rounds, gran_off, gstride;  // (sync_words, gran_off in 32-bit words)
     int64_t bytes;
 };
 
@@ -1212,11 +1852,18 @@ inline EighWs eigh_layout(void *ws, int n) {
     for (int k = 0; k < 2; ++k) w.M[k] = (double *)(p + off), off += np * np * 8;
     for (int k = 0; k < 2; ++k) w.V[k] = (double *)(p + off), off += np * np * 8;
     const int64_t pairs = np / kM2 + 1;
-    w.ucount = 2 * pairs * kUU;
-    for (int k = 0; k < 2; ++k) w.U[k] = (double *)(p + off), off += pairs * kUU * 8;
+    w.ustride = pairs * kUU;
+    w.ucount = 3 * pairs * kUU;
+    for (int k = 0; k < 3; ++k) w.U[k] = (double *)(p + off), off += pairs * kUU * 8;
     w.lam = (double *)(p + off), off += np * 8;
     w.scl = (double *)(p + off), off += np * 8;
     w.inv = (int *)(p + off), off += np * 8;
+    w.pairs16 = (pairs + 15) / 16 * 16;
+    w.rounds = (int64_t)kEighMaxSweeps * (np / kBS - 1) + 2;  // launch numbers of a run
+    w.gran_off = (w.pairs16 + 9 * w.rounds + 15) / 16 * 16;
+    w.gstride = pairs * 2 * kUU;
+    w.sync_words = w.gran_off + 2 * 3 * w.gstride;
+    w.sync = (uint32_t *)(p + off), off += (w.sync_words * 4 + 63) / 64 * 64;
     w.bytes = off;
     return w;
 }
@@ -1238,6 +1885,48 @@ static int refine_env() {
         return e == nullptr ? -1 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1));
     }();
     return v;
+}
+// One resident launch for all rounds of a run (eigh_flow_kernel) instead of one launch per round: OFF unless asked for
+// (sx_eigh_set_flow, or the environment variable SX_EIGH_FLOW = 1 read once) -- measured on MI355X it does not beat the
+// launch per round (profiles/r6_eigh_flow.txt: a rotation handed from CU to CU under the tile workers' traffic takes 3-4.5 us,
+// what a kernel boundary costs).  The resident form needs every workgroup of its grid on the chip at once: processes that
+// SHARE a GPU (the tests' ranks on one device) must not use it.
+static int g_flow_mode = -1;
+static int flow_env() {
+    static const int v = [] {
+        const char *e = getenv("SX_EIGH_FLOW");
+        return e == nullptr ? -1 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1));
+    }();
+    return v;
+}
+static int flow_workers_env() {
+    static const int v = [] {
+        const char *e = getenv("SX_EIGH_FLOW_WORKERS");
+        return e == nullptr ? 0 : atoi(e);
+    }();
+    return v;
+}
+static int flow_gran_env() {
+    static const int v = [] {
+        const char *e = getenv("SX_EIGH_FLOW_GRAN");
+        return e == nullptr ? 0 : atoi(e);
+    }();
+    return v;
+}
+static long long flow_timeout_ticks() {
+    static const long long v = [] {
+        const char *e = getenv("SX_EIGH_FLOW_TIMEOUT_MS");
+        const double ms = e == nullptr ? 2000.0 : atof(e);
+        int khz = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+            khz = 100000;  // wall_clock64 counts at 100 MHz on gfx950
+        return (long long)(ms * (double)khz);
+    }();
+    return v;
+}
+int eigh_flow_on() {
+    const int m = g_flow_mode >= 0 ? g_flow_mode : flow_env();
+    return m == 1 ? 1 : 0;
 }
 int eigh_refine_default() {
     const int m = g_refine_mode >= 0 ? g_refine_mode : refine_env();
@@ -1262,7 +1951,10 @@ int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, dou
     const int npad = eigh_npad(n);
     const int nb = npad / kBS, np = nb / 2, rps = nb - 1;
     SX_REQUIRE(r0 >= 0 && r1 >= r0 && r1 <= kEighMaxSweeps * (n <= kSmallPathMax ? 1 : rps), "sx_eigh: bad round range");
-    if (phases & 1) SX_HIP(hipMemsetAsync(L.info, 0, sizeof(EighInfo), st));
+    if (phases & 1) {
+        SX_HIP(hipMemsetAsync(L.info, 0, sizeof(EighInfo), st));
+        if (n > kSmallPathMax) SX_HIP(hipMemsetAsync(L.sync, 0, (size_t)L.sync_words * 4, st));  // (Guideline 16: every polled word, every call)
+    }
     if (n <= kSmallPathMax) {
         if (phases & 1) {
             const int max_sweeps = std::max(1, std::min(kEighMaxSweeps, r1));  // (one workgroup: r1 counts sweeps here)
@@ -1301,12 +1993,29 @@ int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, dou
         const unsigned grid = (unsigned)(np + np * np + (npad / kM2) * np);
         if (phases & 2) {
             // launch k (0-based) reads the buffer pair k & 1, applies the rotations of round (k - 1) % rps (identities for
-            // k = 0 under any pairing) and works out those of round k % rps; its launch number is k + 1
-            for (int k = r0; k < r1; ++k) {
-                const int cur = k & 1, rprev = k == 0 ? 0 : (k - 1) % rps;
-                hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
-                                   L.V[cur ^ 1], npad, nb, L.U[cur ^ 1], L.U[cur], L.info, k / rps, rprev, k % rps, cur ^ 1, tol, 0,
-                                   k + 1, refine);
+            // k = 0 under any pairing) and works out those of round k % rps; its launch number is k + 1 (RoundPar)
+            // ONE workgroup per CU (193 VGPRs): pair workgroups + workers within the CU count, or nothing is guaranteed resident
+            static const int cus = [] {
+                int dev = 0, v = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+                return v;
+            }();
+            int workers = flow_workers_env() > 0 ? flow_workers_env() : 128;
+            workers = std::max(1, std::min(std::min(workers, np * np), cus - np));
+            const bool flow = eigh_flow_on() && r1 > r0 && np + workers <= cus && 2 * np <= cus && r1 <= (int)L.rounds;
+            if (flow) {
+                const FlowSync S{L.sync, L.sync + L.pairs16, L.sync + L.pairs16 + L.rounds,
+                                 (unsigned long long *)(L.sync + L.gran_off), L.gstride};
+                hipLaunchKernelGGL(eigh_flow_kernel, dim3((unsigned)(np + workers)), dim3(kRoundThreads), 0, st, L.M[0], L.M[1],
+                                   L.V[0], L.V[1], L.U[0], L.ustride, npad, nb, L.info, S, r0, r1, tol, refine, workers,
+                                   flow_timeout_ticks(), flow_gran_env());
+            } else {
+                for (int k = r0; k < r1; ++k) {
+                    const int cur = k & 1, rprev = k == 0 ? 0 : (k - 1) % rps;
+                    hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
+                                       L.V[cur ^ 1], npad, nb, L.U[(k + 2) % 3], L.U[k % 3], L.info, k / rps, rprev, k % rps, cur ^ 1,
+                                       tol, 0, k + 1, refine);
+                }
             }
             SX_LAUNCH_CHECK();
         }
@@ -1314,7 +2023,7 @@ int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, dou
             // apply the last rotations, then close (r1 rounds have been enqueued; a run that ended earlier ignores both)
             const int cur = r1 & 1, rprev = r1 == 0 ? 0 : (r1 - 1) % rps, sweeps = r1 / rps;
             hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
-                               L.V[cur ^ 1], npad, nb, L.U[cur ^ 1], L.U[cur], L.info, sweeps, rprev, 0, cur ^ 1, tol, 1, r1 + 1, 0);
+                               L.V[cur ^ 1], npad, nb, L.U[(r1 + 2) % 3], L.U[r1 % 3], L.info, sweeps, rprev, 0, cur ^ 1, tol, 1, r1 + 1, 0);
             SX_LAUNCH_CHECK();
             hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, sweeps, cur ^ 1, tol, refine,
                                (int *)((char *)L.info + kEighFailsOffset));
@@ -1367,6 +2076,15 @@ extern "C" int sx_eigh_refined(const double *C, int n, const double *V0, double 
 extern "C" int sx_eigh_set_refine(int mode) {
     const int prev = sx::g_refine_mode;
     sx::g_refine_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
+}
+
+// 0: one launch per round (the default); 1: one resident launch for all rounds of a run; -1: SX_EIGH_FLOW or the default.
+// Returns the previous mode (-2: changes nothing and returns the mode in effect, 0 / 1).  Processes that share one GPU must use 0 (see eigh_flow_on).
+extern "C" int sx_eigh_set_flow(int mode) {
+    if (mode == -2) return sx::eigh_flow_on();  // query: the mode in effect (0 / 1), nothing changes
+    const int prev = sx::g_flow_mode;
+    sx::g_flow_mode = mode < 0 ? -1 : (mode ? 1 : 0);
     return prev;
 }
 

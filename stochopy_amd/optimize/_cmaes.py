@@ -211,7 +211,14 @@ class _CmaDeviceRun:
             # generation's stop rules wrote, so the host still waits once per generation (the stop is seen one generation
             # late: what was enqueued in between does nothing).
             rps = int(L.sx_eigh_rounds_per_sweep(n))
-            phased = (world is None and callback is None and look_cap == 1 and rps > 0
+            # Round 6: the solver's rounds run inside ONE resident launch that ends itself (sx_eigh_set_flow, csrc/sx_eigh.hip
+            # eigh_flow_kernel): nothing is launched "in case", so a decomposition gets the full allowance in one piece and
+            # the pieces below are not needed.  Its grid must be on the chip at once: ranks that share a GPU (only possible
+            # without RCCL, i.e. the tests' gloo groups) take the launch-per-round form.
+            if world is not None and world.backend != "nccl":
+                L.sx_eigh_set_flow(0)
+            flow = rps > 0 and int(L.sx_eigh_set_flow(-2)) == 1
+            phased = (world is None and callback is None and look_cap == 1 and rps > 0 and not flow
                       and os.environ.get("SX_CMA_PHASED", "1") != "0")
             warm_rounds = None  # rounds the last phased decomposition needed
             cap_hit = False     # the last phased decomposition was still open when the round cap was reached
@@ -220,7 +227,7 @@ class _CmaDeviceRun:
                 if due:  # 1: first decomposition; 2: start from the previous eigenvectors (C changes by O(c1 + cmu))
                     due = 2 if eigeneval else 1
                     eigeneval = gen * P
-                    a.eig_sweeps = launched = self.COLD_SWEEPS if due == 1 else warm_sweeps
+                    a.eig_sweeps = launched = 60 if flow else (self.COLD_SWEEPS if due == 1 else warm_sweeps)
                     decomposed = True
                 if phased and due:
                     if pin_state is None:

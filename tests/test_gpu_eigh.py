@@ -231,3 +231,40 @@ def test_eigh_with_the_refinement_step(ctx, kind, n):
     good = gap > 1e-6
     if good.any():
         assert np.abs(B[:, good] - Br[:, good]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("kind,n,warm", [("cma", 33, False), ("spd", 64, False), ("cma", 65, True), ("indefinite", 128, False),
+                                         ("cma", 200, True), ("graded", 192, False), ("repeated", 192, False),
+                                         ("cma", 512, True), ("spd", 512, False), ("cma", 1024, True)])
+def test_eigh_resident_launch_is_the_launch_per_round_run(ctx, kind, n, warm):
+    """Round 6: all rounds of a run inside ONE resident launch (sx_eigh_set_flow(1), the default: pair workgroups hand their
+    rotations on through agent-scope words, tile workgroups follow behind counters) against one launch per round
+    (sx_eigh_set_flow(0)): the same arithmetic on the same operands -- eigenvalues, eigenvectors and the run record equal
+    bit for bit, with and without a warm start and the refinement step."""
+    from stochopy_amd import _lib
+
+    L = _lib.lib()
+    rs = np.random.RandomState(1000 + n)
+    Cm = make(kind, n, rs)
+    kw = {}
+    if warm:
+        Cs = np.triu(Cm) + np.triu(Cm, 1).T
+        E = rs.randn(n, n) * 1e-3
+        _, V = np.linalg.eigh(Cs + (E + E.T) * np.abs(Cs).max())
+        kw["start"] = ctx.upload(np.ascontiguousarray(V))
+    outs = []
+    prev = L.sx_eigh_set_flow(-2)
+    try:
+        for refine in (False, True):
+            for mode in (0, 1, 1):
+                L.sx_eigh_set_flow(mode)
+                outs.append((refine, mode) + run(ctx, Cm, refine=refine, **kw))
+    finally:
+        L.sx_eigh_set_flow(prev)
+    for k in range(0, len(outs), 3):
+        ref = outs[k]
+        check(Cm, *ref[2:6])
+        for got in outs[k + 1:k + 3]:
+            assert got[4:6] == ref[4:6], (got[:2], got[4:6], ref[4:6])  # sweeps, converged
+            assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), (kind, n, got[:2])
+            assert abs(got[6] - ref[6]) <= 1e-12 * max(ref[6], 1e-300)  # (sums of atomics: the order of arrival)
