@@ -149,12 +149,13 @@ __global__ __launch_bounds__(sweep_waves(FUN) * kWave) void de_async_kernel(cons
         for (int q0 = 0; q0 < nq; q0 += 4) {  // four row steps share one Philox call, as in the synchronous kernel
             double rr[4] = {2.0, 2.0, 2.0, 2.0};
             if (RNG == SX_RNG_PHILOX) {
-                const U4 w = philox4x32_10((uint32_t)(q0 >> 2) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposeDeCross,
-                                           a.key0, a.key1);
-                rr[0] = u32(w.x);
-                rr[1] = u32(w.y);
-                rr[2] = u32(w.z);
-                rr[3] = u32(w.w);
+#pragma unroll
+                for (int t = 0; t < 4; t += 2) {  // 53-bit crossover uniforms, the synchronous kernel's layout
+                    const U4 w = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen,
+                                               kPurposeDeCross, a.key0, a.key1);
+                    rr[t] = u53(w.x, w.y);
+                    rr[t + 1] = u53(w.z, w.w);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -284,16 +285,17 @@ __global__ __launch_bounds__(sweep_waves(FUN) * kWave) void pso_async_kernel(con
         double beta = __builtin_huge_val();
         const int nq = (n + LPR - 1) / LPR;
         for (int q0 = 0; q0 < nq; q0 += 2) {  // two row steps share one Philox call, as in the synchronous kernel
-            U4 pw = {0u, 0u, 0u, 0u};
-            if (RNG == SX_RNG_PHILOX)
-                pw = philox4x32_10((uint32_t)(q0 >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR1, a.key0,
-                                  a.key1);
+            U4 pw = {0u, 0u, 0u, 0u}, pv = {0u, 0u, 0u, 0u};  // 53-bit r1 / r2, the synchronous kernel's layout
+            if (RNG == SX_RNG_PHILOX) {
+                pw = philox4x32_10((uint32_t)(q0 >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR1, a.key0, a.key1);
+                pv = philox4x32_10((uint32_t)(q0 >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR2, a.key0, a.key1);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
             const int e = (q0 + t) * LPR + l;
             if (e >= n) continue;
             const double x = xr[e], v = vr[e], p = pb[e], g = G[e];
-            double r1 = u32(t ? pw.z : pw.x), r2 = u32(t ? pw.w : pw.y);
+            double r1 = t ? u53(pw.z, pw.w) : u53(pw.x, pw.y), r2 = t ? u53(pv.z, pv.w) : u53(pv.x, pv.y);
             if (RNG == SX_RNG_HOST) {
                 r1 = a.r1[i * (int64_t)n + e];
                 r2 = a.r2[i * (int64_t)n + e];

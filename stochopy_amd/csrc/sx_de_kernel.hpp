@@ -356,13 +356,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (NFIX != 0 && XM <= 1) ? 
             }
         }
         if (RNG == SX_RNG_PHILOX) {
-            // 32-bit crossover uniforms: one call per 4 steps (slot = (q>>2)*LPR + l, word = q&3)
-            const U4 w = philox4x32_10((uint32_t)(q0 >> 2) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposeDeCross,
-                                       a.key0, a.key1);
-            br[0] = u32(w.x);
-            br[1] = u32(w.y);
-            br[2] = u32(w.z);
-            br[3] = u32(w.w);
+            // 53-bit crossover uniforms, as the reference's rand(P, n) draws them (de/_de.py:250): two per call
+            // (slot = (q>>1)*LPR + l, half = q&1), two calls per 4 steps.  (Rounds 1-5 drew 32-bit ones, one call per 4 steps:
+            // +0.3 % at M, +2.4 % at C2 for the reference's own precision -- profiles/r6_philox53.txt.)
+#pragma unroll
+            for (int t = 0; t < kStep; t += 2) {
+                const U4 w = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposeDeCross,
+                                           a.key0, a.key1);
+                br[t] = u53(w.x, w.y);
+                br[t + 1] = u53(w.z, w.w);
+            }
             if (repair) {
 #pragma unroll
                 for (int t = 0; t < kStep; ++t) {

@@ -155,8 +155,6 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
-// 32-bit uniform in [0,1): word * 2^-32 (exact)
-__device__ __forceinline__ double u32(uint32_t a) { return (double)a * (1.0 / 4294967296.0); }
 
 enum : uint32_t {
     kPurposeDeCross = 0,

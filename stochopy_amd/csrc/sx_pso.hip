@@ -186,15 +186,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kerne
             for (int t = 0; t < kStep; ++t) g[t] = gbc[(q0 + t) * LPR + l];
         }
         if (RNG == SX_RNG_PHILOX) {
-            // 32-bit uniforms, one call per 2 steps: words (0,1) -> (r1,r2) of even q, (2,3) of odd q
+            // 53-bit r1 and r2, as the reference's two rand(P, n) blocks (cpso/_cpso.py:262-263): a call per purpose and pair
+            // of steps (slot = (q>>1)*LPR + l, half = q&1).  (Rounds 1-5: 32-bit ones, one call for both -- +2.8 % at C3a / C3b
+            // for the reference's own precision, profiles/r6_philox53.txt.)
 #pragma unroll
             for (int t = 0; t < kStep; t += 2) {
-                const U4 wd = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen,
-                                            kPurposePsoR1, a.key0, a.key1);
-                r1[t] = u32(wd.x);
-                r2[t] = u32(wd.y);
-                r1[t + 1] = u32(wd.z);
-                r2[t + 1] = u32(wd.w);
+                const uint32_t slot = (uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l;
+                const U4 wa = philox4x32_10(slot, grow, gen, kPurposePsoR1, a.key0, a.key1);
+                const U4 wb = philox4x32_10(slot, grow, gen, kPurposePsoR2, a.key0, a.key1);
+                r1[t] = u53(wa.x, wa.y);
+                r1[t + 1] = u53(wa.z, wa.w);
+                r2[t] = u53(wb.x, wb.y);
+                r2[t + 1] = u53(wb.z, wb.w);
             }
         }
         if (RNG == SX_RNG_PHILOX && reseed) {  // X = uniform(lower, upper) keyed like pso_restart_apply_kernel's draws

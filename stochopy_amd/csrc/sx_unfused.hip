@@ -63,12 +63,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_propose_kernel(co
             rs[t] = (RNG == SX_RNG_HOST && in && repair) ? a.resample[row * (int64_t)n + e] : 0.0;
         }
         if (RNG == SX_RNG_PHILOX) {
-            const U4 w = philox4x32_10((uint32_t)(q0 >> 2) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposeDeCross,
-                                       a.key0, a.key1);
-            r[0] = u32(w.x);
-            r[1] = u32(w.y);
-            r[2] = u32(w.z);
-            r[3] = u32(w.w);
+#pragma unroll
+            for (int t = 0; t < kStep; t += 2) {  // 53-bit crossover uniforms, the fused kernel's layout
+                const U4 w = philox4x32_10((uint32_t)((q0 + t) >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposeDeCross,
+                                           a.key0, a.key1);
+                r[t] = u53(w.x, w.y);
+                r[t + 1] = u53(w.z, w.w);
+            }
         }
 #pragma unroll
         for (int t = 0; t < kStep; ++t) {
@@ -109,9 +110,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(cons
     const bool stash = shrink && n <= kWideFrom;
     // raw velocity of the two elements (q0 + t) * LPR + l, t = 0, 1 (one Philox call)
     auto raw = [&](int q0, double(&x)[2], double(&vn)[2]) {
-        U4 pw = {0u, 0u, 0u, 0u};
-        if (RNG == SX_RNG_PHILOX)
+        U4 pw = {0u, 0u, 0u, 0u}, pv = {0u, 0u, 0u, 0u};  // 53-bit r1 / r2, the fused kernel's layout
+        if (RNG == SX_RNG_PHILOX) {
             pw = philox4x32_10((uint32_t)(q0 >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR1, a.key0, a.key1);
+            pv = philox4x32_10((uint32_t)(q0 >> 1) * (uint32_t)LPR + (uint32_t)l, grow, gen, kPurposePsoR2, a.key0, a.key1);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int e = (q0 + t) * LPR + l;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(cons
             if (e >= n) continue;
             const double v = vr[e], p = pb[e], g = gb[e];
             x[t] = xr[e];
-            double r1 = u32(t ? pw.z : pw.x), r2 = u32(t ? pw.w : pw.y);
+            double r1 = t ? u53(pw.z, pw.w) : u53(pw.x, pw.y), r2 = t ? u53(pv.z, pv.w) : u53(pv.x, pv.y);
             if (RNG == SX_RNG_HOST) {
                 r1 = a.r1[rowc * (int64_t)n + e];
                 r2 = a.r2[rowc * (int64_t)n + e];

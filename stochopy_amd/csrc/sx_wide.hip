@@ -635,12 +635,16 @@ __global__ __launch_bounds__(kGenThreads, 4) void wide_de_kernel(const sx_de_arg
             if (repair && in) L.lo[t] = a.lower[e], L.hi[t] = a.upper[e];
         }
     };
-    auto de_consume = [&](int g, int t0, const U4 &w, int e0, int e1, int e1s, DeLoads &L, double *Sd) {
+    auto de_consume = [&](int g, int t0, int e0, int e1, int e1s, DeLoads &L, double *Sd) {
         const int eb = (g >> 6) * 256 + (g & 63);
-        if (RNG == SX_RNG_PHILOX) {
-            const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+        if (RNG == SX_RNG_PHILOX) {  // 53-bit crossover uniforms: slot = (q >> 1) * 64 + l, half = q & 1 (q = 4 (g >> 6) + t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) L.r[t] = u32(wd[t0 + t]);
+            for (int t = 0; t < NT; t += 2) {
+                const U4 w = philox4x32_10((uint32_t)(((g >> 6) * 4 + t0 + t) >> 1) * 64u + (uint32_t)(g & 63), grow, gen,
+                                           kPurposeDeCross, a.key0, a.key1);
+                L.r[t] = u53(w.x, w.y);
+                L.r[t + 1] = u53(w.z, w.w);
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -658,13 +662,11 @@ __global__ __launch_bounds__(kGenThreads, 4) void wide_de_kernel(const sx_de_arg
     };
     const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
         for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
-            U4 w = {0u, 0u, 0u, 0u};
-            if (RNG == SX_RNG_PHILOX) w = philox4x32_10((uint32_t)g, grow, gen, kPurposeDeCross, a.key0, a.key1);
 #pragma unroll
             for (int t0 = 0; t0 < 4; t0 += NT) {
                 DeLoads A;
                 de_issue(g, t0, e0, e1s, A);
-                de_consume(g, t0, w, e0, e1, e1s, A, Sd);
+                de_consume(g, t0, e0, e1, e1s, A, Sd);
             }
         }
     });
@@ -758,8 +760,9 @@ __global__ __launch_bounds__(kGenThreads) void wide_pso_kernel(const sx_pso_args
 #pragma unroll
             for (int t = 0; t < 4; t += 2) {
                 const uint32_t slot = (uint32_t)(((g >> 6) * 4 + t) >> 1) * 64u + (uint32_t)(g & 63);
-                const U4 wd = philox4x32_10(slot, grow, gen, kPurposePsoR1, a.key0, a.key1);
-                L.r1[t] = u32(wd.x), L.r2[t] = u32(wd.y), L.r1[t + 1] = u32(wd.z), L.r2[t + 1] = u32(wd.w);
+                const U4 wa = philox4x32_10(slot, grow, gen, kPurposePsoR1, a.key0, a.key1);
+                const U4 wb = philox4x32_10(slot, grow, gen, kPurposePsoR2, a.key0, a.key1);
+                L.r1[t] = u53(wa.x, wa.y), L.r1[t + 1] = u53(wa.z, wa.w), L.r2[t] = u53(wb.x, wb.y), L.r2[t + 1] = u53(wb.z, wb.w);
                 if (reseed) {
                     const U4 wr = philox4x32_10(slot, grow, gen - 1u, kPurposePsoRestart, a.key0, a.key1);
                     const double u[2] = {u53(wr.x, wr.y), u53(wr.z, wr.w)};
