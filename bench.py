@@ -353,7 +353,30 @@ def main():
     MAX_BLOCKS = 1 << 20
     MIN_TIMED_S = args.min_timed_seconds  # (the driver's GPU-busy sampler and timed-region check need seconds)
 
-    def measure(exchange, objective=objective, n=n, Ptotal=None, strategy=strategy, donors=os.environ.get("SX_DONORS"),
+    def self_check(exchange, gens=3):
+        """First contact with distinct devices validates itself before anything is timed (VERDICT r5 next #6c): `gens`
+        generations of the benchmark's own run over `exchange`, then every rank's (best f, global row, generation count) --
+        they must be ONE answer on all ranks.  Returns it (the caller compares the transports with each other)."""
+        lower, upper = np.full(n, -5.12), np.full(n, 5.12)
+        run = _de._DeRun(_lib.FUN_IDS[objective], lower, upper, None, 2**31 - 2, world * P, 0.5, 0.9, strategy,
+                         None, 0.0, -1.0, False, 1.0, None, "philox", 1234, world, autorun=False, exchange=exchange,
+                         donors=os.environ.get("SX_DONORS") or "shard")
+        try:
+            with torch.cuda.stream(run.ctx.stream):
+                run._setup()
+                run.enqueue(gens)
+                st = run.read_state()
+            mine = (float(st.gfit).hex(), int(st.gbidx), int(st.it))
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            barrier()  # no rank frees its exchange buffer while a peer may still write into it
+        finally:
+            run.close()
+        if any(e != everyone[0] for e in everyone):
+            raise RuntimeError(f"self-check over exchange={exchange!r}: the ranks disagree after {gens} generations: {everyone}")
+        return everyone[0]
+
+    def measure(exchange, objective=objective, n=n, Ptotal=None, strategy=strategy, donors=os.environ.get("SX_DONORS") or "shard",
                 K=K, W=W, kernel_launches=args.kernel_timing_launches):
         """One resident run: W warm-up steps, then blocks of K steps until >= 2 s are timed.  Ptotal None: weak
         scaling (every GPU owns P rows of a global population of world*P; same seed on every rank)."""
@@ -468,12 +491,14 @@ def main():
             return None, str(e)[:300]
 
     transports = None
+    checks = {}
     if world == 1:
         m = measure(None)
     else:
         import threading
 
         threading.Thread(target=watchdog, daemon=True).start()
+        checks = {"rccl": guarded("self-check rccl", 300.0, lambda: self_check("rccl"))}  # (raises: nothing valid to time)
         m_rccl = guarded("rccl", 600.0, lambda: measure("rccl"))
         transports = {"rccl": {"value": m_rccl["rows_total"] * m_rccl["steps_timed"] / m_rccl["dt"],
                                "ms_per_step": m_rccl["dt"] / m_rccl["steps_timed"] * 1e3}}
@@ -543,6 +568,8 @@ def main():
         line["process_group"] = dist.get_backend() if dist is not None else None
         line["transport"] = None if run.world is None else run.exchange
         line["transports"] = transports
+        if run.world is not None:  # (3 generations per transport before anything was timed: one answer on every rank)
+            line["self_check"] = {k: {"best_f": float.fromhex(v[0]), "global_row": v[1], "generation": v[2]} for k, v in checks.items()}
         line["transport_fallback"] = transport_fallback or getattr(run, "exchange_note", None)
         if c5 is not None:
             line["c5"] = c5
@@ -578,6 +605,14 @@ def main():
         p2p_off = ("SX_BENCH_P2P=0" if os.environ.get("SX_BENCH_P2P", "1") == "0" else
                    "SX_EXCHANGE=rccl" if os.environ.get("SX_EXCHANGE") == "rccl" else None)
         if p2p_off is None:
+            # the peer-write transport must give the RCCL transport's answer before it is timed: same (f, row, generation)
+            try:
+                checks["p2p"] = guarded("self-check p2p", 300.0, lambda: self_check("p2p"))
+                if checks["p2p"] != checks["rccl"]:
+                    p2p_off = f"self-check: p2p gave {checks['p2p']}, rccl {checks['rccl']} after 3 generations"
+            except Exception as e:  # noqa: BLE001  (negotiation failed on some rank, a wait timed out, or the ranks disagree)
+                p2p_off = "self-check p2p: " + str(e)[:300]
+        if p2p_off is None:
             m_p2p, p2p_note = measure_p2p_or_none("p2p (peer writes over xGMI)", 300.0)
             if m_p2p is not None:
                 v = m_p2p["rows_total"] * m_p2p["steps_timed"] / m_p2p["dt"]
@@ -595,7 +630,7 @@ def main():
                 transports["p2p"] = {"error": p2p_note}
                 c5["donors_global_p2p"] = {"error": "needs the peer mappings: " + (p2p_note or "")}
         else:
-            p2p_note = p2p_off + " (switched off by the environment)"
+            p2p_note = p2p_off + ("" if p2p_off.startswith("self-check") else " (switched off by the environment)")
             transports["p2p"] = {"skipped": p2p_note}
             c5["donors_global_p2p"] = {"error": "needs the peer exchange: " + p2p_note}
         state["deadline"] = None

@@ -91,6 +91,11 @@ int sx_rows_per_workgroup(int n); /* rows of one workgroup of the row kernels = 
 /* Rows of more than this many elements are served by the one-workgroup-per-row kernels (one record per row, no chained /
  * peer-exchange form): what a host loop needs to know to size its record buffers and to pick the two-kernel path. */
 int sx_wide_from(void);
+/* The same threshold, set for the runs that follow: n <= 0 restores the library's own (2048: where the one-workgroup-per-row
+ * kernels become the faster ones); otherwise clamped to [256, 4096], the range the wavefront-per-row kernels can serve.  A run
+ * that needs the chained kernel's peer exchange or its global-donor gathers on rows of 2049 ... 4096 elements raises it to 4096
+ * for its duration (optimize/_de.py).  Returns the previous value.  Process-wide, not thread-safe. */
+int sx_set_wide_from(int n);
 int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd,
             double *f, double *part_f, int64_t *part_i, void *stream);
 

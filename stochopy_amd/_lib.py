@@ -115,6 +115,7 @@ class SxCmaArgs(C.Structure):
 PROTOTYPES = {
     "sx_abi_version": (C.c_int, []),
     "sx_wide_from": (C.c_int, []),
+    "sx_set_wide_from": (C.c_int, [C.c_int]),
     "sx_last_error": (C.c_char_p, []),
     "sx_device_count": (C.c_int, []),
     "sx_struct_size": (C.c_int, [C.c_int]),

@@ -104,8 +104,19 @@ extern "C" int64_t sx_fun_terms(int fun_id, int n) {
 }
 
 extern "C" int64_t sx_num_partials(int64_t P, int n) { return (int64_t)row_geometry(P, n).blocks; }
-extern "C" int sx_rows_per_workgroup(int n) { return n > kWideFrom ? 1 : rows_per_block(n); }
-extern "C" int sx_wide_from(void) { return kWideFrom; }
+namespace sx {
+int g_wide_from = kWideFrom;
+}
+extern "C" int sx_rows_per_workgroup(int n) { return n > sx::wide_from() ? 1 : rows_per_block(n); }
+extern "C" int sx_wide_from(void) { return sx::wide_from(); }
+// n <= 0: back to the library's own threshold; otherwise clamped to [256, 4096] (what the wavefront-per-row kernels can serve).
+// Returns the previous value.  Process-wide, not thread-safe: set it before a run's first call and restore it after its last
+// (everything that depends on it -- record counts, geometries, which kernels run -- is read per call).
+extern "C" int sx_set_wide_from(int n) {
+    const int prev = sx::g_wide_from;
+    sx::g_wide_from = n <= 0 ? kWideFrom : (n < 256 ? 256 : (n > kMaxDim ? kMaxDim : n));
+    return prev;
+}
 
 namespace sx {
 int make_plan_arg(int fun_id, int n, PlanArg *out) {
@@ -524,7 +535,7 @@ static int64_t eval_r8_min_rows(int64_t dflt) {
     return forced >= 0 ? forced : dflt;
 }
 static bool eval_r8_long_ok(int64_t P, int n, const double *xm, const double *part_f, int clip, int nleaf, bool cheap) {
-    const bool has_rival = n > kWideFrom || n == 512 || n == 1024 || n == 2048;
+    const bool has_rival = n > sx::wide_from() || n == 512 || n == 1024 || n == 2048;
     return eval_r8_long_mode() != 0 && n > 256 && n <= kMaxDim && nleaf >= 1 && nleaf <= kMaxLeaf && xm == nullptr &&
            part_f == nullptr && clip == 0 && P >= eval_r8_min_rows(has_rival ? 32768 : cheap ? 8192 : 16384);
 }

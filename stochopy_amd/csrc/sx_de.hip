@@ -59,7 +59,7 @@ extern "C" int sx_de_generation(const sx_de_args *a, int finalize, void *stream)
     if (int rc = check_args(a)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const Geometry g = geometry(a);
-    if (is_wide(a->n)) {  // rows of more than 4096 elements: one workgroup per row (sx_wide.hip), one record per row
+    if (is_wide(a->n)) {  // rows of more than sx_wide_from() elements: one workgroup per row (sx_wide.hip), one record per row
         if (int rc = wide_de_launch(a, s)) return rc;
     } else {
         PlanArg plan;

@@ -38,6 +38,11 @@ constexpr int kMaxDim = 4096; // leaves hold > 64 terms, so n <= 4096 has at mos
 #endif
 constexpr int kWideFrom = SX_WIDE_FROM;
 static_assert(kWideFrom >= 256 && kWideFrom <= kMaxDim, "the wide kernels take over somewhere inside the narrow kernels' range");
+// The threshold in effect (host side): kWideFrom unless a run needs the wavefront-per-row kernels for longer rows -- the peer
+// exchange and the global-donor gathers live in the chained DE kernel, which serves rows of up to kMaxDim elements
+// (sx_set_wide_from; optimize/_de.py raises it to kMaxDim for exchange="p2p" / donors="global" and restores it afterwards).
+extern int g_wide_from;
+inline int wide_from() { return g_wide_from; }
 
 // Rows of more than 256 elements form their objective terms inside the reduction (row_reduce_leaves_fused:
 // one leaf of <= 128 terms per 8-lane group, so >= 3 of the 8 groups are busy); shorter rows have too few

@@ -1025,7 +1025,7 @@ extern "C" int sx_pso_generation(const sx_pso_args *a, int finalize, void *strea
     if (int rc = check_args(a)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const Geometry g = geometry(a->P, a->n);
-    if (is_wide(a->n)) {  // rows of more than 4096 elements: one workgroup per particle (sx_wide.hip)
+    if (is_wide(a->n)) {  // rows of more than sx_wide_from() elements: one workgroup per particle (sx_wide.hip)
         if (int rc = wide_pso_launch(a, s)) return rc;
     } else {
         PlanArg plan;

@@ -35,7 +35,7 @@ struct Geometry {
 inline Geometry row_geometry(int64_t P, int n) {
     // wide rows (n > kWideFrom, sx_wide.hip): one row and one record per workgroup; the kernels that still walk such a row with
     // ONE wavefront (candidate / selection / radius kernels: no staging) are launched with 64 threads and no dynamic LDS
-    if (n > kWideFrom) return Geometry{(unsigned)P, (unsigned)kWave, 0};
+    if (n > sx::wide_from()) return Geometry{(unsigned)P, (unsigned)kWave, 0};
     const int wpb = waves_per_block(n);
     const int rpb = rows_per_block(n);
     return Geometry{(unsigned)((P + rpb - 1) / rpb), (unsigned)(wpb * kWave),

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void de_propose_kernel(co
 
 // V = w*V + c1*r1*(pbest - X) + c2*r2*(gbest - X); X += V (after Shrink): X and V in place
 template <int RNG, int LPR>
-__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(const sx_pso_args a) {
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(const sx_pso_args a, const int has_stash) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const sx_state *st = a.state;
     if (st->done) return;
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_move_kernel(cons
     const bool shrink = a.constraints != 0;
     double beta = __builtin_huge_val();
     const int nq = (n + LPR - 1) / LPR;
-    // wide rows (n > kWideFrom: one wavefront per row, no dynamic LDS): with Shrink the raw velocities are formed AGAIN
-    // behind the row-wide beta instead of waiting in LDS -- same operands, same operations, same bits
-    const bool stash = shrink && n <= kWideFrom;
+    // wide rows (n > sx_wide_from(): one wavefront per row, no dynamic LDS -- has_stash = 0): with Shrink the raw velocities are
+    // formed AGAIN behind the row-wide beta instead of waiting in LDS -- same operands, same operations, same bits
+    const bool stash = shrink && has_stash;
     // raw velocity of the two elements (q0 + t) * LPR + l, t = 0, 1 (one Philox call)
     auto raw = [&](int q0, double(&x)[2], double(&vn)[2]) {
         U4 pw = {0u, 0u, 0u, 0u}, pv = {0u, 0u, 0u, 0u};  // 53-bit r1 / r2, the fused kernel's layout
@@ -235,13 +235,13 @@ extern "C" int sx_pso_move(const sx_pso_args *a, void *stream) {
     SX_REQUIRE(a->rng != SX_RNG_HOST || (a->r1 && a->r2), "sx_pso_move: host draws missing");
     SX_REQUIRE(a->constraints == 0 || (a->lower && a->upper), "sx_pso_move: bounds missing");
     const Geometry g = row_geometry(a->P, a->n);
-    const size_t lds = a->n > kWideFrom ? 0 : (size_t)rows_per_block(a->n) * a->n * sizeof(double);
+    const size_t lds = a->n > sx::wide_from() ? 0 : (size_t)rows_per_block(a->n) * a->n * sizeof(double);
     if (a->rng == SX_RNG_PHILOX) {
         SX_DISPATCH_LPR(a->n, hipLaunchKernelGGL((pso_move_kernel<SX_RNG_PHILOX, LPR>), dim3(g.blocks), dim3(g.threads), lds,
-                                                 (hipStream_t)stream, *a))
+                                                 (hipStream_t)stream, *a, lds != 0 ? 1 : 0))
     } else {
         SX_DISPATCH_LPR(a->n, hipLaunchKernelGGL((pso_move_kernel<SX_RNG_HOST, LPR>), dim3(g.blocks), dim3(g.threads), lds,
-                                                 (hipStream_t)stream, *a))
+                                                 (hipStream_t)stream, *a, lds != 0 ? 1 : 0))
     }
     SX_LAUNCH_CHECK();
     return 0;

@@ -12,7 +12,7 @@ namespace sx {
 
 constexpr int kWideMaxDim = 262144;  // leaf sums of a row (2 (n/64 + 2) doubles) share the LDS with the stage
 
-inline bool is_wide(int n) { return n > kWideFrom; }
+inline bool is_wide(int n) { return n > wide_from(); }
 
 int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
               double *part_f, int64_t *part_i, int clip, const double *pen_v, double *pen_out, hipStream_t s);

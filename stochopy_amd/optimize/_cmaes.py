@@ -150,7 +150,7 @@ class _CmaDeviceRun:
             from ..parallel import require_world
 
             world = require_world(workers)
-            row0, Pl = world.shard(P)  # popsize must divide evenly
+            row0, Pl = world.shard(P)  # blocks of ceil(P / workers) rows, the last rank short
         with t.cuda.stream(ctx.stream):
             init = _rng.make_init_stream("philox", seed)
             key0, key1 = _rng.philox_key(seed)
@@ -448,7 +448,7 @@ class _CmaRun:
             from ..parallel import require_world
 
             self.world = require_world(workers)
-            self.world.shard(P)  # popsize must divide evenly
+            self.world.shard(P)  # blocks of ceil(P / workers) rows, the last rank short
         self.fun_id, self.lower, self.upper, self.x0 = fun_id, lower, upper, x0
         self.maxiter, self.P, self.n = maxiter, P, len(lower)
         self.sigma0, self.muperc, self.xtol, self.ftol = sigma, muperc, xtol, ftol

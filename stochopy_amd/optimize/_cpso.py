@@ -119,6 +119,11 @@ class _PsoRun:
             if rng != "philox":
                 raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
+            if gamma and P % self.world.size != 0:
+                # (PSO takes any popsize -- blocks of ceil(P / workers) rows, the last rank short; the competitive restart's
+                # swarm-wide selection gathers equal [pbestfit | radii] segments per rank)
+                raise ValueError(f"cpso with workers={self.world.size}: popsize={P} must be a multiple of workers (pso, de, "
+                                 "cmaes and vdcma take any popsize)")
             if immediate:
                 raise ValueError("immediate updating is a single-GPU sweep")
         if immediate and self.external is not None:

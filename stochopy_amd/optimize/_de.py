@@ -10,6 +10,7 @@ best/termination kernel.
 """
 import ctypes as C
 import os
+import warnings
 
 import numpy as np
 
@@ -137,85 +138,119 @@ class _DeRun:
         if donors not in (None, "shard", "global"):
             raise ValueError('donors must be "shard" or "global"')
         self.global_donors = donors == "global" and self.world is not None
+        if self.world is not None and self.world.size > 1 and donors is None and not _DeRun._warned_island:
+            # The reference's invariant is "the backend does not change the result for a seed" (its tests/helpers.py:28-36,
+            # stochopy/optimize/_common.py:58-72).  The DEFAULT here breaks it knowingly: SURVEY.md section 8e / the north star
+            # shard the population "embarrassingly", i.e. donors come from the rank's own rows.  Say so once; donors="shard"
+            # (chosen, no warning) and donors="global" (the unsharded run, bit for bit) are the explicit spellings.
+            _DeRun._warned_island = True
+            warnings.warn('stochopy_amd: de with workers > 1 draws donors from each rank\'s own rows by default (an island model '
+                          'with a shared global best): the result for a seed then depends on the number of workers, unlike the '
+                          'reference\'s parallel backends.  options["donors"]="global" reproduces the workers=1 run bit for bit '
+                          '(donor rows are read over xGMI; needs the peer exchange); options["donors"]="shard" keeps this mode '
+                          'without the warning.  (Shown once.)', UserWarning, stacklevel=4)
         if self.world is not None:
-            if self.P < 2:
-                raise ValueError(f"popsize {self.Ptotal} over {self.world.size} ranks leaves {self.P} row(s) per GPU: "
+            # (every rank checks the SMALLEST shard -- the last rank's, parallel.shard_bounds -- so that all of them raise, or none)
+            smallest = self.Ptotal - (self.world.size - 1) * self.world.shard_rows(self.Ptotal)
+            if smallest < 2:
+                raise ValueError(f"popsize {self.Ptotal} over {self.world.size} ranks leaves {smallest} row(s) on the last GPU: "
                                  "a shard needs at least 2")
-            if (self.Ptotal if self.global_donors else self.P) - 1 < self.k:
+            if (self.Ptotal if self.global_donors else smallest) - 1 < self.k:
                 raise ValueError(f"strategy {strategy} draws {self.k} donors: too few rows "
-                                 f"({'population' if self.global_donors else 'shard'} of "
-                                 f"{self.Ptotal if self.global_donors else self.P})")
+                                 f"({'population' if self.global_donors else 'smallest shard'} of "
+                                 f"{self.Ptotal if self.global_donors else smallest})")
         self.x0 = x0
         # single GPU + in-kernel draws + nothing to report per generation: one kernel per generation
         # ("chained finalize", include/stochopy_hip.h sx_de_chain_launch)
         # -- every wavefront re-reduces the per-workgroup records, so only while those are few (<= 512)
-        npart = int(_lib.lib().sx_num_partials(self.P, self.n))
-        # (rows of more than 4096 elements -- csrc/sx_wide.hip, one workgroup per row -- take the two-kernel path)
-        self.wide = self.n > _lib.wide_from()
-        self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
-                      and npart <= 512 and not immediate and self.external is None and not self.wide)
-        self.launches = 0
-        self.ctx = _device.Context()
-        # multi-GPU: the chained kernel with the peer exchange in its prologue, if the transport checks out
-        self.px = None
-        self.exchange = None
-        if self.world is not None:
-            exchange = exchange or os.environ.get("SX_EXCHANGE") or "auto"
-            if exchange not in ("auto", "p2p", "rccl"):
-                raise ValueError('exchange must be "auto", "p2p" or "rccl"')
-            self.exchange, self.exchange_note = "rccl", None
-            if self.external is not None:
-                if exchange == "p2p" or self.global_donors:
-                    raise ValueError("a caller-supplied objective runs between kernels: the peer exchange lives "
-                                     'inside the fused generation kernel (use exchange="rccl", donors="shard")')
-                exchange = "rccl"
-            if self.wide:  # the peer exchange lives in the chained kernel, which serves rows of <= 4096 elements
-                if exchange == "p2p" or self.global_donors:
-                    raise ValueError(f"rows of {self.n} elements (> {_lib.wide_from()}) exchange the global best with one "
-                                     'all-gather per generation (exchange="rccl", donors="shard")')
-                exchange = "rccl"
-            if exchange != "rccl":
-                from ..parallel import PeerExchange
+        # Rows of more than wide_from() (2048) elements take the one-workgroup-per-row kernels (csrc/sx_wide.hip, two kernels per
+        # generation); the peer exchange and the global-donor gathers live in the chained kernel, which serves rows of up to
+        # NARROW_DIM (4096) elements: a run that ASKS for them on rows of 2049 ... 4096 elements gets the wavefront-per-row
+        # kernels for its duration (sx_set_wide_from; restored by close()).  exchange="auto" keeps the faster wide kernels and
+        # the all-gather there.
+        self._wide_from_prev = None
+        needs_narrow = (self.world is not None and self.external is None
+                        and (donors == "global" or (exchange or os.environ.get("SX_EXCHANGE")) == "p2p"))
+        if needs_narrow and _lib.wide_from() < self.n <= _lib.NARROW_DIM:
+            self._wide_from_prev = int(_lib.lib().sx_set_wide_from(_lib.NARROW_DIM))
+        try:
+            npart = int(_lib.lib().sx_num_partials(self.P, self.n))
+            self.wide = self.n > _lib.wide_from()
+            self.chain = (rng == "philox" and self.world is None and callback is None and not return_all
+                          and npart <= 512 and not immediate and self.external is None and not self.wide)
+            self.launches = 0
+            self.ctx = _device.Context()
+            # multi-GPU: the chained kernel with the peer exchange in its prologue, if the transport checks out
+            self.px = None
+            self.exchange = None
+            if self.world is not None:
+                exchange = exchange or os.environ.get("SX_EXCHANGE") or "auto"
+                if exchange not in ("auto", "p2p", "rccl"):
+                    raise ValueError('exchange must be "auto", "p2p" or "rccl"')
+                self.exchange, self.exchange_note = "rccl", None
+                if self.external is not None:
+                    if exchange == "p2p" or self.global_donors:
+                        raise ValueError("a caller-supplied objective runs between kernels: the peer exchange lives "
+                                         'inside the fused generation kernel (use exchange="rccl", donors="shard")')
+                    exchange = "rccl"
+                if self.wide:  # the peer exchange lives in the chained kernel, which serves rows of <= NARROW_DIM elements
+                    if exchange == "p2p" or self.global_donors:
+                        raise ValueError(f"rows of {self.n} elements (> {_lib.NARROW_DIM}) exchange the global best with one "
+                                         'all-gather per generation (exchange="rccl", donors="shard")')
+                    exchange = "rccl"
+                if exchange != "rccl":
+                    from ..parallel import PeerExchange
 
-                timeout = float(os.environ.get("SX_XCHG_TIMEOUT_S", "20"))
-                self.px, self.exchange_note = PeerExchange.negotiate(self.ctx, self.world, self.n, timeout)
-                if self.px is not None:
-                    self.exchange, self.chain = "p2p", True
-                elif exchange == "p2p":
-                    raise RuntimeError(f'exchange="p2p" is not available: {self.exchange_note}')
-            if self.global_donors and self.px is None:
-                raise RuntimeError('donors="global" needs the peer exchange (exchange="p2p"/"auto"): '
-                                   f'{self.exchange_note or "it was switched off"}')
-        self._graph = None
-        self._chain_graphs = {}
-        self._tail_seen = {}
-        self._ext_graphs, self._ext_graph_note = {}, None
-        self._shard_calls = None
-        self._rccl_graph = None
-        self._rccl_graphs, self._rccl_tail_seen = {}, {}
-        self._rccl_graph_note = None
-        if autorun:
-            t = _device.torch()
-            with t.cuda.stream(self.ctx.stream):
-                ok = False
-                try:
-                    self._run()
-                    ok = True
-                finally:
+                    timeout = float(os.environ.get("SX_XCHG_TIMEOUT_S", "20"))
+                    self.px, self.exchange_note = PeerExchange.negotiate(self.ctx, self.world, self.n, timeout)
+                    if self.px is not None:
+                        self.exchange, self.chain = "p2p", True
+                    elif exchange == "p2p":
+                        raise RuntimeError(f'exchange="p2p" is not available: {self.exchange_note}')
+                if self.global_donors and self.px is None:
+                    raise RuntimeError('donors="global" needs the peer exchange (exchange="p2p"/"auto"): '
+                                       f'{self.exchange_note or "it was switched off"}')
+            self._graph = None
+            self._chain_graphs = {}
+            self._tail_seen = {}
+            self._ext_graphs, self._ext_graph_note = {}, None
+            self._shard_calls = None
+            self._rccl_graph = None
+            self._rccl_graphs, self._rccl_tail_seen = {}, {}
+            self._rccl_graph_note = None
+            if autorun:
+                t = _device.torch()
+                with t.cuda.stream(self.ctx.stream):
+                    ok = False
                     try:
-                        if self.px is not None:
-                            # Peers may still be reading this rank's exchange / population memory (their last kernels,
-                            # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
-                            # stream.  The meeting point is reached by failing ranks too (it carries a success flag):
-                            # a rank whose objective / callback raised makes its peers raise, not hang in a barrier.
-                            if ok:
-                                self.ctx.sync()
-                            if not self.world.all_agree(ok) and ok:
-                                raise RuntimeError("a peer rank failed during the run (its own exception says why)")
+                        self._run()
+                        ok = True
                     finally:
-                        self.close()
+                        try:
+                            if self.px is not None:
+                                # Peers may still be reading this rank's exchange / population memory (their last kernels,
+                                # remote donor rows): nobody unmaps or frees anything before EVERY rank has drained its
+                                # stream.  The meeting point is reached by failing ranks too (it carries a success flag):
+                                # a rank whose objective / callback raised makes its peers raise, not hang in a barrier.
+                                if ok:
+                                    self.ctx.sync()
+                                if not self.world.all_agree(ok) and ok:
+                                    raise RuntimeError("a peer rank failed during the run (its own exception says why)")
+                        finally:
+                            self.close()
+        except BaseException:
+            self._restore_wide_from()
+            raise
+
+    def _restore_wide_from(self):
+        if self._wide_from_prev is not None:
+            _lib.lib().sx_set_wide_from(self._wide_from_prev)
+            self._wide_from_prev = None
 
     def close(self):
+        if self._wide_from_prev is not None:
+            self.ctx.sync()
+            self._restore_wide_from()
         if self._rccl_graph is not None or self._ext_graphs:
             self.ctx.sync()
             self._rccl_graph = None
@@ -255,6 +290,7 @@ class _DeRun:
             _lib.check(ctx.L.sx_de_chain_launch(C.byref(self.args), parity, finalize_only, ctx.stream_ptr),
                        "sx_de_chain_launch")
 
+    _warned_island = False
     TAIL_CHUNK = 10  # a second, short graph: runs of fewer than GRAPH_CHUNK generations are replayed too (even: parity)
 
     def _chain_graph(self, par, size=None):
@@ -404,7 +440,7 @@ class _DeRun:
         self.d_lower, self.d_upper = d_bounds[:n], d_bounds[n:]
         # generation g lives in bufs[g & 1]; the initial population is generation 1
         if self.global_donors:  # buffers every peer maps: donor rows are read from their owners over xGMI
-            self.bufs = list(self.px.share_population(P, n))
+            self.bufs = list(self.px.share_population(P, n, self.Ptotal))
         else:
             self.bufs = [ctx.empty((P, n)), ctx.empty((P, n))]
         if self.x0 is None and self.rng == "philox":

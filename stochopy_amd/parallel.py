@@ -32,12 +32,23 @@ def require_world(workers):
     return World(dist)
 
 
+def shard_rows(popsize, world):
+    """Rows per shard: ceil(popsize / world).  Every rank but the last owns exactly this many."""
+    return -(-int(popsize) // int(world))
+
+
 def shard_bounds(popsize, world, rank):
-    """Rows [row0, row0 + count) of rank `rank`: equal shards (popsize must divide evenly)."""
-    if popsize % world != 0:
-        raise ValueError(f"popsize={popsize} must be a multiple of workers={world}")
-    count = popsize // world
-    return rank * count, count
+    """Rows [row0, row0 + count) of rank `rank`: blocks of ceil(popsize / world) rows in rank order, the LAST rank takes what
+    is left -- any popsize is served, as the reference's MPI loop serves any (stochopy/optimize/_common.py:64-65 strides
+    `range(rank, len(x), size)`; here blocks, so that a row's owner is `row // shard_rows` and a gather of equal-sized,
+    padded blocks holds the population in its first `popsize` rows).  Every rank needs at least one row."""
+    c = shard_rows(popsize, world)
+    last = popsize - (world - 1) * c
+    if last < 1:
+        raise ValueError(f"popsize={popsize} over workers={world}: blocks of {c} rows leave the last rank {last} row(s); "
+                         "use fewer workers or a larger population")
+    row0 = rank * c
+    return row0, min(c, popsize - row0)
 
 
 class World:
@@ -52,6 +63,9 @@ class World:
 
     def shard(self, popsize):
         return shard_bounds(popsize, self.size, self.rank)
+
+    def shard_rows(self, popsize):
+        return shard_rows(popsize, self.size)
 
     # Graph captures that contain collectives of this group.  torch's ProcessGroupNCCL runs a watchdog thread that polls
     # the completion events of outstanding collectives every 100 ms.  If it polls while this thread captures on the
@@ -115,7 +129,25 @@ class World:
         out.copy_(torch.stack(gathered).to(out.device))
 
     def all_gather_rows(self, local, out):
-        """out[(world * rows, ...)] <- every rank's local[(rows, ...)] in rank order (CMA-ES candidates / fitness)."""
+        """out[(total rows, ...)] <- every rank's local[(rows, ...)] in rank order (CMA-ES candidates / fitness).  Shards of
+        ceil(total / world) rows, the last one short (shard_bounds): the blocks then travel padded to equal size and the
+        population is the first `total` rows of what arrives."""
+        import torch
+
+        total, c = int(out.shape[0]), shard_rows(out.shape[0], self.size)
+        if c * self.size != total:
+            key = (tuple(out.shape[1:]), out.dtype, out.device, c)
+            pads = getattr(self, "_pads", None)
+            if pads is None:
+                pads = self._pads = {}
+            if key not in pads:
+                pads[key] = (torch.zeros((c,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device),
+                             torch.empty((c * self.size,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device))
+            mine, everyone = pads[key]
+            mine[:local.shape[0]].copy_(local)
+            self.all_gather_rows(mine, everyone)
+            out.copy_(everyone[:total])
+            return
         if self.backend == "nccl":
             self.dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=self.group)
             return
@@ -228,10 +260,11 @@ class PeerExchange:
         px.args = a
         return px, None
 
-    def share_population(self, rows, n):
+    def share_population(self, rows, n, total=None):
         """Global donors: this rank's two population buffers (rows, n) in memory every peer maps, so that the
         generation kernels can read donor rows from their owners over xGMI.  Returns the two tensors (views of
-        one IPC-exported allocation).  Collective; raises on every rank if any rank fails."""
+        one IPC-exported allocation).  Collective; raises on every rank if any rank fails.  `total`: the whole
+        population (default world * rows); with a short last shard every rank's second buffer starts behind ITS rows."""
         import ctypes as C
 
         from . import _lib
@@ -263,11 +296,12 @@ class PeerExchange:
         if not world.all_agree(ok):
             raise RuntimeError(f'donors="global" is not available: {why or "a peer could not map this population"}')
         a = self.args
+        total = rows * world.size if total is None else int(total)
         for r, b in enumerate(bases):
             a.pop0[r] = b
-            a.pop1[r] = b + rows * n * 8
-        a.shard_rows = rows
-        a.global_rows = rows * world.size
+            a.pop1[r] = b + shard_bounds(total, world.size, r)[1] * n * 8
+        a.shard_rows = shard_rows(total, world.size)  # owner of global row g: g // shard_rows
+        a.global_rows = total
 
         class _Mem:  # zero-copy view of the exported allocation for torch
             __cuda_array_interface__ = {"shape": (2, rows, n), "typestr": "<f8", "data": (own.value, False),

@@ -72,11 +72,13 @@ def cpu_rows_worker(rank, world, port, cfg, out_dir):
         from stochopy_amd import parallel
 
         w = parallel.require_world(world)
-        rows, n = cfg["rows"], cfg["n"]
-        local = torch.arange(rows * n, dtype=torch.float64).reshape(rows, n) + 1000.0 * rank
-        out = torch.empty((world * rows, n), dtype=torch.float64)
+        n = cfg["n"]
+        total = cfg["total"] if "total" in cfg else world * cfg["rows"]
+        rows = w.shard(total)[1]  # (blocks of ceil(total / world) rows, the last rank short)
+        local = (torch.arange(w.shard_rows(total) * n, dtype=torch.float64).reshape(-1, n) + 1000.0 * rank)[:rows].contiguous()
+        out = torch.empty((total, n), dtype=torch.float64)
         w.all_gather_rows(local, out)
-        fit = torch.empty((world * rows,), dtype=torch.float64)
+        fit = torch.empty((total,), dtype=torch.float64)
         w.all_gather_rows(local[:, 0].contiguous(), fit)
         objs = w.all_gather_object({"rank": rank})
         assert [o["rank"] for o in objs] == list(range(world))

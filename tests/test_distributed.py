@@ -55,8 +55,11 @@ def test_shard_bounds_and_record_rule():
     from stochopy_amd import parallel
 
     assert [parallel.shard_bounds(4096, 8, r) for r in (0, 7)] == [(0, 512), (3584, 512)]
+    # any popsize (the reference's MPI loop takes any, _common.py:64-65): blocks of ceil(P / world) rows, the last rank short
+    assert [parallel.shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 3), (9, 1)]
+    assert [parallel.shard_bounds(131073, 8, r) for r in (0, 7)] == [(0, 16385), (114695, 16378)]
     with pytest.raises(ValueError):
-        parallel.shard_bounds(10, 4, 0)
+        parallel.shard_bounds(5, 4, 0)  # blocks of 2 leave the last rank nothing
     rec = np.array([[2.0, 700.0, 0, 0], [1.0, 900.0, 1, 1], [1.0, 300.0, 2, 2], [3.0, 0.0, 3, 3]])
     assert parallel.best_of_records(rec) == (2, 1.0, 300)  # ties -> smallest global row = np.argmin's first minimum
 
@@ -65,11 +68,11 @@ def test_world_exchange_two_ranks_gloo_cpu():
     """world_size 2 on CPU: the product's World exchange vs the one-process simulation of the same semantics."""
     from _dist_workers import cpu_exchange_worker
 
-    cfg = {"n": 12, "P": 48, "gens": 8, "seed": 31337}
-    out = _spawn(cpu_exchange_worker, 2, cfg)
-    ref = _sharded_oracle(cfg, 2)
-    for r in range(2):
-        assert np.array_equal(np.load(os.path.join(out, f"trace_{r}.npy")), np.array(ref["_trace"]))
+    for cfg in ({"n": 12, "P": 48, "gens": 8, "seed": 31337}, {"n": 12, "P": 49, "gens": 8, "seed": 31338}):  # 24 + 24, 25 + 24 rows
+        out = _spawn(cpu_exchange_worker, 2, cfg)
+        ref = _sharded_oracle(cfg, 2)
+        for r in range(2):
+            assert np.array_equal(np.load(os.path.join(out, f"trace_{r}.npy")), np.array(ref["_trace"]))
 
 
 def test_world_row_gather_and_agreement_gloo_cpu():
@@ -79,6 +82,12 @@ def test_world_row_gather_and_agreement_gloo_cpu():
     out = _spawn(cpu_rows_worker, 2, {"rows": 3, "n": 4})
     want = np.concatenate([np.arange(12.0).reshape(3, 4) + 1000.0 * r for r in range(2)])
     for r in range(2):
+        assert np.array_equal(np.load(os.path.join(out, f"rows_{r}.npy")), want)
+        assert np.array_equal(np.load(os.path.join(out, f"fit_{r}.npy")), want[:, 0])
+    # a population the ranks do not divide: 7 rows over 3 ranks = blocks of 3, 3, 1 (padded on the way, parallel.World)
+    out = _spawn(cpu_rows_worker, 3, {"total": 7, "n": 4})
+    want = np.concatenate([(np.arange(12.0).reshape(3, 4) + 1000.0 * r)[:c] for r, c in enumerate((3, 3, 1))])
+    for r in range(3):
         assert np.array_equal(np.load(os.path.join(out, f"rows_{r}.npy")), want)
         assert np.array_equal(np.load(os.path.join(out, f"fit_{r}.npy")), want[:, 0])
 
@@ -111,11 +120,12 @@ def test_cma_candidate_gather_two_ranks_gloo_cpu(method, constraints):
     World.all_gather_rows, model update replicated) -- the unsharded oracle run bit for bit on every rank."""
     from _dist_workers import cpu_cma_worker
 
-    cfg = {"n": 5, "P": 12, "maxiter": 30, "seed": 9, "objective": "rosenbrock", "constraints": constraints, "method": method}
+    P = 12 if constraints is None else 13  # (13 over 2 ranks: 7 + 6 rows, the last rank short)
+    cfg = {"n": 5, "P": P, "maxiter": 30, "seed": 9, "objective": "rosenbrock", "constraints": constraints, "method": method}
     out = _spawn(cpu_cma_worker, 2, cfg)
     run = oe.run_vdcma if method == "vdcma" else oe.run_cmaes
     ref = run(oracle.OBJECTIVES["rosenbrock"], np.full(5, -3.0), np.full(5, 3.0), None, oracle.PhiloxStream(9), maxiter=30,
-              popsize=12, sigma=0.3, constraints=constraints, eigh="canonical")
+              popsize=P, sigma=0.3, constraints=constraints, eigh="canonical")
     for r in range(2):
         got = np.load(os.path.join(out, f"cma_{r}.npz"))
         assert int(got["nit"]) == ref["nit"] and int(got["status"]) == ref["status"] and int(got["calls"]) >= ref["nit"]
@@ -176,6 +186,8 @@ def test_c5_full_size_sharded_over_eight_ranks_matches_oracle():
     dict(n=33, P=48, gens=25, seed=8, strategy="best2bin", constraints="Random"),
     dict(n=16, P=64, gens=400, seed=9, objective="sphere", ftol=1e-3, xtol=1e-8),   # stops on ftol (status 0/1)
     dict(n=2048, P=2200, gens=5, seed=10),                                 # 550 workgroup records per shard (> 512)
+    dict(n=3000, P=40, gens=5, seed=11),        # rows of 2049 ... 4096 elements: the chained kernel for the run's duration
+    dict(n=24, P=131, gens=9, seed=12),         # a population the ranks do not divide: 66 + 65 rows
 ])
 def test_p2p_exchange_cases(case):
     case = dict(case)
@@ -194,6 +206,8 @@ def test_p2p_exchange_cases(case):
     # ONE test GPU (ranks that share a device must all fit at once: a rank's waiting workgroups may otherwise fill it
     # before a peer's record-pushing workgroup is resident -- with one GPU per rank that cannot happen)
     (8, dict(n=1024, P=2048, gens=4, seed=6)),
+    (2, dict(n=3000, P=24, gens=6, seed=12)),    # rows of 2049 ... 4096 elements (refused in round 5)
+    (4, dict(n=24, P=130, gens=12, seed=13)),    # 33 + 33 + 33 + 31 rows: the owner of a donor row is row // 33
 ])
 def test_global_donors_reproduce_the_unsharded_run(world, case):
     """donors="global": donor rows are drawn over the whole population and read from their owners' HBM
@@ -576,3 +590,37 @@ def test_two_physical_gpus_pso_is_exact(method):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
         assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,n,P,world", [("pso", 20, 97, 2), ("pso", 20, 130, 4), ("cmaes", 20, 49, 2), ("vdcma", 40, 27, 2)])
+def test_any_popsize_is_sharded_the_last_rank_short(method, n, P, world):
+    """Round 6 (VERDICT r5 next #6b): popsize need not be a multiple of workers -- blocks of ceil(P / workers) rows, the last
+    rank takes what is left (parallel.shard_bounds; the reference's MPI loop takes any popsize, _common.py:64-65).  PSO is
+    row-local, CMA-ES / VD-CMA gather padded blocks: the sharded run is the unsharded one on every rank."""
+    import stochopy_amd as sa
+    from _dist_workers import gpu_minimize_worker
+
+    opts = {"maxiter": 25, "popsize": P, "seed": 21, "ftol": -1.0, "xtol": 0.0}
+    if method != "pso":
+        opts["rng"] = "philox"
+    cfg = {"n": n, "objective": "rosenbrock", "method": method, "options": opts, "rng": "philox"}
+    out = _spawn(gpu_minimize_worker, world, cfg)
+    if method == "pso":
+        ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method="pso", options=dict(opts), rng="philox")
+    else:  # (the sharded device loop runs the one-GPU resident loop's kernels: bit-identical to it)
+        ref = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method=method, options=dict(opts, backend="hip"))
+    for r in range(world):
+        fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
+        assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
+        assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
+
+
+def test_cpso_restart_needs_equal_shards_and_says_so():
+    """The competitive restart's swarm-wide selection gathers equal segments: an uneven swarm is refused by name, before any
+    collective (every rank raises alike); shard_bounds itself refuses only populations that leave the last rank nothing."""
+    from stochopy_amd import parallel
+
+    assert parallel.shard_bounds(97, 2, 1) == (49, 48)
+    with pytest.raises(ValueError, match="leave the last rank"):
+        parallel.shard_bounds(9, 8, 0)
