@@ -178,6 +178,10 @@ int sx_de_generation(const sx_de_args *a, int finalize, void *stream);
  * copies the new best row into `gbest`, increments state->it.
  * The best row is read from rows[(state->it+1) & 1] (the generation being
  * finalised; pass rows0 == rows1 for state that is updated in place, e.g. PSO pbest).
+ * Rows of more than 4096 elements (three launches: the best record, the row's slices on up to 64 workgroups, the state):
+ * the records are CONSUMED -- the first min(npart, 64) doubles of part_f are reused for the slices' partial squared
+ * distances, so part_f holds no records afterwards (it is declared const for the common case; read the records, if
+ * wanted, before this call).
  * ------------------------------------------------------------------------- */
 int sx_select_finalize(const double *part_f, const int64_t *part_i, int64_t npart, const double *rows0,
                        const double *rows1, int64_t ld, int n, double *gbest, sx_state *state, int maxiter,

@@ -657,6 +657,8 @@ extern "C" int sx_eval(int fun_id, const double *X, int64_t P, int n, int64_t ld
     const bool long_rows = n <= kMaxDim && eval_r8_long_ok(P, n, xm, part_f, 0, 1, cheap) &&
                            (eval_r8_long_mode() == 2 || !cheap || n <= 3584);
     if (is_wide(n) && !long_rows) return wide_eval(fun_id, X, P, n, ldx, xm, xstd, f, part_f, part_i, 0, nullptr, nullptr, s);
+    if (is_wide(n) && n <= kWideMaxDim)
+        if (int rc = wide_warm_plan(fun_id, n, s)) return rc;  // (the generations that follow are wide launches)
     PlanArg plan;
     if (make_plan_arg(fun_id, n, &plan)) return -1;
     switch (fun_id) {
@@ -999,7 +1001,7 @@ extern "C" int sx_select_finalize(const double *part_f, const int64_t *part_i, i
     if (n > kMaxDim) {
         hipStream_t s = (hipStream_t)stream;
         const int nb = wide_final_blocks(npart);
-        double *share = const_cast<double *>(part_f);  // (consumed by the first launch)
+        double *share = const_cast<double *>(part_f);  // (the records are consumed by the first launch: the header says so)
         hipLaunchKernelGGL(wide_finalize_best_kernel, dim3(1), dim3(kFinalThreads), 0, s, part_f, part_i, npart, state);
         hipLaunchKernelGGL(wide_finalize_row_kernel, dim3(nb), dim3(kFinalThreads), 0, s, rows0, rows1, ld, n, gbest, state, share);
         hipLaunchKernelGGL(wide_finalize_state_kernel, dim3(1), dim3(kWave), 0, s, share, nb, state, maxiter, xtol, ftol);

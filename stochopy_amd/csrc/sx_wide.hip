@@ -1002,17 +1002,39 @@ void *pick_de(const sx_de_args *a) {
 void *pick_pso(const sx_pso_args *a) { return a->rng == SX_RNG_PHILOX ? pick_fun<PsoPhK>(a->fun_id) : pick_fun<PsoHoK>(a->fun_id); }
 
 std::mutex g_attr_mutex;
-std::map<void *, size_t> g_attr;  // kernels whose dynamic LDS limit has been raised (per process; devices share code objects)
+std::map<std::pair<int, void *>, size_t> g_attr;  // (device, kernel) -> the dynamic LDS limit it has been given
+// A launch with more than 64 KB of dynamic LDS must have been allowed that much (hipFuncAttributeMaxDynamicSharedMemorySize):
+// resident rows take up to kResidentLds, streamed rows (4240 + 2 (n / 64 + 2)) doubles -- 99 KB at n = 262144 (the
+// limit was always set to kResidentLds, which only worked because this runtime does not enforce it).
 int allow_lds(void *fn, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
+    int dev = 0;
+    SX_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_attr_mutex);
-    auto it = g_attr.find(fn);
+    auto it = g_attr.find({dev, fn});
     if (it != g_attr.end() && it->second >= bytes) return 0;
-    SX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResidentLds));
-    g_attr[fn] = kResidentLds;
+    int cap = 0;
+    SX_HIP(hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    SX_REQUIRE(cap <= 0 || bytes <= (size_t)cap, "wide rows: the row's LDS stage exceeds the device's LDS per workgroup");
+    const size_t want = bytes > kResidentLds ? bytes : kResidentLds;
+    SX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    g_attr[{dev, fn}] = want;
     return 0;
 }
 
+}  // namespace
+namespace sx {
+// Build (and cache) the summation plan of this row length now, unless a capture is running: a later wide launch inside a
+// stream capture then finds it (sx_eval's eight-lanes-per-row route for rows of 2049 ... 4096 elements never
+// built it, and the first captured wide generation failed, silently switching graph replay off for the run).
+int wide_warm_plan(int fun_id, int n, hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
+    CachedPlan cp;
+    return get_plan(sx_fun_terms(fun_id, n), s, &cp);
+}
+}  // namespace sx
+namespace {
 struct GenLaunch {
     void *fn;
     const int32_t *plan;

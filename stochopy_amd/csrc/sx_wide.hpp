@@ -16,6 +16,7 @@ inline bool is_wide(int n) { return n > wide_from(); }
 
 int wide_eval(int fun_id, const double *X, int64_t P, int n, int64_t ldx, const double *xm, const double *xstd, double *f,
               double *part_f, int64_t *part_i, int clip, const double *pen_v, double *pen_out, hipStream_t s);
+int wide_warm_plan(int fun_id, int n, hipStream_t s);
 int wide_de_launch(const sx_de_args *a, hipStream_t s);
 int wide_de_add_node(hipGraph_t graph, hipGraphNode_t *prev, const sx_de_args *a);
 int wide_pso_launch(const sx_pso_args *a, hipStream_t s);

@@ -11,7 +11,11 @@ B and D).  SURVEY.md section 8f rank 3: the covariance model is D (I + v v^T) D,
 * on the host, as in the reference: ranking, the weighted sums over the mu selected rows (moments p, q of
   :428-444), the natural-gradient step for v and d (:447-460), step size, stopping rules -- O(mu n) numpy.
 
-``workers > 1``: candidates sharded by rows like CMA-ES (one all-gather of y, x and the fitness per generation).
+``workers > 1``: candidates sharded by rows like CMA-ES (one all-gather of y, x and the fitness per generation).  The sharded
+run is the one-GPU run bit for bit for models of up to 2048 coordinates.  Longer models (csrc/sx_wide.hip): on one GPU the
+candidates kernel leaves t_k = sum(yd * vn) as a by-product, with yd the step BEFORE it is rounded through y = d * yd; the
+sharded run forms t_k from the gathered y as (y / d) . vn (csrc/sx_vd_loop.hip vd_t_kernel, what the oracle does): the two
+differ in the last bits of every t_k, so there the sharded run follows the one-GPU run to rounding, not bit for bit.
 """
 
 import os
