@@ -350,23 +350,29 @@ __global__ __launch_bounds__(256) void eval_r8_rt_kernel(const double *__restric
         if (t >= nleaf) break;  // (uniform)
         const int b0 = t > 0 ? plan.end[t - 1] : 0, cnt = plan.end[t] - b0;
         double chA = 0.0, chB = identB;
+        // (round 6: objectives without a neighbour term take the whole leaf's 16 loads in one batch -- twice the bytes in
+        //  flight per wave in front of the 16 cosines; SX_EVAL_RT_HB=8 restores the batches of eight for an A/B)
+#ifndef SX_EVAL_RT_HB
+#define SX_EVAL_RT_HB 16
+#endif
+        constexpr int HB = O::NEXT ? 8 : SX_EVAL_RT_HB;
 #pragma unroll
-        for (int h0 = 0; h0 < kLeafBlocks; h0 += 8) {
-            double x[8], xn[8];
+        for (int h0 = 0; h0 < kLeafBlocks; h0 += HB) {
+            double x[HB], xn[O::NEXT ? HB : 1];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < HB; ++u) {
                 const bool in = h0 + u < cnt;
                 const int e = (b0 + h0 + u) * kGroup + j;
                 x[u] = in ? xr[e] : 0.0;
-                xn[u] = (O::NEXT && in) ? xr[e + 1] : 0.0;
+                if constexpr (O::NEXT) xn[u] = in ? xr[e + 1] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < HB; ++u) {
                 const bool in = h0 + u < cnt;
                 const int e = (b0 + h0 + u) * kGroup + j;
                 double a, b;
                 if constexpr (light_objective<FUN>()) {  // a select per term; the cosine objectives branch (registers)
-                    O::term(x[u], xn[u], e, a, b);
+                    O::term(x[u], O::NEXT ? xn[O::NEXT ? u : 0] : 0.0, e, a, b);
                     if (h0 + u == 0) {
                         chA = in ? a : 0.0;
                         chB = in ? b : identB;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256) void eval_r8_rt_kernel(const double *__restric
                         if (TWO) chB = in ? combine<BMUL>(chB, b) : chB;
                     }
                 } else if (in) {
-                    O::term(x[u], xn[u], e, a, b);
+                    O::term(x[u], O::NEXT ? xn[O::NEXT ? u : 0] : 0.0, e, a, b);
                     if (h0 + u == 0) {
                         chA = a;
                         chB = b;
@@ -448,18 +454,24 @@ __global__ __launch_bounds__(256) void eval_r8_long_kernel(const double *__restr
     for (int t = 0; t < nleaf; ++t) {  // (uniform)
         const int b0 = t > 0 ? plan.end[t - 1] : 0, cnt = plan.end[t] - b0;
         double chA = 0.0, chB = identB;
+        // (round 6: objectives without a neighbour term take the whole leaf's 16 loads in one batch -- twice the bytes in
+        //  flight per wave in front of the 16 cosines; SX_EVAL_RT_HB=8 restores the batches of eight for an A/B)
+#ifndef SX_EVAL_RT_HB
+#define SX_EVAL_RT_HB 16
+#endif
+        constexpr int HB = O::NEXT ? 8 : SX_EVAL_RT_HB;
 #pragma unroll
-        for (int h0 = 0; h0 < kLeafBlocks; h0 += 8) {
-            double x[8], xn[8];
+        for (int h0 = 0; h0 < kLeafBlocks; h0 += HB) {
+            double x[HB], xn[O::NEXT ? HB : 1];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < HB; ++u) {
                 const bool in = h0 + u < cnt;
                 const int e = (b0 + h0 + u) * kGroup + j;
                 x[u] = in ? xr[e] : 0.0;
-                xn[u] = (O::NEXT && in) ? xr[e + 1] : 0.0;
+                if constexpr (O::NEXT) xn[u] = in ? xr[e + 1] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < HB; ++u) {
                 const bool in = h0 + u < cnt;
                 const int e = (b0 + h0 + u) * kGroup + j;
                 double a, b;

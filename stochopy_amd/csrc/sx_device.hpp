@@ -197,7 +197,7 @@ constexpr double kTwoPi = 6.283185307179586;  // 2.0 * np.pi
 // the library's result for the SAME rounded argument on |x| <= 100 (2e6 random arguments; 2 ulp at |x| ~ 1e4):
 // tests/test_gpu_de.py::test_objectives_vs_oracle keeps its 1e-13.  Config 2: 7.04 -> 6.85 us per generation, config 3a 35.3 -> 34.5, 3b 51.7 -> 50.1 (same box, alternating).
 #ifndef SX_FAST_COS
-#define SX_FAST_COS 1  // 0: the library's cos (A/B)
+#define SX_FAST_COS 2  // 2: cos_2pi below for the 2 pi x terms (round 6), cos_mid elsewhere; 1: cos_mid everywhere (rounds 4-5); 0: the library's cos (A/B)
 #endif
 __device__ __forceinline__ double cos_mid(double t) {
 #if SX_FAST_COS
@@ -219,6 +219,41 @@ __device__ __forceinline__ double cos_mid(double t) {
     return fabs(t) < 1.0e6 ? fast : cos(t);
 #else
     return cos(t);
+#endif
+}
+
+// cos(2 pi x) for the Ackley / Rastrigin terms (benchmark.py:32, :95: np.cos(2.0 * np.pi * x)), round 6.  The period of the
+// argument is 1 IN x, so the reduction is exact and free: y = x - rint(x) in [-1/2, 1/2], m = rint(2 y) in {-1, 0, 1},
+// r = y - m / 2 in [-1/4, 1/4] (every step exact in binary floating point), cos(2 pi y) = (-1)^m cos(2 pi r), and ONE
+// polynomial in z = r^2 -- the Taylor coefficients (-1)^k (2 pi)^(2k) / (2k)!, k <= 11 (truncation 2e-17 at |2 pi r| = pi/2) --
+// replaces cos_mid's three Cody-Waite steps, its TWO kernels and the quadrant selects: 17 fp64 operations and 4 integer ones
+// against 21 + ~20.  What it returns is cos of the EXACT product 2 pi x where numpy takes the cosine of the ROUNDED one:
+// the two differ by |2 pi x| 2^-53 |sin| -- 3.6e-15 on [-5.12, 5.12], 2.3e-14 on Ackley's [-32.768, 32.768] (the size of
+// the reference's own argument rounding; absolute error of the polynomial itself ~1.5e-16) -- inside the 1e-13 bar on objective values
+// (tests/test_gpu_de.py::test_objectives_vs_oracle, factory_kat.json).  SX_FAST_COS=1: cos_mid(2 pi x) as in rounds 4-5 (A/B).
+__device__ __forceinline__ double cos_2pi(double x) {
+#if SX_FAST_COS == 2
+    const double y = x - rint(x);
+    const double m = rint(2.0 * y);
+    const double r = fma(m, -0.5, y);
+    const double z = r * r;
+    double p = -0x1.52ae4120fde27p-12;
+    p = fma(p, z, 0x1.ef6e308d6d1c4p-9);
+    p = fma(p, z, -0x1.2a0c591af8314p-5);
+    p = fma(p, z, 0x1.20c62c2f2d7f5p-2);
+    p = fma(p, z, -0x1.b6e24f44b128fp+0);
+    p = fma(p, z, 0x1.f9d38a3763cc3p+2);
+    p = fma(p, z, -0x1.a6d1f2a204a8cp+4);
+    p = fma(p, z, 0x1.e1f506891babbp+5);
+    p = fma(p, z, -0x1.55d3c7e3cbffap+6);
+    p = fma(p, z, 0x1.03c1f081b5ac4p+6);
+    p = fma(p, z, -0x1.3bd3cc9be45dep+4);
+    p = fma(p, z, 1.0);
+    // (-1)^m: m is -1, 0 or 1 -- its lowest integer bit moved onto the sign
+    const unsigned flip = ((unsigned)(int)m & 1u) << 31;
+    return __hiloint2double(__double2hiint(p) ^ (int)flip, __double2loint(p));
+#else
+    return cos_mid(kTwoPi * x);
 #endif
 }
 
@@ -251,7 +286,7 @@ struct Obj<SX_FUN_ACKLEY> {  // benchmark.py:14-34
     static constexpr bool NEXT = false, BMUL = false, TWO = true;
     static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
         a = x * x;
-        b = cos_mid(kTwoPi * x);
+        b = cos_2pi(x);
     }
     static __device__ __forceinline__ double finish(double sa, double sb, int n) {
         const double e = 2.7182818284590451;
@@ -289,7 +324,7 @@ template <>
 struct Obj<SX_FUN_RASTRIGIN> {  // benchmark.py:79-97
     static constexpr bool NEXT = false, BMUL = false, TWO = false;
     static __device__ __forceinline__ void term(double x, double, int, double &a, double &b) {
-        a = x * x - 10.0 * cos_mid(kTwoPi * x);
+        a = x * x - 10.0 * cos_2pi(x);
         b = 0.0;
     }
     static __device__ __forceinline__ double finish(double sa, double, int n) { return 10.0 * (double)n + sa; }
