@@ -810,17 +810,99 @@ __global__ __launch_bounds__(kSelThreads) void pso_restart_select_kernel(const s
 // tools/cpso_radius_decisions.py); the undecided ones get the radius from this workgroup's own pass over X.  Before: four
 // dependent launches per generation (generation, best / termination, radius pass over X, selection).
 // ---------------------------------------------------------------------------
+constexpr int kPostHelpers = 63;             // helper workgroups of cpso_post_kernel's rare all-rows radius pass
+constexpr long long kPostHelperWaitTicks = 20000;  // 200 us of the 100 MHz wall clock: how long a helper waits for workgroup 0's word
 constexpr int kPostDxThreads = 256;  // the step of the best is summed exactly as select_finalize_kernel (256 threads) does
 template <int LPR>
 __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_args a, const double *__restrict__ part_f,
                                                                 const int64_t *__restrict__ part_i,
                                                                 const double *__restrict__ part_rold, const int64_t npart,
                                                                 const double xtol, const double delta, const double gamma,
-                                                                unsigned long long *__restrict__ out, const int force_exact) {
+                                                                unsigned long long *__restrict__ out, const int force_exact,
+                                                                unsigned long long *__restrict__ hscratch) {
     constexpr int NW = kSelThreads / kWave, n = 4 * LPR;
     __shared__ double sf[NW];
     __shared__ int64_t si[NW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ---- helper workgroups (round 6; blockIdx >= 1, kPostHelpers of them) ------------------------------------------------
+    // The rare exact-radius pass over ALL rows took ~570 us on this kernel's one workgroup (32 MB of X; the whole chip does it
+    // in 7).  Now the launch has 1 + kPostHelpers workgroups: the helpers wait (bounded) for workgroup 0's word
+    // hscratch[0] = {generation : 32 | help wanted : 1 | best row : 31} -- one agent-scope store, polled past the L1 -- and leave
+    // at once when no help is wanted (every ordinary generation: they are gone before workgroup 0 is).  Wanted: helper h takes
+    // slice h of the rows, stores its maximum (hscratch[2 + h]), drains, stores its tag (hscratch[2 + 64 + h] = generation);
+    // workgroup 0 takes slice 0, waits (bounded) for the tags and, should a helper not have answered, does that slice itself --
+    // the same per-row values and a maximum, which has no order.
+    auto slice_radius = [&](int64_t r0, int64_t r1, const double *__restrict__ srcrow) -> double {
+        constexpr int RPW = kWave / LPR, kRows = 8;
+        const int l = lane & (LPR - 1), sub = lane / LPR;
+        double gn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gn[t] = srcrow[l + t * LPR];
+        double mx = 0.0;
+        for (int64_t j0 = r0 + (int64_t)wv * RPW + sub; j0 < r1; j0 += (int64_t)NW * RPW * kRows) {
+            double xv[kRows][4];
+#pragma unroll
+            for (int q = 0; q < kRows; ++q) {
+                const int64_t j = j0 + (int64_t)q * NW * RPW, row = j < r1 ? j : r1 - 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xv[q][t] = a.X[row * a.ld + l + t * LPR];
+            }
+#pragma unroll
+            for (int q = 0; q < kRows; ++q) {
+                double ac = 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double d = xv[q][t] - gn[t];
+                    ac += d * d;
+                }
+                ac = sqrt(row_sum<LPR>(ac));
+                if (j0 + (int64_t)q * NW * RPW < r1) mx = fmax(mx, ac);
+            }
+        }
+        mx = wave_max_f64(mx);
+        __syncthreads();
+        if (lane == 0) sf[wv] = mx;
+        __syncthreads();
+        double m = sf[0];
+        for (int k = 1; k < NW; ++k) m = fmax(m, sf[k]);
+        return m;
+    };
+    const int64_t per_slice = (a.P + kPostHelpers) / (kPostHelpers + 1);
+    if (blockIdx.x != 0) {
+        if (hscratch == nullptr || a.state->done) return;
+        const unsigned it32 = (unsigned)(a.state->it + 1);
+        __shared__ unsigned long long s_word;
+        if (tid == 0) {
+            unsigned long long w = 0ull;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                w = __hip_atomic_load((__attribute__((address_space(1))) unsigned long long *)hscratch, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) == it32) break;
+                if (wall_clock64() - t0 > kPostHelperWaitTicks) {
+                    w = 0ull;  // (workgroup 0 never spoke: leave; it will do the work itself if it needed help)
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_word = w;
+        }
+        __syncthreads();
+        const unsigned long long w = s_word;
+        if (((w >> 31) & 1ull) == 0ull) return;
+        const int64_t brow = (int64_t)(w & 0x7fffffffull);
+        const int h = (int)blockIdx.x;
+        const int64_t r0 = (int64_t)h * per_slice, r1 = r0 + per_slice < a.P ? r0 + per_slice : a.P;
+        const double m = r0 < r1 ? slice_radius(r0, r1, a.pbest + brow * a.ld) : 0.0;
+        if (tid == 0) {
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long *)(hscratch + 2 + h),
+                               (unsigned long long)__double_as_longlong(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long *)(hscratch + 2 + 64 + h),
+                               (unsigned long long)it32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     // the records and the radii (npart <= 4 per thread at BASELINE config 3), requested before the state word is looked at
     double bf = __builtin_huge_val(), rold = 0.0;
     int64_t bi = INT64_MAX;
@@ -841,6 +923,13 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
     }
     const int done0 = a.state->done;
     const int64_t it = a.state->it + 1;  // the generation being finalised
+    auto tell_helpers = [&](bool wanted, int64_t brow) {  // (thread 0; helpers see `done` themselves when the run is over)
+        if (tid == 0 && hscratch != nullptr)
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long *)hscratch,
+                               ((unsigned long long)(unsigned)it << 32) | (wanted ? 0x80000000ull : 0ull) |
+                                   (unsigned long long)(brow & 0x7fffffff),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     if (done0) {
         if (tid == 0) out[0] = 0;
         return;
@@ -893,12 +982,14 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
     }
     if (status != SX_STATUS_NONE) {  // (what the selection does when it finds the run over)
         if (tid == 0) out[0] = 0;
+        tell_helpers(false, 0);
         return;
     }
     // ---- the restart question, cpso/_cpso.py:405-412 ----
     // (force_exact: SX_CPSO_FORCE_EXACT=1 / 2 at graph creation -- every generation takes the rare branch / its all-rows form; tests)
     const unsigned long long dec = force_exact ? kRadiusExactNeeded : radius_decision(r, dx, delta, n);
     double m = r;
+    if (dec != kRadiusExactNeeded) tell_helpers(false, 0);
     if (dec == kRadiusExactNeeded) {
         // Rare (4 of 1 199 generations at C3b): the radius against the new best (= pbest[best], what gbest holds from now on),
         // row by row as pso_radius_kernel does it -- but only for the rows that can hold the maximum.  A row whose radius
@@ -934,7 +1025,45 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
         }
         __syncthreads();
         const unsigned nc = s_ncand;
-        const bool listed = force_exact != 2 && nc <= (unsigned)kCand;  // (uniform)
+        // (a list is worth walking alone while it is short: 64 workgroups take ALL rows in the time this one takes 256)
+        const bool helpers = hscratch != nullptr && gridDim.x == (unsigned)(kPostHelpers + 1);
+        const bool listed = force_exact != 2 && nc <= (unsigned)(helpers ? 256 : kCand);  // (uniform)
+        tell_helpers(!listed && helpers, bi);
+        if (!listed && helpers) {
+            double mall = slice_radius(0, per_slice < a.P ? per_slice : a.P, src);
+            __shared__ unsigned long long s_tag[kPostHelpers + 1];
+            __shared__ int s_all;
+            const long long t0 = wall_clock64();
+            for (;;) {  // wave 0: the helpers' tags
+                if (tid < kWave) {
+                    const int h = tid;
+                    unsigned long long tg = (unsigned)it;
+                    if (h >= 1 && h <= kPostHelpers)
+                        tg = __hip_atomic_load((__attribute__((address_space(1))) unsigned long long *)(hscratch + 2 + 64 + h),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_tag[h] = tg;
+                    const bool ok = __all(tg == (unsigned long long)(unsigned)it);
+                    if (tid == 0) s_all = ok ? 1 : (wall_clock64() - t0 > 4 * kPostHelperWaitTicks ? -1 : 0);
+                }
+                __syncthreads();
+                const int st_all = s_all;
+                __syncthreads();
+                if (st_all != 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            for (int h = 1; h <= kPostHelpers; ++h) {  // (uniform: s_tag is shared)
+                const int64_t r0 = (int64_t)h * per_slice, r1 = r0 + per_slice < a.P ? r0 + per_slice : a.P;
+                double mh = 0.0;
+                if (s_tag[h] == (unsigned long long)(unsigned)it)
+                    mh = __longlong_as_double((long long)__hip_atomic_load(
+                        (__attribute__((address_space(1))) unsigned long long *)(hscratch + 2 + h), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT));
+                else if (r0 < r1)
+                    mh = slice_radius(r0, r1, src);  // (a helper that never answered: its slice here)
+                mall = fmax(mall, mh);
+            }
+            m = mall;
+        } else {
         const int64_t total = listed ? (int64_t)nc : a.P;
         const int l = lane & (LPR - 1), sub = lane / LPR;
         double gn[4];
@@ -968,6 +1097,7 @@ __global__ __launch_bounds__(kSelThreads) void cpso_post_kernel(const sx_pso_arg
         __syncthreads();
         m = sf[0];
         for (int k = 1; k < NW; ++k) m = fmax(m, sf[k]);
+        }
     }
     const double radius = m / sqrt(4.0 * (double)n);  // (kRadiusAbove / kRadiusBelow: of r, within d of the swarm's)
     int64_t nw = 0;
@@ -1154,8 +1284,9 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     double *part_rold = nullptr;
     if (fused_radius) {
         // (npart per-workgroup maxima, then P per-row radii against the old best: what the rare exact branch looks at first)
-        SX_HIP(hipMalloc(&gr->scratch, ((size_t)g.blocks + (size_t)a->P) * sizeof(double)));
-        SX_HIP(hipMemset(gr->scratch, 0, ((size_t)g.blocks + (size_t)a->P) * sizeof(double)));
+        // ... and 2 + 64 + 64 words for the post kernel's helper workgroups (their word, their maxima, their tags)
+        SX_HIP(hipMalloc(&gr->scratch, ((size_t)g.blocks + (size_t)a->P + 130) * sizeof(double)));
+        SX_HIP(hipMemset(gr->scratch, 0, ((size_t)g.blocks + (size_t)a->P + 130) * sizeof(double)));
         part_rold = (double *)gr->scratch;
     }
     sx_pso_args args = *a;
@@ -1183,7 +1314,11 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
     // (tests: 1 = every generation through the exact branch, 2 = through its all-rows form)
     const char *fe = getenv("SX_CPSO_FORCE_EXACT");
     int force_exact = fe == nullptr ? 0 : (fe[0] == '2' ? 2 : 1);
-    void *post_args[] = {&args, &cpart_f, &cpart_i, &cpart_rold, &npart, &xtol, &delta, &gamma, &sel, &force_exact};
+    // (SX_CPSO_HELPERS=0: the one-workgroup launch of rounds 4-5)
+    const char *he = getenv("SX_CPSO_HELPERS");
+    const bool post_helpers = fused_radius && !(he != nullptr && he[0] == '0') && a->P < (int64_t)0x7fffffff;
+    unsigned long long *hscratch = post_helpers ? (unsigned long long *)((double *)gr->scratch + (size_t)g.blocks + (size_t)a->P) : nullptr;
+    void *post_args[] = {&args, &cpart_f, &cpart_i, &cpart_rold, &npart, &xtol, &delta, &gamma, &sel, &force_exact, &hscratch};
     void *post_fn = nullptr;
     SX_DISPATCH_LPR(a->n, post_fn = post_kernel_ptr<LPR>())
     const int64_t *no_rows = nullptr;
@@ -1206,7 +1341,9 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
                                             inl ? gen_args_inline : gen_args))
             return rc;
         if (fused_radius) {
-            if (int rc = add_kernel_node(gr->graph, &prev, post_fn, dim3(1), dim3(kSelThreads), 0, post_args)) return rc;
+            if (int rc = add_kernel_node(gr->graph, &prev, post_fn, dim3(post_helpers ? kPostHelpers + 1 : 1), dim3(kSelThreads), 0,
+                                         post_args))
+                return rc;
         } else if (int rc = add_finalize_node(gr->graph, &prev, a->part_f, a->part_i, g.blocks, a->pbest, a->pbest, a->ld,
                                               a->n, a->gbest, a->state, a->maxiter, a->xtol, a->ftol))
             return rc;
