@@ -396,12 +396,13 @@ template <int RNG, int LPR, int NFIX = 0>
 de_async_t pick_de(int fun_id) {
     switch (fun_id) {
         case SX_FUN_ACKLEY: return de_async_kernel<SX_FUN_ACKLEY, RNG, LPR, NFIX>;
-        case SX_FUN_GRIEWANK: return de_async_kernel<SX_FUN_GRIEWANK, RNG, LPR, NFIX>;
-        case SX_FUN_QUARTIC: return de_async_kernel<SX_FUN_QUARTIC, RNG, LPR, NFIX>;
         case SX_FUN_RASTRIGIN: return de_async_kernel<SX_FUN_RASTRIGIN, RNG, LPR, NFIX>;
         case SX_FUN_ROSENBROCK: return de_async_kernel<SX_FUN_ROSENBROCK, RNG, LPR, NFIX>;
         case SX_FUN_SPHERE: return de_async_kernel<SX_FUN_SPHERE, RNG, LPR, NFIX>;
-        case SX_FUN_STYBLINSKI_TANG: return de_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, NFIX>;
+        // (the others: the run-time row length only -- hot_objective, sx_device.hpp)
+        case SX_FUN_GRIEWANK: return de_async_kernel<SX_FUN_GRIEWANK, RNG, LPR, 0>;
+        case SX_FUN_QUARTIC: return de_async_kernel<SX_FUN_QUARTIC, RNG, LPR, 0>;
+        case SX_FUN_STYBLINSKI_TANG: return de_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, 0>;
     }
     return nullptr;
 }
@@ -409,12 +410,13 @@ template <int RNG, int LPR, int NFIX = 0>
 pso_async_t pick_pso(int fun_id) {
     switch (fun_id) {
         case SX_FUN_ACKLEY: return pso_async_kernel<SX_FUN_ACKLEY, RNG, LPR, NFIX>;
-        case SX_FUN_GRIEWANK: return pso_async_kernel<SX_FUN_GRIEWANK, RNG, LPR, NFIX>;
-        case SX_FUN_QUARTIC: return pso_async_kernel<SX_FUN_QUARTIC, RNG, LPR, NFIX>;
         case SX_FUN_RASTRIGIN: return pso_async_kernel<SX_FUN_RASTRIGIN, RNG, LPR, NFIX>;
         case SX_FUN_ROSENBROCK: return pso_async_kernel<SX_FUN_ROSENBROCK, RNG, LPR, NFIX>;
         case SX_FUN_SPHERE: return pso_async_kernel<SX_FUN_SPHERE, RNG, LPR, NFIX>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, NFIX>;
+        // (the others: the run-time row length only -- hot_objective, sx_device.hpp)
+        case SX_FUN_GRIEWANK: return pso_async_kernel<SX_FUN_GRIEWANK, RNG, LPR, 0>;
+        case SX_FUN_QUARTIC: return pso_async_kernel<SX_FUN_QUARTIC, RNG, LPR, 0>;
+        case SX_FUN_STYBLINSKI_TANG: return pso_async_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, 0>;
     }
     return nullptr;
 }

@@ -593,7 +593,9 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
     // (plain evaluation only -- the clip / penalty variants keep the general kernel, to keep the build small)
     const int lpr = lanes_per_row(n);
     const bool full = clip == 0 && n % (8 * lpr) == 0 && P % rows_per_block(n) == 0;
-    const bool fix = clip == 0 && n == 4 * lpr && P % rows_per_block(n) == 0;
+    // (the compile-time row lengths -- one-batch rows, n = 512 / 1024 / 2048 -- for the four hot objectives only: hot_objective)
+    constexpr bool kHot = FUN == SX_FUN_ACKLEY || FUN == SX_FUN_RASTRIGIN || FUN == SX_FUN_ROSENBROCK || FUN == SX_FUN_SPHERE;
+    const bool fix = kHot && clip == 0 && n == 4 * lpr && P % rows_per_block(n) == 0;
     size_t lds = (size_t)rows_per_block(n) * gen_row_stride(n) * sizeof(double);  // (n + 8 doubles per row up to 256 elements)
     // (objectives with a cosine per term keep the run-time plan: eight inlined cosines side by side need more registers than
     //  a wavefront slot has, and their arithmetic, not the plan, is their time)
@@ -601,7 +603,7 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
 #define SX_EVAL_GO(...)                                                                                              \
     hipLaunchKernelGGL((eval_kernel<FUN, __VA_ARGS__>), dim3(g.blocks), dim3(g.threads), lds, s, X, P, n, ldx, xm, xstd, f, \
                        plan, part_f, part_i, clip, pen_v, pen_out)
-    const bool grid_long = clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0;
+    const bool grid_long = kHot && clip == 0 && (n == 512 || n == 1024 || n == 2048) && P % rows_per_block(n) == 0;
     if (eval_r8_long_ok(P, n, xm, part_f, clip, plan.nleaf, kLight) && (eval_r8_long_mode() == 2 || !(kLight && grid_long))) {
         // many long rows: eight lanes per row, straight from memory.  Not the cheap objectives at n = 512 / 1024 / 2048: their
         // compile-time plan below stays ahead (Rosenbrock 0.61 / 0.76 / 0.66 of the HBM peak against 0.58 / 0.54 / 0.55);
@@ -612,10 +614,12 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
         // long rows of a compile-time length: numpy's plan as constants (row_reduce_long).  Rosenbrock n = 1024: 0.54 -> 0.84
         // of the HBM peak, n = 512: 0.44 -> 0.76, n = 2048: 0.43 -> 0.70 (profiles/r4_eval_long_rows.txt; a resident,
         // software-pipelined form of the same kernel stayed at 0.72 and was dropped)
-        switch (n) {
-            case 512: SX_EVAL_GO(64, true, 512); break;
-            case 1024: SX_EVAL_GO(64, true, 1024); break;
-            default: SX_EVAL_GO(64, true, 2048); break;
+        if constexpr (kHot) {
+            switch (n) {
+                case 512: SX_EVAL_GO(64, true, 512); break;
+                case 1024: SX_EVAL_GO(64, true, 1024); break;
+                default: SX_EVAL_GO(64, true, 2048); break;
+            }
         }
     } else if (fix && (eval_r8_rt_mode() == 2 || (n == 256 && !kLight)) && eval_r8_rt_ok(P, n, xm, part_f, clip)) {
         // rows of 256 elements with a cosine per term: the run-time form (no staging, 16 terms at a time) is the faster one --
@@ -627,20 +631,24 @@ static int launch_eval(const double *X, int64_t P, int n, int64_t ldx, const dou
         //  faster: 0.81 / 0.84 against 0.78 / 0.77 of the HBM peak at n = 64 / 256, profiles/r5_eval_r8_ab.txt)
         // plain evaluation of many one-batch rows: eight lanes per row, eight rows per wavefront
         const unsigned blocks8 = (unsigned)(P / 32);
-        switch (n) {
-            case 64: hipLaunchKernelGGL((eval_r8_kernel<FUN, 64>), dim3(blocks8), dim3(256), 32 * (64 + 8) * sizeof(double), s, X, ldx, f); break;
-            case 128: hipLaunchKernelGGL((eval_r8_kernel<FUN, 128>), dim3(blocks8), dim3(256), 32 * (128 + 8) * sizeof(double), s, X, ldx, f); break;
-            default: hipLaunchKernelGGL((eval_r8_kernel<FUN, 256>), dim3(blocks8), dim3(256), 32 * (256 + 8) * sizeof(double), s, X, ldx, f); break;
+        if constexpr (kHot) {
+            switch (n) {
+                case 64: hipLaunchKernelGGL((eval_r8_kernel<FUN, 64>), dim3(blocks8), dim3(256), 32 * (64 + 8) * sizeof(double), s, X, ldx, f); break;
+                case 128: hipLaunchKernelGGL((eval_r8_kernel<FUN, 128>), dim3(blocks8), dim3(256), 32 * (128 + 8) * sizeof(double), s, X, ldx, f); break;
+                default: hipLaunchKernelGGL((eval_r8_kernel<FUN, 256>), dim3(blocks8), dim3(256), 32 * (256 + 8) * sizeof(double), s, X, ldx, f); break;
+            }
         }
     } else if (!fix && eval_r8_rt_ok(P, n, xm, part_f, clip) && plan.nleaf <= 3) {
         // many one-batch rows of a length off the compile-time grid: eight lanes per row, straight from memory
         hipLaunchKernelGGL((eval_r8_rt_kernel<FUN>), dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, X, P, n, ldx, f, plan);
     } else if (fix) {
         // the register-chain objective reads the staged vector only: n + 8 doubles per row, not the term arrays' 3n + ...
-        switch (lpr) {
-            case 16: SX_EVAL_GO(16, true, 64); break;
-            case 32: SX_EVAL_GO(32, true, 128); break;
-            default: SX_EVAL_GO(64, true, 256); break;
+        if constexpr (kHot) {
+            switch (lpr) {
+                case 16: SX_EVAL_GO(16, true, 64); break;
+                case 32: SX_EVAL_GO(32, true, 128); break;
+                default: SX_EVAL_GO(64, true, 256); break;
+            }
         }
     } else if (full) {
         SX_DISPATCH_LPR(n, SX_EVAL_GO(LPR, true, 0))

@@ -618,14 +618,19 @@ typedef void (*de_kernel_t)(const sx_state *, const double *, const int64_t *, c
 
 template <int RNG, int XM, int LPR, bool FULL, int NFIX = 0, int STRAT = -1, bool ONEB = false>
 de_kernel_t pick_kernel_lpr(int fun_id) {
+    constexpr bool SPECIAL = STRAT != -1 || ONEB || NFIX != 0;  // (callers route the other objectives to the general form: hot_objective)
     switch (fun_id) {
         case SX_FUN_ACKLEY: return de_generation_kernel<SX_FUN_ACKLEY, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
-        case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
-        case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
         case SX_FUN_RASTRIGIN: return de_generation_kernel<SX_FUN_RASTRIGIN, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
         case SX_FUN_ROSENBROCK: return de_generation_kernel<SX_FUN_ROSENBROCK, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
         case SX_FUN_SPHERE: return de_generation_kernel<SX_FUN_SPHERE, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
-        case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+    }
+    if constexpr (!SPECIAL) {
+        switch (fun_id) {
+            case SX_FUN_GRIEWANK: return de_generation_kernel<SX_FUN_GRIEWANK, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+            case SX_FUN_QUARTIC: return de_generation_kernel<SX_FUN_QUARTIC, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+            case SX_FUN_STYBLINSKI_TANG: return de_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, XM, LPR, FULL, NFIX, STRAT, ONEB>;
+        }
     }
     return nullptr;
 }
@@ -639,14 +644,12 @@ de_kernel_t pick_kernel_fixed(int fun_id, int strategy, int constraints) {
     if constexpr (XM == 2 && LPR != 32) {
         return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX>(fun_id);
     } else {
-        if (constraints != 0) return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX>(fun_id);
-        switch (strategy) {
+        if (constraints != 0 || !hot_objective(fun_id)) return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX>(fun_id);
+        switch (strategy) {  // (rand2bin, best2bin: the run-time strategy of the same kernel)
             case SX_DE_RAND1BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_RAND1BIN : -1>(fun_id);
-            case SX_DE_RAND2BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_RAND2BIN : -1>(fun_id);
             case SX_DE_BEST1BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_BEST1BIN : -1>(fun_id);
-            case SX_DE_BEST2BIN: return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX, NFIX ? SX_DE_BEST2BIN : -1>(fun_id);
         }
-        return nullptr;
+        return pick_kernel_lpr<RNG, XM, LPR, FULL, NFIX>(fun_id);
     }
 }
 
@@ -659,6 +662,7 @@ de_kernel_t pick_kernel_fixed(int fun_id, int strategy, int constraints) {
 template <int RNG, int XM, int LPR>
 de_kernel_t pick_kernel_general(int fun_id, int strategy, int constraints, int n) {
     if constexpr (XM <= 1 && RNG == SX_RNG_PHILOX) {
+        if (!hot_objective(fun_id)) return pick_kernel_lpr<RNG, XM, LPR, false>(fun_id);
         if constexpr (LPR == kWave) {  // whole-wave rows of up to 256 elements: the one-batch form (ONEB)
             if (n <= 4 * kWave && constraints == 0 && strategy == SX_DE_BEST1BIN)
                 return pick_kernel_lpr<RNG, XM, LPR, false, 0, SX_DE_BEST1BIN, true>(fun_id);
@@ -678,7 +682,7 @@ de_kernel_t pick_kernel(int fun_id, int n, int64_t P, int strategy, int constrai
     const bool full = CH && n % (kStep * lpr) == 0 && P % rows_per_block(n) == 0;
     // one batch per row exactly (n = 64, 128, 256) with in-kernel draws: the compile-time row length
     constexpr bool FX = CH && RNG == SX_RNG_PHILOX;
-    const bool fix = FX && full && n == kStep * lpr;
+    const bool fix = FX && full && n == kStep * lpr && hot_objective(fun_id);  // (the others: the run-time row length)
     switch (lpr) {
         case 16:
             if (fix) return pick_kernel_fixed<RNG, XM, 16, CH, FX ? kStep * 16 : 0>(fun_id, strategy, constraints);

@@ -280,6 +280,13 @@ __device__ __forceinline__ void sincos_mid(double t, double &sn_out, double &cs_
 
 template <int FUN>
 struct Obj;
+// Round 6 (920 kernel instantiations): the SPECIALISED forms of the generation kernels -- strategy at
+// compile time, one-batch rows, PLAIN PSO, compile-time row length of the ordered sweeps -- exist for the four objectives the
+// BASELINE configs and the reference's tests use; Griewank, Quartic and Styblinski-Tang take the general form of the same kernel
+// (same arithmetic, same results).  Of the DE strategies only best1bin and rand1bin are specialised.
+inline bool hot_objective(int fun_id) {
+    return fun_id == SX_FUN_ACKLEY || fun_id == SX_FUN_RASTRIGIN || fun_id == SX_FUN_ROSENBROCK || fun_id == SX_FUN_SPHERE;
+}
 
 template <>
 struct Obj<SX_FUN_ACKLEY> {  // benchmark.py:14-34

@@ -335,14 +335,19 @@ typedef void (*pso_kernel_t)(const sx_pso_args, const PlanArg, double *, int, in
 
 template <int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false, bool ONEB = false>
 pso_kernel_t pick_kernel_lpr(int fun_id) {
+    constexpr bool SPECIAL = PLAIN || ONEB || CHAIN;  // (pick_kernel / sx_pso_chain_supported route the other objectives to the general form)
     switch (fun_id) {
         case SX_FUN_ACKLEY: return pso_generation_kernel<SX_FUN_ACKLEY, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
-        case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
-        case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
         case SX_FUN_RASTRIGIN: return pso_generation_kernel<SX_FUN_RASTRIGIN, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
         case SX_FUN_ROSENBROCK: return pso_generation_kernel<SX_FUN_ROSENBROCK, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
         case SX_FUN_SPHERE: return pso_generation_kernel<SX_FUN_SPHERE, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
-        case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+    }
+    if constexpr (!SPECIAL) {
+        switch (fun_id) {
+            case SX_FUN_GRIEWANK: return pso_generation_kernel<SX_FUN_GRIEWANK, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+            case SX_FUN_QUARTIC: return pso_generation_kernel<SX_FUN_QUARTIC, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+            case SX_FUN_STYBLINSKI_TANG: return pso_generation_kernel<SX_FUN_STYBLINSKI_TANG, RNG, LPR, FULL, PLAIN, CHAIN, ONEB>;
+        }
     }
     return nullptr;
 }
@@ -359,6 +364,8 @@ pso_kernel_t pick_chain_kernel(int fun_id, int n) {
 template <int RNG>
 pso_kernel_t pick_kernel(int fun_id, int n, bool plain) {
     constexpr bool PH = RNG == SX_RNG_PHILOX;
+    const bool hot = hot_objective(fun_id);
+    plain = plain && hot;  // (PLAIN and the one-batch form: the four hot objectives; the others take the general kernel)
     const int lpr = lanes_per_row(n);
     // whole-batch rows with in-kernel draws get the constant-length form (host draws: the run is bound by the host)
     const bool full = PH && n == 4 * lpr;
@@ -375,7 +382,7 @@ pso_kernel_t pick_kernel(int fun_id, int n, bool plain) {
             return pl ? pick_kernel_lpr<RNG, 32, false, PH>(fun_id) : pick_kernel_lpr<RNG, 32, false>(fun_id);
     }
     if (full) return plain ? pick_kernel_lpr<RNG, 64, PH, PH>(fun_id) : pick_kernel_lpr<RNG, 64, PH>(fun_id);
-    if (PH && n <= 4 * kWave)  // rows of 129 ... 256 elements off the grid: the one-batch form of the whole-wave kernel
+    if (PH && n <= 4 * kWave && hot)  // rows of 129 ... 256 elements off the grid: the one-batch form of the whole-wave kernel
         return pl ? pick_kernel_lpr<RNG, 64, false, PH, false, PH>(fun_id) : pick_kernel_lpr<RNG, 64, false, false, false, PH>(fun_id);
     return pl ? pick_kernel_lpr<RNG, 64, false, PH>(fun_id) : pick_kernel_lpr<RNG, 64, false>(fun_id);
 }
@@ -1378,7 +1385,7 @@ extern "C" int sx_pso_graph_create(const sx_pso_args *a, int ngen, double *part_
 extern "C" int sx_pso_chain_supported(const sx_pso_args *a) {
     if (check_args(a)) return 0;
     const Geometry g = geometry(a->P, a->n);
-    return a->rng == SX_RNG_PHILOX && a->constraints == 0 && a->pending_restart == nullptr &&
+    return hot_objective(a->fun_id) && a->rng == SX_RNG_PHILOX && a->constraints == 0 && a->pending_restart == nullptr &&
                    a->n == 4 * lanes_per_row(a->n) && (int64_t)g.blocks <= (int64_t)kChainRecPerThread * g.threads
                ? 1
                : 0;

@@ -982,6 +982,16 @@ void *pick_fun(int fun_id) {
     }
     return nullptr;
 }
+template <template <int> class K>
+void *pick_fun_hot(int fun_id) {  // (specialised forms: the four hot objectives, sx_device.hpp hot_objective)
+    switch (fun_id) {
+        case SX_FUN_ACKLEY: return K<SX_FUN_ACKLEY>::ptr();
+        case SX_FUN_RASTRIGIN: return K<SX_FUN_RASTRIGIN>::ptr();
+        case SX_FUN_ROSENBROCK: return K<SX_FUN_ROSENBROCK>::ptr();
+        case SX_FUN_SPHERE: return K<SX_FUN_SPHERE>::ptr();
+    }
+    return nullptr;
+}
 template <int FUN> struct EvalK { static void *ptr() { return (void *)wide_eval_kernel<FUN, false>; } };
 template <int FUN> struct EvalPipeK {
     static void *ptr() { return (void *)wide_eval_kernel<FUN, light_objective<FUN>()>; }  // (heavy: the plain form again)
@@ -995,8 +1005,9 @@ template <int FUN> struct VdCandK { static void *ptr() { return (void *)wide_vd_
 template <int FUN> struct PsoHoK { static void *ptr() { return (void *)wide_pso_kernel<FUN, SX_RNG_HOST>; } };
 void *pick_de(const sx_de_args *a) {
     const bool ph = a->rng == SX_RNG_PHILOX;  // (host draws: the generation waits for the host's streams anyway)
-    if (ph && a->constraints == 0 && a->strategy == SX_DE_BEST1BIN) return pick_fun<DePhBestK>(a->fun_id);
-    if (ph && a->constraints == 0 && a->strategy == SX_DE_RAND1BIN) return pick_fun<DePhRandK>(a->fun_id);
+    const bool hot = hot_objective(a->fun_id);
+    if (hot && ph && a->constraints == 0 && a->strategy == SX_DE_BEST1BIN) return pick_fun_hot<DePhBestK>(a->fun_id);
+    if (hot && ph && a->constraints == 0 && a->strategy == SX_DE_RAND1BIN) return pick_fun_hot<DePhRandK>(a->fun_id);
     return ph ? pick_fun<DePhK>(a->fun_id) : pick_fun<DeHoK>(a->fun_id);
 }
 void *pick_pso(const sx_pso_args *a) { return a->rng == SX_RNG_PHILOX ? pick_fun<PsoPhK>(a->fun_id) : pick_fun<PsoHoK>(a->fun_id); }
