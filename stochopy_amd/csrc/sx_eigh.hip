@@ -104,6 +104,10 @@ struct EighInfo {  // first bytes of the workspace
     int32_t fault;      // resident kernel only: a bounded wait ran out (kFlowWait*): the run record is not to be trusted
     unsigned long long kmax2[kEighMaxSweeps];  // bits of max (M_ij / (M_jj - M_ii))^2 over the significant elements
                                                // of M after each sweep (same launch as offm)
+    double deep_off[2];                        // the same two measurements of M after each deep refinement step (below)
+    unsigned long long deep_k[2];
+    int32_t deep_steps;                        // deep steps carried out (diagnosis)
+    int32_t pad2_;
 };
 
 // The last sweep of a run meets a matrix whose off-diagonal part E is tiny against every gap of the diagonal D: its
@@ -119,6 +123,17 @@ struct EighInfo {  // first bytes of the workspace
 // where d_j - d_i is rounding noise, thus never blocks the step, while a significant element over a tiny gap
 // (max |K| large) does, and the run goes on sweeping as before.
 constexpr double kRefineOff = 1.0e-7, kRefineCap = 1.0e-3, kRefineProd = 1.0e-12;
+// Round 6: the deep refinement step -- the SECOND-to-last sweep's replacement.  After sweep s of a C4-like run off(M) is ~5e-7 |C|_F
+// and max |K| ~1e-2 ... 4e-2: too much for the first-order step above (what it leaves is ~K off), but one EXACT similarity with the
+// first-order rotation squares it away:  T = exp(K) (as the square of a Newton-Schulz-corrected second-order exp(K / 2), see
+// eigh_deep_gemm_kernel),  M' = T^T M T,  V' = V T  -- seven n^3 products on the matrix cores (~90 us at n = 512) where a sweep is 31 launches
+// (~365 us).  M' is then measured like a sweep's result: the first-order step finishes (typically off ~3e-9, K ~1e-4), or a second deep
+// step runs first; if neither gets there the run is reported as not converged (it does not happen on the test matrices: the entry
+// rule keeps K off ~1e-7).  Entry: off(M) <= kDeepOff |C|_F and max |K| <= kDeepCap, measured by the tile workgroups as before;
+// only with the refinement allowed (bit 1 of the `refine` argument) and npad >= 256 (the no-op launches of an unused deep step
+// cost ~20 us, a sweep of a smaller matrix less than ten times that).  info->refine: 1 = the first-order step is due, 2 / 3 = the
+// first / second deep step is due.
+constexpr double kDeepOff = 2.0e-6, kDeepCap = 5.0e-2;
 constexpr int kEighFailsOffset = 2040;  // int32 inside the 2048-byte info block, behind EighInfo: runs that fell short
 
 // Stopping rule, evaluated from the off-diagonal mass a_s = sqrt(acc[s] / |C|_F^2) met DURING the sweeps so far:
@@ -746,8 +761,8 @@ __global__ __launch_bounds__(256) void eigh_gemm_kernel(const double *__restrict
 //   3. V[p] T -> M[p ^ 1]   (the eigenvectors; eigh_colstats / eigh_write read them from there, the eigenvalues stay d)
 __global__ __launch_bounds__(256) void eigh_refine_k_kernel(const double *__restrict__ M0, const double *__restrict__ M1,
                                                             double *K0, double *K1, int npad,
-                                                            const EighInfo *info, double tol) {
-    if (!info->refine) return;
+                                                            const EighInfo *info, double tol, int want, double cap, double scale) {
+    if (info->refine != want) return;
     const double *M = info->parity ? M1 : M0;
     double *K = info->parity ? K0 : K1;
     const double tolel2 = tol * tol * info->norm2 / ((double)npad * (double)npad);
@@ -760,14 +775,14 @@ __global__ __launch_bounds__(256) void eigh_refine_k_kernel(const double *__rest
         const double m = M[(int64_t)a * npad + b];
         const double g = M[(int64_t)b * npad + b] - M[(int64_t)a * npad + a];
         if (m * m > tolel2) k = m / g;
-        if (!(fabs(k) <= 2.0 * kRefineCap)) k = 0.0;  // (cannot happen after the rule held; never divide by noise)
+        if (!(fabs(k) <= 2.0 * cap)) k = 0.0;  // (cannot happen after the rule held; never divide by noise)
         if (i > j) k = -k;
     }
-    K[e] = k;
+    K[e] = k * scale;  // (the deep step works with K / 2: its rotation is the square of exp(K / 2))
 }
 // d_i <- d_i - sum_j K_ij M_ij  (= d_i + sum_j M_ij^2 / (d_i - d_j)), one wavefront per row; runs after step 1
 __global__ __launch_bounds__(256) void eigh_refine_diag_kernel(double *M0, double *M1, int npad, const EighInfo *info) {
-    if (!info->refine) return;
+    if (info->refine != 1) return;
     double *M = info->parity ? M1 : M0;
     const double *K = info->parity ? M0 : M1;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(256) void eigh_refine_gemm_kernel(double *__restric
                                                                double *__restrict__ V0, double *__restrict__ V1, int npad,
                                                                const EighInfo *info, int which) {
     __shared__ double As[2 * kM2 * LDX], Bs[2 * kM2 * LDU];
-    if (!info->refine) return;
+    if (info->refine != 1) return;
     const int p = info->parity;
     double *Kb = p ? M0 : M1, *Tb = p ? V0 : V1;
     const double *Vb = p ? V1 : V0;
@@ -793,6 +808,80 @@ __global__ __launch_bounds__(256) void eigh_refine_gemm_kernel(double *__restric
         eigh_gemm_body<false>(Kb, Kb, Tb, npad, 0.5, 1.0, Kb, As, Bs);
     else
         eigh_gemm_body<false>(Vb, Tb, Kb, npad, 1.0, 0.0, nullptr, As, Bs);
+}
+
+// ---- the deep refinement step (see kDeepOff); every kernel does nothing unless info->refine == want (2: first, 3: second step) ----
+// With p = info->parity, q = p ^ 1:  H = K / 2 -> M[q] (eigh_refine_k_kernel, cap kDeepCap), then `which` =
+//   0: T2 = I + H + H H / 2 -> V[q]      1: E = I - T2^T T2 -> W1      2: Th = T2 + T2 E / 2 -> W2      3: T = Th Th -> W3
+//   4: M[p] T -> W1                      5: T^T (M[p] T) -> M[q]       6: V[p] T -> V[q]
+// (the rotation exp(K) as the SQUARE of a Newton-Schulz-corrected exp(K / 2): T2^T T2 = I + H^4 / 4 exactly, one correction step
+// leaves ~(3/8) (H^4 / 4)^2 -- 4e-15 at max |K| = 5e-2 where the plain form T2(K) + one step left 1e-11 in V^T V -- and the
+// square of an orthogonal matrix is orthogonal), then eigh_deep_measure_kernel on M[q] and eigh_deep_finish_kernel.
+__global__ __launch_bounds__(256) void eigh_deep_gemm_kernel(double *__restrict__ M0, double *__restrict__ M1,
+                                                             double *__restrict__ V0, double *__restrict__ V1,
+                                                             double *__restrict__ W1, double *__restrict__ W2,
+                                                             double *__restrict__ W3, int npad, const EighInfo *info, int want,
+                                                             int which) {
+    __shared__ double As[2 * kM2 * LDX], Bs[2 * kM2 * LDU];
+    if (info->refine != want) return;
+    const int p = info->parity;
+    double *Mp = p ? M1 : M0, *Mq = p ? M0 : M1, *Vp = p ? V1 : V0, *Vq = p ? V0 : V1;
+    switch (which) {
+        case 0: eigh_gemm_body<false>(Mq, Mq, Vq, npad, 0.5, 1.0, Mq, As, Bs); break;
+        case 1: eigh_gemm_body<true>(Vq, Vq, W1, npad, -1.0, 1.0, nullptr, As, Bs); break;
+        case 2: eigh_gemm_body<false>(Vq, W1, W2, npad, 0.5, 0.0, Vq, As, Bs); break;
+        case 3: eigh_gemm_body<false>(W2, W2, W3, npad, 1.0, 0.0, nullptr, As, Bs); break;
+        case 4: eigh_gemm_body<false>(Mp, W3, W1, npad, 1.0, 0.0, nullptr, As, Bs); break;
+        case 5: eigh_gemm_body<true>(W3, W1, Mq, npad, 1.0, 0.0, nullptr, As, Bs); break;
+        default: eigh_gemm_body<false>(Vp, W3, Vq, npad, 1.0, 0.0, nullptr, As, Bs); break;
+    }
+}
+// off(M')^2 and max K^2 of M' = M[q] (the measurements the tile workgroups take of a sweep's result), into deep_off / deep_k[slot]
+__global__ __launch_bounds__(256) void eigh_deep_measure_kernel(const double *__restrict__ M0, const double *__restrict__ M1, int npad,
+                                                                EighInfo *info, double tol, int want, int slot) {
+    __shared__ double s_off[4], s_k[4];
+    if (info->refine != want) return;
+    const double *M = info->parity ? M0 : M1;
+    const double tolel2 = tol * tol * info->norm2 / ((double)npad * (double)npad);
+    double off = 0.0, km = 0.0;
+    const unsigned un = (unsigned)npad, tot = un * un;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < tot; e += gridDim.x * 256u) {
+        const unsigned i = e / un, j = e - i * un;
+        if (i == j) continue;
+        const double m = M[e], a2 = m * m;
+        off += a2;
+        if (a2 > tolel2) {
+            const double g = M[(int64_t)j * npad + j] - M[(int64_t)i * npad + i];
+            km = fmax(km, a2 / (g * g));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o, kWave), km = fmax(km, __shfl_xor(km, o, kWave));
+    if ((threadIdx.x & 63) == 0) s_off[threadIdx.x >> 6] = off, s_k[threadIdx.x >> 6] = km;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (s_off[0] + s_off[1]) + (s_off[2] + s_off[3]);
+        const double k = fmax(fmax(s_k[0], s_k[1]), fmax(s_k[2], s_k[3]));
+        if (t != 0.0) atomicAdd(&info->deep_off[slot], t);
+        if (k > 0.0) atomicMax(&info->deep_k[slot], (unsigned long long)__double_as_longlong(k));
+    }
+}
+__global__ void eigh_deep_finish_kernel(EighInfo *info, double tol, int want, int slot, int *fails) {
+    if (threadIdx.x != 0 || info->refine != want) return;
+    info->parity ^= 1;  // M', V' are the matrices from here on
+    info->deep_steps = slot + 1;
+    const double left = info->deep_off[slot], kmax2 = __longlong_as_double((long long)info->deep_k[slot]), nrm2 = info->norm2;
+    if (left <= tol * tol * nrm2) {
+        info->refine = 0;  // (nothing left above the tolerance)
+    } else if (left <= kRefineOff * kRefineOff * nrm2 && kmax2 <= kRefineCap * kRefineCap &&
+               kmax2 * left <= kRefineProd * kRefineProd * nrm2) {
+        info->refine = 1;  // the first-order step finishes the run
+    } else if (want == 2) {
+        info->refine = 3;  // once more
+    } else {
+        info->refine = 0, info->converged = 0;
+        atomicAdd(fails, 1);
+    }
 }
 
 struct RoundLds {
@@ -920,6 +1009,16 @@ __device__ int round_state(EighInfo *info, int ended, double nrm2, const RoundPa
                     info->sweeps = sweep, info->parity = R.parity_out ^ 1, info->converged = 1;
                     info->thr2 = thr2;
                     info->refine = 1;
+                    info->done_seq = R.seq;
+                }
+                return 2;
+            }
+            if ((refine & 2) && left <= kDeepOff * kDeepOff * nrm2 && kmax2 <= kDeepCap * kDeepCap) {
+                // one sweep earlier still: the deep refinement step(s), then the first-order one
+                if (writer) {
+                    info->sweeps = sweep, info->parity = R.parity_out ^ 1, info->converged = 1;
+                    info->thr2 = thr2;
+                    info->refine = 2;
                     info->done_seq = R.seq;
                 }
                 return 2;
@@ -1717,6 +1816,8 @@ __global__ void eigh_close_kernel(EighInfo *info, int sweeps, int parity, double
         if (left <= kRefineOff * kRefineOff * info->norm2 && kmax2 <= kRefineCap * kRefineCap &&
             kmax2 * left <= kRefineProd * kRefineProd * info->norm2)
             info->refine = 1, conv = 1;
+        else if ((refine & 2) && left <= kDeepOff * kDeepOff * info->norm2 && kmax2 <= kDeepCap * kDeepCap)
+            info->refine = 2, conv = 1;
     }
     info->converged = conv;
     if (!conv) atomicAdd(fails, 1);
@@ -1733,7 +1834,7 @@ __global__ __launch_bounds__(1024) void eigh_colstats_kernel(const double *__res
     __shared__ double s_n2[RS][16], s_mx[RS][16], s_sg[RS][16];
     __shared__ int s_ix[RS][16];
     const double *M = info->parity ? M1 : M0, *V = info->parity ? V1 : V0;
-    if (info->refine) V = info->parity ? M0 : M1;  // the refinement step left the eigenvectors in the free M buffer
+    if (info->refine == 1) V = info->parity ? M0 : M1;  // the refinement step left the eigenvectors in the free M buffer
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + tx;
     double n2 = 0.0, mx = -1.0, sg = 1.0;
@@ -1816,7 +1917,7 @@ __global__ __launch_bounds__(256) void eigh_write_kernel(const double *__restric
                                                          const int *__restrict__ inv, const double *__restrict__ scl,
                                                          double *__restrict__ B) {
     const double *V = info->parity ? V1 : V0;
-    if (info->refine) V = info->parity ? M0 : M1;
+    if (info->refine == 1) V = info->parity ? M0 : M1;
     const int i = blockIdx.x;
     for (int r = threadIdx.x; r < n; r += 256) {
         const int j = inv[r];
@@ -1832,7 +1933,7 @@ inline int eigh_npad(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 64 ? 6
 
 struct EighWs {
     EighInfo *info;
-    double *M[2], *V[2], *U[3], *lam, *scl;
+    double *M[2], *V[2], *U[3], *W[3], *lam, *scl;  // (W: the deep refinement step's work matrices)
     int *inv;
     int64_t ustride;  // doubles per rotation buffer
     int64_t ucount;   // doubles in all three rotation buffers
@@ -1855,6 +1956,7 @@ inline EighWs eigh_layout(void *ws, int n) {
     w.ustride = pairs * kUU;
     w.ucount = 3 * pairs * kUU;
     for (int k = 0; k < 3; ++k) w.U[k] = (double *)(p + off), off += pairs * kUU * 8;
+    for (int k = 0; k < 3; ++k) w.W[k] = (double *)(p + off), off += np * np * 8;
     w.lam = (double *)(p + off), off += np * 8;
     w.scl = (double *)(p + off), off += np * 8;
     w.inv = (int *)(p + off), off += np * 8;
@@ -1949,6 +2051,9 @@ int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, dou
     if (!(tol > 0.0)) tol = 1.0e-14;
     hipStream_t st = (hipStream_t)stream;
     const int npad = eigh_npad(n);
+    // bit 0: the first-order refinement step allowed; bit 1: the deep one too (SX_EIGH_DEEP=0 switches it off)
+    static const bool deep_on = [] { const char *e = getenv("SX_EIGH_DEEP"); return !(e != nullptr && e[0] == '0'); }();
+    refine = refine ? (1 | ((deep_on && npad >= 256) ? 2 : 0)) : 0;
     const int nb = npad / kBS, np = nb / 2, rps = nb - 1;
     SX_REQUIRE(r0 >= 0 && r1 >= r0 && r1 <= kEighMaxSweeps * (n <= kSmallPathMax ? 1 : rps), "sx_eigh: bad round range");
     if (phases & 1) {
@@ -2023,15 +2128,33 @@ int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, dou
             // apply the last rotations, then close (r1 rounds have been enqueued; a run that ended earlier ignores both)
             const int cur = r1 & 1, rprev = r1 == 0 ? 0 : (r1 - 1) % rps, sweeps = r1 / rps;
             hipLaunchKernelGGL(eigh_round_kernel, dim3(grid), dim3(kRoundThreads), 0, st, L.M[cur], L.V[cur], L.M[cur ^ 1],
-                               L.V[cur ^ 1], npad, nb, L.U[(r1 + 2) % 3], L.U[r1 % 3], L.info, sweeps, rprev, 0, cur ^ 1, tol, 1, r1 + 1, 0);
+                               L.V[cur ^ 1], npad, nb, L.U[(r1 + 2) % 3], L.U[r1 % 3], L.info, sweeps, rprev, 0, cur ^ 1, tol, 1, r1 + 1, refine);
+            // (refine: the flush launch measures max |K| of what it writes, like every launch that ends a sweep -- the closing
+            //  kernel's refinement rules read it; round 6: it was 0 here and those rules saw max |K| = 0)
             SX_LAUNCH_CHECK();
             hipLaunchKernelGGL(eigh_close_kernel, dim3(1), dim3(64), 0, st, L.info, sweeps, cur ^ 1, tol, refine,
                                (int *)((char *)L.info + kEighFailsOffset));
             SX_LAUNCH_CHECK();
             if (refine) {
                 const dim3 gg((unsigned)(npad / kM2), (unsigned)(npad / kM2));
-                hipLaunchKernelGGL(eigh_refine_k_kernel, dim3((unsigned)(((int64_t)npad * npad + 255) / 256)), dim3(256), 0, st, L.M[0],
-                                   L.M[1], L.M[0], L.M[1], npad, L.info, tol);
+                const dim3 ge((unsigned)(((int64_t)npad * npad + 255) / 256));
+                if (refine & 2) {  // the deep step, twice (each set does nothing unless the record asks for it)
+                    int *fails = (int *)((char *)L.info + kEighFailsOffset);
+                    for (int step = 0; step < 2; ++step) {
+                        const int want = 2 + step;
+                        hipLaunchKernelGGL(eigh_refine_k_kernel, ge, dim3(256), 0, st, L.M[0], L.M[1], L.M[0], L.M[1], npad, L.info, tol,
+                                           want, kDeepCap, 0.5);
+                        for (int which = 0; which < 7; ++which)
+                            hipLaunchKernelGGL(eigh_deep_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], L.W[0], L.W[1],
+                                               L.W[2], npad, L.info, want, which);
+                        hipLaunchKernelGGL(eigh_deep_measure_kernel, dim3(128), dim3(256), 0, st, L.M[0], L.M[1], npad, L.info, tol, want,
+                                           step);
+                        hipLaunchKernelGGL(eigh_deep_finish_kernel, dim3(1), dim3(64), 0, st, L.info, tol, want, step, fails);
+                    }
+                    SX_LAUNCH_CHECK();
+                }
+                hipLaunchKernelGGL(eigh_refine_k_kernel, ge, dim3(256), 0, st, L.M[0],
+                                   L.M[1], L.M[0], L.M[1], npad, L.info, tol, 1, kRefineCap, 1.0);
                 hipLaunchKernelGGL(eigh_refine_diag_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, st, L.M[0], L.M[1], npad, L.info);
                 hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 0);
                 hipLaunchKernelGGL(eigh_refine_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], npad, L.info, 1);
