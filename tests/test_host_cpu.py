@@ -45,6 +45,9 @@ def test_struct_layouts_match_the_header(lib):
     assert C.sizeof(_lib.SxDeArgs) == lib.sx_struct_size(1)
     assert C.sizeof(_lib.SxPsoArgs) == lib.sx_struct_size(2)
     assert C.sizeof(_lib.SxXchgArgs) == lib.sx_struct_size(3)
+    assert C.sizeof(_lib.SxCmaState) == lib.sx_struct_size(4)
+    assert C.sizeof(_lib.SxCmaArgs) == lib.sx_struct_size(5)
+    assert C.sizeof(_lib.SxVdArgs) == lib.sx_struct_size(6)
     # field offsets of the scalars that follow the pointer block
     assert _lib.SxDeArgs.P.offset == 14 * 8 and _lib.SxDeArgs.key0.offset == C.sizeof(_lib.SxDeArgs) - 8
     assert _lib.SxPsoArgs.P.offset == 14 * 8 and _lib.SxPsoArgs.key0.offset == C.sizeof(_lib.SxPsoArgs) - 8
