@@ -585,7 +585,10 @@ int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, c
  * state: an sx_cma_state whose reserved[0..4] = {ps, |v|^2, |v|, injection flag, sqrt(1 + |v|^2) - 1}; sigma_next,
  * tmp_coef, psnorm unused.  All vectors DEVICE; besthist zero-initialised; hist_x / hist_f as in sx_cma_args or NULL. */
 typedef struct sx_vd_args {
-    double *Z, *ary, *arx;      /* (P,n) normals / steps y / candidates x                              */
+    double *Z, *ary, *arx;      /* (P,n) normals / steps y / candidates x.  Wide models (n > 4096) without hist_x and pen_ws:
+                                 * arx may be NULL -- x = xmean + sigma y is then not kept (a quarter of a generation's memory
+                                 * traffic): the moment sums and the result form it again from y, same bits.  Wide models use
+                                 * Z for t_k (P doubles) and eight words behind them only.                                    */
     double *fit;                /* (P)                                                                */
     double *xmean, *xold, *dx, *dvec, *vvec, *vn, *pc; /* (n)                                         */
     double *zinj, *dy;          /* (n) the injection's normal row ("row P" of the generation) and +-dy */

@@ -688,9 +688,17 @@ __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *_
                                                                  const double *__restrict__ tk, int mu, int n,
                                                                  const double *__restrict__ dvec, const double *__restrict__ vn,
                                                                  double norm_v2, double *__restrict__ part,
-                                                                 const sx_cma_state *st, const int tk_by_row) {
+                                                                 const sx_cma_state *st, const int tk_by_row,
+                                                                 const double *__restrict__ xmean) {
     // tk_by_row: tk holds t of EVERY candidate row (left by the wide candidates kernel, sx_wide.hip), not of the selected ones
+    // arx == NULL (wide device loop, nobody else wants the candidates): x = xmean + sigma y is formed again here, by the
+    // candidates kernel's own expression from the same operands -- the same bits as the stored row would hold
     if (st != nullptr) norm_v2 = st->reserved[1];
+    const bool form_x = arx == nullptr;
+    const double sigma = form_x ? st->sigma : 0.0;
+    double xm0[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) xm0[c] = 0.0;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + tx) * W;
     const int q = blockIdx.y * 4 + ty;
@@ -699,26 +707,50 @@ __global__ __launch_bounds__(256) void vd_moments_partial_kernel(const double *_
     double dv[W], v[W], awx[W], awy[W], ap[W], aq[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) dv[c] = dvec[col + c], v[c] = vn[col + c], awx[c] = 0.0, awy[c] = 0.0, ap[c] = 0.0, aq[c] = 0.0;
-    for (int k = q; k < mu; k += kVdPart) {
-        const int64_t row = idx[k] * (int64_t)n + col;
-        const double wk = w[k], t = tk[tk_by_row ? idx[k] : k];
-        double ax[W], ay[W];
-        if constexpr (W >= 2) {
+    if (form_x) {
 #pragma unroll
-            for (int c = 0; c < W; c += 2) {
-                const double2 a2 = *reinterpret_cast<const double2 *>(arx + row + c), y2 = *reinterpret_cast<const double2 *>(ary + row + c);
-                ax[c] = a2.x, ax[c + 1] = a2.y, ay[c] = y2.x, ay[c + 1] = y2.y;
+        for (int c = 0; c < W; ++c) xm0[c] = xmean[col + c];
+    }
+    // (the selected rows of this slice, B at a time: their loads are in flight together -- a slice is only mu / 64 rows long, one
+    //  memory round trip each when taken one by one -- and enter the sums in the order of k, as before)
+    constexpr int B = 4;
+    for (int k0 = q; k0 < mu; k0 += B * kVdPart) {
+        double ax[B][W], ay[B][W], wk[B], t[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int k = k0 + u * kVdPart;
+            const bool on = k < mu;
+            const int64_t r = on ? idx[k] : idx[k0];
+            const int64_t row = r * (int64_t)n + col;
+            wk[u] = on ? w[k] : 0.0, t[u] = tk[tk_by_row ? r : (on ? k : k0)];
+            if constexpr (W >= 2) {
+#pragma unroll
+                for (int c = 0; c < W; c += 2) {
+                    const double2 y2 = *reinterpret_cast<const double2 *>(ary + row + c);
+                    ay[u][c] = y2.x, ay[u][c + 1] = y2.y;
+                    if (form_x) {
+                        ax[u][c] = xm0[c] + sigma * y2.x, ax[u][c + 1] = xm0[c + 1] + sigma * y2.y;
+                    } else {
+                        const double2 a2 = *reinterpret_cast<const double2 *>(arx + row + c);
+                        ax[u][c] = a2.x, ax[u][c + 1] = a2.y;
+                    }
+                }
+            } else {
+                ay[u][0] = ary[row];
+                ax[u][0] = form_x ? xm0[0] + sigma * ay[u][0] : arx[row];
             }
-        } else {
-            ax[0] = arx[row], ay[0] = ary[row];
         }
 #pragma unroll
-        for (int c = 0; c < W; ++c) {
-            const double y = ay[c] / dv[c];
-            awx[c] += wk * ax[c];
-            awy[c] += wk * ay[c];
-            ap[c] += wk * (y * y - shrink * (t * (y * v[c])) - 1.0);
-            aq[c] += wk * (t * y - (0.5 * (t * t + 1.0 + norm_v2)) * v[c]);
+        for (int u = 0; u < B; ++u) {
+            if (k0 + u * kVdPart >= mu) break;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                const double y = ay[u][c] / dv[c];
+                awx[c] += wk[u] * ax[u][c];
+                awy[c] += wk[u] * ay[u][c];
+                ap[c] += wk[u] * (y * y - shrink * (t[u] * (y * v[c])) - 1.0);
+                aq[c] += wk[u] * (t[u] * y - (0.5 * (t[u] * t[u] + 1.0 + norm_v2)) * v[c]);
+            }
         }
     }
     const int64_t plane = (int64_t)kVdPart * n;
@@ -754,20 +786,21 @@ __global__ __launch_bounds__(256) void vd_moments_finish_kernel(const double *__
 namespace sx {
 int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
                       const double *dvec, const double *vn, double norm_v2, const sx_cma_state *state, double *ws,
-                      double *out, void *stream, const double *tk_rows) {
+                      double *out, void *stream, const double *tk_rows, const double *xmean) {
     hipStream_t st = (hipStream_t)stream;
+    SX_REQUIRE(arx != nullptr || (xmean != nullptr && state != nullptr), "vd_moments_launch: no candidates and nothing to form them from");
     double *tk = ws, *part = ws + ((mu + 7) / 8) * 8;
     if (tk_rows == nullptr)
         hipLaunchKernelGGL(vd_t_kernel, dim3((unsigned)((mu + 3) / 4)), dim3(256), 0, st, ary, idx, mu, n, dvec, vn, tk);
     // (four columns per thread were measured too: 33.9 / 148 us against 33.2 / 128.5 with two, 44.1 / 168.7 with one --
     //  n = 16 384, mu = 512 / 2048: profiles/r5_vdcma_moments_note.txt)
-    const bool pairs = n % 2 == 0 && (((uintptr_t)arx | (uintptr_t)ary) & 15) == 0;
+    const bool pairs = n % 2 == 0 && (((uintptr_t)arx | (uintptr_t)ary) & 15) == 0;  // (arx NULL: its bits are 0)
     if (pairs)
         hipLaunchKernelGGL(vd_moments_partial_kernel<2>, dim3((unsigned)((n / 2 + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary,
-                           idx, w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0);
+                           idx, w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0, xmean);
     else
         hipLaunchKernelGGL(vd_moments_partial_kernel<1>, dim3((unsigned)((n + 63) / 64), kVdPart / 4), dim3(256), 0, st, arx, ary, idx,
-                           w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0);
+                           w, tk_rows ? tk_rows : (const double *)tk, mu, n, dvec, vn, norm_v2, part, state, tk_rows ? 1 : 0, xmean);
     hipLaunchKernelGGL(vd_moments_finish_kernel, dim3((unsigned)((n + 63) / 64), 4), dim3(256), 0, st, part, n, out);
     SX_LAUNCH_CHECK();
     return 0;
@@ -777,5 +810,5 @@ int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, 
 extern "C" int sx_vdcma_moments(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
                                 const double *dvec, const double *vn, double norm_v2, double *ws, double *out, void *stream) {
     SX_REQUIRE(arx && ary && idx && w && dvec && vn && ws && out && mu >= 1 && n >= 1, "sx_vdcma_moments: bad arguments");
-    return sx::vd_moments_launch(arx, ary, idx, w, mu, n, dvec, vn, norm_v2, nullptr, ws, out, stream, nullptr);
+    return sx::vd_moments_launch(arx, ary, idx, w, mu, n, dvec, vn, norm_v2, nullptr, ws, out, stream, nullptr, nullptr);
 }

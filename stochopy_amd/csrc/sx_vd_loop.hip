@@ -23,7 +23,7 @@ int vd_sample_launch(const double *Z, int64_t P, int n, const double *dvec, cons
                      const double *dy, double *ary, double *arx, const sx_cma_state *st, void *stream, int64_t row0 = 0);
 int vd_moments_launch(const double *arx, const double *ary, const int64_t *idx, const double *w, int mu, int n,
                       const double *dvec, const double *vn, double norm_v2, const sx_cma_state *state, double *ws,
-                      double *out, void *stream, const double *tk_rows = nullptr);
+                      double *out, void *stream, const double *tk_rows = nullptr, const double *xmean = nullptr);
 int cma_rank_launch(const double *fit, int64_t P, int64_t *order, sx_cma_state *state, double *besthist, int64_t gen,
                     void *stream);
 int cma_history_launch(const sx_cma_args &h, int64_t gen, void *stream);
@@ -406,6 +406,10 @@ __host__ __device__ inline VwScratch vw_scratch(double *base, int n) {
     w.scal = w.part + 8 * kVwMaxBlocks * kVwSlots;
     return w;
 }
+// The eight barrier words of vw_chain_kernel: NOT in this scratch -- the moments kernels write their partial sums over it
+// between the injection (which zeroes the words) and the chain -- but behind t_k in Z, the (P, n) buffer of which wide
+// models use the first P doubles only.
+__host__ __device__ inline unsigned *vw_sync(const sx_vd_args &a) { return (unsigned *)(a.Z + a.P); }
 inline unsigned vw_blocks(int n) {
     const int b = (n + kVwThreads - 1) / kVwThreads;
     return (unsigned)(b < kVwMaxBlocks ? b : kVwMaxBlocks);
@@ -414,13 +418,25 @@ inline unsigned vw_blocks(int n) {
 // found it: 16 sigma, 17 ps, 18 |v|^2, 19 |v|, 20 inject, 21 fbest, 22 best_row
 enum { kSPos0 = 0, kSPos1, kSDx2, kSVmax, kST, kSSvi, kSVq, kSRi, kSSvn, kSG2, kSMind, kSState = 16 };
 
+// What one workgroup leaves for the others inside vw_chain_kernel -- partial sums and scalars, nothing else: every vector
+// element is written and read by the same thread in every phase (VW_FOR_E) -- goes through agent-scope accesses (sc1:
+// written through, read past the XCD's L2) and the barrier only drains them: no fence.  (A release / acquire pair per
+// barrier writes back and invalidates the XCD's whole L2 -- full of the candidates kernel's rows: the single launch was
+// 10-25 us per generation SLOWER than nine launches that way, profiles/r6_vd_chain.txt.)
+__device__ __forceinline__ double vw_ld(const double *p) {
+    return __hip_atomic_load((__attribute__((address_space(1))) double *)const_cast<double *>(p), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void vw_st(double *p, double v) {
+    __hip_atomic_store((__attribute__((address_space(1))) double *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // the K partial sums of phase `ph` over all workgroups (kind: 0 sum, 1 max, 2 min), in every thread
 template <int K>
 __device__ __forceinline__ void vw_collect(const VwScratch &w, int ph, const int (&kind)[K], double (&v)[K], double (*red)[K]) {
     const double *p = w.part + ((int64_t)ph * kVwMaxBlocks + threadIdx.x) * kVwSlots;
 #pragma unroll
     for (int q = 0; q < K; ++q)
-        v[q] = threadIdx.x < gridDim.x ? p[q] : (kind[q] == 0 ? 0.0 : (kind[q] == 1 ? -__builtin_inf() : __builtin_inf()));
+        v[q] = threadIdx.x < gridDim.x ? vw_ld(p + q) : (kind[q] == 0 ? 0.0 : (kind[q] == 1 ? -__builtin_inf() : __builtin_inf()));
     reduce_many<K, kVwWaves>(v, kind, red);
 }
 template <int K>
@@ -429,7 +445,7 @@ __device__ __forceinline__ void vw_leave(const VwScratch &w, int ph, const int (
     if (threadIdx.x == 0) {
         double *p = w.part + ((int64_t)ph * kVwMaxBlocks + blockIdx.x) * kVwSlots;
 #pragma unroll
-        for (int q = 0; q < K; ++q) p[q] = v[q];
+        for (int q = 0; q < K; ++q) vw_st(p + q, v[q]);
     }
 }
 
@@ -470,6 +486,7 @@ __device__ __forceinline__ double vw_avec(const VwModel &m, double vnn) { return
 __global__ __launch_bounds__(kVwThreads) void vw_inject_norms_kernel(const sx_vd_args a, int64_t gen, double *base) {
     __shared__ double red3[kVwWaves][3];
     const sx_cma_state *state = (const sx_cma_state *)a.state;
+    if (blockIdx.x == 0 && threadIdx.x < 8) vw_sync(a)[threadIdx.x] = 0u;  // (vw_chain_kernel's barrier words)
     if (state->done || state->reserved[3] == 0.0) return;
     const int n = a.n;
     const VwScratch w = vw_scratch(base, n);
@@ -512,17 +529,17 @@ __global__ __launch_bounds__(kVwThreads) void vw_inject_apply_kernel(const sx_vd
 }
 
 // phase A: the injected pair in the ranking (:299-300), mean shift (:292-294)
-__global__ __launch_bounds__(kVwThreads) void vw_a_kernel(const sx_vd_args a, double *base) {
+__device__ __forceinline__ void vw_a_phase(const sx_vd_args &a, double *base) {
     __shared__ double red4[kVwWaves][4];
     const sx_cma_state *state = (const sx_cma_state *)a.state;
-    if (state->done) return;
     const int n = a.n;
     const VwScratch w = vw_scratch(base, n);
     const double *wx = a.mout;
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // the state as this update found it (the last kernel of the chain rewrites it)
-        w.scal[kSState] = state->sigma, w.scal[kSState + 1] = state->reserved[0], w.scal[kSState + 2] = state->reserved[1];
-        w.scal[kSState + 3] = state->reserved[2], w.scal[kSState + 4] = state->reserved[3], w.scal[kSState + 5] = state->fbest;
-        w.scal[kSState + 6] = (double)state->best_row;
+        vw_st(w.scal + kSState, state->sigma), vw_st(w.scal + kSState + 1, state->reserved[0]);
+        vw_st(w.scal + kSState + 2, state->reserved[1]), vw_st(w.scal + kSState + 3, state->reserved[2]);
+        vw_st(w.scal + kSState + 4, state->reserved[3]), vw_st(w.scal + kSState + 5, state->fbest);
+        vw_st(w.scal + kSState + 6, (double)state->best_row);
     }
     double pos0 = 0.0, pos1 = 0.0;
     if (state->reserved[3] != 0.0) {
@@ -548,21 +565,20 @@ __global__ __launch_bounds__(kVwThreads) void vw_a_kernel(const sx_vd_args a, do
 }
 
 // phase B: evolution path (:309-314), t = y . vn, sum of vn^2 invavnn
-__global__ __launch_bounds__(kVwThreads) void vw_b_kernel(const sx_vd_args a, double *base) {
+__device__ __forceinline__ void vw_b_phase(const sx_vd_args &a, double *base) {
     __shared__ double red4[kVwWaves][4];
     __shared__ double red2[kVwWaves][2];
-    const sx_cma_state *state = (const sx_cma_state *)a.state;
-    if (state->done) return;
     const int n = a.n;
     const VwScratch w = vw_scratch(base, n);
     double v4[4];
     const int k4[4] = {0, 0, 0, 1};
     vw_collect<4>(w, 0, k4, v4, red4);
     __shared__ double s_scal[32];
+    __syncthreads();  // (one launch for the whole chain: the previous phase's readers of its s_scal are through)
     if (threadIdx.x < 4) s_scal[threadIdx.x] = v4[threadIdx.x];
-    if (threadIdx.x >= kSState && threadIdx.x < kSState + 8) s_scal[threadIdx.x] = w.scal[threadIdx.x];
+    if (threadIdx.x >= kSState && threadIdx.x < kSState + 8) s_scal[threadIdx.x] = vw_ld(w.scal + threadIdx.x);
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x < 4) w.scal[threadIdx.x] = v4[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 4) vw_st(w.scal + threadIdx.x, v4[threadIdx.x]);
     const VwModel m = vw_model(a, s_scal);
     const double *wy = a.mout + n;
     const double cpc = sqrt(a.cc * (2.0 - a.cc) * a.mueff);
@@ -582,26 +598,25 @@ __global__ __launch_bounds__(kVwThreads) void vw_b_kernel(const sx_vd_args a, do
 }
 
 // phases C .. F (:331-378, :428-460): which = 0 p, q and vn . q;  1 r and r . invavnn;  2 s and s . vn^2;  3 the steps ngv, ngd
-__global__ __launch_bounds__(kVwThreads) void vw_cdef_kernel(const sx_vd_args a, double *base, const int which) {
+__device__ __forceinline__ void vw_cdef_phase(const sx_vd_args &a, double *base, const int which) {
     __shared__ double red2[kVwWaves][2];
     __shared__ double s_scal[32];
-    const sx_cma_state *state = (const sx_cma_state *)a.state;
-    if (state->done) return;
     const int n = a.n;
     const VwScratch w = vw_scratch(base, n);
     // the previous phase's sums (phase 1 + which: two values after B, one after C, D, E)
     double v2[2];
     const int k2[2] = {0, 0};
     vw_collect<2>(w, 1 + which, k2, v2, red2);
-    if (threadIdx.x < 32) s_scal[threadIdx.x] = w.scal[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 32) s_scal[threadIdx.x] = vw_ld(w.scal + threadIdx.x);
     __syncthreads();
     const int slot = which == 0 ? kST : (which == 1 ? kSVq : (which == 2 ? kSRi : kSSvn));
     if (threadIdx.x == 0) {
         s_scal[slot] = v2[0];
         if (which == 0) s_scal[kSSvi] = v2[1];
         if (blockIdx.x == 0) {
-            w.scal[slot] = v2[0];
-            if (which == 0) w.scal[kSSvi] = v2[1];
+            vw_st(w.scal + slot, v2[0]);
+            if (which == 0) vw_st(w.scal + kSSvi, v2[1]);
         }
     }
     __syncthreads();
@@ -659,20 +674,19 @@ __global__ __launch_bounds__(kVwThreads) void vw_cdef_kernel(const sx_vd_args a,
 }
 
 // phase G: update of v and d (:371-378), the stopping rules' per-dimension counts, the best-fitness histories
-__global__ __launch_bounds__(kVwThreads) void vw_g_kernel(const sx_vd_args a, int64_t gen, double *base) {
+__device__ __forceinline__ void vw_g_phase(const sx_vd_args &a, int64_t gen, double *base) {
     __shared__ double red2[kVwWaves][2];
     __shared__ double red10[kVwWaves][10];
     __shared__ double s_scal[32];
-    const sx_cma_state *state = (const sx_cma_state *)a.state;
-    if (state->done) return;
     const int n = a.n;
     const VwScratch w = vw_scratch(base, n);
     double v2[2];
     const int k2[2] = {0, 2};
     vw_collect<2>(w, 5, k2, v2, red2);
-    if (threadIdx.x < 32) s_scal[threadIdx.x] = w.scal[threadIdx.x];
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.scal[kSG2] = v2[0], w.scal[kSMind] = v2[1];
+    if (threadIdx.x < 32) s_scal[threadIdx.x] = vw_ld(w.scal + threadIdx.x);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) vw_st(w.scal + kSG2, v2[0]), vw_st(w.scal + kSMind, v2[1]);
     const VwModel m = vw_model(a, s_scal);
     const bool learn = a.cmu + a.c1 > 0.0;
     double up = 1.0;
@@ -718,18 +732,19 @@ __global__ __launch_bounds__(kVwThreads) void vw_g_kernel(const sx_vd_args a, in
 }
 
 // phase H: vn = v / |v|, the stop rules (cmaes/_cmaes.py:360-434 as vdcma calls them), the result, the state
-__global__ __launch_bounds__(kVwThreads) void vw_h_kernel(const sx_vd_args a, int64_t gen, double *base) {
+// (only workgroup 0 writes the state, at its very end, and nobody reads anything of it after phase A but `done` -- at the
+//  launch's start; raise_done: one launch for the whole chain, where every workgroup has read `done` long before)
+__device__ __forceinline__ void vw_h_phase(const sx_vd_args &a, int64_t gen, double *base, const bool raise_done) {
     __shared__ double red10[kVwWaves][10];
     __shared__ double s_scal[32];
     sx_cma_state *state = (sx_cma_state *)a.state;
-    const int done0 = state->done;  // (only workgroup 0 writes the state, at its very end -- after it has read it -- and nobody
-    if (done0) return;              //  else reads anything but `done`, which this update can only raise for the NEXT launch)
     const int n = a.n;
     const VwScratch w = vw_scratch(base, n);
     double v10[10];
     const int k10[10] = {0, 0, 0, 0, 0, 1, 1, 1, 2, 2};
     vw_collect<10>(w, 6, k10, v10, red10);
-    if (threadIdx.x < 32) s_scal[threadIdx.x] = w.scal[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 32) s_scal[threadIdx.x] = vw_ld(w.scal + threadIdx.x);
     __syncthreads();
     const VwModel m = vw_model(a, s_scal);
     const double nv2n = v10[0], any3 = v10[1], any6 = v10[2], fail8 = v10[3], nan_sd = v10[4], sdmax = v10[5], wmax = v10[6];
@@ -754,9 +769,10 @@ __global__ __launch_bounds__(kVwThreads) void vw_h_kernel(const sx_vd_args a, in
     else if (fail8 == 0.0 && nan_sd == 0.0 && sigma * sdmax < 1.0e-11 * a.insigma)
         status = -8;
     if (status != SX_STATUS_NONE) {  // the caller's result: best candidate of THIS generation, un-standardised
-        const double *row = a.arx + (int64_t)s_scal[kSState + 6] * (int64_t)n;
+        // (arx NULL: the candidates were not kept; the row is formed again from its step -- old mean, old sigma -- as they were)
+        const int64_t br = (int64_t)s_scal[kSState + 6] * (int64_t)n;
         VW_FOR_E {
-            double x = row[e];
+            double x = a.arx != nullptr ? a.arx[br + e] : a.xold[e] + m.sigma0 * a.ary[br + e];
             if (a.pen_ws != nullptr) x = fmin(fmax(x, -1.0), 1.0);
             a.xbest[e] = x * a.xstd[e] + a.xm[e];
         }
@@ -773,12 +789,92 @@ __global__ __launch_bounds__(kVwThreads) void vw_h_kernel(const sx_vd_args a, in
         if (status != SX_STATUS_NONE) {
             state->status = status;
             state->stop_it = gen;
+            if (raise_done) {
+                __threadfence();
+                state->done = 1;
+            }
         }
     }
+}
+// One launch per phase (SX_VD_CHAIN=0, and what the single launch below is checked against) ...
+__global__ __launch_bounds__(kVwThreads) void vw_a_kernel(const sx_vd_args a, double *base) {
+    if (((const sx_cma_state *)a.state)->done) return;
+    vw_a_phase(a, base);
+}
+__global__ __launch_bounds__(kVwThreads) void vw_b_kernel(const sx_vd_args a, double *base) {
+    if (((const sx_cma_state *)a.state)->done) return;
+    vw_b_phase(a, base);
+}
+__global__ __launch_bounds__(kVwThreads) void vw_cdef_kernel(const sx_vd_args a, double *base, const int which) {
+    if (((const sx_cma_state *)a.state)->done) return;
+    vw_cdef_phase(a, base, which);
+}
+__global__ __launch_bounds__(kVwThreads) void vw_g_kernel(const sx_vd_args a, int64_t gen, double *base) {
+    if (((const sx_cma_state *)a.state)->done) return;
+    vw_g_phase(a, gen, base);
+}
+__global__ __launch_bounds__(kVwThreads) void vw_h_kernel(const sx_vd_args a, int64_t gen, double *base) {
+    if (((const sx_cma_state *)a.state)->done) return;
+    vw_h_phase(a, gen, base, false);
 }
 // the `done` flag goes up in a launch of its own: every workgroup of vw_h_kernel has read the state by then
 __global__ void vw_done_kernel(sx_cma_state *state) {
     if (state->status != SX_STATUS_NONE) state->done = 1;
+}
+
+// ... and ONE launch for the chain (round 6): the same phases on the same grid -- the same elements in the same workgroups,
+// the same partial sums added in the same order: the same bits -- with a grid-wide barrier where a kernel boundary was.  A
+// phase is ~1 us of work on <= 256 small workgroups, a kernel boundary ~5 us; a barrier -- every workgroup's first thread
+// drains its write-through stores (vw_st), counts itself in at word k of the sync area and waits for the count to reach
+// the grid's size -- is ~2 us on an idle chip.  The grid (<= 256 workgroups of 256 threads) is resident at once on any free device
+// with >= 32 CUs; a wait that a foreign kernel stretches beyond kVwWaitTicks gives up: status kVwFault, done = 1 (the
+// host raises).  The eight words are zeroed by vw_inject_norms_kernel, which every generation launches before its candidates.
+constexpr long long kVwWaitTicks = 400000000LL;  // ~4 s of the 100 MHz wall clock
+constexpr int kVwFault = -99;
+constexpr int kVwSyncWords = 8;
+__device__ __forceinline__ bool vw_grid_barrier(unsigned *word) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wavefront's partial sums / scalars have been written through)
+        __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > kVwWaitTicks) {
+                ok = 0;
+                break;
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+__global__ __launch_bounds__(kVwThreads) void vw_chain_kernel(const sx_vd_args a, int64_t gen, double *base, unsigned *sync) {
+    sx_cma_state *state = (sx_cma_state *)a.state;
+    if (state->done) return;
+    bool ok = true;
+    vw_a_phase(a, base);
+    ok = ok && vw_grid_barrier(sync + 0);
+    if (ok) vw_b_phase(a, base);
+    ok = ok && vw_grid_barrier(sync + 1);
+#pragma unroll
+    for (int which = 0; which < 4; ++which) {
+        if (ok) vw_cdef_phase(a, base, which);
+        ok = ok && vw_grid_barrier(sync + 2 + which);
+    }
+    if (ok) vw_g_phase(a, gen, base);
+    ok = ok && vw_grid_barrier(sync + 6);
+    if (ok) {
+        vw_h_phase(a, gen, base, true);
+    } else if (threadIdx.x == 0) {  // (whoever gave up says so; the others follow as their own waits run out or find the grid gone)
+        state->status = kVwFault;
+        state->stop_it = gen;
+        __threadfence();
+        state->done = 1;
+    }
 }
 
 }  // namespace
@@ -790,12 +886,14 @@ namespace {
 double *vd_wide_scratch(const sx_vd_args *a) { return a->mws + ((a->mu + 7) / 8) * 8; }
 
 int check_vd_args(const sx_vd_args *a, int64_t gen) {
-    SX_REQUIRE(a && a->Z && a->ary && a->arx && a->fit && a->xmean && a->xold && a->dx && a->dvec && a->vvec && a->vn &&
+    SX_REQUIRE(a && a->Z && a->ary && a->fit && a->xmean && a->xold && a->dx && a->dvec && a->vvec && a->vn &&
                    a->pc && a->zinj && a->dy && a->w && a->mws && a->mout && a->besthist && a->xm && a->xstd && a->xbest &&
                    a->order && a->state,
                "sx_vdcma_generation: null pointer");
     SX_REQUIRE(a->P >= 2 && a->n >= 1 && a->mu >= 1 && a->mu <= a->P && gen >= 1 && gen <= a->maxiter,
                "sx_vdcma_generation: bad shape or generation number");
+    SX_REQUIRE(a->arx != nullptr || (a->n > kVdPer * kVdThreads && a->hist_x == nullptr && a->pen_ws == nullptr),
+               "sx_vdcma_generation: arx may be NULL for wide models without history / Penalize only");
     return 0;
 }
 
@@ -844,7 +942,7 @@ extern "C" int sx_vdcma_generation_stage(const sx_vd_args *a, int64_t gen, int s
                                          double *ary_loc, double *arx_loc, double *fit_loc, void *stream) {
     if (int rc = check_vd_args(a, gen)) return rc;
     if (stage == 0) {
-        SX_REQUIRE(ary_loc && arx_loc && fit_loc && row0 >= 0 && rows >= 1 && row0 + rows <= a->P,
+        SX_REQUIRE(ary_loc && (arx_loc || a->arx == nullptr) && fit_loc && row0 >= 0 && rows >= 1 && row0 + rows <= a->P,
                    "sx_vdcma_generation_stage: bad shard");
         return vd_candidates(a, gen, row0, rows, ary_loc, arx_loc, fit_loc, stream);
     }
@@ -874,13 +972,19 @@ int vd_model_update(const sx_vd_args *a, int64_t gen, void *stream, bool vd_wide
     // (wide models, whole generation on this GPU: t_k of every row was left by the candidates kernel)
     const double *tk_rows = wide && vd_wide_has_tk ? a->Z : nullptr;
     if ((rc = sx::vd_moments_launch(a->arx, a->ary, a->order, a->w, a->mu, n, a->dvec, a->vn, 0.0, state, a->mws, a->mout,
-                                    stream, tk_rows)))
+                                    stream, tk_rows, a->xmean)))
         return rc;
     if (!wide) {
         hipLaunchKernelGGL(vd_update_kernel, dim3(1), dim3(kVdThreads), 0, st, *a, gen);
     } else {
         double *ws = vd_wide_scratch(a);
         const dim3 g(vw_blocks(n)), b(kVwThreads);
+        static const bool one_launch = getenv("SX_VD_CHAIN") == nullptr || getenv("SX_VD_CHAIN")[0] != '0';
+        if (one_launch) {
+            hipLaunchKernelGGL(vw_chain_kernel, g, b, 0, st, *a, gen, ws, vw_sync(*a));
+            SX_LAUNCH_CHECK();
+            return 0;
+        }
         hipLaunchKernelGGL(vw_a_kernel, g, b, 0, st, *a, ws);
         hipLaunchKernelGGL(vw_b_kernel, g, b, 0, st, *a, ws);
         for (int which = 0; which < 4; ++which) hipLaunchKernelGGL(vw_cdef_kernel, g, b, 0, st, *a, ws, which);

@@ -894,7 +894,9 @@ __global__ __launch_bounds__(T) void wide_vd_candidates_kernel(const sx_vd_args 
     const double sgn = grow == 0 ? 1.0 : -1.0;
     const bool clip = a.pen_ws != nullptr;
     double *__restrict__ yo = ary_out + row * (int64_t)n;
-    double *__restrict__ xo = arx_out + row * (int64_t)n;
+    // (arx_out may be NULL: x = xmean + sigma y is not kept -- whoever needs it later forms it again from y, sx_vd_args.arx)
+    const bool keep_x = arx_out != nullptr;
+    double *__restrict__ xo = keep_x ? arx_out + row * (int64_t)n : nullptr;
     auto block_sum = [&](double v) {
         v = wave_sum_butterfly(v, tid & 63);
         __syncthreads();
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(T) void wide_vd_candidates_kernel(const sx_vd_args 
                 const double x = xm0[u] + sigma * y;
                 if (e < e1) {  // (the look-ahead element is written -- and its z read -- by its own chunk)
                     yo[e] = y;
-                    xo[e] = x;
+                    if (keep_x) xo[e] = x;
                     tkacc += (inj ? y / dd[u] : yd) * vv[u];  // (the division only for the injected pair: rounding apart the same)
                 }
                 const double xc = clip ? fmin(fmax(x, -1.0), 1.0) : x;  // cmaes/_constraints.py:29-31

@@ -130,13 +130,20 @@ class _VdDeviceRun:
             with _common.host_blas_single_thread():  # (a threaded BLAS wakes 64+ spinning threads for this one dot product)
                 norm_v2 = float(np.dot(vvec, vvec))
             norm_v = float(np.sqrt(norm_v2))
+            # wide models whose candidates nobody else wants (no callback, history, Penalize, sharding): x = xmean + sigma y
+            # is not kept -- the moments kernel forms it again from y, bit for bit (sx_vd_args.arx NULL): a quarter of a
+            # generation's memory traffic
+            keep_x = not (run and n > _lib.NARROW_DIM and callback is None and not return_all and not penalize and world is None
+                          and os.environ.get("SX_VD_KEEP_X", "0") != "1")
             keep = self.buffers = dict(
-                Z=ctx.empty((P, n)), ary=ctx.empty((P, n)), arx=ctx.empty((P, n)), fit=ctx.empty((P,)),
+                Z=ctx.empty((P, n)), ary=ctx.empty((P, n)), fit=ctx.empty((P,)),
                 xmean=ctx.upload(xmean), xold=ctx.zeros((n,)), dx=ctx.zeros((n,)), dvec=ctx.upload(np.ones(n)),
                 vvec=ctx.upload(vvec), vn=ctx.upload(vvec / norm_v), pc=ctx.zeros((n,)), zinj=ctx.empty((n,)),
                 dy=ctx.zeros((n,)), w=ctx.upload(w), mws=ctx.empty((((mu + 7) // 8) * 8 + 4 * 64 * n,)),
                 mout=ctx.empty((4, n)), besthist=ctx.zeros((maxiter,)), xm=ctx.upload(xm), xstd=ctx.upload(xstd),
                 xbest=ctx.zeros((n,)), order=ctx.empty((P,), dtype=t.int64))
+            if keep_x:
+                keep["arx"] = ctx.empty((P, n))
             if penalize:  # cmaes/_constraints.py:4-82 on the device: weights 0, spread history [1.0], both phase flags as at the start
                 pw = np.zeros(2 * n + P + 256 + 4)
                 pw[2 * n + P] = 1.0
@@ -206,6 +213,9 @@ class _VdDeviceRun:
                     since = 0
             if not state.done:  # cannot happen: generation maxiter sets status -1
                 raise RuntimeError("VD-CMA device loop ended without a status")
+            if state.status == -99:  # csrc/sx_vd_loop.hip kVwFault
+                raise RuntimeError("VD-CMA model update: a grid-wide wait of the single-launch chain ran out (is another kernel "
+                                   "holding the device?); SX_VD_CHAIN=0 runs the chain as one launch per phase")
             nit = int(state.stop_it)
             self._res = OptimizeResult(x=keep["xbest"].cpu().numpy(), success=state.status >= 0, status=int(state.status),
                                        message=_common.messages[int(state.status)], fun=float(state.fbest),

@@ -236,6 +236,42 @@ def test_wide_vdcma_device_loop_matches_oracle(sa, n, P, maxiter, monkeypatch):
     assert np.allclose(t_host, t_ref, rtol=1e-6) and (host.nit, host.status) == (ref.nit, ref.status)
 
 
+_CHAIN_AB = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["SX_REPO"])
+import stochopy_amd as sa
+out = []
+for n, P, maxiter, extra in [(4097, 12, 12, {}), (8192, 64, 9, {}), (16384, 40, 6, {"constraints": "Penalize"}),
+                             (5000, 16, 300, {"ftol": 1.0e8}), (70000, 8, 5, {}), (100003, 6, 4, {})]:
+    opts = dict({"maxiter": maxiter, "popsize": P, "seed": 11, "sigma": 0.3, "backend": "hip", "rng": "philox"}, **extra)
+    trace = []
+    r = sa.optimize.minimize(sa.factory.rosenbrock, [[-3.0, 3.0]] * n, method="vdcma", options=opts,
+                             callback=lambda X, r: trace.append(float(r.fun).hex()))
+    out.append([trace, float(r.fun).hex(), r.x.tobytes().hex()[:4096], int(r.nit), int(r.nfev), int(r.status)])
+print("RESULT" + json.dumps(out))
+"""
+
+
+def test_wide_vdcma_chain_in_one_launch_is_the_chain_of_launches():
+    """The wide model update as ONE launch with grid-wide barriers (csrc/sx_vd_loop.hip vw_chain_kernel, the default) against
+    the same phases as one launch each (SX_VD_CHAIN=0, read once per process: two child processes): every generation's
+    best-f, the result and the counters bit for bit -- ordinary runs, Penalize, a run that stops on ftol, n up to 100 003."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for chain in ("1", "0"):
+        env = dict(os.environ, SX_VD_CHAIN=chain, SX_REPO=repo)
+        p = subprocess.run([sys.executable, "-c", _CHAIN_AB], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got[chain] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0][6:])
+    assert got["1"] == got["0"]
+    assert got["1"][3][5] == 1 and got["1"][3][3] < 300  # (the ftol run stopped early)
+
+
 def test_wide_vdcma_matches_the_reference_at_n_8192(sa):
     """A run captured from the reference itself (tests/golden/make_golden.py, numpy-legacy draws, n = 8192 -- the size
     VD-CMA exists for, vdcma/_vdcma.py:144-458): best-f of every generation within 1e-6, the result within 1e-5."""
