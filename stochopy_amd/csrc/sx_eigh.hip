@@ -104,8 +104,8 @@ struct EighInfo {  // first bytes of the workspace
     int32_t fault;      // resident kernel only: a bounded wait ran out (kFlowWait*): the run record is not to be trusted
     unsigned long long kmax2[kEighMaxSweeps];  // bits of max (M_ij / (M_jj - M_ii))^2 over the significant elements
                                                // of M after each sweep (same launch as offm)
-    double deep_off[2];                        // the same two measurements of M after each deep refinement step (below)
-    unsigned long long deep_k[2];
+    double deep_off[4];                        // the same two measurements of M after each deep refinement step (below)
+    unsigned long long deep_k[4];
     int32_t deep_steps;                        // deep steps carried out (diagnosis)
     int32_t pad2_;
 };
@@ -133,7 +133,21 @@ constexpr double kRefineOff = 1.0e-7, kRefineCap = 1.0e-3, kRefineProd = 1.0e-12
 // only with the refinement allowed (bit 1 of the `refine` argument) and npad >= 256 (the no-op launches of an unused deep step
 // cost ~20 us, a sweep of a smaller matrix less than ten times that).  info->refine: 1 = the first-order step is due, 2 / 3 = the
 // first / second deep step is due.
-constexpr double kDeepOff = 2.0e-6, kDeepCap = 5.0e-2;
+#ifndef SX_DEEP_OFF
+#define SX_DEEP_OFF 2.0e-6
+#endif
+#ifndef SX_DEEP_CAP
+#define SX_DEEP_CAP 5.0e-2
+#endif
+#ifndef SX_DEEP_STEPS
+#define SX_DEEP_STEPS 2
+#endif
+#ifndef SX_DEEP_ATAN
+#define SX_DEEP_ATAN 0
+#endif
+constexpr double kDeepOff = SX_DEEP_OFF, kDeepCap = SX_DEEP_CAP;
+constexpr int kDeepSteps = SX_DEEP_STEPS;   // deep steps a run may take (<= 4: EighInfo::deep_off)
+constexpr double kDeepNs2 = 5.0e-2;         // max |K| above which exp(K / 2) gets a second Newton-Schulz correction
 constexpr int kEighFailsOffset = 2040;  // int32 inside the 2048-byte info block, behind EighInfo: runs that fell short
 
 // Stopping rule, evaluated from the off-diagonal mass a_s = sqrt(acc[s] / |C|_F^2) met DURING the sweeps so far:
@@ -776,6 +790,9 @@ __global__ __launch_bounds__(256) void eigh_refine_k_kernel(const double *__rest
         const double g = M[(int64_t)b * npad + b] - M[(int64_t)a * npad + a];
         if (m * m > tolel2) k = m / g;
         if (!(fabs(k) <= 2.0 * cap)) k = 0.0;  // (cannot happen after the rule held; never divide by noise)
+        // (deep steps: the 2 x 2 problem's own angle instead of its first-order value -- the same to second order, and what
+        //  an isolated pair needs exactly when K is not small)
+        if (SX_DEEP_ATAN && want >= 2) k = 0.5 * atan(2.0 * k);
         if (i > j) k = -k;
     }
     K[e] = k * scale;  // (the deep step works with K / 2: its rotation is the square of exp(K / 2))
@@ -826,11 +843,18 @@ __global__ __launch_bounds__(256) void eigh_deep_gemm_kernel(double *__restrict_
     if (info->refine != want) return;
     const int p = info->parity;
     double *Mp = p ? M1 : M0, *Mq = p ? M0 : M1, *Vp = p ? V1 : V0, *Vq = p ? V0 : V1;
+    // a second correction (7: E2 = I - Th^T Th -> W1, 8: Th + Th E2 / 2 -> V[q], between 2 and 3) when max |K| of the matrix
+    // this step starts from is above kDeepNs2: T2^T T2 - I = H^4 / 4 is 2.5e-5 at max |K| = 0.2, one step leaves 2e-10, two 1e-20
+    const double k2 = __longlong_as_double((long long)(want == 2 ? info->kmax2[info->sweeps - 1] : info->deep_k[want - 3]));
+    const bool twice = k2 > kDeepNs2 * kDeepNs2;
+    if ((which == 7 || which == 8) && !twice) return;
     switch (which) {
         case 0: eigh_gemm_body<false>(Mq, Mq, Vq, npad, 0.5, 1.0, Mq, As, Bs); break;
         case 1: eigh_gemm_body<true>(Vq, Vq, W1, npad, -1.0, 1.0, nullptr, As, Bs); break;
         case 2: eigh_gemm_body<false>(Vq, W1, W2, npad, 0.5, 0.0, Vq, As, Bs); break;
-        case 3: eigh_gemm_body<false>(W2, W2, W3, npad, 1.0, 0.0, nullptr, As, Bs); break;
+        case 7: eigh_gemm_body<true>(W2, W2, W1, npad, -1.0, 1.0, nullptr, As, Bs); break;
+        case 8: eigh_gemm_body<false>(W2, W1, Vq, npad, 0.5, 0.0, W2, As, Bs); break;
+        case 3: eigh_gemm_body<false>(twice ? Vq : W2, twice ? Vq : W2, W3, npad, 1.0, 0.0, nullptr, As, Bs); break;
         case 4: eigh_gemm_body<false>(Mp, W3, W1, npad, 1.0, 0.0, nullptr, As, Bs); break;
         case 5: eigh_gemm_body<true>(W3, W1, Mq, npad, 1.0, 0.0, nullptr, As, Bs); break;
         default: eigh_gemm_body<false>(Vp, W3, Vq, npad, 1.0, 0.0, nullptr, As, Bs); break;
@@ -876,8 +900,8 @@ __global__ void eigh_deep_finish_kernel(EighInfo *info, double tol, int want, in
     } else if (left <= kRefineOff * kRefineOff * nrm2 && kmax2 <= kRefineCap * kRefineCap &&
                kmax2 * left <= kRefineProd * kRefineProd * nrm2) {
         info->refine = 1;  // the first-order step finishes the run
-    } else if (want == 2) {
-        info->refine = 3;  // once more
+    } else if (want < 1 + kDeepSteps) {
+        info->refine = want + 1;  // once more
     } else {
         info->refine = 0, info->converged = 0;
         atomicAdd(fails, 1);
@@ -2140,13 +2164,16 @@ int eigh_enqueue_phased(const double *C, int n, const double *V0, double *w, dou
                 const dim3 ge((unsigned)(((int64_t)npad * npad + 255) / 256));
                 if (refine & 2) {  // the deep step, twice (each set does nothing unless the record asks for it)
                     int *fails = (int *)((char *)L.info + kEighFailsOffset);
-                    for (int step = 0; step < 2; ++step) {
+                    for (int step = 0; step < kDeepSteps; ++step) {
                         const int want = 2 + step;
                         hipLaunchKernelGGL(eigh_refine_k_kernel, ge, dim3(256), 0, st, L.M[0], L.M[1], L.M[0], L.M[1], npad, L.info, tol,
                                            want, kDeepCap, 0.5);
-                        for (int which = 0; which < 7; ++which)
+                        static const int order[9] = {0, 1, 2, 7, 8, 3, 4, 5, 6};
+                        for (int o = 0; o < 9; ++o) {
+                            if (kDeepCap <= kDeepNs2 && (order[o] == 7 || order[o] == 8)) continue;  // (never taken: not launched)
                             hipLaunchKernelGGL(eigh_deep_gemm_kernel, gg, dim3(256), 0, st, L.M[0], L.M[1], L.V[0], L.V[1], L.W[0], L.W[1],
-                                               L.W[2], npad, L.info, want, which);
+                                               L.W[2], npad, L.info, want, order[o]);
+                        }
                         hipLaunchKernelGGL(eigh_deep_measure_kernel, dim3(128), dim3(256), 0, st, L.M[0], L.M[1], npad, L.info, tol, want,
                                            step);
                         hipLaunchKernelGGL(eigh_deep_finish_kernel, dim3(1), dim3(64), 0, st, L.info, tol, want, step, fails);
