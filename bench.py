@@ -214,7 +214,10 @@ def other_configs():
     out["VD_vdcma_rosenbrock_n16384_p1024"] = {
         "evals_per_s": 1024 / t, "us_per_generation": t * 1e6, "bound": "hbm", "frac": 32 * 16384 * 1024 / t / (HBM_PEAK_GBS * 1e9),
         "note": "algorithmic bytes 32 n per candidate: y and x written (16 n), x read by the objective (8 n), x and y of the "
-                "mu = P/2 selected rows read by the moment sums (8 n per candidate on average); DESIGN.md section 4"}
+                "mu = P/2 selected rows read by the moment sums (8 n per candidate on average); DESIGN.md section 4.  Since "
+                "round 6 the device-resident run does not keep x (the moment sums form it again from y): the kernels move "
+                "~24 n per candidate incl. the normals parked between a streamed row's two passes; the basis of `frac` stays "
+                "the 32 n of rounds 5's line"}
     c3 = {"popsize": 16384, "updating": "deferred"}
     t = per_gen("pso", sa.factory.ackley, 256, c3, 200, 1200)
     out["C3a_pso_ackley_n256_p16384"] = {"evals_per_s": 16384 / t, "us_per_generation": t * 1e6, "bound": "hbm",
