@@ -517,7 +517,7 @@ def main():
             try:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc.sh), with the
                 rec = json.load(open(pmc))  # commit they were measured at: not measured inside this run
                 traffic = rec.get(args.workload, {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc passes (tools/r4_profiles.sh) at commit %s" % rec.get(
+                traffic_src = "profiles/pmc_latest.json: rocprofv3 --pmc passes (tools/r6_profiles.sh) at commit %s" % rec.get(
                     "_commit", "unrecorded")
             except Exception:
                 traffic = None
@@ -587,7 +587,7 @@ def main():
         c5kw = dict(objective="rosenbrock", n=1024, Ptotal=131072, strategy="best1bin", K=20, W=10, kernel_launches=50)
         c5 = {"workload": "de_rosenbrock_n1024_p131072 (total), best1bin", "n_ranks_seen": dist.get_world_size(),
               "rows_per_gpu": 131072 // world, "scaling": "strong",
-              "n1_reference": "configs.C5_full_de_n1024_p131072_1gpu of the N = 1 line (profiles/r5_bench_N1.json)"}
+              "n1_reference": "configs.C5_full_de_n1024_p131072_1gpu of the N = 1 line (profiles/r6_bench_N1.json)"}
 
         def c5_entry(r, mode):
             return {"value": 131072 * r["steps_timed"] / r["dt"], "unit": "evals/s",
