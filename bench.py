@@ -230,8 +230,8 @@ def other_configs():
     flops = 2.0 * 1024 * 512**2 + 2.0 * 512 * 512**2
     out["C4_cmaes_rosenbrock_n512_p1024"] = {
         "evals_per_s": 1024 / t, "ms_per_generation": t * 1e3, "bound": "mfma", "frac": flops / t / mfma_f64,
-        "note": "generations 10-50 of a run (every generation decomposes the covariance: 6 Jacobi sweeps + the first-order "
-                "refinement step there, 5 + the step later); frac = sampling + rank-mu flops (8.05e8) / generation time / 78.6 TF -- the generation "
+        "note": "generations 10-50 of a run (every generation decomposes the covariance: 5-6 Jacobi sweeps, then -- round 6 -- one or "
+                "two deep refinement steps (an exact similarity with exp(K) on the matrix cores) and the first-order one); frac = sampling + rank-mu flops (8.05e8) / generation time / 78.6 TF -- the generation "
                 "is the eigendecomposition's latency chain, not these two contractions.  Parity of this mode (device eigensolver, Philox "
                 "draws): every single generation is pinned to the oracle's model of that generation and runs agree with the oracle "
                 "(LAPACK + canonical signs) within 1e-6 over windows of 16-24 generations; whole-run agreement at this size is a statement "
