@@ -936,24 +936,27 @@ __global__ __launch_bounds__(T) void wide_vd_candidates_kernel(const sx_vd_args 
     const double fc = wide_row<FUN, T>(c, n, chunk_leaves, S, LA, LB, [&](int e0, int e1, int e1s, double *Sd) {
         for (int g = (e0 >> 8) * 64 + tid; g < ((e1s + 255) >> 8) * 64; g += T) {
             const int eb = (g >> 6) * 256 + (g & 63);
-            double z[4], vv[4], dd[4], xm0[4], dj[4];
+            // (z: the row's normal -- or, in the injected pair's rows, dy: one array; the un-standardisation's xstd / xm ride in
+            //  the same batch of loads: a second dependent trip per batch otherwise, 8 per row of 16 384 elements)
+            double z[4], vv[4], dd[4], xm0[4], xs[4], xo0[4];
             bool in[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = eb + 64 * u;
                 in[u] = e >= e0 && e < e1s;
-                z[u] = (in[u] && !inj) ? (resident ? Sd[stage_pos(e)] : yo[e]) : 0.0;
+                z[u] = in[u] ? (inj ? a.dy[e] : (resident ? Sd[stage_pos(e)] : yo[e])) : 0.0;
                 vv[u] = in[u] ? a.vn[e] : 0.0;
                 dd[u] = in[u] ? a.dvec[e] : 1.0;
                 xm0[u] = in[u] ? a.xmean[e] : 0.0;
-                dj[u] = (in[u] && inj) ? a.dy[e] : 0.0;
+                xs[u] = in[u] ? a.xstd[e] : 0.0;
+                xo0[u] = in[u] ? a.xm[e] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = eb + 64 * u;
                 if (!in[u]) continue;
                 const double yd = z[u] + coef * (t * vv[u]);  // y / d of an ordinary row
-                const double y = inj ? sgn * dj[u] : dd[u] * yd;
+                const double y = inj ? sgn * z[u] : dd[u] * yd;
                 const double x = xm0[u] + sigma * y;
                 if (e < e1) {  // (the look-ahead element is written -- and its z read -- by its own chunk)
                     yo[e] = y;
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(T) void wide_vd_candidates_kernel(const sx_vd_args 
                     tkacc += (inj ? y / dd[u] : yd) * vv[u];  // (the division only for the injected pair: rounding apart the same)
                 }
                 const double xc = clip ? fmin(fmax(x, -1.0), 1.0) : x;  // cmaes/_constraints.py:29-31
-                stage_put<Obj<FUN>::NEXT>(Sd, e, e0, xc * a.xstd[e] + a.xm[e]);  // cmaes/_cmaes.py:171
+                stage_put<Obj<FUN>::NEXT>(Sd, e, e0, xc * xs[u] + xo0[u]);  // cmaes/_cmaes.py:171
             }
         }
     });
