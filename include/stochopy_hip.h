@@ -612,7 +612,9 @@ typedef struct sx_vd_args {
 
 int sx_vdcma_generation(const sx_vd_args *a, int64_t gen, void *stream);
 /* two steps around one all-gather for candidates sharded over ranks, as sx_cmaes_generation_stage (stage 0 fills
- * ary_loc / arx_loc (rows,n) and fit_loc (rows) for rows [row0, row0 + rows); the injected pair is global rows 0, 1) */
+ * ary_loc / arx_loc (rows,n) and fit_loc (rows) for rows [row0, row0 + rows); the injected pair is global rows 0, 1).
+ * Stage 1 of a generation follows stage 0 of the SAME generation on the same stream: for wide models stage 0 also zeroes the
+ * barrier words (behind t_k in Z) of the one-launch model update that stage 1 enqueues. */
 int sx_vdcma_generation_stage(const sx_vd_args *a, int64_t gen, int stage, int64_t row0, int64_t rows, double *ary_loc,
                               double *arx_loc, double *fit_loc, void *stream);
 
