@@ -81,7 +81,7 @@ def cpu_baseline(objective, n, P, strategy, budget_s=12.0):
     try:
         oracle.minimize(objective, [[-5.12, 5.12]] * n, method="de", callback=cb,
                         options={"maxiter": 10**6, "popsize": P, "seed": 0, "strategy": strategy, "ftol": -1.0,
-                                 "xtol": 0.0})
+                                 "xtol": 0.0, "updating": "deferred"})
     except StopIteration:
         pass
     done = len(gens) - 1  # generations after the initial evaluation
@@ -271,7 +271,7 @@ def cpu_baseline_loky(objective, n, P, strategy, budget_s=6.0):
         try:
             oracle.minimize(fobj, [[-5.12, 5.12]] * n, method="de", callback=cb,
                             options={"maxiter": 10**6, "popsize": P, "seed": 0, "strategy": strategy, "ftol": -1.0,
-                                     "xtol": 0.0})
+                                     "xtol": 0.0, "updating": "deferred"})
         except StopIteration:
             pass
     done, dt = len(stamps) - 1, stamps[-1] - stamps[0]

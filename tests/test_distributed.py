@@ -291,7 +291,7 @@ def test_sharded_pso_on_gpu_is_exact(exchange):
     opts = {"maxiter": 40, "popsize": 96, "seed": 77, "ftol": -1.0, "xtol": 0.0}
     cfg = {"n": 20, "objective": "rosenbrock", "method": "pso", "options": opts, "env": {"SX_EXCHANGE": exchange}}
     out = _spawn(gpu_minimize_worker, 2, cfg)
-    ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * 20, method="pso", options=dict(opts), rng="philox")
+    ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * 20, method="pso", options=dict(opts, updating="deferred"), rng="philox")
     for r in range(2):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
         assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
@@ -311,7 +311,7 @@ def test_sharded_cpso_restart_is_exact(world, exchange):
     opts = {"maxiter": 30, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
     cfg = {"n": 16, "objective": "sphere", "method": "cpso", "options": opts, "env": {"SX_EXCHANGE": exchange}}
     out = _spawn(gpu_minimize_worker, world, cfg)
-    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method="cpso", options=dict(opts), rng="philox")
+    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method="cpso", options=dict(opts, updating="deferred"), rng="philox")
     assert len(ref["_restarts"]) > 0
     for r in range(world):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
@@ -340,7 +340,7 @@ def test_sharded_callbacks_and_return_all(method, extra, env, with_callback):
     out = _spawn(gpu_minimize_worker, world, cfg)
     seen = []
     oopts = {k: v for k, v in opts.items() if k not in ("exchange", "donors")}
-    ref = oracle.minimize(cfg["objective"], [[-5.12, 5.12]] * n, method=method, options=oopts, rng="philox",
+    ref = oracle.minimize(cfg["objective"], [[-5.12, 5.12]] * n, method=method, options=dict(oopts, updating="deferred"), rng="philox",
                           callback=lambda X, r: seen.append((X.copy(), float(r.fun), int(r.nit), int(r.nfev))))
     for r in range(world):
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
@@ -368,7 +368,7 @@ def test_sharded_run_with_a_caller_supplied_objective(method):
         ref = oe.run_de_sharded(oracle.OBJECTIVES["sphere"], np.full(n, -5.12), np.full(n, 5.12), oracle.PhiloxStream(8),
                                 2, maxiter=20, popsize=64, ftol=-1.0, xtol=0.0)
     else:
-        ref = oracle.minimize("sphere", [[-5.12, 5.12]] * n, method=method, options=dict(opts), rng="philox")
+        ref = oracle.minimize("sphere", [[-5.12, 5.12]] * n, method=method, options=dict(opts, updating="deferred"), rng="philox")
     for r in range(2):
         assert np.array_equal(np.load(os.path.join(out, f"x_{r}.npy")), ref.x)
         assert np.load(os.path.join(out, f"meta_{r}.npy"))[0] == ref.fun
@@ -510,7 +510,7 @@ def test_sharded_pso_rccl_graph_capture_single_rank(method):
     cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts, "env": {"SX_EXCHANGE": "rccl"},
            "flight_recorder": method == "pso"}  # pso: the capture waits on torch's flight recorder; cpso: it sleeps
     out = _spawn(nccl_single_rank_worker, 1, cfg)
-    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts), rng="philox")
+    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts, updating="deferred"), rng="philox")
     fun, nit, nfev, status = np.load(os.path.join(out, "meta_0.npy"))
     assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
     assert np.array_equal(np.load(os.path.join(out, "x_0.npy")), ref.x)
@@ -532,7 +532,7 @@ def test_callbacks_and_return_all_over_rccl_single_rank(method):
     out = _spawn(nccl_single_rank_worker, 1, cfg)
     seen = []
     oopts = {k: v for k, v in opts.items() if k != "exchange"}
-    ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method=method, options=oopts, rng="philox",
+    ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method=method, options=dict(oopts, updating="deferred"), rng="philox",
                           callback=lambda X, r: seen.append(X.copy()))
     assert np.array_equal(np.load(os.path.join(out, "x_0.npy")), ref.x)
     assert np.array_equal(np.load(os.path.join(out, "xall_0.npy")), ref.xall)
@@ -585,7 +585,7 @@ def test_two_physical_gpus_pso_is_exact(method):
     opts = {"maxiter": 70, "popsize": 256, "seed": 5, "ftol": -1.0, "xtol": 0.0}
     cfg = {"n": 16, "objective": "sphere", "method": method, "options": opts}
     out = _spawn(nccl_multi_gpu_worker, world, cfg)
-    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts), rng="philox")
+    ref = oracle.minimize("sphere", [[-5.12, 5.12]] * 16, method=method, options=dict(opts, updating="deferred"), rng="philox")
     for r in range(world):
         fun, nit, nfev, status = np.load(os.path.join(out, f"meta_{r}.npy"))
         assert (fun, nit, nfev, status) == (ref.fun, ref.nit, ref.nfev, ref.status)
@@ -607,7 +607,7 @@ def test_any_popsize_is_sharded_the_last_rank_short(method, n, P, world):
     cfg = {"n": n, "objective": "rosenbrock", "method": method, "options": opts, "rng": "philox"}
     out = _spawn(gpu_minimize_worker, world, cfg)
     if method == "pso":
-        ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method="pso", options=dict(opts), rng="philox")
+        ref = oracle.minimize("rosenbrock", [[-5.12, 5.12]] * n, method="pso", options=dict(opts, updating="deferred"), rng="philox")
     else:  # (the sharded device loop runs the one-GPU resident loop's kernels: bit-identical to it)
         ref = sa.optimize.minimize(sa.factory.rosenbrock, [[-5.12, 5.12]] * n, method=method, options=dict(opts, backend="hip"))
     for r in range(world):

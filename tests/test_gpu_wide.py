@@ -115,7 +115,7 @@ def test_wide_de_graph_equals_stepwise_and_oracle(sa):
     a = sa.optimize.minimize(sa.factory.sphere, bounds, method="de", options=dict(o))
     b = sa.optimize.minimize(sa.factory.sphere, bounds, method="de", options=dict(o), callback=lambda X, r: None)
     assert a.nit == b.nit == 120 and a.fun == b.fun and np.array_equal(a.x, b.x)
-    ref = oracle.minimize("sphere", bounds, method="de", options={"maxiter": 120, "popsize": P, "seed": 5, "ftol": -1.0, "xtol": 0.0},
+    ref = oracle.minimize("sphere", bounds, method="de", options={"maxiter": 120, "popsize": P, "seed": 5, "ftol": -1.0, "xtol": 0.0, "updating": "deferred"},
                           rng="philox")
     assert ref.fun == a.fun and np.array_equal(ref.x, a.x)
 
@@ -137,7 +137,8 @@ def test_wide_default_call_defers_with_a_warning(sa):
     with pytest.warns(RuntimeWarning, match="deferred"):
         r = sa.optimize.minimize(sa.factory.sphere, [[-1.0, 1.0]] * n, method="de",
                                  options={"maxiter": 3, "popsize": 8, "seed": 0, "rng": "philox"})
-    ref = oracle.minimize("sphere", [[-1.0, 1.0]] * n, method="de", options={"maxiter": 3, "popsize": 8, "seed": 0}, rng="philox")
+    ref = oracle.minimize("sphere", [[-1.0, 1.0]] * n, method="de", options={"maxiter": 3, "popsize": 8, "seed": 0, "updating": "deferred"},
+                          rng="philox")
     assert r.fun == ref.fun and np.array_equal(r.x, ref.x)
 
 

@@ -286,3 +286,16 @@ def test_na_oracle_matches_reference_bit_for_bit(case):
     assert hashlib.sha256(np.ascontiguousarray(pops[-1]).tobytes()).hexdigest() == case["pop_last_sha"]
     if "xref_from_reference_tests" in case:
         assert np.allclose(case["xref_from_reference_tests"], res.x)
+
+
+@pytest.mark.parametrize("method", ["de", "pso", "cpso"])
+def test_default_updating_is_the_references(method):
+    """oracle.minimize without `updating` runs the reference's default (de/_de.py:27, cpso/_cpso.py:29: "immediate"), not the
+    synchronous form the throughput paths use -- a caller comparing the two packages' defaults compares the same algorithm."""
+    opts = {"maxiter": 12, "popsize": 10, "seed": 3}
+    bounds = [[-5.12, 5.12]] * 6
+    default = oracle.minimize("ackley", bounds, method=method, options=dict(opts))
+    immediate = oracle.minimize("ackley", bounds, method=method, options=dict(opts, updating="immediate"))
+    deferred = oracle.minimize("ackley", bounds, method=method, options=dict(opts, updating="deferred"))
+    assert default["fun"] == immediate["fun"] and np.array_equal(default["x"], immediate["x"])
+    assert default["fun"] != deferred["fun"]
