@@ -326,6 +326,23 @@ def resolve_workers(workers, fun_id=None):
     return int(workers)
 
 
+_warned_replicated = set()
+
+
+def replicated_workers(method, workers, why):
+    """`workers > 1` where the run cannot be sharded (the reference's own random stream for DE / PSO / CPSO: one host
+    stream, drawn in the order of the whole population; NA: every walk reads the whole model store): every rank -- or the one
+    process there is -- carries the WHOLE run on its GPU.  The reference's invariant holds as it does for its parallel
+    backends (tests/helpers.py:28-36: the backend must not change the result for a seed); there is nothing to gain either:
+    such a run is bound by the host stream / one workgroup row per sample, not by the objective evaluations the reference
+    hands to its workers (_common.py:58-72).  Says so once per method.  Returns 1."""
+    if method not in _warned_replicated:
+        _warned_replicated.add(method)
+        warnings.warn(f"stochopy_amd: {method} with workers={workers} runs replicated -- {why}: same result as workers=1 on "
+                      "every rank, no speed-up.  (Shown once.)", UserWarning, stacklevel=4)
+    return 1
+
+
 def resolve_rng(rng):
     rng = "numpy-legacy" if rng is None else rng
     if rng not in RNG_MODES:

@@ -112,12 +112,16 @@ class _PsoRun:
         self.immediate = immediate  # pso_async: one sequential sweep per generation (csrc/sx_async.hip)
         import os
 
+        if workers != 1 and rng != "philox":
+            workers = _common.replicated_workers("cpso" if gamma else "pso", workers,
+                                                 'rng="numpy-legacy" replays ONE host stream in the order of the whole swarm '
+                                                 '(rng="philox" shards: draws keyed by the global row)')
         if workers != 1 or os.environ.get("SX_FORCE_SHARDED") == "1":  # env switch: a 1-rank group (tests)
             from ..parallel import require_world
 
             self.world = require_world(workers)
             if rng != "philox":
-                raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
+                raise ValueError('a sharded run needs rng="philox" (draws keyed by the global row; see parallel.py)')
             self.row0, self.P = self.world.shard(P)  # self.P is the LOCAL swarm from here on
             if gamma and P % self.world.size != 0:
                 # (PSO takes any popsize -- blocks of ceil(P / workers) rows, the last rank short; the competitive restart's

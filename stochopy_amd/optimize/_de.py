@@ -123,12 +123,15 @@ class _DeRun:
         self.Ptotal = P
         self.row0 = 0
         self.immediate = immediate  # de_async: one sequential sweep per generation (csrc/sx_async.hip)
+        if workers != 1 and rng != "philox":
+            workers = _common.replicated_workers("de", workers, 'rng="numpy-legacy" replays ONE host stream in the order of the '
+                                                 'whole population (rng="philox" shards: draws keyed by the global row)')
         if workers != 1 or os.environ.get("SX_FORCE_SHARDED") == "1":  # the env switch lets a 1-rank group
             from ..parallel import require_world                         # exercise the exchange path (tests)
 
             self.world = require_world(workers)
             if rng != "philox":
-                raise ValueError('workers > 1 needs rng="philox" (draws keyed by the global row; see parallel.py)')
+                raise ValueError('a sharded run needs rng="philox" (draws keyed by the global row; see parallel.py)')
             self.row0, self.P = self.world.shard(P)  # this rank's rows; self.P is the LOCAL population from here on
             if immediate:
                 raise ValueError("immediate updating is a single-GPU sweep")

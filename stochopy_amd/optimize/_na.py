@@ -61,8 +61,8 @@ def minimize(
     rng = _common.resolve_rng(rng)
     if popsize > 65535:
         raise ValueError("method 'na': popsize <= 65535 (one workgroup row of the cell-walk kernels per sample)")
-    if _common.resolve_workers(workers, fun_id) != 1:
-        raise ValueError("method 'na' runs on one GPU (workers=1): every walk reads the whole model store")
+    if _common.resolve_workers(workers, fun_id) != 1:  # (the reference's NA takes workers like every method: na/_na.py:131)
+        _common.replicated_workers("na", workers, "every walk reads the whole model store, which lives on one GPU")
     return _NaRun(fun_id, lower, upper, x0, int(maxiter), int(popsize), float(nrperc), float(xtol), float(ftol),
                   bool(return_all), float(verbosity), callback, rng, seed).result()
 

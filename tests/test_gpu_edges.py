@@ -226,3 +226,28 @@ def test_concurrent_calls_from_two_host_threads(sa):
         for tag in pair:
             assert (out[tag].nit, out[tag].status) == (serial[tag].nit, serial[tag].status)
             assert out[tag].fun == serial[tag].fun and np.array_equal(out[tag].x, serial[tag].x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["de", "pso", "cpso", "na"])
+def test_workers_with_the_references_own_stream_do_not_change_the_result(sa, method):
+    """The reference's invariant (tests/helpers.py:28-36, stochopy/optimize/_common.py:58-72): the parallel backend must not
+    change the result for a seed.  With rng="numpy-legacy" (one sequential host stream) and for NA a run cannot be sharded: it
+    runs replicated -- workers=3 returns the workers=1 result bit for bit and says so once -- where rounds 1-5 raised."""
+    import warnings
+
+    from stochopy_amd.optimize import _common
+
+    _common._warned_replicated.discard(method)
+    opts = {"maxiter": 15, "popsize": 24, "seed": 9, "rng": "numpy-legacy", "backend": "hip"}
+    if method != "na":
+        opts["updating"] = "deferred"  # (what the reference itself runs with a parallel backend: de/_de.py:142-145)
+    bounds = [[-5.12, 5.12]] * 8
+    one = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method=method, options=dict(opts))
+    with pytest.warns(UserWarning, match="replicated"):
+        three = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method=method, options=dict(opts, workers=3))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", UserWarning)  # (once per method)
+        again = sa.optimize.minimize(sa.factory.rosenbrock, bounds, method=method, options=dict(opts, workers=3))
+    for r in (three, again):
+        assert r.fun == one.fun and np.array_equal(r.x, one.x) and (r.nit, r.nfev, r.status) == (one.nit, one.nfev, one.status)
