@@ -473,3 +473,17 @@ def test_philox_latin_hypercube_oracle_properties(P, n):
     assert np.array_equal(np.vstack(parts), X)
     assert not np.array_equal(X, oracle.PhiloxStream(100).lhs_population(P, n, lo, up))
     assert np.array_equal(oe.latin_hypercube(oracle.PhiloxStream(99), P, n, lo, up), X)  # what oracle.minimize starts from
+
+
+def test_replicated_workers_says_so_once_per_method():
+    """workers > 1 where a run cannot be sharded (optimize/_common.py replicated_workers): one warning per method, workers -> 1."""
+    import warnings
+
+    from stochopy_amd.optimize import _common
+
+    _common._warned_replicated.discard("unit-test")
+    with pytest.warns(UserWarning, match="replicated"):
+        assert _common.replicated_workers("unit-test", 4, "a reason") == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert _common.replicated_workers("unit-test", 4, "a reason") == 1
