@@ -13,6 +13,11 @@
 //                                             only the LAST individual's status survives the sweep)
 //   stochopy/optimize/cpso/_constraints.py:56-64  Shrink, one-row form
 // (the ordered sweeps sit at their 128-VGPR cap: the reduction keeps the form with fewer live values -- tools/isa_survey.py)
+// Two translation units (the longest compile of the library otherwise, ~95 s, the build's critical path): this file compiles the DE
+// sweeps; sx_async_pso.hip includes it with SX_ASYNC_PART = 1 for the PSO / CPSO sweeps.
+#ifndef SX_ASYNC_PART
+#define SX_ASYNC_PART 0
+#endif
 #define SX_FUSED_TAIL_BY_LANE 0
 #include "sx_device.hpp"
 #include "sx_host.hpp"
@@ -432,6 +437,7 @@ int launch_sweep(K kern, const SweepGeometry &g, hipStream_t s, const void *args
 
 }  // namespace
 
+#if SX_ASYNC_PART == 0
 // One asynchronous DE generation (the whole sweep + status), population a->buf0 in place, best row a->gbest
 // (in/out), a->state: it, gfit in/out; status, done out.  a->buf1 / part_f / part_i are not used.
 extern "C" int sx_de_async_generation(const sx_de_args *a, void *stream) {
@@ -461,6 +467,7 @@ extern "C" int sx_de_async_generation(const sx_de_args *a, void *stream) {
     return 0;
 }
 
+#else
 // One asynchronous PSO generation: X, V, pbest, pbestfit in place, a->gbest in/out, a->state as above.
 extern "C" int sx_pso_async_generation(const sx_pso_args *a, void *stream) {
     SX_REQUIRE(a != nullptr, "sx_pso_async: null args");
@@ -485,3 +492,4 @@ extern "C" int sx_pso_async_generation(const sx_pso_args *a, void *stream) {
     SX_LAUNCH_CHECK();
     return 0;
 }
+#endif

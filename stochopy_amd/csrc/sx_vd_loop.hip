@@ -409,6 +409,7 @@ __host__ __device__ inline VwScratch vw_scratch(double *base, int n) {
 // The eight barrier words of vw_chain_kernel: NOT in this scratch -- the moments kernels write their partial sums over it
 // between the injection (which zeroes the words) and the chain -- but behind t_k in Z, the (P, n) buffer of which wide
 // models use the first P doubles only.
+constexpr int kVwSyncWords = 8;  // (seven barriers; a 64-byte line)
 __host__ __device__ inline unsigned *vw_sync(const sx_vd_args &a) { return (unsigned *)(a.Z + a.P); }
 inline unsigned vw_blocks(int n) {
     const int b = (n + kVwThreads - 1) / kVwThreads;
@@ -486,7 +487,7 @@ __device__ __forceinline__ double vw_avec(const VwModel &m, double vnn) { return
 __global__ __launch_bounds__(kVwThreads) void vw_inject_norms_kernel(const sx_vd_args a, int64_t gen, double *base) {
     __shared__ double red3[kVwWaves][3];
     const sx_cma_state *state = (const sx_cma_state *)a.state;
-    if (blockIdx.x == 0 && threadIdx.x < 8) vw_sync(a)[threadIdx.x] = 0u;  // (vw_chain_kernel's barrier words)
+    if (blockIdx.x == 0 && threadIdx.x < kVwSyncWords) vw_sync(a)[threadIdx.x] = 0u;  // (vw_chain_kernel's barrier words)
     if (state->done || state->reserved[3] == 0.0) return;
     const int n = a.n;
     const VwScratch w = vw_scratch(base, n);
@@ -831,7 +832,6 @@ __global__ void vw_done_kernel(sx_cma_state *state) {
 // host raises).  The eight words are zeroed by vw_inject_norms_kernel, which every generation launches before its candidates.
 constexpr long long kVwWaitTicks = 400000000LL;  // ~4 s of the 100 MHz wall clock
 constexpr int kVwFault = -99;
-constexpr int kVwSyncWords = 8;
 __device__ __forceinline__ bool vw_grid_barrier(unsigned *word) {
     __shared__ int s_ok;
     __syncthreads();
