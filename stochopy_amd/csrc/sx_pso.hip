@@ -48,8 +48,11 @@ constexpr int kChainRecPerThread = 8;
 // ONEB (round 5): a whole-wave kernel instantiated for rows of 129 ... 256 elements of run-time length: one batch, the objective's
 // run-time register chain only -- the general whole-wave kernel carries the long rows' summation plans in its register budget
 // (111 VGPRs with Ackley: two workgroups per CU, where the n = 256 kernel runs four)
+#ifndef SX_PSO_RAD_WAVES
+#define SX_PSO_RAD_WAVES 6
+#endif
 template <int FUN, int RNG, int LPR, bool FULL, bool PLAIN = false, bool CHAIN = false, bool ONEB = false>
-__global__ __launch_bounds__(kMaxWavesPerBlock *kWave) void pso_generation_kernel(const sx_pso_args a,
+__global__ __launch_bounds__(kMaxWavesPerBlock *kWave, (FULL && !PLAIN && !CHAIN && LPR == kWave) ? SX_PSO_RAD_WAVES : 1) void pso_generation_kernel(const sx_pso_args a,
                                                                                 const PlanArg plan,
                                                                                 double *__restrict__ best_rows,
                                                                                 const int chain_p, const int mode,
